@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X belief-propagation engine.
+
+Metric (BASELINE.json): clique-tree messages/sec (+ log-likelihood evals/sec), homogeneous BM,
+16 traits, 50k-tip random bifurcating tree, clique tree (SURVEY.md section 8(d) "cfg3").
+One "step" = one calibrate!() (postorder + preorder over the whole clique tree = 2 * n_sepsets
+directed canonical messages, src/calibration.jl:72-84) on factors already resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, each calibrating its own replica of the workload (one big tree does
+not shard -- "replicas only"); no data-path collective; timing = barrier +
+synchronize on both sides, MAX over ranks; value = all ranks' messages / that time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def build_workload(ntips, p, seed, graph):
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(seed)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    mu = np.zeros(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    if graph == "cliquetree":
+        prob = S.cliquetree_of_tree(tr, p)
+        packed = S.bm_factors_cliquetree(tr, prob, R, mu, X)
+    else:
+        prob = S.bethe_of_tree(tr, p)
+        packed = S.bm_factors_bethe(tr, prob, R, mu, X)
+    ll_check = S.bm_loglik_pruning(tr, R, mu, X)
+    return tr, prob, packed, ll_check
+
+
+def cpu_baseline(prob, packed, budget_s=20.0):
+    """The oracle's plain-C sequential engine (reference message order, 1 core) on a bounded sample:
+    whole calibrate!() passes over the same workload until ~budget_s of CPU time is spent."""
+    try:
+        from oracle import cengine
+    except Exception as ex:  # oracle not built: report, never fake
+        return {"value": None, "unit": "messages/s", "cores": 1, "kind": "port", "sample": f"unavailable: {ex}"}
+    eng = cengine.Engine(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    pa, ch = prob.schedule[0]
+    nmsg = 2 * len(pa)
+    t_total, passes = 0.0, 0
+    ll = None
+    while t_total < budget_s and passes < 50:
+        eng.reset()
+        t0 = time.perf_counter()
+        ok = eng.calibrate(pa, ch, 1)
+        t_total += time.perf_counter() - t0
+        passes += 1
+        assert ok
+    ll = eng.integrate(prob.root_cluster)[1]
+    return {"value": nmsg * passes / t_total, "unit": "messages/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} full calibrate!() passes of the same workload ({nmsg} messages each), "
+                      f"oracle/c sequential engine, {t_total:.1f} s",
+            "loglik": ll}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ntips", type=int, default=50000)
+    ap.add_argument("--traits", type=int, default=16)
+    ap.add_argument("--graph", default="cliquetree", choices=["cliquetree", "bethe"])
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import pgbp_amd
+    from pgbp_amd import _lib as L
+    lib = pgbp_amd.load()
+
+    tr, prob, packed, ll_check = build_workload(args.ntips, args.traits, args.seed + rank, args.graph)
+    cgb = pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off,
+                                                  prob.scope_idx, packed, device=local_rank)
+    cgb.set_schedule(prob.schedule)
+    eng = cgb._eng
+    opts = cgb._opts()
+    bytes_per_cal, msgs_per_cal = cgb.traffic_model()
+
+    def check(code):
+        if code != 0:
+            raise RuntimeError(lib.pgbp_last_error(eng).decode())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- parity gate for the timed configuration: log-likelihood vs the independent pruning check
+    norm = np.zeros(1)
+    info = np.zeros(1, dtype=np.int32)
+    check(lib.pgbp_enqueue_loglik(eng, 1, C.byref(opts)))
+    check(lib.pgbp_fetch_loglik(eng, L.f64p(norm), L.i32p(info)))
+    rel = abs(norm[0] - ll_check) / max(1.0, abs(ll_check))
+    if not (info[0] == 0 and rel <= 1e-8):
+        raise SystemExit(f"parity gate failed: loglik {norm[0]!r} vs {ll_check!r} (rel {rel:.3e}, info {info[0]})")
+
+    # ---- warmup + timed calibrate steps
+    check(lib.pgbp_reset_from_factors(eng))
+    check(lib.pgbp_enqueue_calibrate(eng, args.warmup, 0, C.byref(opts)))
+    barrier()
+    t0 = time.perf_counter()
+    check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
+    check(lib.pgbp_sync(eng))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * msgs_per_cal * args.steps / dt
+
+    # after the timed region: the calibrated beliefs still integrate to the right log-likelihood
+    mu_, n2, i2 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
+    rel2 = abs(n2[0] - ll_check) / max(1.0, abs(ll_check))
+    if not (i2[0] == 0 and rel2 <= 1e-8):
+        raise SystemExit(f"post-run parity failed: {n2[0]!r} vs {ll_check!r}")
+
+    out = None
+    if rank == 0:
+        # ---- secondary metric: log-likelihood evaluations / s (reset from factors + postorder + integrate)
+        ms = C.c_float()
+        check(lib.pgbp_time_enqueued(eng, 1, max(3, args.steps // 2), 1, C.byref(opts), C.byref(ms)))
+        ll_evals = max(3, args.steps // 2) / (ms.value * 1e-3)
+        # ---- roofline of the dominant kernel: HIP events around every message-level launch
+        nl = C.c_int32()
+        reps = max(2, min(5, args.steps))
+        check(lib.pgbp_time_message_kernels(eng, reps, C.byref(opts), C.byref(ms), C.byref(nl)))
+        kern_ms = ms.value
+        achieved = bytes_per_cal * reps / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "clique-tree messages/sec (calibrate!: postorder+preorder), 16-trait BM",
+            "value": value, "unit": "messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg3: homogeneous BM, {args.traits} traits, {args.ntips}-tip random "
+                                   f"bifurcating tree (seed {args.seed}), {args.graph}, fixed root",
+                       "clusters": int(prob.nclusters), "sepsets": int(len(prob.dims) - prob.nclusters),
+                       "messages_per_step": int(msgs_per_cal), "tree_depth": int(tr.depth().max()),
+                       "parallelism": "replicas only" if world > 1 else "single GPU"},
+            "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel),
+            "ll_evals_per_s": ll_evals,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "bp_level_generic", "launches_per_step": nl.value // reps,
+                         "algorithmic_bytes_per_step": bytes_per_cal,
+                         "kernel_ms_per_step": kern_ms / reps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prob, packed[0] if packed.ndim > 1 else packed, args.cpu_budget)
+            if out["cpu_baseline"].get("value"):
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * pgbp.h -- C ABI of the MI355X-native Gaussian belief-propagation calibration engine.
+ *
+ * Drop-in boundary for the message-passing hot path of
+ * JuliaPhylo/PhyloGaussianBeliefProp.jl (reference paths relative to its repo root).
+ * The reference has no FFI of its own; each entry point below replaces one Julia
+ * function (cited), and is what a Julia `@ccall` shim binds.
+ *
+ * Conventions
+ *   - all indices 0-based (the shim converts from Julia's 1-based);
+ *   - a "belief" is a cluster (index < n_clusters) or a sepset (index >= n_clusters),
+ *     clusters first, exactly like ClusterGraphBelief.belief (src/clustergraphbeliefs.jl:26-53);
+ *   - "packed" belief storage = for each belief in index order: J (m*m doubles,
+ *     column-major, full square), h (m), g (1); no padding; `pgbp_packed_size` doubles
+ *     per site.  This is byte-for-byte what Julia's Matrix{Float64}/Vector{Float64}
+ *     hold (src/beliefs.jl:122-127);
+ *   - a directed message id is 2*k + dir for sepset k = (a, b): dir 0 is the message
+ *     RECEIVED by a (sent by b), dir 1 the message received by b -- the (receiver, sender)
+ *     key convention of ClusterGraphBelief.messageresidual (src/clustergraphbeliefs.jl:11-20);
+ *   - n_sites >= 1 independent replicas ("sites": same graph, same scopes, different
+ *     numbers) live in one engine; packed buffers are site-major;
+ *   - every function returns PGBP_OK (0) or an error code; text via pgbp_last_error;
+ *   - an engine owns one HIP stream; calls on one engine are not re-entrant
+ *     (same as the reference: src/calibration.jl has no locking).
+ *   - there is NO CPU fallback: pgbp_create fails with PGBP_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef PGBP_H
+#define PGBP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGBP_VERSION 1
+#define PGBP_MAX_DIM 64 /* largest belief dimension the kernels accept (refused above) */
+
+enum pgbp_status {
+  PGBP_OK = 0,
+  PGBP_ERR_INVALID = 1,    /* malformed description / argument (ErrorException in the reference: src/beliefs.jl:398-401) */
+  PGBP_ERR_HIP = 2,        /* HIP runtime error */
+  PGBP_ERR_NOT_TREE = 3,   /* a schedule entry is not a preorder edge list of a tree (src/clustergraph.jl:885-894) */
+  PGBP_ERR_TOO_LARGE = 4,  /* a belief dimension exceeds PGBP_MAX_DIM */
+  PGBP_ERR_NO_DEVICE = 5,  /* no HIP device: the engine has no CPU path */
+  PGBP_ERR_STATE = 6       /* call out of order (e.g. calibrate before set_schedule) */
+};
+
+/* Static description of a cluster graph with allocated scopes: what
+ * allocatebeliefs (src/beliefs.jl:478-594) + ClusterGraphBelief (src/clustergraphbeliefs.jl:89-109)
+ * establish, with scopeindex(sepset, cluster) (src/beliefs.jl:389-405) precomputed once. */
+typedef struct pgbp_desc {
+  int32_t n_clusters;
+  int32_t n_sepsets;
+  const int32_t* dims;            /* [n_clusters + n_sepsets] dimension(belief) */
+  const int32_t* sepset_clusters; /* [2*n_sepsets] the two incident clusters (a, b) of each sepset */
+  const int64_t* scope_off;       /* [2*n_sepsets + 1] offsets into scope_idx; entry 2k+side */
+  const int32_t* scope_idx;       /* scopeindex(sepset k, cluster a) then (sepset k, cluster b): positions
+                                     of the sepset's variables inside the cluster, strictly increasing */
+  int32_t n_sites;                /* >= 1 */
+  int32_t device;                 /* HIP device ordinal */
+} pgbp_desc;
+
+/* calibrate! keyword arguments (src/calibration.jl:35-44) and the tolerance of
+ * iscalibrated_residnorm! (src/beliefs.jl:994). */
+typedef struct pgbp_opts {
+  int32_t auto_stop;           /* auto */
+  int32_t update_residualnorm; /* default 1 */
+  int32_t update_residualkldiv;/* must be 0 (off by default in the reference: src/calibration.jl:43) */
+  int32_t reserved;
+  double  atol;                /* 1e-5 */
+} pgbp_opts;
+
+/* Outcome of a traversal / calibration for one site. */
+typedef struct pgbp_result {
+  int32_t succ;         /* 1 unless a message failed (first tuple element of calibrate!: src/calibration.jl:59,82) */
+  int32_t iscal;        /* iscalibrated_residnorm(beliefs) (src/clustergraphbeliefs.jl:168-169) */
+  int32_t iter_reached; /* 1-based iteration / schedule tree at which calibration was first reached   */
+  int32_t tree_reached; /*   ("calibration reached: iteration $i, schedule tree $j", src/calibration.jl:54); 0 if never */
+  int32_t fail_iter;    /* 1-based iteration / tree / direction (0 post, 1 pre) / edge (0-based position in  */
+  int32_t fail_tree;    /*   the tree's edge list) of the FIRST failing message in the reference's sequential */
+  int32_t fail_dir;     /*   order (src/calibration.jl:121,147); fail_info = PosDefException.info             */
+  int32_t fail_edge;    /*   (src/beliefupdates.jl:69-76). All 0 / -1 when succ == 1.                          */
+  int32_t fail_info;
+  int32_t reserved;
+} pgbp_result;
+
+typedef struct pgbp_engine pgbp_engine; /* opaque: device-resident ClusterGraphBelief */
+typedef struct pgbp_plan pgbp_plan;     /* opaque: host-only layout + level schedule (no GPU needed) */
+
+/* ---- host-only planning (no GPU): layout, message table, level schedule ------------- */
+int  pgbp_plan_create(const pgbp_desc* desc, pgbp_plan** out);
+void pgbp_plan_destroy(pgbp_plan* p);
+/* schedule = vector of spanning trees, each the (pa_j, ch_j) index vectors of
+ * spanningtree_clusterlist in preorder (src/clustergraph.jl:885-894); tree t owns
+ * entries [tree_off[t], tree_off[t+1]). */
+int  pgbp_plan_set_schedule(pgbp_plan* p, int32_t n_trees, const int32_t* tree_off,
+                            const int32_t* pa_j, const int32_t* ch_j);
+int64_t pgbp_plan_packed_size(const pgbp_plan* p);    /* doubles per site, beliefs */
+int64_t pgbp_plan_residual_size(const pgbp_plan* p);  /* doubles per site, residuals: per message dJ (s*s) then dh (s) */
+int32_t pgbp_plan_n_messages(const pgbp_plan* p);     /* 2 * n_sepsets */
+/* level structure of one traversal (dir 0 = postorder, 1 = preorder): number of levels,
+ * tasks and message entries; then the arrays (caller-allocated):
+ * level_off[n_levels+1] -> tasks, task_off[n_tasks+1] -> entries,
+ * entry_msg[n_entries] directed message id, entry_edge[n_entries] position in the tree's edge list,
+ * entry_reuse[n_entries] 1 if the marginal of the previous entry of the task is reused. */
+int  pgbp_plan_traversal_sizes(const pgbp_plan* p, int32_t tree, int32_t dir,
+                               int32_t* n_levels, int32_t* n_tasks, int32_t* n_entries);
+int  pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_off,
+                         int32_t* task_off, int32_t* entry_msg, int32_t* entry_edge, int32_t* entry_reuse);
+const char* pgbp_plan_last_error(const pgbp_plan* p);
+
+/* ---- engine lifetime ------------------------------------------------------------------ */
+/* ClusterGraphBelief(beliefs, ...) constructor (src/clustergraphbeliefs.jl:89-109): allocates
+ * beliefs, factors, message residuals (flags false / kldiv -1; empty messages born calibrated:
+ * src/beliefs.jl:914-924) on the device. */
+int  pgbp_create(const pgbp_desc* desc, pgbp_engine** out);
+void pgbp_destroy(pgbp_engine* e);
+const char* pgbp_last_error(const pgbp_engine* e); /* e == NULL: error of the last failed create */
+int64_t pgbp_packed_size(const pgbp_engine* e);
+int64_t pgbp_residual_size(const pgbp_engine* e);
+int32_t pgbp_n_messages(const pgbp_engine* e);
+
+/* ---- state transfer ------------------------------------------------------------------- */
+/* Upload all beliefs of all sites (packed, site-major; host pointer). If snapshot_factors != 0 the
+ * cluster part is also stored as the factors (init_factors_allocate, src/beliefs.jl:628-637). */
+int  pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_factors);
+int  pgbp_get_beliefs(pgbp_engine* e, double* packed);
+int  pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* rec); /* J,h,g of one belief */
+int  pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec);
+/* init_factors_frombeliefs! (src/beliefs.jl:746-761) */
+int  pgbp_init_factors_frombeliefs(pgbp_engine* e);
+/* init_beliefs_reset_fromfactors! (src/clustergraphbeliefs.jl:126-139) */
+int  pgbp_reset_from_factors(pgbp_engine* e);
+/* init_messagecalibrationflags_reset!(beliefs, reset_kl) (src/clustergraphbeliefs.jl:146-150) */
+int  pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl);
+/* MessageResidual fields of every directed message, site-major: dJ,dh packed (pgbp_residual_size
+ * doubles per site), iscalibrated_resid flags and kldiv (n_messages per site). Any pointer may be NULL. */
+int  pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+int  pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off,
+                       const int32_t* pa_j, const int32_t* ch_j);
+/* propagate_belief!(cluster_to, sepset, cluster_from, residual) (src/beliefupdates.jl:634-665) for
+ * every site. info[site] = 0 ok, > 0 PosDefException.info (belief state of that site untouched,
+ * exception "returned not thrown"); `sepset` is a belief index (>= n_clusters). */
+int  pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from,
+                    const pgbp_opts* opts, int32_t* info);
+/* propagate_1traversal_postorder! / _preorder! (src/calibration.jl:111-161), dir 0 / 1.
+ * results[n_sites]: succ, fail_* filled. */
+int  pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* opts, pgbp_result* results);
+/* calibrate!(beliefs, schedule, niter; ...) (src/calibration.jl:35-84). results[n_sites].
+ * With auto_stop the loop ends after the first schedule tree at which EVERY site is calibrated
+ * (n_sites == 1: exactly the reference's `auto`). */
+int  pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_result* results);
+/* integratebelief!(obj, beliefindex) (src/clustergraphbeliefs.jl:194, src/beliefupdates.jl:168-200) for
+ * every site: mu[n_sites * m] (may be NULL), norm[n_sites], info[n_sites] (0 ok, >0 not PD, may be NULL).
+ * An all-zero belief gives mu = Inf, norm = g (src/beliefupdates.jl:189-191). */
+int  pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int32_t* info);
+
+/* ---- device-side access for benchmarking / zero-copy callers ----------------------------- */
+/* Enqueue `reps` full calibrate iterations (all trees, post+pre, flag reduction) without any host
+ * synchronisation; the caller brackets with pgbp_sync. Resets beliefs from factors before each
+ * repetition if reset_each != 0. */
+int  pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts);
+/* Enqueue one log-likelihood evaluation body: reset from factors, postorder traversal of tree 0,
+ * integrate the root cluster (src/calibration.jl:205-212 minus the host-side factor fill). The
+ * per-site norms stay on the device until pgbp_fetch_loglik. */
+int  pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts);
+int  pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info);
+int  pgbp_sync(pgbp_engine* e);
+/* Time `reps` repetitions of the enqueued work with HIP events on the engine's stream; returns the
+ * total milliseconds in *ms_total and, per kernel family, accumulated device time is NOT measured here
+ * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik. */
+int  pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each,
+                        const pgbp_opts* opts, float* ms_total);
+/* Time only the message-kernel launches of `reps` calibrate iterations: HIP events bracket every
+ * level launch on the engine's stream; *ms_kernels = sum over launches, *n_launches their number. */
+int  pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opts,
+                               float* ms_kernels, int32_t* n_launches);
+/* Algorithmic bytes of one full calibrate iteration over all sites (SURVEY.md section 8(d) formula:
+ * 8*[(mf^2+mf+1) + 4*(s^2+s+1) + (s^2+s)] per message) and message count. */
+int  pgbp_traffic_model(const pgbp_engine* e, double* bytes_per_calibrate, int64_t* messages_per_calibrate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGBP_H */

@@ -1,0 +1,17 @@
+"""
+MI355X-native engine for the canonical-form Gaussian belief-propagation hot path of
+PhyloGaussianBeliefProp.jl: host-side mirror (Python) of the reference's
+ClusterGraphBelief / calibrate! / propagate_belief! surface over the C ABI of
+include/pgbp.h (HIP kernels in csrc/).  Import as `pgbp_amd` (see /pgbp_amd.py).
+"""
+from ._lib import LIB_PATH, PgbpError, load
+from .beliefs import CanonicalBelief, MessageResidual, bclustertype, bsepsettype, scopeindex
+from .beliefupdates import BPPosDefException, integratebelief_, propagate_belief_
+from .calibration import calibrate_, propagate_1traversal_postorder_, propagate_1traversal_preorder_
+from .clustergraphbeliefs import ClusterGraphBelief
+
+__all__ = [
+    "CanonicalBelief", "MessageResidual", "ClusterGraphBelief", "BPPosDefException", "scopeindex",
+    "bclustertype", "bsepsettype", "calibrate_", "propagate_1traversal_postorder_",
+    "propagate_1traversal_preorder_", "propagate_belief_", "integratebelief_", "load", "LIB_PATH", "PgbpError",
+]

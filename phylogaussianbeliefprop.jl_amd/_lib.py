@@ -1,0 +1,138 @@
+"""ctypes binding of include/pgbp.h (libpgbp.so, built in-tree by csrc/Makefile).
+
+There is no CPU fallback: if the library is missing, loading raises; if no GPU is
+present, `pgbp_create` returns PGBP_ERR_NO_DEVICE and the host layer raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpgbp.so")
+
+PGBP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_TREE, ERR_TOO_LARGE, ERR_NO_DEVICE, ERR_STATE = range(7)
+PGBP_MAX_DIM = 64
+
+
+class PgbpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pgbp error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Desc(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("n_sepsets", C.c_int32),
+                ("dims", C.POINTER(C.c_int32)), ("sepset_clusters", C.POINTER(C.c_int32)),
+                ("scope_off", C.POINTER(C.c_int64)), ("scope_idx", C.POINTER(C.c_int32)),
+                ("n_sites", C.c_int32), ("device", C.c_int32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("auto_stop", C.c_int32), ("update_residualnorm", C.c_int32),
+                ("update_residualkldiv", C.c_int32), ("reserved", C.c_int32), ("atol", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("succ", "iscal", "iter_reached", "tree_reached", "fail_iter",
+                                         "fail_tree", "fail_dir", "fail_edge", "fail_info", "reserved")]
+
+
+# every symbol include/pgbp.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_I32P = C.POINTER(C.c_int32)
+_I64P = C.POINTER(C.c_int64)
+_F64P = C.POINTER(C.c_double)
+SYMBOLS = {
+    "pgbp_plan_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_P)]),
+    "pgbp_plan_destroy": (None, [_P]),
+    "pgbp_plan_set_schedule": (C.c_int, [_P, C.c_int32, _I32P, _I32P, _I32P]),
+    "pgbp_plan_packed_size": (C.c_int64, [_P]),
+    "pgbp_plan_residual_size": (C.c_int64, [_P]),
+    "pgbp_plan_n_messages": (C.c_int32, [_P]),
+    "pgbp_plan_traversal_sizes": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P]),
+    "pgbp_plan_traversal": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P, _I32P]),
+    "pgbp_plan_last_error": (C.c_char_p, [_P]),
+    "pgbp_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_P)]),
+    "pgbp_destroy": (None, [_P]),
+    "pgbp_last_error": (C.c_char_p, [_P]),
+    "pgbp_packed_size": (C.c_int64, [_P]),
+    "pgbp_residual_size": (C.c_int64, [_P]),
+    "pgbp_n_messages": (C.c_int32, [_P]),
+    "pgbp_set_beliefs": (C.c_int, [_P, _F64P, C.c_int32]),
+    "pgbp_get_beliefs": (C.c_int, [_P, _F64P]),
+    "pgbp_set_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
+    "pgbp_get_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
+    "pgbp_init_factors_frombeliefs": (C.c_int, [_P]),
+    "pgbp_reset_from_factors": (C.c_int, [_P]),
+    "pgbp_reset_flags": (C.c_int, [_P, C.c_int32]),
+    "pgbp_get_residuals": (C.c_int, [_P, _F64P, _I32P, _F64P]),
+    "pgbp_set_schedule": (C.c_int, [_P, C.c_int32, _I32P, _I32P, _I32P]),
+    "pgbp_propagate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Opts), _I32P]),
+    "pgbp_traverse": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
+    "pgbp_calibrate": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
+    "pgbp_integrate": (C.c_int, [_P, C.c_int32, _F64P, _F64P, _I32P]),
+    "pgbp_enqueue_calibrate": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_enqueue_loglik": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),
+    "pgbp_sync": (C.c_int, [_P]),
+    "pgbp_time_enqueued": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Opts), C.POINTER(C.c_float)]),
+    "pgbp_time_message_kernels": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(C.c_float), _I32P]),
+    "pgbp_traffic_model": (C.c_int, [_P, _F64P, _I64P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpgbp.so (once). Raises if it has not been built: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP engine first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C phylogaussianbeliefprop.jl_amd/csrc). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def i32p(a):
+    return a.ctypes.data_as(_I32P)
+
+
+def i64p(a):
+    return a.ctypes.data_as(_I64P)
+
+
+def f64p(a):
+    return a.ctypes.data_as(_F64P)
+
+
+def make_desc(dims, sepset_clusters, scope_off, scope_idx, n_sites=1, device=0):
+    """Returns (Desc, keepalive) -- keepalive holds the numpy arrays the Desc points into."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    sc = np.ascontiguousarray(sepset_clusters, dtype=np.int32).reshape(-1)
+    so = np.ascontiguousarray(scope_off, dtype=np.int64)
+    si = np.ascontiguousarray(scope_idx, dtype=np.int32)
+    if si.size == 0:
+        si = np.zeros(1, dtype=np.int32)
+    if sc.size == 0:
+        sc = np.zeros(2, dtype=np.int32)
+    ns = sc.size // 2 if len(np.atleast_1d(sepset_clusters)) else 0
+    d = Desc()
+    d.n_sepsets = int(len(so) - 1) // 2
+    d.n_clusters = int(len(dims) - d.n_sepsets)
+    d.dims = i32p(dims)
+    d.sepset_clusters = i32p(sc)
+    d.scope_off = i64p(so)
+    d.scope_idx = i32p(si)
+    d.n_sites = int(n_sites)
+    d.device = int(device)
+    return d, (dims, sc, so, si)

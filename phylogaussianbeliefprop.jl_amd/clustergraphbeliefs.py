@@ -1,0 +1,323 @@
+"""ClusterGraphBelief (src/clustergraphbeliefs.jl:26-109) backed by the device engine."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .beliefs import CanonicalBelief, MessageResidual, bclustertype, bsepsettype, scopeindex
+from .beliefupdates import BPPosDefException
+
+
+def _check(code, eng=None, lib=None):
+    if code != L.PGBP_OK:
+        lib = lib or L.load()
+        msg = lib.pgbp_last_error(eng).decode() if lib else "?"
+        raise L.PgbpError(code, msg)
+
+
+class _BeliefList:
+    """belief vector: CanonicalBelief objects whose h/J/g are views of the packed host mirror."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def __len__(self):
+        return self._o.nbeliefs
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self._o._belief_view(i)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class ClusterGraphBelief:
+    """Device-resident ClusterGraphBelief.
+
+    ClusterGraphBelief(beliefs, node2cluster, node2family, node2fixed, cluster2nodes)
+    mirrors src/clustergraphbeliefs.jl:89-109: clusters first, sepsets last; builds cdict,
+    sdict, the message residuals and the factors (copies of the initial cluster beliefs),
+    precomputes scopeindex(sepset, cluster) for both ends of every sepset, and uploads.
+    `ClusterGraphBelief.from_arrays` is the bulk constructor for large synthetic graphs."""
+
+    def __init__(self, beliefs, node2cluster=None, node2family=None, node2fixed=None, cluster2nodes=None,
+                 device=0):
+        types = [b.type for b in beliefs]
+        nc = types.index(bsepsettype) if bsepsettype in types else len(beliefs)
+        if not all(t == bclustertype for t in types[:nc]):
+            raise ValueError("clusters are not consecutive")
+        if not all(t == bsepsettype for t in types[nc:]):
+            raise ValueError("sepsets are not consecutive")
+        cdict = {beliefs[j].metadata: j for j in range(nc)}
+        dims = np.array([b.dimension for b in beliefs], dtype=np.int32)
+        sepcl, off, idx = [], [0], []
+        for j in range(nc, len(beliefs)):
+            l1, l2 = beliefs[j].metadata
+            a, b = cdict[l1], cdict[l2]
+            sepcl += [a, b]
+            for c in (a, b):
+                ind = scopeindex(beliefs[j], beliefs[c])
+                idx.append(ind)
+                off.append(off[-1] + len(ind))
+        idx = np.concatenate(idx) if idx else np.zeros(0, np.int32)
+        self._init_common(dims, np.array(sepcl, np.int32), np.array(off, np.int64), idx, 1, device)
+        self._objs = list(beliefs)
+        self.cdict = cdict
+        self.sdict = {frozenset(beliefs[j].metadata): j for j in range(nc, len(beliefs))}
+        self.node2cluster, self.node2family = node2cluster, node2family
+        self.node2fixed, self.cluster2nodes = node2fixed, cluster2nodes
+        # copy h,J,g into the packed mirror and re-bind the objects' arrays to views of it
+        for i, b in enumerate(self._objs):
+            J, h, g = self._views(0, i)
+            J[...] = b.J
+            h[...] = b.h
+            g[...] = b.g
+            b.J, b.h, b.g = J, h, g
+        self._upload(snapshot_factors=True)
+
+    @classmethod
+    def from_arrays(cls, dims, sepset_clusters, scope_off, scope_idx, packed, n_sites=1, device=0,
+                    labels=None):
+        """Bulk constructor: description arrays of include/pgbp.h + packed (J,h,g) beliefs
+        [n_sites, packed_size]; the cluster part is snapshot as the factors."""
+        self = cls.__new__(cls)
+        self._init_common(np.asarray(dims, np.int32), np.asarray(sepset_clusters, np.int32).reshape(-1),
+                          np.asarray(scope_off, np.int64), np.asarray(scope_idx, np.int32), n_sites, device)
+        self._objs = None
+        self._labels = labels
+        self.cdict = self.sdict = None
+        self._packed[...] = np.asarray(packed, dtype=np.float64).reshape(self._packed.shape)
+        self._upload(snapshot_factors=True)
+        return self
+
+    # ------------------------------------------------------------------ internals
+    def _init_common(self, dims, sepcl, scope_off, scope_idx, n_sites, device):
+        self._lib = L.load()
+        self._eng = None
+        self.n_sites = int(n_sites)
+        self._dims = dims
+        self.nsepsets = (len(scope_off) - 1) // 2
+        self.nclusters = len(dims) - self.nsepsets
+        self.nbeliefs = len(dims)
+        self._sepcl = sepcl.reshape(-1, 2) if sepcl.size else np.zeros((0, 2), np.int32)
+        self._scope_off, self._scope_idx = scope_off, scope_idx
+        desc, self._keep = L.make_desc(dims, sepcl, scope_off, scope_idx, n_sites, device)
+        eng = C.c_void_p()
+        code = self._lib.pgbp_create(C.byref(desc), C.byref(eng))
+        if code != L.PGBP_OK:
+            raise L.PgbpError(code, self._lib.pgbp_last_error(None).decode())
+        self._eng = eng
+        m = dims.astype(np.int64)
+        self._poff = np.concatenate([[0], np.cumsum(m * m + m + 1)])
+        s = np.repeat(dims[self.nclusters:].astype(np.int64), 2)
+        self._roff = np.concatenate([[0], np.cumsum(s * s + s)])
+        assert self._poff[-1] == self._lib.pgbp_packed_size(eng)
+        assert self._roff[-1] == self._lib.pgbp_residual_size(eng)
+        self._packed = np.zeros((self.n_sites, int(self._poff[-1])))
+        self._res = None
+        self._flg = None
+        self._kl = None
+        self._schedule = None
+        self.site = 0  # which site the belief views / residual views show
+        self.belief = _BeliefList(self)
+        self.messageresidual = _ResidualDict(self)
+        self.last_results = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_eng", None):
+                self._lib.pgbp_destroy(self._eng)
+                self._eng = None
+        except Exception:
+            pass
+
+    def _views(self, site, i):
+        m = int(self._dims[i])
+        rec = self._packed[site, self._poff[i]: self._poff[i + 1]]
+        return rec[: m * m].reshape(m, m, order="F"), rec[m * m: m * m + m], rec[m * m + m:]
+
+    def _belief_view(self, i):
+        if self._objs is not None and self.site == 0:
+            return self._objs[i]
+        J, h, g = self._views(self.site, i)
+        b = CanonicalBelief.__new__(CanonicalBelief)
+        b.nodelabel, b.ntraits, b.inscope = None, None, None
+        b.J, b.h, b.g, b.mu = J, h, g, np.zeros(len(h))
+        b.type = bclustertype if i < self.nclusters else bsepsettype
+        b.metadata = self._labels[i] if getattr(self, "_labels", None) is not None else i
+        return b
+
+    def _upload(self, snapshot_factors=False):
+        _check(self._lib.pgbp_set_beliefs(self._eng, L.f64p(self._packed), int(snapshot_factors)), self._eng)
+
+    def push(self):
+        """host mirror -> device (after editing belief arrays on the host)."""
+        self._upload(False)
+
+    def pull(self):
+        """device -> host mirror: beliefs, residuals, flags (the write-back a Julia shim does)."""
+        _check(self._lib.pgbp_get_beliefs(self._eng, L.f64p(self._packed)), self._eng)
+        nm = 2 * self.nsepsets
+        self._res = np.zeros((self.n_sites, max(1, int(self._roff[-1]))))
+        self._flg = np.zeros((self.n_sites, max(1, nm)), dtype=np.int32)
+        self._kl = np.zeros((self.n_sites, max(1, nm)))
+        _check(self._lib.pgbp_get_residuals(self._eng, L.f64p(self._res), L.i32p(self._flg), L.f64p(self._kl)),
+               self._eng)
+
+    def _residual_record(self, d):
+        if self._res is None:
+            self.pull()
+        return self._res[self.site, self._roff[d]: self._roff[d + 1]]
+
+    def _flags(self):
+        if self._flg is None:
+            self.pull()
+        return self._flg[self.site]
+
+    def _kldiv(self):
+        if self._kl is None:
+            self.pull()
+        return self._kl[self.site]
+
+    def _msg_id(self, receiver, sender):
+        for k in range(self.nsepsets):
+            a, b = self._sepcl[k]
+            if a == receiver and b == sender:
+                return 2 * k
+            if b == receiver and a == sender:
+                return 2 * k + 1
+        raise KeyError((receiver, sender))
+
+    def _opts(self, auto=False, update_residualnorm=True, update_residualkldiv=False, atol=1e-5):
+        return L.Opts(int(auto), int(update_residualnorm), int(update_residualkldiv), 0, float(atol))
+
+    def _integrate_index_1based(self, sender, sepset_k, side):
+        o0, o1 = self._scope_off[2 * sepset_k + side], self._scope_off[2 * sepset_k + side + 1]
+        keep = set(self._scope_idx[o0:o1].tolist())
+        return [i + 1 for i in range(int(self._dims[sender])) if i not in keep]
+
+    def _exception_for(self, sender, sepset_k, info):
+        """"belief $metadata, integrating $(integrate_index)" (src/beliefupdates.jl:71)."""
+        side = 0 if self._sepcl[sepset_k][0] == sender else 1
+        meta = self._belief_label(sender)
+        idx = self._integrate_index_1based(sender, sepset_k, side)
+        return BPPosDefException(f"belief {meta}, integrating {idx}", info)
+
+    def _belief_label(self, i):
+        if self._objs is not None:
+            return self._objs[i].metadata
+        if getattr(self, "_labels", None) is not None:
+            return self._labels[i]
+        return i
+
+    def _propagate(self, cluster_to, sepset, cluster_from, sync=True):
+        info = np.zeros(self.n_sites, dtype=np.int32)
+        o = self._opts()
+        _check(self._lib.pgbp_propagate(self._eng, int(cluster_to), int(sepset), int(cluster_from), C.byref(o),
+                                        L.i32p(info)), self._eng)
+        if sync:
+            self.pull()
+        if info[self.site] != 0:
+            return self._exception_for(cluster_from, sepset - self.nclusters, int(info[self.site]))
+        return None
+
+    # ------------------------------------------------------------------ reference API
+    def clusterindex(self, label):
+        return self.cdict[label]
+
+    def sepsetindex(self, l1, l2):
+        return self.sdict[frozenset((l1, l2))]
+
+    def set_schedule(self, schedule):
+        """schedule: list of spanning trees (pa_lab, ch_lab, pa_j, ch_j) as spanningtree_clusterlist
+        returns them (src/clustergraph.jl:885-894), or just (pa_j, ch_j); 0-based cluster indices."""
+        trees = [(np.asarray(t[-2], np.int32), np.asarray(t[-1], np.int32)) for t in schedule]
+        off = np.zeros(len(trees) + 1, dtype=np.int32)
+        for i, (pa, _) in enumerate(trees):
+            off[i + 1] = off[i] + len(pa)
+        pa = np.concatenate([t[0] for t in trees]) if trees else np.zeros(0, np.int32)
+        ch = np.concatenate([t[1] for t in trees]) if trees else np.zeros(0, np.int32)
+        pa = np.ascontiguousarray(pa if pa.size else np.zeros(1, np.int32))
+        ch = np.ascontiguousarray(ch if ch.size else np.zeros(1, np.int32))
+        _check(self._lib.pgbp_set_schedule(self._eng, len(trees), L.i32p(off), L.i32p(pa), L.i32p(ch)), self._eng)
+        self._schedule = [(t[0].copy(), t[1].copy()) for t in trees]
+        self._schedule_key = [tuple(map(tuple, t)) for t in self._schedule]
+
+    def _ensure_schedule(self, schedule):
+        trees = [(np.asarray(t[-2], np.int32), np.asarray(t[-1], np.int32)) for t in schedule]
+        key = [tuple(map(tuple, t)) for t in trees]
+        if self._schedule is None or key != self._schedule_key:
+            self.set_schedule(schedule)
+
+    def init_beliefs_reset_fromfactors_(self, sync=True):
+        """init_beliefs_reset_fromfactors! (src/clustergraphbeliefs.jl:126-139)."""
+        _check(self._lib.pgbp_reset_from_factors(self._eng), self._eng)
+        if sync:
+            self.pull()
+
+    def init_factors_frombeliefs_(self):
+        """init_factors_frombeliefs! (src/beliefs.jl:746-761) on the device state."""
+        _check(self._lib.pgbp_init_factors_frombeliefs(self._eng), self._eng)
+
+    def init_messagecalibrationflags_reset_(self, reset_kl=True):
+        """init_messagecalibrationflags_reset! (src/clustergraphbeliefs.jl:146-150)."""
+        _check(self._lib.pgbp_reset_flags(self._eng, int(reset_kl)), self._eng)
+        self._flg = None
+
+    def iscalibrated_residnorm(self):
+        """iscalibrated_residnorm(beliefs) (src/clustergraphbeliefs.jl:168-169)."""
+        self.pull()
+        return bool(np.all(self._flg[self.site][: 2 * self.nsepsets] != 0))
+
+    def integratebelief_(self, j, all_sites=False):
+        """integratebelief!(obj, beliefindex) (src/clustergraphbeliefs.jl:194): (mu, norm)."""
+        m = int(self._dims[j])
+        mu = np.zeros((self.n_sites, max(1, m)))
+        norm = np.zeros(self.n_sites)
+        info = np.zeros(self.n_sites, dtype=np.int32)
+        _check(self._lib.pgbp_integrate(self._eng, int(j), L.f64p(mu), L.f64p(norm), L.i32p(info)), self._eng)
+        mu = mu.reshape(-1)[: self.n_sites * m].reshape(self.n_sites, m)
+        if all_sites:
+            return mu, norm, info
+        if info[self.site] != 0:
+            raise np.linalg.LinAlgError(
+                f"PosDefException: matrix is not positive definite; Cholesky factorization failed (info={info[self.site]}).")
+        if self._objs is not None and self.site == 0:
+            self._objs[j].mu = mu[0].copy()
+        return mu[self.site].copy(), float(norm[self.site])
+
+    def default_sepset1(self):
+        """default_sepset1 (src/clustergraphbeliefs.jl:197-202)."""
+        for j in range(self.nclusters, self.nbeliefs):
+            if len(self._objs[j].nodelabel) == 1:
+                return j
+        raise ValueError("no sepset with a single node")
+
+    def traffic_model(self):
+        b = C.c_double()
+        n = C.c_int64()
+        _check(self._lib.pgbp_traffic_model(self._eng, C.byref(b), C.byref(n)), self._eng)
+        return b.value, n.value
+
+
+class _ResidualDict:
+    """messageresidual: (label_to, label_from) -> MessageResidual (src/clustergraphbeliefs.jl:11-20).
+    Keys may also be (index_to, index_from)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def __getitem__(self, key):
+        o = self._o
+        to, frm = key
+        if o.cdict is not None and to in o.cdict:
+            to, frm = o.cdict[to], o.cdict[frm]
+        d = o._msg_id(to, frm)
+        return MessageResidual(o, d, int(o._dims[o.nclusters + d // 2]))
+
+    def __len__(self):
+        return 2 * self._o.nsepsets

@@ -1,0 +1,709 @@
+// Device-resident ClusterGraphBelief + calibration driver behind the C ABI of include/pgbp.h.
+// One engine = one HIP stream; every level of a traversal is one kernel launch on it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pgbp_internal.hpp"
+#include "pgbp_kernels.hpp"
+
+using namespace pgbp;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevTraversal {
+  int32_t* d_task_off = nullptr;
+  Entry* d_entries = nullptr;
+};
+
+}  // namespace
+
+struct pgbp_engine {
+  Plan plan;
+  hipStream_t st = nullptr;
+  // device state
+  double* d_pool = nullptr;    // [n_sites][pool_stride] beliefs
+  double* d_fpool = nullptr;   // [n_sites][cluster_stride] factors
+  double* d_rpool = nullptr;   // [n_sites][rpool_stride] residuals
+  MsgDesc* d_msgs = nullptr;
+  int32_t* d_idx = nullptr;
+  int32_t* d_flags = nullptr;
+  int32_t* d_status = nullptr;
+  double* d_kldiv = nullptr;
+  unsigned long long* d_fail = nullptr;
+  int32_t* d_poison = nullptr;      // [n_sites][n_clusters]
+  int32_t* d_iscal = nullptr;       // [n_sites]
+  int32_t* d_iscal_hist = nullptr;  // [hist_cap][n_sites]
+  int64_t hist_cap = 0;
+  int64_t* d_boff = nullptr;        // record offset tables for pack/unpack
+  int64_t* d_packed_off = nullptr;
+  int64_t* d_roff = nullptr;
+  int64_t* d_rpacked_off = nullptr;
+  double* d_mu = nullptr;    // [n_sites][max_dim]
+  double* d_norm = nullptr;  // [n_sites]
+  int32_t* d_info = nullptr; // [n_sites]
+  int32_t* d_one_task_off = nullptr;  // single-message task for pgbp_propagate
+  Entry* d_one_entry = nullptr;
+  std::vector<DevTraversal> dpost, dpre;
+  bool have_factors = false;
+  std::string err;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+};
+
+#define HIPCHK(e, call)                                                                          \
+  do {                                                                                           \
+    hipError_t _rc = (call);                                                                     \
+    if (_rc != hipSuccess)                                                                       \
+      return (e)->fail(PGBP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_rc));        \
+  } while (0)
+
+namespace {
+
+// forget earlier failures: fail keys and the downstream-of-a-failure marks
+int reset_fail(pgbp_engine* e);
+
+template <class T>
+int dev_alloc(pgbp_engine* e, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(e, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return PGBP_OK;
+}
+
+template <class T>
+int upload(pgbp_engine* e, T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(e, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(e, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PGBP_OK;
+}
+
+DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
+  DevState S;
+  S.pool = e->d_pool;
+  S.pool_stride = e->plan.pool_stride();
+  S.rpool = e->d_rpool;
+  S.rpool_stride = e->plan.rpool_stride();
+  S.msgs = e->d_msgs;
+  S.idx = e->d_idx;
+  S.flags = e->d_flags;
+  S.status = e->d_status;
+  S.fail = e->d_fail;
+  S.poison = e->d_poison;
+  S.n_clusters = e->plan.n_clusters;
+  S.n_msgs = e->plan.n_msgs();
+  S.update_resnorm = o ? o->update_residualnorm : 1;
+  S.atol = o ? o->atol : 1e-5;
+  return S;
+}
+
+int reset_fail(pgbp_engine* e) {
+  const size_t ns = (size_t)e->plan.n_sites;
+  HIPCHK(e, hipMemsetAsync(e->d_fail, 0xFF, sizeof(unsigned long long) * ns, e->st));
+  HIPCHK(e, hipMemsetAsync(e->d_poison, 0, sizeof(int32_t) * ns * (size_t)e->plan.n_clusters, e->st));
+  return PGBP_OK;
+}
+
+void free_traversals(pgbp_engine* e) {
+  for (auto* v : {&e->dpost, &e->dpre}) {
+    for (auto& d : *v) {
+      if (d.d_task_off) (void)hipFree(d.d_task_off);
+      if (d.d_entries) (void)hipFree(d.d_entries);
+    }
+    v->clear();
+  }
+}
+
+int check_opts(pgbp_engine* e, const pgbp_opts* o) {
+  if (o && o->update_residualkldiv)
+    return e->fail(PGBP_ERR_INVALID, "update_residualkldiv is not supported (off by default in the reference)");
+  return PGBP_OK;
+}
+
+unsigned long long seq_stride(const pgbp_engine* e) {
+  size_t mx = 0;
+  for (const Tree& t : e->plan.trees) mx = std::max(mx, t.pa.size());
+  return 2ull * (mx + 1);
+}
+
+// enqueue one traversal: one launch per level
+void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, unsigned long long pair_index,
+                       std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev = nullptr) {
+  const Tree& T = e->plan.trees[tree];
+  const Traversal& tr = dir == 0 ? T.post : T.pre;
+  const DevTraversal& d = dir == 0 ? e->dpost[tree] : e->dpre[tree];
+  const unsigned long long seq_base = pair_index * seq_stride(e);
+  // preorder does not run at all once the postorder of the same tree failed (src/calibration.jl:80-82)
+  const unsigned long long stop_below = seq_base + (dir == 0 ? 0ull : (unsigned long long)T.pa.size());
+  const int nlev = (int)tr.level_off.size() - 1;
+  for (int L = 0; L < nlev; ++L) {
+    const int t0 = tr.level_off[L], nt = tr.level_off[L + 1] - t0;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (ev) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, e->st);
+    }
+    launch_level_generic(S, d.d_task_off, d.d_entries, t0, nt, e->plan.n_sites, seq_base, stop_below, tr.max_mf, e->st);
+    if (ev) {
+      (void)hipEventRecord(b, e->st);
+      ev->push_back({a, b});
+    }
+  }
+}
+
+int reset_from_factors_async(pgbp_engine* e) {
+  if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "no factors: call pgbp_set_beliefs(snapshot) or pgbp_init_factors_frombeliefs first");
+  const Plan& p = e->plan;
+  launch_copy_strided(e->d_fpool, p.cluster_stride(), e->d_pool, p.pool_stride(), p.cluster_stride(), p.n_sites, e->st);
+  launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
+                      p.n_sites, e->st);
+  return PGBP_OK;
+}
+
+void decode_fail(const pgbp_engine* e, unsigned long long key, pgbp_result& r) {
+  const unsigned long long q = key >> kInfoBits;
+  r.fail_info = (int32_t)(key & ((1ull << kInfoBits) - 1));
+  const unsigned long long stride = seq_stride(e);
+  const unsigned long long pair = q / stride, seq = q % stride;
+  const int nt = (int)e->plan.trees.size();
+  r.fail_iter = (int32_t)(pair / nt) + 1;
+  r.fail_tree = (int32_t)(pair % nt) + 1;
+  const int n = (int)e->plan.trees[pair % nt].pa.size();
+  if ((int)seq < n) {
+    r.fail_dir = 0;
+    r.fail_edge = n - 1 - (int)seq;
+  } else {
+    r.fail_dir = 1;
+    r.fail_edge = (int)seq - n;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pgbp_last_error(const pgbp_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+void pgbp_destroy(pgbp_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->plan.device);
+  free_traversals(e);
+  for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
+                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_fail, (void*)e->d_poison,
+                  (void*)e->d_iscal,
+                  (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
+                  (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
+                  (void*)e->d_one_task_off, (void*)e->d_one_entry})
+    if (p) (void)hipFree(p);
+  if (e->st) (void)hipStreamDestroy(e->st);
+  delete e;
+}
+
+int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
+  if (!out) return PGBP_ERR_INVALID;
+  *out = nullptr;
+  std::unique_ptr<pgbp_engine> up(new pgbp_engine());
+  pgbp_engine* e = up.get();
+  int rc = plan_build(e->plan, desc);
+  if (rc) {
+    g_create_error = e->plan.err;
+    return rc;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || desc->device < 0 || desc->device >= ndev) {
+    g_create_error = "no usable HIP device (device " + std::to_string(desc->device) + " of " + std::to_string(ndev) +
+                     "): the engine has no CPU path";
+    return PGBP_ERR_NO_DEVICE;
+  }
+  auto bail = [&](int code) {
+    g_create_error = e->err;
+    pgbp_destroy(up.release());
+    return code;
+  };
+  if (hipSetDevice(desc->device) != hipSuccess) {
+    e->err = "hipSetDevice failed";
+    return bail(PGBP_ERR_HIP);
+  }
+  if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) {
+    e->err = "hipStreamCreate failed";
+    return bail(PGBP_ERR_HIP);
+  }
+  const Plan& p = e->plan;
+  const size_t ns = (size_t)p.n_sites;
+  const size_t nm = (size_t)p.n_msgs();
+  if ((rc = dev_alloc(e, &e->d_pool, ns * p.pool_stride()))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_fpool, ns * p.cluster_stride()))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_rpool, ns * p.rpool_stride()))) return bail(rc);
+  if ((rc = upload(e, &e->d_msgs, p.msgs))) return bail(rc);
+  if ((rc = upload(e, &e->d_idx, p.idxpool))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_flags, ns * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_status, ns * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_kldiv, ns * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_fail, ns))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_poison, ns * (size_t)p.n_clusters))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_iscal, ns))) return bail(rc);
+  if ((rc = upload(e, &e->d_boff, p.boff))) return bail(rc);
+  if ((rc = upload(e, &e->d_packed_off, p.packed_off))) return bail(rc);
+  if ((rc = upload(e, &e->d_roff, p.roff))) return bail(rc);
+  if ((rc = upload(e, &e->d_rpacked_off, p.rpacked_off))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_mu, ns * (size_t)std::max(1, p.max_dim)))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_norm, ns))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_info, ns))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_one_task_off, 2))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_one_entry, 1))) return bail(rc);
+  // beliefs = constant function 1 (h, J, g all 0: src/beliefs.jl:108-132); residuals 0;
+  // flags false / kldiv -1, empty messages born calibrated (src/beliefs.jl:914-924)
+  if (hipMemsetAsync(e->d_pool, 0, ns * p.pool_stride() * sizeof(double), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_fpool, 0, ns * p.cluster_stride() * sizeof(double), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_rpool, 0, ns * p.rpool_stride() * sizeof(double), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_status, 0, ns * nm * sizeof(int32_t), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_poison, 0, ns * (size_t)p.n_clusters * sizeof(int32_t), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_fail, 0xFF, ns * sizeof(unsigned long long), e->st) != hipSuccess) {
+    e->err = "hipMemsetAsync failed";
+    return bail(PGBP_ERR_HIP);
+  }
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, (int)nm, p.n_sites, 1, e->st);
+  if (hipStreamSynchronize(e->st) != hipSuccess) {
+    e->err = "initialisation kernels failed";
+    return bail(PGBP_ERR_HIP);
+  }
+  *out = up.release();
+  return PGBP_OK;
+}
+
+int64_t pgbp_packed_size(const pgbp_engine* e) { return e ? e->plan.packed_off.back() : -1; }
+int64_t pgbp_residual_size(const pgbp_engine* e) { return e ? e->plan.rpacked_off.back() : -1; }
+int32_t pgbp_n_messages(const pgbp_engine* e) { return e ? e->plan.n_msgs() : -1; }
+
+int pgbp_sync(pgbp_engine* e) {
+  if (!e) return PGBP_ERR_INVALID;
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  return PGBP_OK;
+}
+
+int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
+  if (!e) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  launch_copy_strided(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), p.cluster_stride(), p.n_sites,
+                      e->st);
+  e->have_factors = true;
+  return pgbp_sync(e);
+}
+
+int pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_factors) {
+  if (!e || !packed) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  const int64_t psz = p.packed_off.back();
+  double* stage = nullptr;
+  HIPCHK(e, hipMalloc((void**)&stage, sizeof(double) * (size_t)psz * p.n_sites));
+  hipError_t rc = hipMemcpyAsync(stage, packed, sizeof(double) * (size_t)psz * p.n_sites, hipMemcpyHostToDevice, e->st);
+  if (rc == hipSuccess) {
+    launch_records(stage, psz, e->d_packed_off, e->d_pool, p.pool_stride(), e->d_boff, e->d_packed_off,
+                   p.n_beliefs(), p.n_sites, e->st);
+    rc = hipStreamSynchronize(e->st);
+  }
+  (void)hipFree(stage);
+  if (rc != hipSuccess) return e->fail(PGBP_ERR_HIP, std::string("pgbp_set_beliefs: ") + hipGetErrorString(rc));
+  if (snapshot_factors) return pgbp_init_factors_frombeliefs(e);
+  return PGBP_OK;
+}
+
+int pgbp_get_beliefs(pgbp_engine* e, double* packed) {
+  if (!e || !packed) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  const int64_t psz = p.packed_off.back();
+  double* stage = nullptr;
+  HIPCHK(e, hipMalloc((void**)&stage, sizeof(double) * (size_t)psz * p.n_sites));
+  launch_records(e->d_pool, p.pool_stride(), e->d_boff, stage, psz, e->d_packed_off, e->d_packed_off, p.n_beliefs(),
+                 p.n_sites, e->st);
+  hipError_t rc = hipMemcpyAsync(packed, stage, sizeof(double) * (size_t)psz * p.n_sites, hipMemcpyDeviceToHost, e->st);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(e->st);
+  (void)hipFree(stage);
+  if (rc != hipSuccess) return e->fail(PGBP_ERR_HIP, std::string("pgbp_get_beliefs: ") + hipGetErrorString(rc));
+  return PGBP_OK;
+}
+
+static int belief_rec(pgbp_engine* e, int32_t site, int32_t b, double** dptr, int64_t* len) {
+  const Plan& p = e->plan;
+  if (site < 0 || site >= p.n_sites || b < 0 || b >= p.n_beliefs())
+    return e->fail(PGBP_ERR_INVALID, "site or belief index out of range");
+  *dptr = e->d_pool + (int64_t)site * p.pool_stride() + p.boff[b];
+  *len = p.packed_off[b + 1] - p.packed_off[b];
+  return PGBP_OK;
+}
+
+int pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* rec) {
+  if (!e || !rec) return PGBP_ERR_INVALID;
+  double* d;
+  int64_t len;
+  int rc = belief_rec(e, site, belief, &d, &len);
+  if (rc) return rc;
+  HIPCHK(e, hipMemcpyAsync(d, rec, sizeof(double) * len, hipMemcpyHostToDevice, e->st));
+  return pgbp_sync(e);
+}
+
+int pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec) {
+  if (!e || !rec) return PGBP_ERR_INVALID;
+  double* d;
+  int64_t len;
+  int rc = belief_rec(e, site, belief, &d, &len);
+  if (rc) return rc;
+  HIPCHK(e, hipMemcpyAsync(rec, d, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
+  return pgbp_sync(e);
+}
+
+int pgbp_reset_from_factors(pgbp_engine* e) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = reset_from_factors_async(e);
+  if (rc) return rc;
+  return pgbp_sync(e);
+}
+
+int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
+  if (!e) return PGBP_ERR_INVALID;
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st);
+  return pgbp_sync(e);
+}
+
+int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv) {
+  if (!e) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  const size_t ns = (size_t)p.n_sites, nm = (size_t)p.n_msgs();
+  if (packed) {
+    const int64_t rsz = p.rpacked_off.back();
+    double* stage = nullptr;
+    HIPCHK(e, hipMalloc((void**)&stage, sizeof(double) * (size_t)std::max<int64_t>(1, rsz) * ns));
+    launch_records(e->d_rpool, p.rpool_stride(), e->d_roff, stage, rsz, e->d_rpacked_off, e->d_rpacked_off,
+                   (int)nm, p.n_sites, e->st);
+    hipError_t rc = hipMemcpyAsync(packed, stage, sizeof(double) * (size_t)rsz * ns, hipMemcpyDeviceToHost, e->st);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(e->st);
+    (void)hipFree(stage);
+    if (rc != hipSuccess) return e->fail(PGBP_ERR_HIP, std::string("pgbp_get_residuals: ") + hipGetErrorString(rc));
+  }
+  if (iscalibrated_resid)
+    HIPCHK(e, hipMemcpyAsync(iscalibrated_resid, e->d_flags, sizeof(int32_t) * ns * nm, hipMemcpyDeviceToHost, e->st));
+  if (kldiv) HIPCHK(e, hipMemcpyAsync(kldiv, e->d_kldiv, sizeof(double) * ns * nm, hipMemcpyDeviceToHost, e->st));
+  return pgbp_sync(e);
+}
+
+int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
+                      const int32_t* ch_j) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = plan_set_schedule(e->plan, n_trees, tree_off, pa_j, ch_j);
+  if (rc) return e->fail(rc, e->plan.err);
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  free_traversals(e);
+  e->dpost.resize(n_trees);
+  e->dpre.resize(n_trees);
+  for (int t = 0; t < n_trees; ++t) {
+    for (int dir = 0; dir < 2; ++dir) {
+      const Traversal& tr = dir == 0 ? e->plan.trees[t].post : e->plan.trees[t].pre;
+      DevTraversal& d = dir == 0 ? e->dpost[t] : e->dpre[t];
+      if ((rc = upload(e, &d.d_task_off, tr.task_off))) return rc;
+      if ((rc = upload(e, &d.d_entries, tr.entries))) return rc;
+    }
+  }
+  return PGBP_OK;
+}
+
+int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from, const pgbp_opts* opts,
+                   int32_t* info) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  const Plan& p = e->plan;
+  const int k = sepset - p.n_clusters;
+  if (k < 0 || k >= p.n_sepsets) return e->fail(PGBP_ERR_INVALID, "pgbp_propagate: not a sepset index");
+  const int a = p.sepset_clusters[2 * k], b = p.sepset_clusters[2 * k + 1];
+  int dir;
+  if (cluster_to == a && cluster_from == b)
+    dir = 0;
+  else if (cluster_to == b && cluster_from == a)
+    dir = 1;
+  else
+    return e->fail(PGBP_ERR_INVALID, "pgbp_propagate: the sepset does not connect these two clusters");
+  const int32_t toff[2] = {0, 1};
+  Entry en{2 * k + dir, 0, 0, 0};
+  HIPCHK(e, hipMemcpyAsync(e->d_one_task_off, toff, sizeof(toff), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
+  if ((rc = reset_fail(e))) return rc;
+  DevState S = dev_state(e, opts);
+  launch_level_generic(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+  std::vector<unsigned long long> keys(p.n_sites);
+  HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * p.n_sites, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());
+  if (info)
+    for (int s = 0; s < p.n_sites; ++s)
+      info[s] = keys[s] == kNoFail ? 0 : (int32_t)(keys[s] & ((1ull << kInfoBits) - 1));
+  return PGBP_OK;
+}
+
+static int need_schedule(pgbp_engine* e, int tree) {
+  if (e->plan.trees.empty()) return e->fail(PGBP_ERR_STATE, "no schedule: call pgbp_set_schedule first");
+  if (tree < 0 || tree >= (int)e->plan.trees.size()) return e->fail(PGBP_ERR_INVALID, "schedule tree index out of range");
+  return PGBP_OK;
+}
+
+static int collect_results(pgbp_engine* e, pgbp_result* results, const std::vector<int32_t>* hist, int n_pairs) {
+  const Plan& p = e->plan;
+  const int ns = p.n_sites;
+  std::vector<unsigned long long> keys(ns);
+  std::vector<int32_t> iscal(ns);
+  HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(e, hipMemcpyAsync(iscal.data(), e->d_iscal, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());
+  const int nt = std::max<int>(1, (int)p.trees.size());
+  for (int s = 0; s < ns; ++s) {
+    pgbp_result r;
+    std::memset(&r, 0, sizeof(r));
+    r.fail_edge = -1;
+    if (keys[s] != kNoFail) {
+      r.succ = 0;
+      r.iscal = 0;  // (false, false): src/calibration.jl:82
+      decode_fail(e, keys[s], r);
+    } else {
+      r.succ = 1;
+      r.iscal = iscal[s];
+    }
+    if (hist && r.succ) {
+      for (int q = 0; q < n_pairs; ++q)
+        if ((*hist)[(size_t)q * ns + s]) {
+          r.iter_reached = q / nt + 1;
+          r.tree_reached = q % nt + 1;
+          break;
+        }
+    }
+    results[s] = r;
+  }
+  return PGBP_OK;
+}
+
+int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* opts, pgbp_result* results) {
+  if (!e || !results || dir < 0 || dir > 1) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, tree))) return rc;
+  const Plan& p = e->plan;
+  if ((rc = reset_fail(e))) return rc;
+  DevState S = dev_state(e, opts);
+  enqueue_traversal(e, S, tree, dir, (unsigned long long)tree);
+  launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
+  return collect_results(e, results, nullptr, 0);
+}
+
+int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_result* results) {
+  if (!e || !results || niter < 0) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  const Plan& p = e->plan;
+  const int ns = p.n_sites, nt = (int)p.trees.size();
+  const bool auto_stop = opts && opts->auto_stop;
+  const int64_t n_pairs_max = (int64_t)niter * nt;
+  if (n_pairs_max > e->hist_cap) {
+    if (e->d_iscal_hist) (void)hipFree(e->d_iscal_hist);
+    e->d_iscal_hist = nullptr;
+    e->hist_cap = 0;
+    if ((rc = dev_alloc(e, &e->d_iscal_hist, (size_t)n_pairs_max * ns))) return rc;
+    e->hist_cap = n_pairs_max;
+  }
+  if ((rc = reset_fail(e))) return rc;
+  HIPCHK(e, hipMemsetAsync(e->d_iscal, 0, sizeof(int32_t) * ns, e->st));
+  DevState S = dev_state(e, opts);
+  int pairs_done = 0;
+  bool stop = false;
+  std::vector<int32_t> now(ns);
+  std::vector<unsigned long long> keys(ns);
+  for (int i = 0; i < niter && !stop; ++i) {
+    for (int j = 0; j < nt && !stop; ++j) {
+      const unsigned long long pair = (unsigned long long)i * nt + j;
+      enqueue_traversal(e, S, j, 0, pair);
+      enqueue_traversal(e, S, j, 1, pair);
+      launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st);
+      ++pairs_done;
+      if (auto_stop) {
+        // `auto`: stop after the first tree at which calibration is reached (src/calibration.jl:53-56);
+        // also stop launching once a site has failed
+        HIPCHK(e, hipMemcpyAsync(now.data(), e->d_iscal_hist + pair * ns, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(e, hipStreamSynchronize(e->st));
+        bool all_cal = true, any_fail = false;
+        for (int s = 0; s < ns; ++s) {
+          all_cal &= now[s] != 0;
+          any_fail |= keys[s] != kNoFail;
+        }
+        if (all_cal || (any_fail && ns == 1)) stop = true;
+      }
+    }
+  }
+  std::vector<int32_t> hist((size_t)std::max(1, pairs_done) * ns, 0);
+  if (pairs_done > 0) {
+    HIPCHK(e, hipMemcpyAsync(hist.data(), e->d_iscal_hist, sizeof(int32_t) * (size_t)pairs_done * ns, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemcpyAsync(e->d_iscal, e->d_iscal_hist + (size_t)(pairs_done - 1) * ns, sizeof(int32_t) * ns, hipMemcpyDeviceToDevice, e->st));
+  }
+  return collect_results(e, results, &hist, pairs_done);
+}
+
+int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int32_t* info) {
+  if (!e || !norm) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  if (belief < 0 || belief >= p.n_beliefs()) return e->fail(PGBP_ERR_INVALID, "belief index out of range");
+  const int m = p.dims[belief];
+  const int ns = p.n_sites;
+  launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], m, mu ? e->d_mu : nullptr, std::max(1, p.max_dim),
+                   e->d_norm, e->d_info, ns, e->st);
+  HIPCHK(e, hipMemcpyAsync(norm, e->d_norm, sizeof(double) * ns, hipMemcpyDeviceToHost, e->st));
+  std::vector<double> mus;
+  if (mu && m > 0) {
+    mus.resize((size_t)ns * std::max(1, p.max_dim));
+    HIPCHK(e, hipMemcpyAsync(mus.data(), e->d_mu, sizeof(double) * mus.size(), hipMemcpyDeviceToHost, e->st));
+  }
+  std::vector<int32_t> inf(ns);
+  HIPCHK(e, hipMemcpyAsync(inf.data(), e->d_info, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());
+  if (mu && m > 0)
+    for (int s = 0; s < ns; ++s)
+      std::memcpy(mu + (size_t)s * m, mus.data() + (size_t)s * std::max(1, p.max_dim), sizeof(double) * m);
+  if (info) std::copy(inf.begin(), inf.end(), info);
+  return PGBP_OK;
+}
+
+// ---- benchmarking / zero-copy entry points ---------------------------------------------------
+
+static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_each,
+                                  std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev) {
+  const Plan& p = e->plan;
+  if (reset_each) {
+    int rc = reset_from_factors_async(e);
+    if (rc) return rc;
+    launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
+  }
+  for (int j = 0; j < (int)p.trees.size(); ++j) {
+    enqueue_traversal(e, S, j, 0, (unsigned long long)j, ev);
+    enqueue_traversal(e, S, j, 1, (unsigned long long)j, ev);
+    launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
+  }
+  return PGBP_OK;
+}
+
+int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  if ((rc = reset_fail(e))) return rc;
+  DevState S = dev_state(e, opts);
+  for (int r = 0; r < reps; ++r)
+    if ((rc = enqueue_calibrate_once(e, S, reset_each, nullptr))) return rc;
+  return PGBP_OK;
+}
+
+static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
+  const Plan& p = e->plan;
+  int rc = reset_from_factors_async(e);
+  if (rc) return rc;
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
+  enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
+  const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
+  launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], nullptr, std::max(1, p.max_dim),
+                   e->d_norm, e->d_info, p.n_sites, e->st);                                  // :212
+  return PGBP_OK;
+}
+
+int pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  if ((rc = reset_fail(e))) return rc;
+  DevState S = dev_state(e, opts);
+  for (int r = 0; r < reps; ++r)
+    if ((rc = enqueue_loglik_once(e, S))) return rc;
+  return PGBP_OK;
+}
+
+int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
+  if (!e || !norm) return PGBP_ERR_INVALID;
+  const int ns = e->plan.n_sites;
+  HIPCHK(e, hipMemcpyAsync(norm, e->d_norm, sizeof(double) * ns, hipMemcpyDeviceToHost, e->st));
+  if (info) HIPCHK(e, hipMemcpyAsync(info, e->d_info, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());
+  if (info) {
+    // a failed postorder message also invalidates the likelihood
+    std::vector<unsigned long long> keys(ns);
+    HIPCHK(e, hipMemcpy(keys.data(), e->d_fail, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost));
+    for (int s = 0; s < ns; ++s)
+      if (keys[s] != kNoFail && info[s] == 0) info[s] = (int32_t)(keys[s] & ((1ull << kInfoBits) - 1));
+  }
+  return PGBP_OK;
+}
+
+int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each, const pgbp_opts* opts,
+                       float* ms_total) {
+  if (!e || !ms_total) return PGBP_ERR_INVALID;
+  hipEvent_t a, b;
+  HIPCHK(e, hipEventCreate(&a));
+  HIPCHK(e, hipEventCreate(&b));
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipEventRecord(a, e->st));
+  int rc = kind == 0 ? pgbp_enqueue_calibrate(e, reps, reset_each, opts) : pgbp_enqueue_loglik(e, reps, opts);
+  if (rc == PGBP_OK) {
+    HIPCHK(e, hipEventRecord(b, e->st));
+    HIPCHK(e, hipEventSynchronize(b));
+    HIPCHK(e, hipEventElapsedTime(ms_total, a, b));
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return rc;
+}
+
+int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opts, float* ms_kernels,
+                              int32_t* n_launches) {
+  if (!e || !ms_kernels) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  if ((rc = reset_fail(e))) return rc;
+  DevState S = dev_state(e, opts);
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  for (int r = 0; r < reps; ++r)
+    if ((rc = enqueue_calibrate_once(e, S, 1, &ev))) break;
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  double total = 0;
+  for (auto& pr : ev) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) total += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  *ms_kernels = (float)total;
+  if (n_launches) *n_launches = (int32_t)ev.size();
+  return rc;
+}
+
+int pgbp_traffic_model(const pgbp_engine* e, double* bytes_per_calibrate, int64_t* messages_per_calibrate) {
+  if (!e) return PGBP_ERR_INVALID;
+  int64_t nm = 0;
+  double b = plan_bytes_per_calibrate(e->plan, &nm);
+  if (bytes_per_calibrate) *bytes_per_calibrate = b;
+  if (messages_per_calibrate) *messages_per_calibrate = nm;
+  return PGBP_OK;
+}
+
+}  // extern "C"

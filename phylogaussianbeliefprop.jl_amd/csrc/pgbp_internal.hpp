@@ -1,0 +1,80 @@
+// Internal structures shared by the host planner (pgbp_plan.cpp), the engine
+// (pgbp_engine.hip) and the kernels (pgbp_kernels.hip).  Not part of the ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pgbp.h"
+
+namespace pgbp {
+
+constexpr int kRecAlign = 16;  // records padded to 16 doubles = 128 B (one L2 line)
+constexpr int kWave = 64;
+
+// One directed message (sepset k, direction dir); static for the life of the engine.
+// Offsets are in doubles inside ONE SITE's belief pool / residual pool.
+struct MsgDesc {
+  int64_t from_off, to_off, sep_off, res_off;
+  int32_t mf, mt, s, ni;           // dims: sender, receiver, sepset; ni = mf - s integrated
+  int32_t keep_map, up_map, int_map;  // offsets into the int32 index pool
+  int32_t keep0;                   // first keep index if the keep indices are contiguous, else -1
+  int32_t up0;                     // first update index if contiguous, else -1
+  int32_t from_b, to_b, sep_b;     // belief indices (diagnostics / failure text)
+};
+static_assert(sizeof(MsgDesc) == 72 || sizeof(MsgDesc) == 80, "MsgDesc layout");
+
+// One message inside a task of a level.
+struct Entry {
+  int32_t msg;    // directed message id
+  int32_t edge;   // position in the tree's edge list
+  int32_t reuse;  // 1: same sender and same keep indices as the previous entry of the task
+  int32_t seq;    // position in the reference's sequential order of one (post, pre) pair
+};
+
+struct Traversal {
+  std::vector<int32_t> level_off;  // [n_levels+1] -> tasks
+  std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
+  std::vector<Entry> entries;
+  int32_t max_mf = 0;
+};
+
+struct Tree {
+  std::vector<int32_t> pa, ch, sep;  // per edge: parent cluster, child cluster, sepset (0-based among sepsets)
+  Traversal post, pre;
+};
+
+struct Plan {
+  int32_t n_clusters = 0, n_sepsets = 0, n_sites = 1, device = 0;
+  std::vector<int32_t> dims;
+  std::vector<int32_t> sepset_clusters;
+  std::vector<int64_t> scope_off;
+  std::vector<int32_t> scope_idx;
+  // layout
+  std::vector<int64_t> boff;        // [n_beliefs+1] padded record offsets (doubles)
+  std::vector<int64_t> packed_off;  // [n_beliefs+1] unpadded (ABI "packed")
+  std::vector<int64_t> roff;        // [n_msgs+1] padded residual records
+  std::vector<int64_t> rpacked_off; // [n_msgs+1]
+  std::vector<MsgDesc> msgs;        // [2*n_sepsets]
+  std::vector<int32_t> idxpool;
+  std::vector<Tree> trees;
+  int32_t max_dim = 0;
+  std::string err;
+
+  int32_t n_beliefs() const { return n_clusters + n_sepsets; }
+  int32_t n_msgs() const { return 2 * n_sepsets; }
+  int64_t pool_stride() const { return boff.back(); }
+  int64_t cluster_stride() const { return boff[n_clusters]; }
+  int64_t rpool_stride() const { return roff.back(); }
+};
+
+int plan_build(Plan& p, const pgbp_desc* d);
+int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
+                      const int32_t* ch_j);
+double plan_bytes_per_calibrate(const Plan& p, int64_t* n_messages);
+
+}  // namespace pgbp
+
+struct pgbp_plan {
+  pgbp::Plan p;
+};

@@ -1,0 +1,382 @@
+// HIP kernels for gfx950 (MI355X, CDNA4; wave64).
+//
+// bp_level_generic: one wavefront = one task of a BP level = an ordered list of
+// canonical-form messages (src/beliefupdates.jl:650-665) that share a target
+// (postorder) or a sender (preorder).  For each message:
+//   marginalize (src/beliefupdates.jl:55-83)  -> Schur complement by in-LDS elimination
+//   divide!     (src/beliefupdates.jl:579-587) -> residual + sepset overwrite
+//   mult!       (src/beliefupdates.jl:483-488) -> scatter-add into the receiver
+//   iscalibrated_residnorm! (src/beliefs.jl:994-1003)
+// Handles any belief dimension <= PGBP_MAX_DIM and arbitrary (ragged) scope index maps.
+#include <hip/hip_runtime.h>
+
+#include "pgbp_kernels.hpp"
+
+namespace pgbp {
+
+#define PGBP_LOG2PI 1.8378770664093454835606594728112
+#define PGBP_EPS 2.220446049250313e-16
+
+static constexpr int kPermDoubles = 32;  // PGBP_MAX_DIM int32 = 256 B at the front of LDS
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ int pow2_at_least(int n) {  // n in [1, 64] -> smallest power of two >= n
+  return n <= 1 ? 1 : 1 << (32 - __clz(n - 1));
+}
+
+extern __shared__ double lds[];
+
+// Eliminate the leading `ni` variables of the (mf x (mf+1)) augmented system held row-major in W
+// (leading dimension ld): W[i][j] -= (W[i][k] / W[k][k]) * W[k][j].  Returns 0 or the 1-based index of
+// the first non-positive pivot (LAPACK potrf `info`, src/beliefupdates.jl:68-76). Accumulates
+// sum log(d_k) and sum h~_k^2 / d_k.  All 64 lanes take part; results are wave-uniform.
+__device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int ni, int lane, double& logdet,
+                                                 double& quad) {
+  logdet = 0.0;
+  quad = 0.0;
+  for (int k = 0; k < ni; ++k) {
+    const double d = W[k * ld + k];
+    if (!(d > 0.0)) return k + 1;
+    const double rd = 1.0 / d;
+    const double hk = W[k * ld + mf];
+    logdet += log(d);
+    quad += hk * hk * rd;
+    const int nc = mf - k;      // columns k+1 .. mf (the last one is h)
+    const int nr = mf - 1 - k;  // rows k+1 .. mf-1
+    const int L = pow2_at_least(nc);
+    const int R = kWave / L;
+    const int jj = lane & (L - 1);
+    const int i0 = lane / L;
+    if (jj < nc) {
+      const int j = k + 1 + jj;
+      const double pkj = W[k * ld + j];
+      for (int ii = i0; ii < nr; ii += R) {
+        const int i = k + 1 + ii;
+        W[i * ld + j] -= (W[i * ld + k] * rd) * pkj;
+      }
+    }
+    __syncthreads();
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t* __restrict__ task_off,
+                                                       const Entry* __restrict__ entries, int task0,
+                                                       unsigned long long seq_base,
+                                                       unsigned long long stop_below) {
+  const int lane = threadIdx.x;
+  const int site = blockIdx.y;
+  // A message of an EARLIER traversal failed: the reference has stopped (src/calibration.jl:82,129-132).
+  // Failures inside the current traversal only stop what is downstream of them (poison), so that the
+  // minimum fail key is the first failure of the reference's sequential order.
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  const int task = task0 + blockIdx.x;
+  double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
+  double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  int32_t* perm = reinterpret_cast<int32_t*>(lds);
+  double* W = lds + kPermDoubles;
+
+  const int e0 = task_off[task], e1 = task_off[task + 1];
+  int mf = 0, ni = 0, ld = 1;
+  double gmsg = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const Entry en = entries[e];
+    const MsgDesc m = S.msgs[en.msg];
+    if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
+      if (lane == 0) S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+      return;
+    }
+    if (!en.reuse) {
+      const double* __restrict__ from = pool + m.from_off;
+      mf = m.mf;
+      ni = m.ni;
+      ld = (mf + 1) | 1;  // odd leading dimension: conflict-free column walks
+      __syncthreads();    // W / perm of the previous entry no longer needed
+      for (int i = lane; i < mf; i += kWave)
+        perm[i] = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];
+      __syncthreads();
+      // gather: integrated variables first, kept variables last; h as the extra column
+      {
+        const int L = pow2_at_least(mf > 0 ? mf : 1);
+        const int R = kWave / L;
+        const int i = lane & (L - 1);
+        if (i < mf) {
+          const int pi = perm[i];
+          for (int j = lane / L; j < mf; j += R) W[i * ld + j] = from[pi + (int64_t)perm[j] * mf];
+          if (lane / L == 0) W[i * ld + mf] = from[(int64_t)mf * mf + pi];
+        }
+      }
+      gmsg = from[(int64_t)mf * mf + mf];
+      __syncthreads();
+      if (ni > 0) {
+        // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
+        bool nz = false;
+        for (int idx = lane; idx < mf * ni; idx += kWave) {
+          const int j = idx / mf, i = idx - j * mf;
+          nz |= fabs(W[i * ld + j]) > PGBP_EPS;
+        }
+        for (int i = lane; i < ni; i += kWave) nz |= fabs(W[i * ld + mf]) > PGBP_EPS;
+        const bool fake = !__any(nz);
+        if (!fake) {
+          // Symmetric(J_I): upper triangle only (:68); pivot rows get J_SI' for the kept columns (:77)
+          for (int idx = lane; idx < ni * mf; idx += kWave) {
+            const int i = idx / mf, j = idx - i * mf;
+            if (j > i) {
+              const double v = (j < ni) ? W[i * ld + j] : W[j * ld + i];
+              W[i * ld + j] = v;
+              if (j < ni) W[j * ld + i] = v;
+            }
+          }
+          __syncthreads();
+          double logdet, quad;
+          const int info = eliminate_leading(W, ld, mf, ni, lane, logdet, quad);
+          if (info != 0) {
+            if (lane == 0) {
+              S.status[(int64_t)site * S.n_msgs + en.msg] = info;
+              S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+              atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) |
+                                           (unsigned long long)info);
+            }
+            return;  // nothing of this message is applied; later messages of the task do not run
+          }
+          gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);  // :81
+        }
+      }
+    }
+    // ---- divide! and mult!
+    double* __restrict__ sep = pool + m.sep_off;
+    double* __restrict__ to = pool + m.to_off;
+    double* __restrict__ res = rpool + m.res_off;
+    const int s = m.s, mt = m.mt;
+    const int32_t* __restrict__ up = S.idx + m.up_map;
+    double maxJ = 0.0, maxh = 0.0;
+    if (s > 0) {
+      const int L = pow2_at_least(s);
+      const int R = kWave / L;
+      const int a = lane & (L - 1);
+      if (a < s) {
+        const int ua = up[a];
+        for (int b = lane / L; b < s; b += R) {
+          const double msg = W[(ni + a) * ld + ni + b];
+          const int64_t o = a + (int64_t)b * s;
+          const double dJ = msg - sep[o];
+          sep[o] = msg;
+          res[o] = dJ;
+          to[ua + (int64_t)up[b] * mt] += dJ;
+          maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+        }
+        if (lane / L == 0) {
+          const double msg = W[(ni + a) * ld + mf];
+          const int64_t o = (int64_t)s * s + a;
+          const double dh = msg - sep[o];
+          sep[o] = msg;
+          res[o] = dh;
+          to[(int64_t)mt * mt + ua] += dh;
+          maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
+        }
+      }
+    }
+    if (lane == 0) {
+      const int64_t og = (int64_t)s * s + s;
+      const double dg = gmsg - sep[og];
+      sep[og] = gmsg;
+      to[(int64_t)mt * mt + mt] += dg;
+      S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
+    }
+    if (S.update_resnorm) {
+      // iscalibrated_residnorm!: max|dh|/sqrt(s) <= atol && max|dJ|/s <= atol (src/beliefs.jl:994-1003)
+      maxJ = wave_max(maxJ);
+      maxh = wave_max(maxh);
+      if (lane == 0) {
+        const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+        S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
+      }
+    }
+    __threadfence_block();  // next entry of the task may read-modify-write the same receiver
+  }
+}
+
+size_t generic_lds_bytes(int max_mf) {
+  const int mf = max_mf < 1 ? 1 : max_mf;
+  const int ld = (mf + 1) | 1;
+  return sizeof(double) * (size_t)(kPermDoubles + mf * ld);
+}
+
+void launch_level_generic(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0,
+                          int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below,
+                          int max_mf, hipStream_t st) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(bp_level_generic, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S,
+                     d_task_off, d_entries, task0, seq_base, stop_below);
+}
+
+// integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2
+__global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict__ pool_all, int64_t pool_stride,
+                                                       int64_t rec_off, int m, double* __restrict__ mu,
+                                                       int mu_stride, double* __restrict__ norm,
+                                                       int32_t* __restrict__ info_out) {
+  const int lane = threadIdx.x;
+  const int site = blockIdx.x;
+  const double* __restrict__ rec = pool_all + (int64_t)site * pool_stride + rec_off;
+  double* W = lds + kPermDoubles;
+  const int ld = (m + 1) | 1;
+  const double g = rec[(int64_t)m * m + m];
+  bool nz = false;
+  for (int idx = lane; idx < m * m; idx += kWave) {
+    const int j = idx / m, i = idx - j * m;
+    const double raw = rec[idx];
+    nz |= raw != 0.0;
+    // PDMat(Symmetric(J)): read the upper triangle
+    W[i * ld + j] = (i <= j) ? raw : rec[j + (int64_t)i * m];
+  }
+  for (int i = lane; i < m; i += kWave) {
+    const double hv = rec[(int64_t)m * m + i];
+    nz |= hv != 0.0;
+    W[i * ld + m] = hv;
+  }
+  __syncthreads();
+  if (!__any(nz)) {  // constant belief: mu = Inf, norm = g (:189-191)
+    if (mu)
+      for (int i = lane; i < m; i += kWave) mu[(int64_t)site * mu_stride + i] = INFINITY;
+    if (lane == 0) {
+      norm[site] = g;
+      if (info_out) info_out[site] = 0;
+    }
+    return;
+  }
+  double logdet, quad;
+  const int info = eliminate_leading(W, ld, m, m, lane, logdet, quad);
+  if (info != 0) {
+    if (lane == 0) {
+      norm[site] = NAN;
+      if (info_out) info_out[site] = info;
+    }
+    return;
+  }
+  if (mu) {
+    // back substitution on the upper-triangular system left by the elimination
+    for (int k = m - 1; k >= 0; --k) {
+      if (lane == 0) W[k * ld + m] = W[k * ld + m] / W[k * ld + k];
+      __syncthreads();
+      const double xk = W[k * ld + m];
+      for (int i = lane; i < k; i += kWave) W[i * ld + m] -= W[i * ld + k] * xk;
+      __syncthreads();
+    }
+    for (int i = lane; i < m; i += kWave) mu[(int64_t)site * mu_stride + i] = W[i * ld + m];
+  }
+  if (lane == 0) {
+    norm[site] = g + 0.5 * ((double)m * PGBP_LOG2PI - logdet + quad);
+    if (info_out) info_out[site] = 0;
+  }
+}
+
+void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, double* d_mu, int mu_stride,
+                      double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
+  hipLaunchKernelGGL(integrate_kernel, dim3(n_sites), dim3(kWave), generic_lds_bytes(m), st, pool, pool_stride,
+                     rec_off, m, d_mu, mu_stride, d_norm, d_info);
+}
+
+// ---- record gather/scatter between the ABI's packed layout and the padded device records
+__global__ void records_kernel(const double* __restrict__ src, int64_t src_stride,
+                               const int64_t* __restrict__ src_off, double* __restrict__ dst, int64_t dst_stride,
+                               const int64_t* __restrict__ dst_off, const int64_t* __restrict__ len_off,
+                               int n_records) {
+  const int site = blockIdx.y;
+  for (int r = blockIdx.x; r < n_records; r += gridDim.x) {
+    const int64_t len = len_off[r + 1] - len_off[r];
+    const double* __restrict__ s = src + (int64_t)site * src_stride + src_off[r];
+    double* __restrict__ d = dst + (int64_t)site * dst_stride + dst_off[r];
+    for (int64_t t = threadIdx.x; t < len; t += blockDim.x) d[t] = s[t];
+  }
+}
+
+void launch_records(const double* src, int64_t src_stride, const int64_t* d_src_off, double* dst, int64_t dst_stride,
+                    const int64_t* d_dst_off, const int64_t* d_len_off, int n_records, int n_sites, hipStream_t st) {
+  if (n_records <= 0) return;
+  const int gx = n_records < 65535 ? n_records : 65535;
+  hipLaunchKernelGGL(records_kernel, dim3(gx, n_sites), dim3(256), 0, st, src, src_stride, d_src_off, dst,
+                     dst_stride, d_dst_off, d_len_off, n_records);
+}
+
+__global__ void copy_strided_kernel(const double2* __restrict__ src, int64_t src_stride2, double2* __restrict__ dst,
+                                    int64_t dst_stride2, int64_t n2) {
+  const int site = blockIdx.y;
+  const double2* __restrict__ s = src + (int64_t)site * src_stride2;
+  double2* __restrict__ d = dst + (int64_t)site * dst_stride2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = s[i];
+}
+
+__global__ void zero_strided_kernel(double2* __restrict__ dst, int64_t dst_stride2, int64_t n2) {
+  const int site = blockIdx.y;
+  double2* __restrict__ d = dst + (int64_t)site * dst_stride2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = make_double2(0.0, 0.0);
+}
+
+static int grid_for(int64_t n, int n_sites) {
+  int64_t g = (n + 255) / 256;
+  const int64_t cap = n_sites >= 8 ? 256 : 2048;  // ~8 blocks per CU in total
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// all strides / offsets / counts are multiples of 2 doubles (records are padded to 16)
+void launch_copy_strided(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, int64_t n,
+                         int n_sites, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for(n / 2, n_sites), n_sites), dim3(256), 0, st,
+                     reinterpret_cast<const double2*>(src), src_stride / 2, reinterpret_cast<double2*>(dst),
+                     dst_stride / 2, n / 2);
+}
+
+void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(zero_strided_kernel, dim3(grid_for(n / 2, n_sites), n_sites), dim3(256), 0, st,
+                     reinterpret_cast<double2*>(dst), dst_stride / 2, n / 2);
+}
+
+// init_messagecalibrationflags_reset! (src/beliefs.jl:973-979): empty messages stay calibrated
+__global__ void reset_flags_kernel(const MsgDesc* __restrict__ msgs, int32_t* __restrict__ flags,
+                                   double* __restrict__ kldiv, int n_msgs, int reset_kl) {
+  const int site = blockIdx.y;
+  for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < n_msgs; d += gridDim.x * blockDim.x) {
+    const bool empty = msgs[d].s == 0;
+    flags[(int64_t)site * n_msgs + d] = empty ? 1 : 0;
+    if (empty)
+      kldiv[(int64_t)site * n_msgs + d] = 0.0;
+    else if (reset_kl)
+      kldiv[(int64_t)site * n_msgs + d] = -1.0;
+  }
+}
+
+void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int n_msgs, int n_sites, int reset_kl,
+                        hipStream_t st) {
+  if (n_msgs <= 0) return;
+  hipLaunchKernelGGL(reset_flags_kernel, dim3(grid_for(n_msgs, n_sites), n_sites), dim3(256), 0, st, msgs, flags,
+                     kldiv, n_msgs, reset_kl);
+}
+
+// iscalibrated_residnorm(beliefs) = all flags (src/clustergraphbeliefs.jl:168-169)
+__global__ __launch_bounds__(256) void reduce_flags_kernel(const int32_t* __restrict__ flags, int n_msgs,
+                                                           int32_t* __restrict__ iscal) {
+  const int site = blockIdx.x;
+  __shared__ int any_false;
+  if (threadIdx.x == 0) any_false = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int d = threadIdx.x; d < n_msgs; d += blockDim.x) bad |= (flags[(int64_t)site * n_msgs + d] == 0);
+  if (bad) any_false = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) iscal[site] = any_false ? 0 : 1;
+}
+
+void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_flags_kernel, dim3(n_sites), dim3(256), 0, st, flags, n_msgs, d_iscal);
+}
+
+}  // namespace pgbp

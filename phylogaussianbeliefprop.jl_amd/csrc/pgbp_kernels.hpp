@@ -1,0 +1,51 @@
+// Kernel launch wrappers (defined in pgbp_kernels.hip), called by the engine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pgbp_internal.hpp"
+
+namespace pgbp {
+
+constexpr unsigned long long kNoFail = ~0ull;
+constexpr int kInfoBits = 20;  // fail key = (global sequence number << kInfoBits) | info
+
+// Everything a message kernel needs, passed by value.
+struct DevState {
+  double* pool;
+  int64_t pool_stride;  // doubles per site
+  double* rpool;
+  int64_t rpool_stride;
+  const MsgDesc* msgs;
+  const int32_t* idx;
+  int32_t* flags;              // [n_sites][n_msgs] iscalibrated_resid
+  int32_t* status;             // [n_sites][n_msgs] 0 ok, >0 PosDefException.info of the last attempt
+  unsigned long long* fail;    // [n_sites] min over failing messages of the fail key
+  int32_t* poison;             // [n_sites][n_clusters] 1: the cluster sits downstream of a failed message
+  int32_t n_clusters;
+  int32_t n_msgs;
+  int32_t update_resnorm;
+  double atol;
+};
+
+size_t generic_lds_bytes(int max_mf);
+
+void launch_level_generic(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0,
+                          int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
+                          hipStream_t st);
+
+void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, double* d_mu, int mu_stride,
+                      double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
+
+// dst[site*dst_stride + dst_off[r] + t] = src[site*src_stride + src_off[r] + t], t < src_off'[r+1]-..: record copy
+void launch_records(const double* src, int64_t src_stride, const int64_t* d_src_off, double* dst, int64_t dst_stride,
+                    const int64_t* d_dst_off, const int64_t* d_len_off, int n_records, int n_sites, hipStream_t st);
+
+void launch_copy_strided(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, int64_t n,
+                         int n_sites, hipStream_t st);
+void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites, hipStream_t st);
+
+void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int n_msgs, int n_sites, int reset_kl,
+                        hipStream_t st);
+void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st);
+
+}  // namespace pgbp

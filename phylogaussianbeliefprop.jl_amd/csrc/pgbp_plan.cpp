@@ -1,0 +1,381 @@
+// Host-only planner: belief/residual record layout, the static table of directed
+// messages with their precomputed scope index maps, and the level-synchronous
+// schedule of each spanning tree.  No GPU needed (covered by the CPU test-suite).
+//
+// Reference behaviour restated here:
+//   * scopeindex(sepset, cluster) is computed ONCE per (sepset, side) by the caller
+//     instead of twice per message (src/beliefs.jl:389-405, src/beliefupdates.jl:659,663);
+//   * integrate_index = setdiff(1:m, keep_index), ascending (src/beliefupdates.jl:52);
+//   * postorder = edges in reverse, child -> parent, residual key (pa, ch);
+//     preorder = edges in order, parent -> child, key (ch, pa) (src/calibration.jl:121-151).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+#include "pgbp_internal.hpp"
+
+namespace pgbp {
+
+static int64_t pad_to(int64_t n, int64_t a) { return (n + a - 1) / a * a; }
+
+int plan_build(Plan& p, const pgbp_desc* d) {
+  if (!d || d->n_clusters <= 0 || d->n_sepsets < 0 || !d->dims || d->n_sites < 1) {
+    p.err = "invalid description (null pointers, no clusters, or n_sites < 1)";
+    return PGBP_ERR_INVALID;
+  }
+  if (d->n_sepsets > 0 && (!d->sepset_clusters || !d->scope_off || !d->scope_idx)) {
+    p.err = "invalid description: sepset arrays missing";
+    return PGBP_ERR_INVALID;
+  }
+  p.n_clusters = d->n_clusters;
+  p.n_sepsets = d->n_sepsets;
+  p.n_sites = d->n_sites;
+  p.device = d->device;
+  const int nb = p.n_beliefs();
+  p.dims.assign(d->dims, d->dims + nb);
+  p.max_dim = 0;
+  for (int b = 0; b < nb; ++b) {
+    if (p.dims[b] < 0) {
+      p.err = "negative belief dimension";
+      return PGBP_ERR_INVALID;
+    }
+    p.max_dim = std::max(p.max_dim, p.dims[b]);
+  }
+  if (p.max_dim > PGBP_MAX_DIM) {
+    p.err = "belief dimension " + std::to_string(p.max_dim) + " exceeds PGBP_MAX_DIM=" +
+            std::to_string(PGBP_MAX_DIM);
+    return PGBP_ERR_TOO_LARGE;
+  }
+  p.sepset_clusters.assign(d->sepset_clusters, d->sepset_clusters + 2 * (size_t)p.n_sepsets);
+  p.scope_off.assign(d->scope_off, d->scope_off + 2 * (size_t)p.n_sepsets + 1);
+  p.scope_idx.assign(d->scope_idx, d->scope_idx + (p.n_sepsets ? p.scope_off.back() : 0));
+
+  // record layout: [J m*m | h m | g] padded to 128 B; clusters first, then sepsets
+  p.boff.assign(nb + 1, 0);
+  p.packed_off.assign(nb + 1, 0);
+  for (int b = 0; b < nb; ++b) {
+    int64_t m = p.dims[b];
+    int64_t len = m * m + m + 1;
+    p.packed_off[b + 1] = p.packed_off[b] + len;
+    p.boff[b + 1] = p.boff[b] + pad_to(len, kRecAlign);
+  }
+  const int nm = p.n_msgs();
+  p.roff.assign(nm + 1, 0);
+  p.rpacked_off.assign(nm + 1, 0);
+  p.msgs.assign(nm, MsgDesc{});
+  p.idxpool.clear();
+  for (int k = 0; k < p.n_sepsets; ++k) {
+    const int a = p.sepset_clusters[2 * k], b = p.sepset_clusters[2 * k + 1];
+    const int sb = p.n_clusters + k;
+    const int s = p.dims[sb];
+    if (a < 0 || a >= p.n_clusters || b < 0 || b >= p.n_clusters || a == b) {
+      p.err = "sepset " + std::to_string(k) + ": bad incident clusters";
+      return PGBP_ERR_INVALID;
+    }
+    int32_t mapoff[2], intoff[2], first[2];
+    for (int side = 0; side < 2; ++side) {
+      const int c = side == 0 ? a : b;
+      const int m = p.dims[c];
+      const int64_t o0 = p.scope_off[2 * k + side], o1 = p.scope_off[2 * k + side + 1];
+      if (o1 - o0 != s) {
+        p.err = "sepset " + std::to_string(k) + ": scope index length != sepset dimension";
+        return PGBP_ERR_INVALID;
+      }
+      mapoff[side] = (int32_t)p.idxpool.size();
+      int prev = -1;
+      bool contig = true;
+      for (int64_t t = o0; t < o1; ++t) {
+        int v = p.scope_idx[t];
+        // src/beliefs.jl:398-401: labels in order, subset, in the cluster's scope
+        if (v <= prev || v >= m) {
+          p.err = "sepset " + std::to_string(k) + ": scope indices must be strictly increasing and inside the cluster";
+          return PGBP_ERR_INVALID;
+        }
+        if (prev >= 0 && v != prev + 1) contig = false;
+        prev = v;
+        p.idxpool.push_back(v);
+      }
+      first[side] = (s > 0 && contig) ? p.scope_idx[o0] : (s == 0 ? 0 : -1);
+      // integrate indices = complement, ascending
+      intoff[side] = (int32_t)p.idxpool.size();
+      int64_t t = o0;
+      for (int v = 0; v < m; ++v) {
+        if (t < o1 && p.scope_idx[t] == v) {
+          ++t;
+        } else {
+          p.idxpool.push_back(v);
+        }
+      }
+    }
+    for (int dir = 0; dir < 2; ++dir) {
+      // dir 0: received by a, sent by b
+      const int to = dir == 0 ? a : b, from = dir == 0 ? b : a;
+      const int sfrom = dir == 0 ? 1 : 0, sto = dir == 0 ? 0 : 1;
+      MsgDesc& m = p.msgs[2 * k + dir];
+      m.from_off = p.boff[from];
+      m.to_off = p.boff[to];
+      m.sep_off = p.boff[sb];
+      m.mf = p.dims[from];
+      m.mt = p.dims[to];
+      m.s = s;
+      m.ni = m.mf - s;
+      m.keep_map = mapoff[sfrom];
+      m.int_map = intoff[sfrom];
+      m.up_map = mapoff[sto];
+      m.keep0 = first[sfrom];
+      m.up0 = first[sto];
+      m.from_b = from;
+      m.to_b = to;
+      m.sep_b = sb;
+      const int64_t rlen = (int64_t)s * s + s;
+      const int id = 2 * k + dir;
+      p.rpacked_off[id + 1] = p.rpacked_off[id] + rlen;
+      p.roff[id + 1] = p.roff[id] + pad_to(rlen, kRecAlign);
+      m.res_off = p.roff[id];
+    }
+  }
+  p.trees.clear();
+  return PGBP_OK;
+}
+
+static void build_traversals(const Plan& p, Tree& t) {
+  const int n = (int)t.pa.size();
+  // message id of edge i in each direction: sepset k = (a, b); dir 0 is received by a
+  auto msg_to = [&](int i, int receiver) {
+    const int k = t.sep[i];
+    return 2 * k + (p.sepset_clusters[2 * k] == receiver ? 0 : 1);
+  };
+  // ---- postorder: level = height of the child in the schedule tree
+  {
+    std::unordered_map<int, int> hnode;
+    std::vector<int> lvl(n);
+    int nlev = 0;
+    for (int i = n - 1; i >= 0; --i) {
+      int h = 0;
+      auto it = hnode.find(t.ch[i]);
+      if (it != hnode.end()) h = it->second;
+      lvl[i] = h;
+      int& hp = hnode[t.pa[i]];
+      hp = std::max(hp, h + 1);
+      nlev = std::max(nlev, h + 1);
+    }
+    // tasks: group by (level, target parent); entries in reference order (decreasing i)
+    std::vector<std::vector<int>> bylevel(nlev);
+    for (int i = n - 1; i >= 0; --i) bylevel[lvl[i]].push_back(i);
+    Traversal& tr = t.post;
+    tr = Traversal{};
+    tr.level_off.push_back(0);
+    tr.task_off.push_back(0);
+    for (int L = 0; L < nlev; ++L) {
+      std::unordered_map<int, int> task_of_target;
+      std::vector<std::vector<int>> tasks;
+      for (int i : bylevel[L]) {
+        auto it = task_of_target.find(t.pa[i]);
+        if (it == task_of_target.end()) {
+          task_of_target[t.pa[i]] = (int)tasks.size();
+          tasks.push_back({i});
+        } else {
+          tasks[it->second].push_back(i);
+        }
+      }
+      for (auto& tk : tasks) {
+        for (int i : tk) {
+          Entry e;
+          e.msg = msg_to(i, t.pa[i]);
+          e.edge = i;
+          e.reuse = 0;
+          e.seq = n - 1 - i;
+          tr.entries.push_back(e);
+          tr.max_mf = std::max(tr.max_mf, p.msgs[e.msg].mf);
+        }
+        tr.task_off.push_back((int)tr.entries.size());
+      }
+      tr.level_off.push_back((int)tr.task_off.size() - 1);
+    }
+  }
+  // ---- preorder: level = depth of the parent; tasks group by sender
+  {
+    std::unordered_map<int, int> dnode;
+    std::vector<int> lvl(n);
+    int nlev = 0;
+    for (int i = 0; i < n; ++i) {
+      int dpt = 0;
+      auto it = dnode.find(t.pa[i]);
+      if (it != dnode.end()) dpt = it->second;
+      lvl[i] = dpt;
+      dnode[t.ch[i]] = dpt + 1;
+      nlev = std::max(nlev, dpt + 1);
+    }
+    std::vector<std::vector<int>> bylevel(nlev);
+    for (int i = 0; i < n; ++i) bylevel[lvl[i]].push_back(i);
+    Traversal& tr = t.pre;
+    tr = Traversal{};
+    tr.level_off.push_back(0);
+    tr.task_off.push_back(0);
+    for (int L = 0; L < nlev; ++L) {
+      std::unordered_map<int, int> task_of_sender;
+      std::vector<std::vector<int>> tasks;
+      for (int i : bylevel[L]) {
+        auto it = task_of_sender.find(t.pa[i]);
+        if (it == task_of_sender.end()) {
+          task_of_sender[t.pa[i]] = (int)tasks.size();
+          tasks.push_back({i});
+        } else {
+          tasks[it->second].push_back(i);
+        }
+      }
+      for (auto& tk : tasks) {
+        int prev_msg = -1;
+        for (int i : tk) {
+          Entry e;
+          e.msg = msg_to(i, t.ch[i]);
+          e.edge = i;
+          e.seq = n + i;
+          e.reuse = 0;
+          if (prev_msg >= 0) {
+            const MsgDesc& a = p.msgs[prev_msg];
+            const MsgDesc& b = p.msgs[e.msg];
+            if (a.from_b == b.from_b && a.s == b.s && b.ni > 0 &&
+                std::equal(p.idxpool.begin() + a.keep_map, p.idxpool.begin() + a.keep_map + a.s,
+                           p.idxpool.begin() + b.keep_map))
+              e.reuse = 1;
+          }
+          prev_msg = e.msg;
+          tr.entries.push_back(e);
+          tr.max_mf = std::max(tr.max_mf, p.msgs[e.msg].mf);
+        }
+        tr.task_off.push_back((int)tr.entries.size());
+      }
+      tr.level_off.push_back((int)tr.task_off.size() - 1);
+    }
+  }
+}
+
+int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
+                      const int32_t* ch_j) {
+  if (n_trees < 0 || (n_trees > 0 && (!tree_off || !pa_j || !ch_j))) {
+    p.err = "invalid schedule arguments";
+    return PGBP_ERR_INVALID;
+  }
+  std::map<std::pair<int, int>, int> sepmap;
+  for (int k = 0; k < p.n_sepsets; ++k) {
+    int a = p.sepset_clusters[2 * k], b = p.sepset_clusters[2 * k + 1];
+    sepmap[{std::min(a, b), std::max(a, b)}] = k;  // sdict: Set of the 2 labels -> sepset (clustergraphbeliefs.jl:73-76)
+  }
+  std::vector<Tree> trees(n_trees);
+  for (int t = 0; t < n_trees; ++t) {
+    const int n = tree_off[t + 1] - tree_off[t];
+    if (n < 0) {
+      p.err = "tree_off must be non-decreasing";
+      return PGBP_ERR_INVALID;
+    }
+    Tree& T = trees[t];
+    T.pa.assign(pa_j + tree_off[t], pa_j + tree_off[t + 1]);
+    T.ch.assign(ch_j + tree_off[t], ch_j + tree_off[t + 1]);
+    T.sep.resize(n);
+    std::unordered_map<int, int> seen;  // cluster -> 1 if already placed in the tree
+    for (int i = 0; i < n; ++i) {
+      const int a = T.pa[i], c = T.ch[i];
+      if (a < 0 || a >= p.n_clusters || c < 0 || c >= p.n_clusters) {
+        p.err = "schedule tree " + std::to_string(t) + ": cluster index out of range";
+        return PGBP_ERR_INVALID;
+      }
+      if (i == 0) seen[a] = 1;
+      if (!seen.count(a) || seen.count(c)) {
+        p.err = "schedule tree " + std::to_string(t) + ", edge " + std::to_string(i) +
+                ": not a preorder edge list of a tree (parent unseen or child seen twice)";
+        return PGBP_ERR_NOT_TREE;
+      }
+      seen[c] = 1;
+      auto it = sepmap.find({std::min(a, c), std::max(a, c)});
+      if (it == sepmap.end()) {
+        p.err = "schedule tree " + std::to_string(t) + ", edge " + std::to_string(i) +
+                ": no sepset between clusters " + std::to_string(a) + " and " + std::to_string(c);
+        return PGBP_ERR_INVALID;
+      }
+      T.sep[i] = it->second;
+    }
+    build_traversals(p, T);
+  }
+  p.trees.swap(trees);
+  return PGBP_OK;
+}
+
+double plan_bytes_per_calibrate(const Plan& p, int64_t* n_messages) {
+  // 8*[(mf^2+mf+1) + 4*(s^2+s+1) + (s^2+s)] per message
+  double bytes = 0;
+  int64_t nm = 0;
+  for (const Tree& t : p.trees) {
+    for (const Traversal* tr : {&t.post, &t.pre}) {
+      for (const Entry& e : tr->entries) {
+        const MsgDesc& m = p.msgs[e.msg];
+        const double mf = m.mf, s = m.s;
+        bytes += 8.0 * ((mf * mf + mf + 1) + 4.0 * (s * s + s + 1) + (s * s + s));
+        ++nm;
+      }
+    }
+  }
+  if (n_messages) *n_messages = nm * p.n_sites;
+  return bytes * p.n_sites;
+}
+
+}  // namespace pgbp
+
+// ------------------------------------------------------------------ C ABI (host-only part)
+using pgbp::Plan;
+
+extern "C" {
+
+int pgbp_plan_create(const pgbp_desc* desc, pgbp_plan** out) {
+  if (!out) return PGBP_ERR_INVALID;
+  pgbp_plan* pl = new pgbp_plan();
+  int rc = pgbp::plan_build(pl->p, desc);
+  *out = pl;  // returned even on error so that the message can be read
+  return rc;
+}
+
+void pgbp_plan_destroy(pgbp_plan* p) { delete p; }
+
+int pgbp_plan_set_schedule(pgbp_plan* p, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
+                           const int32_t* ch_j) {
+  if (!p) return PGBP_ERR_INVALID;
+  return pgbp::plan_set_schedule(p->p, n_trees, tree_off, pa_j, ch_j);
+}
+
+int64_t pgbp_plan_packed_size(const pgbp_plan* p) { return p ? p->p.packed_off.back() : -1; }
+int64_t pgbp_plan_residual_size(const pgbp_plan* p) { return p ? p->p.rpacked_off.back() : -1; }
+int32_t pgbp_plan_n_messages(const pgbp_plan* p) { return p ? p->p.n_msgs() : -1; }
+
+static const pgbp::Traversal* get_trav(const pgbp_plan* p, int32_t tree, int32_t dir) {
+  if (!p || tree < 0 || tree >= (int)p->p.trees.size() || dir < 0 || dir > 1) return nullptr;
+  return dir == 0 ? &p->p.trees[tree].post : &p->p.trees[tree].pre;
+}
+
+int pgbp_plan_traversal_sizes(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_levels,
+                              int32_t* n_tasks, int32_t* n_entries) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr) return PGBP_ERR_INVALID;
+  if (n_levels) *n_levels = (int32_t)tr->level_off.size() - 1;
+  if (n_tasks) *n_tasks = (int32_t)tr->task_off.size() - 1;
+  if (n_entries) *n_entries = (int32_t)tr->entries.size();
+  return PGBP_OK;
+}
+
+int pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_off, int32_t* task_off,
+                        int32_t* entry_msg, int32_t* entry_edge, int32_t* entry_reuse) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr) return PGBP_ERR_INVALID;
+  if (level_off) std::copy(tr->level_off.begin(), tr->level_off.end(), level_off);
+  if (task_off) std::copy(tr->task_off.begin(), tr->task_off.end(), task_off);
+  for (size_t i = 0; i < tr->entries.size(); ++i) {
+    if (entry_msg) entry_msg[i] = tr->entries[i].msg;
+    if (entry_edge) entry_edge[i] = tr->entries[i].edge;
+    if (entry_reuse) entry_reuse[i] = tr->entries[i].reuse;
+  }
+  return PGBP_OK;
+}
+
+const char* pgbp_plan_last_error(const pgbp_plan* p) { return p ? p->p.err.c_str() : "null plan"; }
+
+}  // extern "C"

@@ -48,3 +48,63 @@ def oracle_setup(net, cg, model, tbl, taxa):
     b, (n2c, n2f, n2fix, n2d, c2n) = OB.allocatebeliefs(tbl, taxa, net, cg, model)
     OB.assignfactors(b, model, tbl, taxa, net, n2c, n2f, n2fix)
     return OB.ClusterGraphBelief(b, n2c, n2f, n2fix, c2n)
+
+
+# ---------------------------------------------------------------------------
+# bridges between the oracle's objects and the product's host mirror
+# ---------------------------------------------------------------------------
+
+def product_beliefs_from_oracle(obeliefs):
+    """Oracle CanonicalBelief list -> product CanonicalBelief list (same scopes, same h,J,g)."""
+    import pgbp_amd
+    out = []
+    for b in obeliefs:
+        pb = pgbp_amd.CanonicalBelief(b.nodelabel, b.ntraits, b.inscope, b.type, b.metadata)
+        pb.h[:] = b.h
+        pb.J[:] = b.J
+        pb.g[:] = b.g
+        out.append(pb)
+    return out
+
+
+def oracle_cgb_from_problem(prob, packed, p):
+    """Oracle ClusterGraphBelief with the scopes / values of a pgbp_amd.synth clique-tree Problem."""
+    nb = len(prob.dims)
+    nc = prob.nclusters
+    beliefs = []
+    for i in range(nb):
+        m = int(prob.dims[i])
+        if i < nc:
+            labs = [int(x) for x in prob.cluster_nodes[i]]
+            # which of (child, parent) is in scope: recover from dims and the scope maps
+            insc = np.zeros((p, 2), dtype=bool)
+            child_dim = prob.meta["child_dim"][i]
+            insc[:, 0] = child_dim > 0
+            insc[:, 1] = (m - child_dim) > 0
+            b = OB.CanonicalBelief(labs, p, insc, OB.CLUSTER, i)
+        else:
+            k = i - nc
+            a, c = prob.sepset_clusters[k]
+            b = OB.CanonicalBelief([int(prob.sepset_nodes[k])], p, np.full((p, 1), m > 0), OB.SEPSET, (int(a), int(c)))
+        o = prob.packed_off[i]
+        b.J[:] = packed[o:o + m * m].reshape(m, m, order="F")
+        b.h[:] = packed[o + m * m:o + m * m + m]
+        b.g[0] = packed[o + m * m + m]
+        beliefs.append(b)
+    return OB.ClusterGraphBelief(beliefs, None, None, None, None)
+
+
+def oracle_schedule(prob):
+    pa, ch = prob.schedule[0]
+    return ([int(x) for x in pa], [int(x) for x in ch], [int(x) for x in pa], [int(x) for x in ch])
+
+
+def pack_oracle(cgb, prob):
+    out = np.zeros(int(prob.packed_off[-1]))
+    for i, b in enumerate(cgb.belief):
+        m = b.dimension
+        o = prob.packed_off[i]
+        out[o:o + m * m] = b.J.reshape(-1, order="F")
+        out[o + m * m:o + m * m + m] = b.h
+        out[o + m * m + m] = b.g[0]
+    return out

@@ -1,0 +1,323 @@
+"""
+GPU parity tests (pytest -m gpu): the HIP engine, called through the C ABI
+(include/pgbp.h via the ctypes host mirror), against the CPU oracle on the same
+inputs and against the reference's golden values.
+
+Tolerance (BASELINE.json north_star: "log-likelihood matching to 1e-8"): relative,
+RTOL = 1e-8 on log-likelihoods; calibrated (J, h, g) within 1e-8 * max(1, |.|_inf)
+per belief (SURVEY.md section 8(d) parity gate).
+"""
+import logging
+
+import numpy as np
+import pytest
+
+from helpers import (goldens, make_model, oracle_cgb_from_problem, oracle_schedule, oracle_setup, pack_oracle,
+                     product_beliefs_from_oracle)
+from oracle import beliefs as OB
+from oracle import calibration as OC
+from oracle import clustergraph as OCG
+from oracle import network as ON
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+G = goldens()
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pgbp_amd
+    pgbp_amd.load()
+    return pgbp_amd
+
+
+def rel_close(a, b, rtol=RTOL):
+    return abs(a - b) <= rtol * max(1.0, abs(a), abs(b))
+
+
+def assert_beliefs_close(prod, orac, rtol=RTOL):
+    """prod: product ClusterGraphBelief (pulled); orac: oracle ClusterGraphBelief."""
+    for i, ob in enumerate(orac.belief):
+        pb = prod.belief[i]
+        for name, x, y in (("J", pb.J, ob.J), ("h", pb.h, ob.h), ("g", pb.g, ob.g)):
+            x, y = np.asarray(x), np.asarray(y)
+            if x.size == 0:
+                continue
+            scale = max(1.0, float(np.max(np.abs(y))))
+            err = float(np.max(np.abs(x - y)))
+            assert err <= rtol * scale, f"belief {i} {name}: err {err:.3e} scale {scale:.3e}"
+
+
+def build_both(P, net, cg, model, tbl, taxa):
+    ocgb = oracle_setup(net, cg, model, tbl, taxa)
+    pb = product_beliefs_from_oracle(ocgb.belief)
+    pcgb = P.ClusterGraphBelief(pb, ocgb.node2cluster, ocgb.node2family, ocgb.node2fixed, ocgb.cluster2nodes)
+    return ocgb, pcgb
+
+
+# ----------------------------------------------------------------------------- goldens
+
+def test_canonicalform_six_messages(P):
+    """test/test_canonicalform.jl:100-109 through pgbp_propagate."""
+    g = G["canonicalform_six_messages"]
+    net = ON.read_newick(g["net"])
+    net.set_preorder(g["preorder"])
+    names = [n.name for n in net.vec_node]
+    clusters = [("".join(names[i - 1] for i in nl), nl) for nl in g["cluster_nodelabels"]]
+    cg = OB.ClusterGraph(clusters, [tuple(e) for e in g["sepsets"]], "cliquetree")
+    ocgb, pcgb = build_both(P, net, cg, make_model(g["model"]), [g["y"]], g["taxa"])
+    for (to, sep, frm) in g["messages_1based"]:
+        assert P.propagate_belief_(pcgb, to - 1, sep - 1, frm - 1) is None
+        ob = ocgb.belief
+        assert OB.propagate_belief(ob[to - 1], ob[sep - 1], ob[frm - 1], OB.MessageResidual(ob[sep - 1].dimension)) is None
+        assert_beliefs_close(pcgb, ocgb)
+    mu, ll = P.integratebelief_(pcgb, g["root_belief_1based"] - 1)
+    assert rel_close(ll, g["ll"])
+    omu, oll = ocgb.integratebelief(g["root_belief_1based"] - 1)
+    assert np.allclose(mu, omu, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", G["evomodels_postorder"]["cases"], ids=lambda c: c["name"])
+def test_evomodels_postorder_ll(P, case):
+    """test/test_evomodels.jl:74-264: postorder traversal + integratebelief! at the root cluster."""
+    g = G["evomodels_postorder"]
+    net = ON.read_newick(g["net"])
+    tbl = [g[t] for t in case["traits"]]
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(case["model"]), tbl, g["taxa"])
+    assert P.propagate_1traversal_postorder_(pcgb, *spt)
+    _, ll = P.integratebelief_(pcgb, spt[2][0])
+    assert rel_close(ll, case["ll"]), (ll, case["ll"])
+    assert OC.propagate_1traversal_postorder(ocgb, *spt)
+    assert_beliefs_close(pcgb, ocgb)
+
+
+def _calibrate_every_belief(P, g, tbl, ll, atol=None):
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(g["model"]), tbl, g["taxa"])
+    succ, iscal = P.calibrate_(pcgb, [spt])
+    osucc, oiscal = OC.calibrate(ocgb, [spt])
+    assert succ and osucc and iscal == oiscal
+    assert_beliefs_close(pcgb, ocgb)
+    for i in range(len(ocgb.belief)):
+        mu, n = pcgb.integratebelief_(i)
+        omu, on = ocgb.integratebelief(i)
+        if atol is None:
+            assert rel_close(n, ll), (i, n, ll)
+        else:
+            assert abs(n - ll) <= atol
+        assert np.allclose(mu, omu, rtol=1e-8, atol=1e-8, equal_nan=True)
+    # residuals and calibration flags of every directed message
+    for key, omr in ocgb.messageresidual.items():
+        pmr = pcgb.messageresidual[key]
+        assert np.allclose(pmr.dJ, omr.dJ, rtol=1e-8, atol=1e-9)
+        assert np.allclose(pmr.dh, omr.dh, rtol=1e-8, atol=1e-9)
+        assert pmr.iscalibrated_resid == omr.iscalibrated_resid, key
+    return net, ct, spt, ocgb, pcgb
+
+
+def test_exactBM_tree_calibrate(P):
+    g = G["exactBM_tree_calibrate"]
+    _calibrate_every_belief(P, g, [g["y"]], g["ll"], atol=g["atol"])
+
+
+def test_calibration_cliquetree_level1(P):
+    g = G["calibration_cliquetree_level1"]
+    net, ct, spt, ocgb, pcgb = _calibrate_every_belief(P, g, [g["y"]], g["ll_every_belief"])
+    root_ind = next(i for i, be in enumerate(ocgb.belief) if 1 in be.nodelabel)
+    mu, _ = pcgb.integratebelief_(root_ind)
+    assert abs(mu[-1] - g["posterior_root_mean"]) <= g["rtol_posterior"] * abs(g["posterior_root_mean"])
+    # init_beliefs_reset_fromfactors! then calibrate again (test/test_calibration.jl:65-76)
+    pcgb.init_beliefs_reset_fromfactors_()
+    ocgb.init_beliefs_reset_fromfactors()
+    assert_beliefs_close(pcgb, ocgb, rtol=0.0)
+    assert P.calibrate_(pcgb, [spt])[0]
+    assert rel_close(pcgb.integratebelief_(0)[1], g["ll_every_belief"])
+
+
+def test_calibration_tree_2traits_missing(P):
+    """ragged scopes, a dimension-0 sepset, and the all-zero ("fake") marginalisation exit."""
+    g = G["calibration_tree_2traits_missing"]
+    _calibrate_every_belief(P, g, [g["y1"], g["y2"]], g["ll_every_belief"])
+
+
+def test_doctest_lazaridis(P):
+    g = G["doctest_lazaridis"]
+    _calibrate_every_belief(P, g, [g["x"]], g["ll"])
+
+
+# ----------------------------------------------------------------------------- failure semantics
+
+def test_bpposdef_returned_not_thrown(P, caplog):
+    """src/beliefupdates.jl:640-644, src/calibration.jl:129-132: a non-PD block is reported with the
+    reference's message text, nothing of that message is applied, calibrate! returns (false, false)."""
+    frm = P.CanonicalBelief([2, 1], 1, np.ones((1, 2), bool), P.bclustertype, "c21")
+    to = P.CanonicalBelief([3, 2], 1, np.ones((1, 2), bool), P.bclustertype, "c32")
+    sep = P.CanonicalBelief([2], 1, np.ones((1, 1), bool), P.bsepsettype, ("c32", "c21"))
+    frm.J[:] = [[1.0, 0.2], [0.2, -1.0]]
+    to.J[:] = [[2.0, 0.0], [0.0, 2.0]]
+    cgb = P.ClusterGraphBelief([frm, to, sep])
+    flag = P.propagate_belief_(cgb, 1, 2, 0)
+    assert isinstance(flag, P.BPPosDefException) and flag.info == 1
+    assert flag.msg == "belief c21, integrating [2]"
+    assert flag.showerror() == "BPPosDefException: belief c21, integrating [2]\nmatrix is not positive definite."
+    assert np.array_equal(cgb.belief[1].J, [[2.0, 0.0], [0.0, 2.0]]) and not cgb.belief[2].J.any()
+    with pytest.raises(P.BPPosDefException):
+        P.propagate_belief_(cgb, 1, 2, 0, withresidual=False)
+    spt = (["c32"], ["c21"], [1], [0])
+    with caplog.at_level(logging.INFO, logger="PhyloGaussianBeliefProp"):
+        assert P.calibrate_(cgb, [spt], 3, info=True) == (False, False)
+    assert "belief c21, integrating [2]" in caplog.text
+    assert "propagation failed: iteration 1, schedule tree 1" in caplog.text
+    r = cgb.last_results[0]
+    assert (r.fail_iter, r.fail_tree, r.fail_dir, r.fail_edge, r.fail_info) == (1, 1, 0, 0, 1)
+    # the other direction works: marginalising c32 (J = 2I) onto node 2
+    assert P.propagate_belief_(cgb, 0, 2, 1) is None
+
+
+def test_first_failure_is_the_reference_order_first(P):
+    """Two failing leaf messages in the same level: the reported one is the first in the reference's
+    sequential order (postorder = decreasing edge index, src/calibration.jl:121)."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(11)
+    tr = S.random_tree(40, rng)
+    p = 2
+    prob = S.cliquetree_of_tree(tr, p)
+    R = S.random_rate_matrix(p, rng)
+    mu = np.zeros(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    packed = S.bm_factors_cliquetree(tr, prob, R, mu, X)
+    pa, ch = prob.schedule[0]
+    # break two internal cliques whose messages integrate something (dim 2p senders)
+    senders = [i for i in range(len(pa)) if prob.dims[ch[i]] == 2 * p]
+    bad = [senders[2], senders[-3]]
+    for i in bad:
+        o = prob.packed_off[ch[i]]
+        packed[o] = -1.0e6   # J[0,0] << 0 even after the children's messages: first pivot fails, info = 1
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    assert P.calibrate_(cgb, prob.schedule, verbose=False) == (False, False)
+    r = cgb.last_results[0]
+    assert r.fail_dir == 0 and r.fail_info == 1 and r.fail_edge == max(bad)
+
+
+def test_auto_stop_and_info_log(P, caplog):
+    """calibrate!(...; auto=true, info=true): on a clique tree calibration is reached at iteration 2
+    (the second pass changes nothing), and the log line is the reference's (src/calibration.jl:54)."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(g["model"]), [g["y"]], g["taxa"])
+    olog = []
+    ores = OC.calibrate(ocgb, [spt], 5, auto=True, info=True, log=olog)
+    with caplog.at_level(logging.INFO, logger="PhyloGaussianBeliefProp"):
+        pres = P.calibrate_(pcgb, [spt], 5, auto=True, info=True)
+    assert pres == ores == (True, True)
+    assert olog[-1][1] in caplog.text
+    assert_beliefs_close(pcgb, ocgb)
+
+
+# ----------------------------------------------------------------------------- random trees vs the oracle
+
+@pytest.mark.parametrize("ntips,p,kind", [(2, 1, "random"), (3, 1, "random"), (9, 1, "random"), (33, 2, "random"),
+                                          (64, 3, "random"), (100, 8, "random"), (60, 16, "random"),
+                                          (24, 16, "caterpillar"), (17, 32, "random")])
+def test_random_tree_cliquetree_vs_oracle(P, ntips, p, kind):
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(1000 * p + ntips)
+    tr = S.random_tree(ntips, rng) if kind == "random" else S.caterpillar_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    mu = rng.standard_normal(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, mu, X)
+    pcgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    ocgb = oracle_cgb_from_problem(prob, packed, p)
+    spt = oracle_schedule(prob)
+    # postorder only -> log-likelihood (src/calibration.jl:205-212)
+    assert P.propagate_1traversal_postorder_(pcgb, *spt)
+    assert OC.propagate_1traversal_postorder(ocgb, *spt)
+    ll = pcgb.integratebelief_(prob.root_cluster)[1]
+    assert rel_close(ll, ocgb.integratebelief(prob.root_cluster)[1])
+    assert rel_close(ll, S.bm_loglik_pruning(tr, R, mu, X))
+    # full calibration
+    pcgb.init_beliefs_reset_fromfactors_()
+    pcgb.init_messagecalibrationflags_reset_()
+    ocgb.init_beliefs_reset_fromfactors()
+    ocgb.init_messagecalibrationflags_reset()
+    pres = P.calibrate_(pcgb, prob.schedule, 2)
+    ores = OC.calibrate(ocgb, [spt], 2)
+    assert pres == ores == (True, True)
+    assert_beliefs_close(pcgb, ocgb)
+    ref = pack_oracle(ocgb, prob)
+    # every belief integrates to the same log-likelihood
+    for i in range(0, len(prob.dims), max(1, len(prob.dims) // 25)):
+        assert rel_close(pcgb.integratebelief_(i)[1], ll)
+
+
+def test_multi_site_batch(P):
+    """n_sites independent replicas (different data) in one engine == one engine per site."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(77)
+    tr = S.random_tree(30, rng)
+    p, ns = 2, 5
+    prob = S.cliquetree_of_tree(tr, p)
+    R = S.random_rate_matrix(p, rng)
+    mu = np.zeros(p)
+    packs, lls = [], []
+    for s in range(ns):
+        X = S.simulate_bm(tr, R, mu, rng)
+        packs.append(S.bm_factors_cliquetree(tr, prob, R, mu, X))
+        lls.append(S.bm_loglik_pruning(tr, R, mu, X))
+    big = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                           np.stack(packs), n_sites=ns)
+    assert P.calibrate_(big, prob.schedule) == (True, True)
+    mu_all, norm, info = big.integratebelief_(prob.root_cluster, all_sites=True)
+    assert not info.any()
+    for s in range(ns):
+        assert rel_close(norm[s], lls[s])
+        single = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off,
+                                                  prob.scope_idx, packs[s])
+        assert P.calibrate_(single, prob.schedule) == (True, True)
+        assert np.array_equal(single._packed[0], big._packed[s])   # bit-identical
+
+
+def test_bethe_tree_vs_cliquetree(P):
+    """cfg2 shape: the Bethe cluster graph of a tree is a tree, so one calibration is exact."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(5)
+    tr = S.random_tree(50, rng)
+    p = 3
+    R = S.random_rate_matrix(p, rng)
+    mu = rng.standard_normal(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    prob = S.bethe_of_tree(tr, p)
+    n = tr.ntips
+    assert prob.nclusters == 3 * n - 3 and len(prob.dims) - prob.nclusters == 3 * n - 4  # test_clustergraph.jl:41-52
+    packed = S.bm_factors_bethe(tr, prob, R, mu, X)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
+    ll = S.bm_loglik_pruning(tr, R, mu, X)
+    for i in range(0, len(prob.dims), 7):
+        assert rel_close(cgb.integratebelief_(i)[1], ll)
+
+
+def test_run_to_run_bitwise_deterministic(P):
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(9)
+    tr = S.random_tree(200, rng)
+    p = 4
+    R = S.random_rate_matrix(p, rng)
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    outs = []
+    for _ in range(3):
+        cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+        assert P.calibrate_(cgb, prob.schedule) == (True, True)
+        outs.append(cgb._packed.copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

@@ -1,0 +1,227 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/pgbp.h
+declares; the host-only planner (layout, message table, level schedule) is correct;
+the product has no CPU fallback; the vectorised synthetic factor fill agrees with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pgbp_amd
+from pgbp_amd import _lib as L
+from pgbp_amd import synth as S
+
+from helpers import oracle_cgb_from_problem, oracle_schedule, pack_oracle
+from oracle import beliefs as OB
+from oracle import calibration as OC
+from oracle import clustergraph as OCG
+from oracle import models as OM
+from oracle import network as ON
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pgbp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pgbp_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = C.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libpgbp.so does not export {name}"
+    assert declared == set(L.SYMBOLS.keys())
+    pgbp_amd.load()
+
+
+def _plan(prob, n_sites=1):
+    lib = pgbp_amd.load()
+    desc, keep = L.make_desc(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, n_sites, 0)
+    pl = C.c_void_p()
+    code = lib.pgbp_plan_create(C.byref(desc), C.byref(pl))
+    return lib, pl, code, keep
+
+
+def _set_sched(lib, pl, schedule):
+    off = np.zeros(len(schedule) + 1, np.int32)
+    for i, (pa, ch) in enumerate(schedule):
+        off[i + 1] = off[i] + len(pa)
+    pa = np.ascontiguousarray(np.concatenate([s[0] for s in schedule]).astype(np.int32))
+    ch = np.ascontiguousarray(np.concatenate([s[1] for s in schedule]).astype(np.int32))
+    return lib.pgbp_plan_set_schedule(pl, len(schedule), L.i32p(off), L.i32p(pa), L.i32p(ch))
+
+
+def _traversal(lib, pl, tree, d):
+    nl, nt, ne = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.pgbp_plan_traversal_sizes(pl, tree, d, C.byref(nl), C.byref(nt), C.byref(ne)) == 0
+    lo = np.zeros(nl.value + 1, np.int32)
+    to = np.zeros(nt.value + 1, np.int32)
+    em, ee, er = (np.zeros(max(1, ne.value), np.int32) for _ in range(3))
+    assert lib.pgbp_plan_traversal(pl, tree, d, L.i32p(lo), L.i32p(to), L.i32p(em), L.i32p(ee), L.i32p(er)) == 0
+    return lo, to, em[:ne.value], ee[:ne.value], er[:ne.value]
+
+
+@pytest.mark.parametrize("ntips,p,kind", [(2, 1, "random"), (3, 2, "random"), (40, 3, "random"), (500, 2, "random"),
+                                          (30, 2, "caterpillar")])
+def test_level_schedule_invariants(ntips, p, kind):
+    rng = np.random.default_rng(ntips)
+    tr = S.random_tree(ntips, rng) if kind == "random" else S.caterpillar_tree(ntips, rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0, lib.pgbp_plan_last_error(pl)
+    assert lib.pgbp_plan_packed_size(pl) == prob.packed_off[-1]
+    assert lib.pgbp_plan_n_messages(pl) == 2 * (len(prob.dims) - prob.nclusters)
+    assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
+    pa, ch = prob.schedule[0]
+    n = len(pa)
+    sepcl = prob.sepset_clusters
+    for d in (0, 1):
+        lo, to, em, ee, er = _traversal(lib, pl, 0, d)
+        assert sorted(ee.tolist()) == list(range(n))          # every edge exactly once
+        level_of_edge = np.zeros(n, int)
+        for Lv in range(len(lo) - 1):
+            targets, senders = set(), set()
+            for t in range(lo[Lv], lo[Lv + 1]):
+                ents = list(range(to[t], to[t + 1]))
+                assert ents
+                for e in ents:
+                    i = ee[e]
+                    level_of_edge[i] = Lv
+                    snd, rcv = (ch[i], pa[i]) if d == 0 else (pa[i], ch[i])
+                    k = em[e] // 2
+                    assert {int(sepcl[k][0]), int(sepcl[k][1])} == {int(pa[i]), int(ch[i])}
+                    assert int(sepcl[k][em[e] % 2]) == int(rcv)   # dir 0: received by a
+                    senders.add(int(snd))
+                    targets.add(int(rcv))
+                edges = [ee[e] for e in ents]
+                if d == 0:   # one task per target, entries in the reference's order (decreasing edge index)
+                    assert len({int(pa[i]) for i in edges}) == 1
+                    assert edges == sorted(edges, reverse=True)
+                else:        # one task per sender, increasing edge index
+                    assert len({int(pa[i]) for i in edges}) == 1
+                    assert edges == sorted(edges)
+                    assert er[to[t]] == 0
+            if d == 0:
+                tl = [int(pa[ee[to[t]]]) for t in range(lo[Lv], lo[Lv + 1])]
+                assert len(tl) == len(set(tl))                  # distinct targets across tasks
+            assert not (targets & senders)                      # no cluster both read and written in a level
+        # dependencies: postorder: a child's incoming messages precede its outgoing one
+        child_edge = {int(c): i for i, c in enumerate(ch)}
+        for i in range(n):
+            if int(pa[i]) in child_edge:
+                j = child_edge[int(pa[i])]   # edge above pa[i]
+                if d == 0:
+                    assert level_of_edge[i] < level_of_edge[j]
+                else:
+                    assert level_of_edge[j] < level_of_edge[i]
+        if kind == "caterpillar" and d == 1:
+            assert len(lo) - 1 >= ntips - 2
+    lib.pgbp_plan_destroy(pl)
+
+
+def test_preorder_marginal_reuse_flag():
+    rng = np.random.default_rng(1)
+    tr = S.random_tree(50, rng)
+    prob = S.cliquetree_of_tree(tr, 2)
+    lib, pl, code, keep = _plan(prob)
+    assert _set_sched(lib, pl, prob.schedule) == 0
+    lo, to, em, ee, er = _traversal(lib, pl, 0, 1)
+    assert er.sum() > 0          # internal cliques send the same marginal to both children
+    lo, to, em, ee, er = _traversal(lib, pl, 0, 0)
+    assert er.sum() == 0
+    lib.pgbp_plan_destroy(pl)
+
+
+def test_plan_rejects_bad_input():
+    rng = np.random.default_rng(5)
+    tr = S.random_tree(6, rng)
+    prob = S.cliquetree_of_tree(tr, 2)
+    lib, pl, code, keep = _plan(prob)
+    pa, ch = prob.schedule[0]
+    # child seen twice / parent unseen -> not a tree
+    bad = (pa.copy(), ch.copy())
+    bad[1][-1] = bad[1][0]
+    assert _set_sched(lib, pl, [bad]) == L.ERR_NOT_TREE
+    bad = (pa[::-1].copy(), ch[::-1].copy())
+    assert _set_sched(lib, pl, [bad]) in (L.ERR_NOT_TREE, L.ERR_INVALID)
+    assert b"schedule tree 0" in lib.pgbp_plan_last_error(pl)
+    lib.pgbp_plan_destroy(pl)
+    # scope indices not increasing (labels out of order: src/beliefs.jl:398)
+    p2 = S.cliquetree_of_tree(tr, 2)
+    k = np.nonzero(np.diff(p2.scope_off) == 2)[0][0]
+    p2.scope_idx[p2.scope_off[k]:p2.scope_off[k] + 2] = p2.scope_idx[p2.scope_off[k]:p2.scope_off[k] + 2][::-1]
+    lib, pl, code, keep = _plan(p2)
+    assert code == L.ERR_INVALID and b"strictly increasing" in lib.pgbp_plan_last_error(pl)
+    lib.pgbp_plan_destroy(pl)
+    # dimension above PGBP_MAX_DIM is refused, not silently mishandled
+    p3 = S.cliquetree_of_tree(tr, 40)
+    lib, pl, code, keep = _plan(p3)
+    assert code == L.ERR_TOO_LARGE
+    lib.pgbp_plan_destroy(pl)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly (skipped on a GPU box)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    tr = S.random_tree(4, np.random.default_rng(0))
+    prob = S.cliquetree_of_tree(tr, 1)
+    with pytest.raises(pgbp_amd.PgbpError) as ei:
+        pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                                np.zeros(int(prob.packed_off[-1])))
+    assert ei.value.code == L.ERR_NO_DEVICE
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "phylogaussianbeliefprop.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert "oracle/" not in txt, f
+
+
+@pytest.mark.parametrize("ntips,p", [(2, 1), (5, 1), (12, 2), (40, 3)])
+def test_synth_factors_match_oracle_assignfactors(ntips, p):
+    """pgbp_amd.synth's vectorised BM factor fill == the oracle's assignfactors! restatement, and the
+    oracle's calibrated log-likelihood == dense MVN == the pruning check."""
+    from oracle import densemvn as OD
+    rng = np.random.default_rng(100 + ntips)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    mu = rng.standard_normal(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, mu, X)
+    # oracle route: Newick -> network -> our explicit clique tree -> allocate + assignfactors
+    names = [f"n{i}" for i in range(tr.nnodes)]
+    net = ON.read_newick(tr.newick(names))
+    net.set_preorder(names)
+    taxa = [names[i] for i in range(tr.nnodes) if tr.is_leaf[i]]
+    tbl = [[float(X[i, t]) for i in range(tr.nnodes) if tr.is_leaf[i]] for t in range(p)]
+    clusters = [(str(i), [int(a), int(b)]) for i, (a, b) in enumerate(prob.cluster_nodes)]
+    edges = [(int(a), int(b), [int(prob.sepset_nodes[k])]) for k, (a, b) in enumerate(prob.sepset_clusters)]
+    cg = OB.ClusterGraph(clusters, edges, "cliquetree")
+    model = OM.MvFullBrownianMotion(R, mu)
+    b, (n2c, n2f, n2fix, n2d, c2n) = OB.allocatebeliefs(tbl, taxa, net, cg, model)
+    assert [x.dimension for x in b] == prob.dims.tolist()
+    OB.assignfactors(b, model, tbl, taxa, net, n2c, n2f, n2fix)
+    cgb = OB.ClusterGraphBelief(b, n2c, n2f, n2fix, c2n)
+    ref = pack_oracle(cgb, prob)
+    assert np.allclose(packed, ref, rtol=1e-12, atol=1e-12)
+    # scope maps agree with the reference's scopeindex
+    for k, (a, c) in enumerate(prob.sepset_clusters):
+        sb = b[prob.nclusters + k]
+        for side, cl in enumerate((a, c)):
+            ind = OB.scopeindex(sb, b[cl])
+            o0, o1 = prob.scope_off[2 * k + side], prob.scope_off[2 * k + side + 1]
+            assert ind.tolist() == prob.scope_idx[o0:o1].tolist()
+    spt = ([str(x) for x in prob.schedule[0][0]], [str(x) for x in prob.schedule[0][1]],
+           prob.schedule[0][0].tolist(), prob.schedule[0][1].tolist())
+    assert OC.calibrate(cgb, [spt])[0]
+    ll = cgb.integratebelief(prob.root_cluster)[1]
+    dense = OD.loglik(net, model, tbl, taxa)
+    assert abs(ll - dense) <= 1e-9 * max(1, abs(dense))
+    assert abs(S.bm_loglik_pruning(tr, R, mu, X) - dense) <= 1e-9 * max(1, abs(dense))
