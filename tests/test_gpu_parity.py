@@ -275,14 +275,14 @@ def test_multi_site_batch(P):
         lls.append(S.bm_loglik_pruning(tr, R, mu, X))
     big = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
                                            np.stack(packs), n_sites=ns)
-    assert P.calibrate_(big, prob.schedule) == (True, True)
+    assert P.calibrate_(big, prob.schedule, 2) == (True, True)
     mu_all, norm, info = big.integratebelief_(prob.root_cluster, all_sites=True)
     assert not info.any()
     for s in range(ns):
         assert rel_close(norm[s], lls[s])
         single = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off,
                                                   prob.scope_idx, packs[s])
-        assert P.calibrate_(single, prob.schedule) == (True, True)
+        assert P.calibrate_(single, prob.schedule, 2) == (True, True)
         assert np.array_equal(single._packed[0], big._packed[s])   # bit-identical
 
 
@@ -318,6 +318,6 @@ def test_run_to_run_bitwise_deterministic(P):
     outs = []
     for _ in range(3):
         cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
-        assert P.calibrate_(cgb, prob.schedule) == (True, True)
+        assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
         outs.append(cgb._packed.copy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
