@@ -108,6 +108,9 @@ int  pgbp_plan_traversal_sizes(const pgbp_plan* p, int32_t tree, int32_t dir,
                                int32_t* n_levels, int32_t* n_tasks, int32_t* n_entries);
 int  pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_off,
                          int32_t* task_off, int32_t* entry_msg, int32_t* entry_edge, int32_t* entry_reuse);
+/* level_nfast[n_levels]: how many tasks of each level (they come first) run on the register-resident
+ * kernel; the rest run on the generic in-LDS kernel. */
+int  pgbp_plan_level_nfast(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_nfast);
 const char* pgbp_plan_last_error(const pgbp_plan* p);
 
 /* ---- engine lifetime ------------------------------------------------------------------ */

@@ -155,7 +155,10 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
       (void)hipEventCreate(&b);
       (void)hipEventRecord(a, e->st);
     }
-    launch_level_generic(S, d.d_task_off, d.d_entries, t0, nt, e->plan.n_sites, seq_base, stop_below, tr.max_mf, e->st);
+    const int nf = tr.level_nfast[L];
+    launch_level_fast16(S, d.d_task_off, d.d_entries, t0, nf, e->plan.n_sites, seq_base, stop_below, e->st);
+    launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
+                         tr.max_mf, e->st);
     if (ev) {
       (void)hipEventRecord(b, e->st);
       ev->push_back({a, b});
@@ -477,7 +480,7 @@ static int collect_results(pgbp_engine* e, pgbp_result* results, const std::vect
       decode_fail(e, keys[s], r);
     } else {
       r.succ = 1;
-      r.iscal = iscal[s];
+      r.iscal = iscal[s] != 0;
     }
     if (hist && r.succ) {
       for (int q = 0; q < n_pairs; ++q)

@@ -30,10 +30,14 @@ struct Entry {
   int32_t edge;   // position in the tree's edge list
   int32_t reuse;  // 1: same sender and same keep indices as the previous entry of the task
   int32_t seq;    // position in the reference's sequential order of one (post, pre) pair
+  int32_t tflags; // fast kernels: bit 0 = load the receiver's block before this entry, bit 1 = store it after
+  int32_t pad[3];
 };
+constexpr int kTLoad = 1, kTStore = 2;
 
 struct Traversal {
-  std::vector<int32_t> level_off;  // [n_levels+1] -> tasks
+  std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first
+  std::vector<int32_t> level_nfast;  // [n_levels] how many of the level's tasks run on the fast kernel
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;
@@ -59,6 +63,7 @@ struct Plan {
   std::vector<int32_t> idxpool;
   std::vector<Tree> trees;
   int32_t max_dim = 0;
+  int32_t fast_p = 0;  // sepset dimension the register-resident kernel is instantiated for (0: none)
   std::string err;
 
   int32_t n_beliefs() const { return n_clusters + n_sepsets; }

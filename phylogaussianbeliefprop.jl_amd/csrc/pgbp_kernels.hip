@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
         S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
       }
     }
-    __threadfence_block();  // next entry of the task may read-modify-write the same receiver
+    if (e + 1 < e1) __threadfence_block();  // next entry of the task may read-modify-write the same receiver
   }
 }
 
@@ -361,22 +361,22 @@ void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int 
                      kldiv, n_msgs, reset_kl);
 }
 
-// iscalibrated_residnorm(beliefs) = all flags (src/clustergraphbeliefs.jl:168-169)
+// iscalibrated_residnorm(beliefs) = all flags (src/clustergraphbeliefs.jl:168-169).
+// iscal[site] is preset to non-zero by a memset node; any block that sees a false flag clears it.
 __global__ __launch_bounds__(256) void reduce_flags_kernel(const int32_t* __restrict__ flags, int n_msgs,
                                                            int32_t* __restrict__ iscal) {
-  const int site = blockIdx.x;
-  __shared__ int any_false;
-  if (threadIdx.x == 0) any_false = 0;
-  __syncthreads();
+  const int site = blockIdx.y;
   int bad = 0;
-  for (int d = threadIdx.x; d < n_msgs; d += blockDim.x) bad |= (flags[(int64_t)site * n_msgs + d] == 0);
-  if (bad) any_false = 1;
-  __syncthreads();
-  if (threadIdx.x == 0) iscal[site] = any_false ? 0 : 1;
+  for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < n_msgs; d += gridDim.x * blockDim.x)
+    bad |= (flags[(int64_t)site * n_msgs + d] == 0);
+  if (__any(bad) && (threadIdx.x & 63) == 0) iscal[site] = 0;
 }
 
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_flags_kernel, dim3(n_sites), dim3(256), 0, st, flags, n_msgs, d_iscal);
+  (void)hipMemsetAsync(d_iscal, 0x01, sizeof(int32_t) * (size_t)n_sites, st);
+  if (n_msgs <= 0) return;
+  hipLaunchKernelGGL(reduce_flags_kernel, dim3(grid_for(n_msgs, n_sites), n_sites), dim3(256), 0, st, flags,
+                     n_msgs, d_iscal);
 }
 
 }  // namespace pgbp

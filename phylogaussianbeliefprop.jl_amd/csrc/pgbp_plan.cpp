@@ -136,7 +136,61 @@ int plan_build(Plan& p, const pgbp_desc* d) {
     }
   }
   p.trees.clear();
+  // the register-resident kernel exists for sepsets of dimension 16 (pgbp_fast.hip)
+  p.fast_p = 0;
+  for (int k = 0; k < p.n_sepsets; ++k)
+    if (p.dims[p.n_clusters + k] == 16) p.fast_p = 16;
   return PGBP_OK;
+}
+
+// Shape class of the register-resident kernel (pgbp_fast.hip): sepset of dimension P, sender of
+// dimension P (nothing integrated) or 2P (the other P-block integrated), receiver of dimension P or 2P,
+// every index map one contiguous P-block.  This is every message of a BM clique tree / Bethe graph of a
+// tree without missing data (m = k*p, s = p).
+static bool fast_msg(const MsgDesc& m, int P) {
+  if (P <= 0 || m.s != P) return false;
+  const bool snd = (m.mf == P && m.ni == 0 && m.keep0 == 0) ||
+                   (m.mf == 2 * P && m.ni == P && (m.keep0 == 0 || m.keep0 == P));
+  const bool rcv = (m.mt == P && m.up0 == 0) || (m.mt == 2 * P && (m.up0 == 0 || m.up0 == P));
+  return snd && rcv;
+}
+
+// Reorder the tasks of every level so that fast-class tasks come first; set the receiver load/store flags.
+static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
+  const int nlev = (int)tr.level_off.size() - 1;
+  std::vector<int32_t> new_task_off{0};
+  std::vector<Entry> new_entries;
+  new_entries.reserve(tr.entries.size());
+  tr.level_nfast.assign(nlev, 0);
+  tr.max_mf = 0;
+  for (int L = 0; L < nlev; ++L) {
+    std::vector<int> fast, slow;
+    for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) {
+      bool f = true;
+      for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e) f = f && fast_msg(p.msgs[tr.entries[e].msg], p.fast_p);
+      (f ? fast : slow).push_back(t);
+    }
+    tr.level_nfast[L] = (int32_t)fast.size();
+    for (const auto* grp : {&fast, &slow})
+      for (int t : *grp) {
+        const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];
+        bool same_block = postorder;
+        for (int e = e0 + 1; e < e1 && same_block; ++e) {
+          const MsgDesc& x = p.msgs[tr.entries[e0].msg];
+          const MsgDesc& y = p.msgs[tr.entries[e].msg];
+          same_block = x.to_b == y.to_b && x.up0 == y.up0 && x.s == y.s && x.up0 >= 0;
+        }
+        for (int e = e0; e < e1; ++e) {
+          Entry en = tr.entries[e];
+          en.tflags = same_block ? ((e == e0 ? kTLoad : 0) | (e == e1 - 1 ? kTStore : 0)) : (kTLoad | kTStore);
+          new_entries.push_back(en);
+          if (grp == &slow) tr.max_mf = std::max(tr.max_mf, p.msgs[en.msg].mf);
+        }
+        new_task_off.push_back((int32_t)new_entries.size());
+      }
+  }
+  tr.task_off.swap(new_task_off);
+  tr.entries.swap(new_entries);
 }
 
 static void build_traversals(const Plan& p, Tree& t) {
@@ -181,7 +235,7 @@ static void build_traversals(const Plan& p, Tree& t) {
       }
       for (auto& tk : tasks) {
         for (int i : tk) {
-          Entry e;
+          Entry e{};
           e.msg = msg_to(i, t.pa[i]);
           e.edge = i;
           e.reuse = 0;
@@ -193,6 +247,7 @@ static void build_traversals(const Plan& p, Tree& t) {
       }
       tr.level_off.push_back((int)tr.task_off.size() - 1);
     }
+    finalize_traversal(p, tr, true);
   }
   // ---- preorder: level = depth of the parent; tasks group by sender
   {
@@ -228,7 +283,7 @@ static void build_traversals(const Plan& p, Tree& t) {
       for (auto& tk : tasks) {
         int prev_msg = -1;
         for (int i : tk) {
-          Entry e;
+          Entry e{};
           e.msg = msg_to(i, t.ch[i]);
           e.edge = i;
           e.seq = n + i;
@@ -249,6 +304,7 @@ static void build_traversals(const Plan& p, Tree& t) {
       }
       tr.level_off.push_back((int)tr.task_off.size() - 1);
     }
+    finalize_traversal(p, tr, false);
   }
 }
 
@@ -359,6 +415,13 @@ int pgbp_plan_traversal_sizes(const pgbp_plan* p, int32_t tree, int32_t dir, int
   if (n_levels) *n_levels = (int32_t)tr->level_off.size() - 1;
   if (n_tasks) *n_tasks = (int32_t)tr->task_off.size() - 1;
   if (n_entries) *n_entries = (int32_t)tr->entries.size();
+  return PGBP_OK;
+}
+
+int pgbp_plan_level_nfast(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_nfast) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr || !level_nfast) return PGBP_ERR_INVALID;
+  std::copy(tr->level_nfast.begin(), tr->level_nfast.end(), level_nfast);
   return PGBP_OK;
 }
 
