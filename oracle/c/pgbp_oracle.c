@@ -65,7 +65,7 @@ orc_t* orc_create(int nc, int ns, const int32_t* dims, const int32_t* sepcl, con
   o->pool = (double*)xmalloc(sizeof(double) * o->off[nb]);
   memcpy(o->pool, packed, sizeof(double) * o->off[nb]);
   o->res = (double*)calloc((size_t)(o->roff[2 * ns] ? o->roff[2 * ns] : 1), sizeof(double));
-  o->flags = (int32_t*)xmalloc(sizeof(int32_t) * (2 * ns ? 2 * ns : 1));
+  o->flags = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(ns > 0 ? 2 * ns : 1));
   for (int d = 0; d < 2 * ns; ++d) o->flags[d] = dims[nc + d / 2] == 0;  /* empty messages born calibrated */
   int M = o->maxdim;
   o->work = (double*)xmalloc(sizeof(double) * (size_t)(4 * M * M + 8 * M + 8));
@@ -254,7 +254,7 @@ int orc_integrate(orc_t* o, int b, double* mu, double* norm) {
   for (int i = 0; i < m * m && !nz; ++i) if (J[i] != 0.0) nz = 1;
   for (int i = 0; i < m && !nz; ++i) if (h[i] != 0.0) nz = 1;
   if (!nz) { for (int i = 0; i < m; ++i) mu[i] = INFINITY; *norm = g; return 0; }
-  double* U = (double*)xmalloc(sizeof(double) * (size_t)(m * m ? m * m : 1));
+  double* U = (double*)xmalloc(sizeof(double) * (size_t)(m > 0 ? m * m : 1));
   for (int c = 0; c < m; ++c) for (int r = 0; r <= c; ++r) U[r + (size_t)c * m] = J[r + (size_t)c * m];
   int info = chol_upper(U, m);
   if (info) { free(U); *norm = NAN; return info; }

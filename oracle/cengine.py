@@ -19,8 +19,9 @@ def use_native_build():
     Must be called before the first lib()."""
     global _lib
     so = os.path.join(_HERE, "_build", "libpgbp_oracle_native.so")
-    subprocess.check_call(["make", "-B", "-C", os.path.join(_HERE, "c"), f"OUT={so}",
-                           "CFLAGS=-O3 -march=native -std=c99 -fPIC -shared -Wall"])
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(_HERE, "c"), f"OUT={so}",
+                           "CFLAGS=-O3 -march=native -std=c99 -fPIC -shared -w"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     _lib = None
     return _load(so)
 
@@ -36,7 +37,7 @@ def _load(so):
 def lib():
     if _lib is None:
         if not os.path.exists(_SO):
-            subprocess.check_call(["make", "-C", os.path.join(_HERE, "c")])
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "c")], stdout=subprocess.DEVNULL)
         _load(_SO)
     return _lib
 

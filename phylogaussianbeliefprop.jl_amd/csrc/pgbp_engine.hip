@@ -21,6 +21,7 @@ std::string g_create_error;
 struct DevTraversal {
   int32_t* d_task_off = nullptr;
   Entry* d_entries = nullptr;
+  FEntry* d_fentries = nullptr;
 };
 
 }  // namespace
@@ -120,6 +121,7 @@ void free_traversals(pgbp_engine* e) {
     for (auto& d : *v) {
       if (d.d_task_off) (void)hipFree(d.d_task_off);
       if (d.d_entries) (void)hipFree(d.d_entries);
+      if (d.d_fentries) (void)hipFree(d.d_fentries);
     }
     v->clear();
   }
@@ -156,7 +158,8 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
       (void)hipEventRecord(a, e->st);
     }
     const int nf = tr.level_nfast[L];
-    launch_level_fast16(S, d.d_task_off, d.d_entries, t0, nf, e->plan.n_sites, seq_base, stop_below, e->st);
+    launch_level_fast16(S, d.d_fentries + tr.level_fbase[L], tr.level_fk[L], nf, e->plan.n_sites, seq_base,
+                        stop_below, e->st);
     launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
                          tr.max_mf, e->st);
     if (ev) {
@@ -416,6 +419,7 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       DevTraversal& d = dir == 0 ? e->dpost[t] : e->dpre[t];
       if ((rc = upload(e, &d.d_task_off, tr.task_off))) return rc;
       if ((rc = upload(e, &d.d_entries, tr.entries))) return rc;
+      if ((rc = upload(e, &d.d_fentries, tr.fentries))) return rc;
     }
   }
   return PGBP_OK;

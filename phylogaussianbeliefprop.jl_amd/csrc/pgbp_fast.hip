@@ -86,52 +86,75 @@ __device__ __forceinline__ int eliminate(Frag& f, const int a, const int b, doub
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void bp_level_fast16(DevState S, const int32_t* __restrict__ task_off,
-                                                      const Entry* __restrict__ entries, int task0,
-                                                      unsigned long long seq_base, unsigned long long stop_below) {
-  const int lane = threadIdx.x;
+// LDS hand-over slot of one wave: 2 x 2 block per lane (256 doubles, lane-major), h (16), g, status
+constexpr int kSlotJ = 0, kSlotH = 256, kSlotG = 272, kSlotStatus = 273, kSlotDoubles = 288;
+
+extern __shared__ double fast_lds[];
+
+// One workgroup = one task; wave w of the workgroup = message w of the task (records padded to K per task).
+//   * accumulate tasks (postorder, several children into one receiver block): every wave computes its
+//     message and divides; waves > 0 hand their delta to wave 0 through LDS; wave 0 adds the deltas in the
+//     reference's order and stores the receiver block once;
+//   * reuse (preorder, one sender, several children): the providing wave computes the marginal once and
+//     hands it to the others through LDS; every wave divides by its own sepset and updates its own receiver.
+__global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry* __restrict__ recs, int K,
+                                                       unsigned long long seq_base,
+                                                       unsigned long long stop_below) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
-  if ((S.fail[site] >> kInfoBits) < stop_below) return;  // an earlier traversal failed (see bp_level_generic)
-  const int task = task0 + blockIdx.x;
   const int a = lane & 7, b = lane >> 3;
+  const FEntry en = recs[(int64_t)blockIdx.x * K + wave];
+  const unsigned long long failkey = S.fail[site];
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  double* slot = fast_lds + wave * kSlotDoubles;
 
-  double mJ[2][2] = {{0, 0}, {0, 0}}, mh[2] = {0, 0}, gmsg = 0.0;  // the message: rows 2a+ii, cols 2b+jj
-  double tJ[2][2] = {{0, 0}, {0, 0}}, th[2] = {0, 0}, tg = 0.0;    // receiver block accumulators
-  const int e0 = task_off[task], e1 = task_off[task + 1];
-  for (int e = e0; e < e1; ++e) {
-    const Entry en = entries[e];
-    const MsgDesc m = S.msgs[en.msg];
-    if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
-      if (lane == 0) S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
-      return;
+  // state 0: nothing to do / stopped; 1: message available; 2: failed (not PD); 3: sender poisoned
+  int state = (en.valid && !((failkey >> kInfoBits) < stop_below)) ? 1 : 0;
+  const bool has_block = en.s > 0;                // the message has a J/h part
+  const bool own = (en.mode & kFOwn) != 0;        // this wave loads/stores the receiver block
+  const bool accum = (en.mode & kFAccum) != 0;
+  const bool provider = en.src_wave == wave;      // computes the marginal itself
+
+  double* __restrict__ sep = pool + en.sep_off;
+  double* __restrict__ to = pool + en.to_off;
+  double* __restrict__ res = rpool + en.res_off;
+  const int mt = en.mt, up0 = en.up0;
+  const int64_t so = 2 * a + P * (2 * b);
+  const int64_t tO = (up0 + 2 * a) + (int64_t)mt * (up0 + 2 * b);
+
+  double mJ[2][2] = {{0, 0}, {0, 0}}, mh[2] = {0, 0}, gmsg = 0.0;
+  double tJ[2][2] = {{0, 0}, {0, 0}}, th[2] = {0, 0}, tg = 0.0;
+  double2 s0 = make_double2(0.0, 0.0), s1 = s0, sh = s0;
+  double sg = 0.0;
+  int info = 0;
+  if (state == 1) {
+    const int poisoned = S.poison[(int64_t)site * S.n_clusters + en.from_b];
+    // ---- every load of this message is issued before any arithmetic
+    if (has_block) {
+      s0 = *reinterpret_cast<const double2*>(sep + so);
+      s1 = *reinterpret_cast<const double2*>(sep + so + P);
+      if (b == 0) sh = *reinterpret_cast<const double2*>(sep + P * P + 2 * a);
     }
-    // ---- issue every load of this entry up front: sepset, receiver block, sender
-    double* __restrict__ sep = pool + m.sep_off;
-    double* __restrict__ to = pool + m.to_off;
-    double* __restrict__ res = rpool + m.res_off;
-    const int mt = m.mt, up0 = m.up0;
-    const int64_t so = 2 * a + P * (2 * b);
-    const int64_t tO = (up0 + 2 * a) + (int64_t)mt * (up0 + 2 * b);
-    const double2 s0 = *reinterpret_cast<const double2*>(sep + so);
-    const double2 s1 = *reinterpret_cast<const double2*>(sep + so + P);
-    double2 sh = make_double2(0.0, 0.0);
-    if (b == 0) sh = *reinterpret_cast<const double2*>(sep + P * P + 2 * a);
-    const double sg = sep[P * P + P];
-    if (en.tflags & kTLoad) {
-      const double2 t0 = *reinterpret_cast<const double2*>(to + tO);
-      const double2 t1 = *reinterpret_cast<const double2*>(to + tO + mt);
-      tJ[0][0] = t0.x; tJ[1][0] = t0.y; tJ[0][1] = t1.x; tJ[1][1] = t1.y;
-      if (b == 0) {
-        const double2 t2 = *reinterpret_cast<const double2*>(to + (int64_t)mt * mt + up0 + 2 * a);
-        th[0] = t2.x; th[1] = t2.y;
+    sg = sep[(int)en.s * en.s + en.s];
+    if (own) {
+      if (accum || has_block) {
+        const double2 t0 = *reinterpret_cast<const double2*>(to + tO);
+        const double2 t1 = *reinterpret_cast<const double2*>(to + tO + mt);
+        tJ[0][0] = t0.x; tJ[1][0] = t0.y; tJ[0][1] = t1.x; tJ[1][1] = t1.y;
+        if (b == 0) {
+          const double2 t2 = *reinterpret_cast<const double2*>(to + (int64_t)mt * mt + up0 + 2 * a);
+          th[0] = t2.x; th[1] = t2.y;
+        }
       }
       tg = to[(int64_t)mt * mt + mt];
     }
-    if (!en.reuse) {
-      const double* __restrict__ from = pool + m.from_off;
-      if (m.ni == 0) {
+    if (provider) {
+      const double* __restrict__ from = pool + en.from_off;
+      if (en.mf == 0) {
+        gmsg = from[0];  // a constant factor
+      } else if (en.mf == P && has_block) {
         // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
         const double2 c0 = *reinterpret_cast<const double2*>(from + so);
         const double2 c1 = *reinterpret_cast<const double2*>(from + so + P);
@@ -140,29 +163,42 @@ __global__ __launch_bounds__(64) void bp_level_fast16(DevState S, const int32_t*
         mh[0] = ch.x; mh[1] = ch.y;
         gmsg = from[P * P + P];
       } else {
-        // logical index = original index rotated so that the integrated block comes first
-        const int rot = (m.keep0 == 0) ? P : 0;
-        const int r0 = (2 * a + rot) & 31, r1 = (2 * a + P + rot) & 31;
         Frag f;
+        if (en.mf == P) {
+          // everything is integrated (dimension-0 sepset): the 16 x 16 precision is the integrated block
+          const double2 v0 = *reinterpret_cast<const double2*>(from + so);
+          const double2 v1 = *reinterpret_cast<const double2*>(from + so + P);
+          const double2 vh = *reinterpret_cast<const double2*>(from + P * P + 2 * a);
+          f.w[0][0] = v0.x; f.w[1][0] = v0.y; f.w[0][1] = v1.x; f.w[1][1] = v1.y;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cl = 2 * b + (j & 1) + (j >> 1) * P;  // logical column C_b(j)
-          const int64_t co = (int64_t)((cl + rot) & 31) * 32;
-          if (j < 2) {
-            const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
-            f.w[0][j] = v.x; f.w[1][j] = v.y;
-          } else {
-            f.w[0][j] = 0.0; f.w[1][j] = 0.0;
+          for (int j = 0; j < 4; ++j) {
+            f.w[2][j] = 0.0; f.w[3][j] = 0.0;
+            if (j >= 2) { f.w[0][j] = 0.0; f.w[1][j] = 0.0; }
           }
-          const double2 u = *reinterpret_cast<const double2*>(from + r1 + co);
-          f.w[2][j] = u.x; f.w[3][j] = u.y;
-        }
-        {
+          f.h[0] = vh.x; f.h[1] = vh.y; f.h[2] = 0.0; f.h[3] = 0.0;
+          gmsg = from[P * P + P];
+        } else {
+          // logical index = original index rotated so that the integrated block comes first
+          const int rot = (en.keep0 == 0) ? P : 0;
+          const int r0 = (2 * a + rot) & 31, r1 = (2 * a + P + rot) & 31;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cl = 2 * b + (j & 1) + (j >> 1) * P;  // logical column C_b(j)
+            const int64_t co = (int64_t)((cl + rot) & 31) * 32;
+            if (j < 2) {
+              const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
+              f.w[0][j] = v.x; f.w[1][j] = v.y;
+            } else {
+              f.w[0][j] = 0.0; f.w[1][j] = 0.0;
+            }
+            const double2 u = *reinterpret_cast<const double2*>(from + r1 + co);
+            f.w[2][j] = u.x; f.w[3][j] = u.y;
+          }
           const double2 v = *reinterpret_cast<const double2*>(from + 32 * 32 + r0);
           const double2 u = *reinterpret_cast<const double2*>(from + 32 * 32 + r1);
           f.h[0] = v.x; f.h[1] = v.y; f.h[2] = u.x; f.h[3] = u.y;
+          gmsg = from[32 * 32 + 32];
         }
-        gmsg = from[32 * 32 + 32];
         // "fake" message: J_I, J_SI, h_I all ~ 0 (src/beliefupdates.jl:62-66), tested on the raw values
         bool nz = fabs(f.h[0]) > PGBP_EPS || fabs(f.h[1]) > PGBP_EPS;
 #pragma unroll
@@ -178,69 +214,138 @@ __global__ __launch_bounds__(64) void bp_level_fast16(DevState S, const int32_t*
           if (2 * a + 1 > 2 * b + 1) f.w[1][1] = t11;
           double mant = 1.0, quad = 0.0;
           int expo = 0;
-          const int info = eliminate<0>(f, a, b, mant, expo, quad);
-          if (info != 0) {
-            if (lane == 0) {
-              S.status[(int64_t)site * S.n_msgs + en.msg] = info;
-              S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
-              atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) |
-                                           (unsigned long long)info);
-            }
-            return;
+          info = eliminate<0>(f, a, b, mant, expo, quad);
+          if (info == 0) {
+            const double logdet = log(mant) + (double)expo * PGBP_LN2;
+            gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
           }
-          const double logdet = log(mant) + (double)expo * PGBP_LN2;
-          gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
         }
         mJ[0][0] = f.w[2][2]; mJ[1][0] = f.w[3][2]; mJ[0][1] = f.w[2][3]; mJ[1][1] = f.w[3][3];
         mh[0] = f.h[2]; mh[1] = f.h[3];
       }
     }
-    // ---- divide! (src/beliefupdates.jl:579-587) and mult! (:483-488)
-    const double d00 = mJ[0][0] - s0.x, d10 = mJ[1][0] - s0.y, d01 = mJ[0][1] - s1.x, d11 = mJ[1][1] - s1.y;
-    *reinterpret_cast<double2*>(sep + so) = make_double2(mJ[0][0], mJ[1][0]);
-    *reinterpret_cast<double2*>(sep + so + P) = make_double2(mJ[0][1], mJ[1][1]);
-    *reinterpret_cast<double2*>(res + so) = make_double2(d00, d10);
-    *reinterpret_cast<double2*>(res + so + P) = make_double2(d01, d11);
-    tJ[0][0] += d00; tJ[1][0] += d10; tJ[0][1] += d01; tJ[1][1] += d11;
-    double maxJ = fmax(fmax(fabs(d00), fabs(d10)), fmax(fabs(d01), fabs(d11)));
-    if (d00 != d00 || d10 != d10 || d01 != d01 || d11 != d11) maxJ = INFINITY;
-    double maxh = 0.0;
-    if (b == 0) {
-      const double dh0 = mh[0] - sh.x, dh1 = mh[1] - sh.y;
-      *reinterpret_cast<double2*>(sep + P * P + 2 * a) = make_double2(mh[0], mh[1]);
-      *reinterpret_cast<double2*>(res + P * P + 2 * a) = make_double2(dh0, dh1);
-      th[0] += dh0; th[1] += dh1;
-      maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
+    if (poisoned) state = 3;
+    else if (info != 0) state = 2;
+  }
+  if (K > 1) {
+    // hand the marginal over to the waves that reuse it
+    if (provider && en.valid && !accum) {
+      if (state == 1) {
+        *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(mJ[0][0], mJ[1][0], mJ[0][1], mJ[1][1]);
+        if (b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(mh[0], mh[1]);
+      }
+      if (lane == 0) {
+        slot[kSlotG] = gmsg;
+        slot[kSlotStatus] = (double)state;
+      }
     }
+    __syncthreads();
+    if (!provider && state == 1) {
+      const double* src = fast_lds + en.src_wave * kSlotDoubles;
+      const int pst = (int)src[kSlotStatus];
+      if (pst == 1) {
+        const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
+        mJ[0][0] = v.x; mJ[1][0] = v.y; mJ[0][1] = v.z; mJ[1][1] = v.w;
+        if (b == 0) {
+          const double2 u = *reinterpret_cast<const double2*>(src + kSlotH + 2 * a);
+          mh[0] = u.x; mh[1] = u.y;
+        }
+        gmsg = src[kSlotG];
+      } else {
+        state = 3;  // the marginal it depends on failed or was skipped: as good as a poisoned sender
+      }
+    }
+  }
+  // ---- divide! (src/beliefupdates.jl:579-587): every wave for its own sepset
+  double d00 = 0.0, d10 = 0.0, d01 = 0.0, d11 = 0.0, dh0 = 0.0, dh1 = 0.0, dg = 0.0;
+  if (state == 1) {
+    double maxJ = 0.0, maxh = 0.0;
+    if (has_block) {
+      d00 = mJ[0][0] - s0.x; d10 = mJ[1][0] - s0.y; d01 = mJ[0][1] - s1.x; d11 = mJ[1][1] - s1.y;
+      *reinterpret_cast<double2*>(sep + so) = make_double2(mJ[0][0], mJ[1][0]);
+      *reinterpret_cast<double2*>(sep + so + P) = make_double2(mJ[0][1], mJ[1][1]);
+      *reinterpret_cast<double2*>(res + so) = make_double2(d00, d10);
+      *reinterpret_cast<double2*>(res + so + P) = make_double2(d01, d11);
+      maxJ = fmax(fmax(fabs(d00), fabs(d10)), fmax(fabs(d01), fabs(d11)));
+      if (d00 != d00 || d10 != d10 || d01 != d01 || d11 != d11) maxJ = INFINITY;
+      if (b == 0) {
+        dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
+        *reinterpret_cast<double2*>(sep + P * P + 2 * a) = make_double2(mh[0], mh[1]);
+        *reinterpret_cast<double2*>(res + P * P + 2 * a) = make_double2(dh0, dh1);
+        maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
+      }
+    }
+    dg = gmsg - sg;
     if (lane == 0) {
-      sep[P * P + P] = gmsg;
-      tg += gmsg - sg;
+      sep[(int)en.s * en.s + en.s] = gmsg;
       S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
     }
-    if (en.tflags & kTStore) {
-      *reinterpret_cast<double2*>(to + tO) = make_double2(tJ[0][0], tJ[1][0]);
-      *reinterpret_cast<double2*>(to + tO + mt) = make_double2(tJ[0][1], tJ[1][1]);
-      if (b == 0) *reinterpret_cast<double2*>(to + (int64_t)mt * mt + up0 + 2 * a) = make_double2(th[0], th[1]);
-      if (lane == 0) to[(int64_t)mt * mt + mt] = tg;
-    }
     if (S.update_resnorm) {
-      // iscalibrated_residnorm! (src/beliefs.jl:994-1003)
+      // iscalibrated_residnorm! (src/beliefs.jl:994-1003); an empty message is calibrated
       maxJ = wave_max_f64(maxJ);
       maxh = wave_max_f64(maxh);
       if (lane == 0)
         S.flags[(int64_t)site * S.n_msgs + en.msg] =
-            (maxh / sqrt((double)P) <= S.atol && maxJ / sqrt((double)P * (double)P) <= S.atol) ? 1 : 0;
+            (!has_block || (maxh / sqrt((double)P) <= S.atol && maxJ / sqrt((double)P * (double)P) <= S.atol)) ? 1 : 0;
     }
-    if (e + 1 < e1) __threadfence_block();  // a later entry may read-modify-write the same receiver through memory
+  } else if (state >= 2 && lane == 0) {
+    // not positive definite, or downstream of a failure: nothing of this message is applied
+    S.poison[(int64_t)site * S.n_clusters + en.to_b] = 1;
+    if (state == 2) {
+      S.status[(int64_t)site * S.n_msgs + en.msg] = info;
+      atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
+    }
+  }
+  // ---- mult! (src/beliefupdates.jl:483-488)
+  if (accum) {
+    // waves > 0 publish their delta; wave 0 adds them in the reference's order
+    if (wave > 0) {
+      if (state == 1) {
+        *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(d00, d10, d01, d11);
+        if (b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(dh0, dh1);
+      }
+      if (lane == 0) {
+        slot[kSlotG] = dg;
+        slot[kSlotStatus] = en.valid ? (double)state : 0.0;  // padding waves end the list
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && state == 1) {
+      tJ[0][0] += d00; tJ[1][0] += d10; tJ[0][1] += d01; tJ[1][1] += d11;
+      th[0] += dh0; th[1] += dh1;
+      tg += dg;
+      for (int w = 1; w < K; ++w) {
+        const double* src = fast_lds + w * kSlotDoubles;
+        if ((int)src[kSlotStatus] != 1) break;  // the reference stops at the first failing message
+        const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
+        tJ[0][0] += v.x; tJ[1][0] += v.y; tJ[0][1] += v.z; tJ[1][1] += v.w;
+        if (b == 0) {
+          const double2 u = *reinterpret_cast<const double2*>(src + kSlotH + 2 * a);
+          th[0] += u.x; th[1] += u.y;
+        }
+        tg += src[kSlotG];
+      }
+    }
+  } else if (state == 1) {
+    tJ[0][0] += d00; tJ[1][0] += d10; tJ[0][1] += d01; tJ[1][1] += d11;
+    th[0] += dh0; th[1] += dh1;
+    tg += dg;
+  }
+  if (own && state == 1) {
+    if (accum || has_block) {
+      *reinterpret_cast<double2*>(to + tO) = make_double2(tJ[0][0], tJ[1][0]);
+      *reinterpret_cast<double2*>(to + tO + mt) = make_double2(tJ[0][1], tJ[1][1]);
+      if (b == 0) *reinterpret_cast<double2*>(to + (int64_t)mt * mt + up0 + 2 * a) = make_double2(th[0], th[1]);
+    }
+    if (lane == 0) to[(int64_t)mt * mt + mt] = tg;
   }
 }
 
-void launch_level_fast16(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0,
-                         int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below,
-                         hipStream_t st) {
+void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
+                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(bp_level_fast16, dim3(ntasks, n_sites), dim3(kWave), 0, st, S, d_task_off, d_entries, task0,
-                     seq_base, stop_below);
+  hipLaunchKernelGGL(bp_level_fast16, dim3(ntasks, n_sites), dim3(kWave * K),
+                     K > 1 ? sizeof(double) * kSlotDoubles * K : 0, st, S, d_recs, K, seq_base, stop_below);
 }
 
 }  // namespace pgbp

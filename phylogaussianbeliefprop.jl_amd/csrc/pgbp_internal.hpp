@@ -35,9 +35,32 @@ struct Entry {
 };
 constexpr int kTLoad = 1, kTStore = 2;
 
+// Self-contained message record of the register-resident kernel (pgbp_fast.hip): everything a wavefront
+// needs is in ONE 64-byte line, so the dependent-load chain is  record -> data.  A fast task owns K
+// consecutive records (K = waves per workgroup of its level); records beyond the task's length have
+// valid = 0.
+struct FEntry {
+  int64_t from_off, to_off, sep_off, res_off;  // doubles, inside one site's pools
+  int32_t msg, seq, from_b, to_b;
+  uint8_t valid;
+  uint8_t mf, mt, s;     // dims of sender, receiver, sepset
+  uint8_t keep0;         // first kept index in the sender (0 or P)
+  uint8_t up0;           // first index of the receiver's block
+  uint8_t src_wave;      // wave of the workgroup that computes this record's marginal (== own index unless reused)
+  uint8_t mode;          // bit 0: this wave loads+stores the receiver block itself; bit 1: accumulate task
+                         // (wave 0 owns the receiver block, the other waves hand their delta over through LDS)
+  int32_t pad[2];
+};
+static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
+constexpr int kFOwn = 1, kFAccum = 2;
+constexpr int kFastMaxWaves = 4;
+
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first
   std::vector<int32_t> level_nfast;  // [n_levels] how many of the level's tasks run on the fast kernel
+  std::vector<FEntry> fentries;      // padded records of the fast tasks, level after level
+  std::vector<int64_t> level_fbase;  // [n_levels] first record of the level in fentries
+  std::vector<int32_t> level_fk;     // [n_levels] records (= waves) per fast task of the level
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;

@@ -34,9 +34,8 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
                           hipStream_t st);
 
 // register-resident kernel for sepsets of dimension 16 (pgbp_fast.hip)
-void launch_level_fast16(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0,
-                         int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below,
-                         hipStream_t st);
+void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
+                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, double* d_mu, int mu_stride,
                       double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);

@@ -143,34 +143,105 @@ int plan_build(Plan& p, const pgbp_desc* d) {
   return PGBP_OK;
 }
 
-// Shape class of the register-resident kernel (pgbp_fast.hip): sepset of dimension P, sender of
-// dimension P (nothing integrated) or 2P (the other P-block integrated), receiver of dimension P or 2P,
-// every index map one contiguous P-block.  This is every message of a BM clique tree / Bethe graph of a
-// tree without missing data (m = k*p, s = p).
+// Shape classes of the register-resident kernel (pgbp_fast.hip), P = sepset dimension it is built for:
+//   sender  : dim P, nothing integrated | dim 2P, the other P-block integrated
+//             | dim P, everything integrated into a dimension-0 sepset | dim 0 (a constant) into a dimension-0 sepset
+//   receiver: dim P or 2P with the sepset on one contiguous P-block; anything (only g is touched) for s = 0.
+// This is every message of a BM clique tree / Bethe graph of a tree without missing data
+// (m = k*p, s = p, plus the {root} sepset of a fixed-root model).
 static bool fast_msg(const MsgDesc& m, int P) {
-  if (P <= 0 || m.s != P) return false;
+  if (P <= 0) return false;
+  if (m.s == 0) return (m.mf == P || m.mf == 0) && m.mt <= 255;
+  if (m.s != P) return false;
   const bool snd = (m.mf == P && m.ni == 0 && m.keep0 == 0) ||
                    (m.mf == 2 * P && m.ni == P && (m.keep0 == 0 || m.keep0 == P));
   const bool rcv = (m.mt == P && m.up0 == 0) || (m.mt == 2 * P && (m.up0 == 0 || m.up0 == P));
   return snd && rcv;
 }
 
-// Reorder the tasks of every level so that fast-class tasks come first; set the receiver load/store flags.
+// Can the whole task run as ONE workgroup of the register-resident kernel, one wave per message?
+static bool fast_task(const Plan& p, const Traversal& tr, int t, bool postorder, int* block_up0, int* block_mt) {
+  const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];
+  if (e1 - e0 > kFastMaxWaves) return false;
+  int up0 = -1, mt = -1;
+  for (int e = e0; e < e1; ++e) {
+    const MsgDesc& m = p.msgs[tr.entries[e].msg];
+    if (!fast_msg(m, p.fast_p)) return false;
+    if (postorder && m.s > 0) {  // all deltas must land on the same receiver block
+      if (up0 >= 0 && (m.up0 != up0 || m.mt != mt)) return false;
+      up0 = m.up0;
+      mt = m.mt;
+    }
+  }
+  if (postorder && e1 - e0 > 1 && up0 < 0) return false;  // several g-only messages: leave to the generic kernel
+  *block_up0 = up0 < 0 ? 0 : up0;
+  *block_mt = mt;
+  return true;
+}
+
+// Reorder the tasks of every level so that fast-class tasks come first, build their padded records, set the
+// receiver load/store flags of the generic tasks.
 static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   const int nlev = (int)tr.level_off.size() - 1;
   std::vector<int32_t> new_task_off{0};
   std::vector<Entry> new_entries;
   new_entries.reserve(tr.entries.size());
   tr.level_nfast.assign(nlev, 0);
+  tr.level_fbase.assign(nlev, 0);
+  tr.level_fk.assign(nlev, 1);
+  tr.fentries.clear();
   tr.max_mf = 0;
   for (int L = 0; L < nlev; ++L) {
     std::vector<int> fast, slow;
+    std::vector<std::pair<int, int>> blk;  // (up0, mt) of the receiver block of each fast task
+    int K = 1;
     for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) {
-      bool f = true;
-      for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e) f = f && fast_msg(p.msgs[tr.entries[e].msg], p.fast_p);
-      (f ? fast : slow).push_back(t);
+      int up0 = 0, mt = 0;
+      if (fast_task(p, tr, t, postorder, &up0, &mt)) {
+        fast.push_back(t);
+        blk.push_back({up0, mt});
+        K = std::max(K, tr.task_off[t + 1] - tr.task_off[t]);
+      } else {
+        slow.push_back(t);
+      }
     }
     tr.level_nfast[L] = (int32_t)fast.size();
+    tr.level_fbase[L] = (int64_t)tr.fentries.size();
+    tr.level_fk[L] = K;
+    for (size_t q = 0; q < fast.size(); ++q) {
+      const int t = fast[q];
+      const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];
+      const bool accum = postorder && (e1 - e0 > 1);
+      int provider = 0;
+      for (int w = 0; w < K; ++w) {
+        FEntry f{};
+        if (e0 + w < e1) {
+          const Entry& en = tr.entries[e0 + w];
+          const MsgDesc& m = p.msgs[en.msg];
+          f.from_off = m.from_off; f.to_off = m.to_off; f.sep_off = m.sep_off; f.res_off = m.res_off;
+          f.msg = en.msg; f.seq = en.seq; f.from_b = m.from_b; f.to_b = m.to_b;
+          f.valid = 1;
+          f.mf = (uint8_t)m.mf; f.mt = (uint8_t)m.mt; f.s = (uint8_t)m.s;
+          f.keep0 = (uint8_t)(m.keep0 < 0 ? 0 : m.keep0);
+          f.up0 = (uint8_t)(m.s > 0 ? m.up0 : 0);
+          if (!en.reuse) provider = w;
+          f.src_wave = (uint8_t)provider;
+          if (accum) {
+            // wave 0 owns the shared receiver block (even if its own message is g-only)
+            f.mode = (uint8_t)(kFAccum | (w == 0 ? kFOwn : 0));
+            if (w == 0 && m.s == 0) {
+              f.up0 = (uint8_t)blk[q].first;
+              f.mt = (uint8_t)(blk[q].second >= 0 ? blk[q].second : m.mt);
+            }
+          } else {
+            f.mode = kFOwn;
+          }
+        } else if (accum) {
+          f.mode = kFAccum;  // padding record of an accumulate task: its wave still joins the barriers
+        }
+        tr.fentries.push_back(f);
+      }
+    }
     for (const auto* grp : {&fast, &slow})
       for (int t : *grp) {
         const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];

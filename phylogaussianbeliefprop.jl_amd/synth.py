@@ -102,6 +102,42 @@ def random_tree(ntips: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> Tree:
     return Tree(parent, length, is_leaf)
 
 
+def random_multifurcating_tree(ntips: int, maxdeg: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> Tree:
+    """Random tree whose internal nodes have 2..maxdeg children (polytomies): exercises tasks with
+    more than two messages per receiver / sender."""
+    par = {}
+    active = list(range(ntips))
+    nxt = ntips
+    while len(active) > 1:
+        k = min(len(active), int(rng.integers(2, maxdeg + 1)))
+        pick = sorted(rng.choice(len(active), size=k, replace=False).tolist(), reverse=True)
+        for i in pick:
+            par[active[i]] = nxt
+            active.pop(i)
+        active.append(nxt)
+        nxt += 1
+    N = nxt
+    root = N - 1
+    children = [[] for _ in range(N)]
+    for v, q in par.items():
+        children[q].append(v)
+    order, stack = [], [root]
+    while stack:
+        v = stack.pop()
+        order.append(v)
+        stack.extend(reversed(sorted(children[v])))
+    new = np.empty(N, dtype=np.int64)
+    new[np.array(order)] = np.arange(N)
+    parent = np.full(N, -1, dtype=np.int64)
+    for v, q in par.items():
+        parent[new[v]] = new[q]
+    is_leaf = np.ones(N, dtype=bool)
+    is_leaf[parent[1:]] = False
+    length = rng.uniform(lo, hi, size=N)
+    length[0] = 0.0
+    return Tree(parent, length, is_leaf)
+
+
 def caterpillar_tree(ntips: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> Tree:
     """Maximally unbalanced tree (depth = ntips - 1): the worst case for level parallelism."""
     N = 2 * ntips - 1

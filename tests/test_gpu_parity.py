@@ -225,11 +225,18 @@ def test_auto_stop_and_info_log(P, caplog):
 
 @pytest.mark.parametrize("ntips,p,kind", [(2, 1, "random"), (3, 1, "random"), (9, 1, "random"), (33, 2, "random"),
                                           (64, 3, "random"), (100, 8, "random"), (60, 16, "random"),
-                                          (24, 16, "caterpillar"), (17, 32, "random")])
+                                          (24, 16, "caterpillar"), (17, 32, "random"),
+                                          (2, 16, "random"), (3, 16, "random"), (150, 16, "random"),
+                                          (80, 16, "poly3"), (120, 16, "poly4"), (90, 16, "poly7"), (40, 3, "poly5")])
 def test_random_tree_cliquetree_vs_oracle(P, ntips, p, kind):
     from pgbp_amd import synth as S
     rng = np.random.default_rng(1000 * p + ntips)
-    tr = S.random_tree(ntips, rng) if kind == "random" else S.caterpillar_tree(ntips, rng)
+    if kind == "random":
+        tr = S.random_tree(ntips, rng)
+    elif kind == "caterpillar":
+        tr = S.caterpillar_tree(ntips, rng)
+    else:
+        tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
     R = S.random_rate_matrix(p, rng)
     mu = rng.standard_normal(p)
     X = S.simulate_bm(tr, R, mu, rng)

@@ -62,10 +62,15 @@ def _traversal(lib, pl, tree, d):
 
 
 @pytest.mark.parametrize("ntips,p,kind", [(2, 1, "random"), (3, 2, "random"), (40, 3, "random"), (500, 2, "random"),
-                                          (30, 2, "caterpillar")])
+                                          (30, 2, "caterpillar"), (60, 16, "random"), (70, 16, "poly6")])
 def test_level_schedule_invariants(ntips, p, kind):
     rng = np.random.default_rng(ntips)
-    tr = S.random_tree(ntips, rng) if kind == "random" else S.caterpillar_tree(ntips, rng)
+    if kind == "random":
+        tr = S.random_tree(ntips, rng)
+    elif kind == "caterpillar":
+        tr = S.caterpillar_tree(ntips, rng)
+    else:
+        tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
     prob = S.cliquetree_of_tree(tr, p)
     lib, pl, code, keep = _plan(prob)
     assert code == 0, lib.pgbp_plan_last_error(pl)
@@ -95,7 +100,7 @@ def test_level_schedule_invariants(ntips, p, kind):
                     targets.add(int(rcv))
                 edges = [ee[e] for e in ents]
                 if d == 0:   # one task per target, entries in the reference's order (decreasing edge index)
-                    assert len({int(pa[i]) for i in edges}) == 1
+                    assert len({int(pa[i]) for i in edges}) == 1, (Lv, edges)
                     assert edges == sorted(edges, reverse=True)
                 else:        # one task per sender, increasing edge index
                     assert len({int(pa[i]) for i in edges}) == 1
@@ -104,6 +109,11 @@ def test_level_schedule_invariants(ntips, p, kind):
             if d == 0:
                 tl = [int(pa[ee[to[t]]]) for t in range(lo[Lv], lo[Lv + 1])]
                 assert len(tl) == len(set(tl))                  # distinct targets across tasks
+            nf = np.zeros(len(lo) - 1, np.int32)
+            assert lib.pgbp_plan_level_nfast(pl, 0, d, L.i32p(nf)) == 0
+            assert 0 <= nf[Lv] <= lo[Lv + 1] - lo[Lv]
+            if p == 16 and kind == "random" and ntips > 3:
+                assert nf[Lv] == lo[Lv + 1] - lo[Lv]            # a 16-trait bifurcating tree is all fast-class
             assert not (targets & senders)                      # no cluster both read and written in a level
         # dependencies: postorder: a child's incoming messages precede its outgoing one
         child_edge = {int(c): i for i, c in enumerate(ch)}
