@@ -49,38 +49,72 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   return v;
 }
 
-// Elimination steps K .. 15 (pivot K lives in lane row/col K>>1, register K&1). Returns 0 or the 1-based
-// index of the first non-positive pivot.
-template <int K>
-__device__ __forceinline__ int eliminate(Frag& f, const int a, const int b, double& mant, int& expo, double& quad) {
-  if constexpr (K == P) {
+// Wave-synchronous exchange through LDS: the hardware executes a wave's DS instructions in order, but the
+// compiler reasons per thread; this fence pair + wave barrier stops it from forwarding a lane's own stale
+// store to its later load or moving loads across the other lanes' stores.  Emits no instruction.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Blocked elimination of the 16 integrated variables, two pivots per round (8 rounds).
+// Round R: the 8 lanes with b == R own columns 2R, 2R+1 of W; they publish them (rows R_a) in the wave's
+// private LDS strip; every lane reads back the entries of the rows R_a (xr) and C_b (xc) plus the 2 x 2 pivot
+// block D and h_2R, h_2R+1, and applies  W <- W - X D^-1 X',  h <- h - X D^-1 h_K.  Mathematically identical
+// to two successive rank-1 eliminations (src/beliefupdates.jl:68-81); D^-1 by v_rcp_f64 + 2 Newton steps.
+// Returns 0, or the 1-based index of the first non-positive pivot (LAPACK potrf info).
+constexpr int kColStride = 10;                       // doubles per owner-lane slot (80 B: conflict-free b128 reads)
+constexpr int kColDoubles = 8 * kColStride + 4;      // + h_2R, h_2R+1
+
+template <int R>
+__device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, double* __restrict__ col, double& mant,
+                                          int& expo, double& quad) {
+  if constexpr (R == P / 2) {
     return 0;
   } else {
-    constexpr int kk = K >> 1, ik = K & 1;
-    const int src_r = kk * 8 + a;  // lane (a, kk): column K entries for my rows R_a
-    const int src_c = kk * 8 + b;  // lane (b, kk): column K entries for the rows C_b (my columns)
-    double xr[4], xc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xr[i] = __shfl(f.w[i][ik], src_r);
-      xc[i] = __shfl(f.w[i][ik], src_c);
+    if (b == R) {
+      double* dst = col + a * kColStride;
+      *reinterpret_cast<double4*>(dst) = make_double4(f.w[0][0], f.w[1][0], f.w[2][0], f.w[3][0]);
+      *reinterpret_cast<double4*>(dst + 4) = make_double4(f.w[0][1], f.w[1][1], f.w[2][1], f.w[3][1]);
+      if (a == R) *reinterpret_cast<double2*>(col + 8 * kColStride) = make_double2(f.h[0], f.h[1]);
     }
-    const double d = readlane_f64(f.w[ik][ik], kk * 8 + kk);
-    const double hk = readlane_f64(f.h[ik], kk);
-    if (!(d > 0.0)) return K + 1;
-    const double rd = 1.0 / d;
+    wave_sync_lds();  // other LANES wrote what this lane reads: not visible to per-thread alias analysis
+    const double4 xr0 = *reinterpret_cast<const double4*>(col + a * kColStride);
+    const double4 xr1 = *reinterpret_cast<const double4*>(col + a * kColStride + 4);
+    const double4 xc0 = *reinterpret_cast<const double4*>(col + b * kColStride);
+    const double4 xc1 = *reinterpret_cast<const double4*>(col + b * kColStride + 4);
+    const double2 p0 = *reinterpret_cast<const double2*>(col + R * kColStride);      // W[2R][2R], W[2R+1][2R]
+    const double2 p1 = *reinterpret_cast<const double2*>(col + R * kColStride + 4);  // W[2R][2R+1], W[2R+1][2R+1]
+    const double2 hk = *reinterpret_cast<const double2*>(col + 8 * kColStride);
+    wave_sync_lds();  // the next round overwrites the strip
+    const double d00 = p0.x, d01 = p1.x, d11 = p1.y;  // upper triangle of the pivot block
+    const double det = fma(d00, d11, -(d01 * d01));
+    const int bad = __builtin_amdgcn_readfirstlane(!(d00 > 0.0) ? 2 * R + 1 : (!(det > 0.0) ? 2 * R + 2 : 0));
+    if (bad) return bad;
+    double rdet = __builtin_amdgcn_rcp(det);
+    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+    const double e00 = d11 * rdet, e01 = -(d01 * rdet), e11 = d00 * rdet;
     int e;
-    mant *= frexp(d, &e);
+    mant *= frexp(det, &e);
     expo += e;
-    quad = fma(hk * hk, rd, quad);
+    // y = D^-1 x_c for my 4 columns; g = D^-1 h_K
+    const double xc0v[4] = {xc0.x, xc0.y, xc0.z, xc0.w}, xc1v[4] = {xc1.x, xc1.y, xc1.z, xc1.w};
+    const double xr0v[4] = {xr0.x, xr0.y, xr0.z, xr0.w}, xr1v[4] = {xr1.x, xr1.y, xr1.z, xr1.w};
+    const double g0 = fma(e00, hk.x, e01 * hk.y), g1 = fma(e01, hk.x, e11 * hk.y);
+    quad = fma(hk.x, g0, fma(hk.y, g1, quad));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      const double y0 = fma(e00, xc0v[j], e01 * xc1v[j]);
+      const double y1 = fma(e01, xc0v[j], e11 * xc1v[j]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(i < 2 && j >= 2)) f.w[i][j] = fma(-(xr[i] * xc[j]), rd, f.w[i][j]);  // (x_r x_c) first: exactly symmetric
-      f.h[i] = fma(-(xr[i] * hk), rd, f.h[i]);
+      for (int i = 0; i < 4; ++i)
+        if (!(i < 2 && j >= 2)) f.w[i][j] = fma(-xr0v[i], y0, fma(-xr1v[i], y1, f.w[i][j]));
     }
-    return eliminate<K + 1>(f, a, b, mant, expo, quad);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
+    return eliminate2<R + 1>(f, a, b, col, mant, expo, quad);
   }
 }
 
@@ -109,6 +143,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   double* slot = fast_lds + wave * kSlotDoubles;
+  double* col = fast_lds + K * kSlotDoubles + wave * kColDoubles;  // private strip of this wave
 
   // state 0: nothing to do / stopped; 1: message available; 2: failed (not PD); 3: sender poisoned
   int state = (en.valid && !((failkey >> kInfoBits) < stop_below)) ? 1 : 0;
@@ -214,7 +249,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
           if (2 * a + 1 > 2 * b + 1) f.w[1][1] = t11;
           double mant = 1.0, quad = 0.0;
           int expo = 0;
-          info = eliminate<0>(f, a, b, mant, expo, quad);
+          info = eliminate2<0>(f, a, b, col, mant, expo, quad);
           if (info == 0) {
             const double logdet = log(mant) + (double)expo * PGBP_LN2;
             gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
@@ -345,7 +380,8 @@ void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int nta
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
   hipLaunchKernelGGL(bp_level_fast16, dim3(ntasks, n_sites), dim3(kWave * K),
-                     K > 1 ? sizeof(double) * kSlotDoubles * K : 0, st, S, d_recs, K, seq_base, stop_below);
+                     sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K, st, S, d_recs, K, seq_base,
+                     stop_below);
 }
 
 }  // namespace pgbp
