@@ -76,6 +76,43 @@ def cpu_baseline(prob, packed, budget_s=20.0):
             "loglik": ll}
 
 
+def timed_region(enqueue_and_wait, dist, device_sync, reduce_device="cuda"):
+    """The timing contract: barrier + device sync on both sides of the timed work, MAX over ranks.
+    `enqueue_and_wait()` runs exactly the K timed steps of THIS rank.  Returns seconds (same on all ranks).
+    Factored out so that the N > 1 path is covered by a 2-rank gloo test on CPU (tests/test_bench_dist.py)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        device_sync()
+    barrier()
+    t0 = time.perf_counter()
+    enqueue_and_wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device=reduce_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def whole_job_rate(units_per_rank_step, steps, world, dt):
+    """value = the units ALL ranks processed / the max-over-ranks time (weak scaling: per-rank work fixed)."""
+    return world * units_per_rank_step * steps / dt
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the message kernel from the committed rocprofv3 PMC passes
+    (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json); None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,17 +175,12 @@ def main():
     # ---- warmup + timed calibrate steps
     check(lib.pgbp_reset_from_factors(eng))
     check(lib.pgbp_enqueue_calibrate(eng, args.warmup, 0, C.byref(opts)))
-    barrier()
-    t0 = time.perf_counter()
-    check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
-    check(lib.pgbp_sync(eng))
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = world * msgs_per_cal * args.steps / dt
+
+    def k_steps():
+        check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
+        check(lib.pgbp_sync(eng))
+    dt = timed_region(k_steps, dist, torch.cuda.synchronize)
+    value = whole_job_rate(msgs_per_cal, args.steps, world, dt)
 
     # after the timed region: the calibrated beliefs still integrate to the right log-likelihood
     mu_, n2, i2 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
@@ -167,6 +199,7 @@ def main():
         reps = max(2, min(5, args.steps))
         check(lib.pgbp_time_message_kernels(eng, reps, C.byref(opts), C.byref(ms), C.byref(nl)))
         kern_ms = ms.value
+        pmc = load_pmc_traffic()
         achieved = bytes_per_cal * reps / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "clique-tree messages/sec (calibrate!: postorder+preorder), 16-trait BM",
@@ -181,7 +214,11 @@ def main():
             "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel), "parity_skipped": skip_parity,
             "ll_evals_per_s": ll_evals,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                                         "profiles/pmc_traffic_latest.json)",
+                         "algorithmic_bytes_per_launch": bytes_per_cal / max(1, nl.value // reps),
                          "kernel": "bp_level_fast16", "launches_per_step": nl.value // reps,
                          "algorithmic_bytes_per_step": bytes_per_cal,
                          "kernel_ms_per_step": kern_ms / reps},

@@ -177,8 +177,9 @@ int  pgbp_sync(pgbp_engine* e);
  * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik. */
 int  pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each,
                         const pgbp_opts* opts, float* ms_total);
-/* Time only the message-kernel launches of `reps` calibrate iterations: HIP events bracket every
- * level launch on the engine's stream; *ms_kernels = sum over launches, *n_launches their number. */
+/* Time only the message-kernel launches of `reps` calibrate iterations (reset from factors before each):
+ * one HIP event pair on the engine's stream brackets the back-to-back level launches of every traversal;
+ * *ms_kernels = sum over traversals, *n_launches = number of level launches inside them. */
 int  pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opts,
                                float* ms_kernels, int32_t* n_launches);
 /* Algorithmic bytes of one full calibrate iteration over all sites (SURVEY.md section 8(d) formula:

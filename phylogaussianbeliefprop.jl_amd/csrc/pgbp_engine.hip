@@ -141,7 +141,7 @@ unsigned long long seq_stride(const pgbp_engine* e) {
 
 // enqueue one traversal: one launch per level
 void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, unsigned long long pair_index,
-                       std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev = nullptr) {
+                       std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev = nullptr, int* n_launches = nullptr) {
   const Tree& T = e->plan.trees[tree];
   const Traversal& tr = dir == 0 ? T.post : T.pre;
   const DevTraversal& d = dir == 0 ? e->dpost[tree] : e->dpre[tree];
@@ -149,23 +149,28 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
   // preorder does not run at all once the postorder of the same tree failed (src/calibration.jl:80-82)
   const unsigned long long stop_below = seq_base + (dir == 0 ? 0ull : (unsigned long long)T.pa.size());
   const int nlev = (int)tr.level_off.size() - 1;
+  // timing mode: ONE event pair brackets all level launches of the traversal (they run back to back on
+  // the stream), so that sum / launches is the average launch duration without per-launch event overhead
+  hipEvent_t a = nullptr, b = nullptr;
+  if (ev) {
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, e->st);
+  }
+  int launches = 0;
   for (int L = 0; L < nlev; ++L) {
     const int t0 = tr.level_off[L], nt = tr.level_off[L + 1] - t0;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (ev) {
-      (void)hipEventCreate(&a);
-      (void)hipEventCreate(&b);
-      (void)hipEventRecord(a, e->st);
-    }
     const int nf = tr.level_nfast[L];
     launch_level_fast16(S, d.d_fentries + tr.level_fbase[L], tr.level_fk[L], nf, e->plan.n_sites, seq_base,
                         stop_below, e->st);
     launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
                          tr.max_mf, e->st);
-    if (ev) {
-      (void)hipEventRecord(b, e->st);
-      ev->push_back({a, b});
-    }
+    launches += (nf > 0) + (nt - nf > 0);
+  }
+  if (ev) {
+    (void)hipEventRecord(b, e->st);
+    ev->push_back({a, b});
+    if (n_launches) *n_launches += launches;
   }
 }
 
@@ -593,7 +598,7 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
 // ---- benchmarking / zero-copy entry points ---------------------------------------------------
 
 static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_each,
-                                  std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev) {
+                                  std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev, int* n_launches = nullptr) {
   const Plan& p = e->plan;
   if (reset_each) {
     int rc = reset_from_factors_async(e);
@@ -601,8 +606,8 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
     launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
   }
   for (int j = 0; j < (int)p.trees.size(); ++j) {
-    enqueue_traversal(e, S, j, 0, (unsigned long long)j, ev);
-    enqueue_traversal(e, S, j, 1, (unsigned long long)j, ev);
+    enqueue_traversal(e, S, j, 0, (unsigned long long)j, ev, n_launches);
+    enqueue_traversal(e, S, j, 1, (unsigned long long)j, ev, n_launches);
     launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
   }
   return PGBP_OK;
@@ -689,8 +694,9 @@ int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opt
   if ((rc = reset_fail(e))) return rc;
   DevState S = dev_state(e, opts);
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int launches = 0;
   for (int r = 0; r < reps; ++r)
-    if ((rc = enqueue_calibrate_once(e, S, 1, &ev))) break;
+    if ((rc = enqueue_calibrate_once(e, S, 1, &ev, &launches))) break;
   HIPCHK(e, hipStreamSynchronize(e->st));
   double total = 0;
   for (auto& pr : ev) {
@@ -700,7 +706,7 @@ int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opt
     (void)hipEventDestroy(pr.second);
   }
   *ms_kernels = (float)total;
-  if (n_launches) *n_launches = (int32_t)ev.size();
+  if (n_launches) *n_launches = (int32_t)launches;
   return rc;
 }
 

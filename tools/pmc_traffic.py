@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""
+Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; collected in SEPARATE runs, as
+/opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes) of `bench.py` into per-launch HBM
+traffic of the message kernel.
+
+gfx950 corrections (same guide): counters are in KiB; FETCH_SIZE reports exactly 1/2 of the bytes of a
+16-B-per-lane coalesced read -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  The correction is
+re-validated inside the same run on `copy_strided_kernel`, whose byte count is known exactly
+(cluster part of the belief pool, read once and written once).
+
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json
+"""
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    d = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            d.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+    return d
+
+
+def main():
+    f_csv, w_csv, copy_bytes, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+    F = per_kernel(f_csv, "FETCH_SIZE")
+    W = per_kernel(w_csv, "WRITE_SIZE")
+    cal_f = 2.0 * 1024 * sum(F["pgbp::copy_strided_kernel"]) / len(F["pgbp::copy_strided_kernel"])
+    cal_w = 1024 * sum(W["pgbp::copy_strided_kernel"]) / len(W["pgbp::copy_strided_kernel"])
+    k = "pgbp::bp_level_fast16"
+    n = len(F[k])
+    fetch = 2.0 * 1024 * sum(F[k])
+    write = 1024 * sum(W[k])
+    res = {
+        "kernel": "bp_level_fast16", "launches": n,
+        "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / len(W[k]),
+        "hbm_bytes_per_launch": fetch / n + write / len(W[k]),
+        "corrections": "KiB units; FETCH_SIZE x2 (16-B/lane reads on gfx950); WRITE_SIZE exact",
+        "calibration_copy_kernel": {"known_bytes_each_way": copy_bytes, "fetch_corrected": cal_f, "write": cal_w,
+                                    "fetch_ratio": cal_f / copy_bytes, "write_ratio": cal_w / copy_bytes},
+        "note": "average over every bp_level_fast16 launch of one bench.py run (postorder and preorder levels)",
+    }
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
