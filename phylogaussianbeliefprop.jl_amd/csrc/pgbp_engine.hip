@@ -50,6 +50,11 @@ struct pgbp_engine {
   double* d_mu = nullptr;    // [n_sites][max_dim]
   double* d_norm = nullptr;  // [n_sites]
   int32_t* d_info = nullptr; // [n_sites]
+  int32_t* d_bdim = nullptr;        // [n_beliefs] dims (layout conversion)
+  int32_t* d_rdim = nullptr;        // [n_msgs] sepset dim of every directed message
+  int32_t* d_symflag = nullptr;     // != 0: some precision matrix is not symmetric
+  bool layout_bs16 = false;         // current device layout of 16/32-dim beliefs and 16-dim residuals
+  bool sym_known = false, sym_ok = false;
   int32_t* d_one_task_off = nullptr;  // single-message task for pgbp_propagate
   Entry* d_one_entry = nullptr;
   std::vector<DevTraversal> dpost, dpre;
@@ -106,6 +111,7 @@ DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
   S.n_msgs = e->plan.n_msgs();
   S.update_resnorm = o ? o->update_residualnorm : 1;
   S.atol = o ? o->atol : 1e-5;
+  S.bs16 = e->layout_bs16 ? 1 : 0;
   return S;
 }
 
@@ -115,6 +121,37 @@ int reset_fail(pgbp_engine* e) {
   HIPCHK(e, hipMemsetAsync(e->d_poison, 0, sizeof(int32_t) * ns * (size_t)e->plan.n_clusters, e->st));
   return PGBP_OK;
 }
+
+// Switch the device layout of every 16/32-dimensional belief (beliefs + factors) and every 16-dimensional
+// residual between plain (ABI order, what the generic kernel and all transfers use) and BS16 (symmetric
+// block-packed, what the register-resident kernel streams).  plain -> BS16 keeps the upper triangle, so it
+// is only taken when every precision matrix is symmetric (checked once per upload).
+int ensure_layout(pgbp_engine* e, bool want_bs16) {
+  const Plan& p = e->plan;
+  if (want_bs16 == e->layout_bs16) return PGBP_OK;
+  if (want_bs16) {
+    if (!e->sym_known) {
+      HIPCHK(e, hipMemsetAsync(e->d_symflag, 0, sizeof(int32_t), e->st));
+      launch_check_symmetry(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_beliefs(), p.n_sites, e->d_symflag, e->st);
+      launch_check_symmetry(e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters, p.n_sites, e->d_symflag, e->st);
+      int32_t flag = 0;
+      HIPCHK(e, hipMemcpyAsync(&flag, e->d_symflag, sizeof(flag), hipMemcpyDeviceToHost, e->st));
+      HIPCHK(e, hipStreamSynchronize(e->st));
+      e->sym_known = true;
+      e->sym_ok = flag == 0;
+    }
+    if (!e->sym_ok) return PGBP_OK;  // stay plain: exact reference semantics for asymmetric input
+  }
+  const int to = want_bs16 ? 1 : 0;
+  launch_convert_layout(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_beliefs(), p.n_sites, to, 0, e->st);
+  launch_convert_layout(e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters, p.n_sites, to, 0, e->st);
+  launch_convert_layout(e->d_rpool, p.rpool_stride(), e->d_roff, e->d_rdim, p.n_msgs(), p.n_sites, to, 1, e->st);
+  e->layout_bs16 = want_bs16;
+  return PGBP_OK;
+}
+
+// layout wanted by the traversals of the current schedule
+bool want_bs16(const pgbp_engine* e) { return e->plan.all_fast && e->plan.fast_p == 16; }
 
 void free_traversals(pgbp_engine* e) {
   for (auto* v : {&e->dpost, &e->dpre}) {
@@ -216,7 +253,8 @@ void pgbp_destroy(pgbp_engine* e) {
                   (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
-                  (void*)e->d_one_task_off, (void*)e->d_one_entry})
+                  (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_bdim, (void*)e->d_rdim,
+                  (void*)e->d_symflag})
     if (p) (void)hipFree(p);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
@@ -272,6 +310,13 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   if ((rc = dev_alloc(e, &e->d_mu, ns * (size_t)std::max(1, p.max_dim)))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_norm, ns))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_info, ns))) return bail(rc);
+  {
+    std::vector<int32_t> rdim(nm);
+    for (size_t d = 0; d < nm; ++d) rdim[d] = p.dims[p.n_clusters + d / 2];
+    if ((rc = upload(e, &e->d_bdim, p.dims))) return bail(rc);
+    if ((rc = upload(e, &e->d_rdim, rdim))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_symflag, 1))) return bail(rc);
+  }
   if ((rc = dev_alloc(e, &e->d_one_task_off, 2))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_one_entry, 1))) return bail(rc);
   // beliefs = constant function 1 (h, J, g all 0: src/beliefs.jl:108-132); residuals 0;
@@ -316,6 +361,11 @@ int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
 int pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_factors) {
   if (!e || !packed) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
+  {
+    int rc0 = ensure_layout(e, false);  // factors / residuals that stay must be in the layout the upload uses
+    if (rc0) return rc0;
+    e->sym_known = false;
+  }
   const int64_t psz = p.packed_off.back();
   double* stage = nullptr;
   HIPCHK(e, hipMalloc((void**)&stage, sizeof(double) * (size_t)psz * p.n_sites));
@@ -334,6 +384,10 @@ int pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_fact
 int pgbp_get_beliefs(pgbp_engine* e, double* packed) {
   if (!e || !packed) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
+  {
+    int rc0 = ensure_layout(e, false);
+    if (rc0) return rc0;
+  }
   const int64_t psz = p.packed_off.back();
   double* stage = nullptr;
   HIPCHK(e, hipMalloc((void**)&stage, sizeof(double) * (size_t)psz * p.n_sites));
@@ -361,6 +415,8 @@ int pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* 
   int64_t len;
   int rc = belief_rec(e, site, belief, &d, &len);
   if (rc) return rc;
+  if ((rc = ensure_layout(e, false))) return rc;
+  e->sym_known = false;
   HIPCHK(e, hipMemcpyAsync(d, rec, sizeof(double) * len, hipMemcpyHostToDevice, e->st));
   return pgbp_sync(e);
 }
@@ -371,6 +427,7 @@ int pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec) {
   int64_t len;
   int rc = belief_rec(e, site, belief, &d, &len);
   if (rc) return rc;
+  if ((rc = ensure_layout(e, false))) return rc;
   HIPCHK(e, hipMemcpyAsync(rec, d, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
   return pgbp_sync(e);
 }
@@ -391,6 +448,10 @@ int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
 int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv) {
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
+  if (packed) {
+    int rc0 = ensure_layout(e, false);
+    if (rc0) return rc0;
+  }
   const size_t ns = (size_t)p.n_sites, nm = (size_t)p.n_msgs();
   if (packed) {
     const int64_t rsz = p.rpacked_off.back();
@@ -446,6 +507,7 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
     dir = 1;
   else
     return e->fail(PGBP_ERR_INVALID, "pgbp_propagate: the sepset does not connect these two clusters");
+  if ((rc = ensure_layout(e, false))) return rc;  // single messages run on the generic kernel
   const int32_t toff[2] = {0, 1};
   Entry en{2 * k + dir, 0, 0, 0};
   HIPCHK(e, hipMemcpyAsync(e->d_one_task_off, toff, sizeof(toff), hipMemcpyHostToDevice, e->st));
@@ -511,6 +573,7 @@ int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* op
   if ((rc = need_schedule(e, tree))) return rc;
   const Plan& p = e->plan;
   if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
   DevState S = dev_state(e, opts);
   enqueue_traversal(e, S, tree, dir, (unsigned long long)tree);
   launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
@@ -535,6 +598,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   }
   if ((rc = reset_fail(e))) return rc;
   HIPCHK(e, hipMemsetAsync(e->d_iscal, 0, sizeof(int32_t) * ns, e->st));
+  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
   DevState S = dev_state(e, opts);
   int pairs_done = 0;
   bool stop = false;
@@ -576,8 +640,8 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
   if (belief < 0 || belief >= p.n_beliefs()) return e->fail(PGBP_ERR_INVALID, "belief index out of range");
   const int m = p.dims[belief];
   const int ns = p.n_sites;
-  launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], m, mu ? e->d_mu : nullptr, std::max(1, p.max_dim),
-                   e->d_norm, e->d_info, ns, e->st);
+  launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], m, e->layout_bs16 ? 1 : 0, mu ? e->d_mu : nullptr,
+                   std::max(1, p.max_dim), e->d_norm, e->d_info, ns, e->st);
   HIPCHK(e, hipMemcpyAsync(norm, e->d_norm, sizeof(double) * ns, hipMemcpyDeviceToHost, e->st));
   std::vector<double> mus;
   if (mu && m > 0) {
@@ -619,6 +683,7 @@ int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, con
   if (rc) return rc;
   if ((rc = need_schedule(e, 0))) return rc;
   if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
   DevState S = dev_state(e, opts);
   for (int r = 0; r < reps; ++r)
     if ((rc = enqueue_calibrate_once(e, S, reset_each, nullptr))) return rc;
@@ -632,8 +697,8 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
   enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
-  launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], nullptr, std::max(1, p.max_dim),
-                   e->d_norm, e->d_info, p.n_sites, e->st);                                  // :212
+  launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, nullptr,
+                   std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);         // :212
   return PGBP_OK;
 }
 
@@ -643,6 +708,7 @@ int pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
   if (rc) return rc;
   if ((rc = need_schedule(e, 0))) return rc;
   if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
   DevState S = dev_state(e, opts);
   for (int r = 0; r < reps; ++r)
     if ((rc = enqueue_loglik_once(e, S))) return rc;
@@ -692,6 +758,7 @@ int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opt
   if (rc) return rc;
   if ((rc = need_schedule(e, 0))) return rc;
   if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
   DevState S = dev_state(e, opts);
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int launches = 0;

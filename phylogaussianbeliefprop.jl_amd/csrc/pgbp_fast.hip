@@ -20,6 +20,7 @@
 // log det J_I is accumulated as mantissa product + exponent sum (one log per message).
 #include <hip/hip_runtime.h>
 
+#include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
 
 namespace pgbp {
@@ -125,12 +126,46 @@ constexpr int kSlotJ = 0, kSlotH = 256, kSlotG = 272, kSlotStatus = 273, kSlotDo
 
 extern __shared__ double fast_lds[];
 
+// 2 x 2 block of a lane as (x, y, z, w) = (T(2a,2b), T(2a+1,2b), T(2a,2b+1), T(2a+1,2b+1))
+struct Blk { double x, y, z, w; };
+
+// Load / store the lane's block of a 16 x 16 symmetric quantity (sepset J, residual dJ, receiver sub-block,
+// a 16-dim sender).  Plain layout: column-major with leading dimension ld, all 64 lanes (two double2).
+// BS16: packed upper blocks, lanes a <= b only (one double4), pgbp_bs16.hpp.
+template <bool BS>
+__device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld, int a, int b, bool up, int kidx) {
+  Blk r{0.0, 0.0, 0.0, 0.0};
+  if constexpr (BS) {
+    if (up) {
+      const double4 v = *reinterpret_cast<const double4*>(base + kidx);
+      r = Blk{v.x, v.y, v.z, v.w};
+    }
+  } else {
+    const double2 c0 = *reinterpret_cast<const double2*>(base + 2 * a + (int64_t)ld * (2 * b));
+    const double2 c1 = *reinterpret_cast<const double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1));
+    r = Blk{c0.x, c0.y, c1.x, c1.y};
+  }
+  return r;
+}
+template <bool BS>
+__device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int a, int b, bool up, int kidx,
+                                          const Blk& v) {
+  if constexpr (BS) {
+    if (up) *reinterpret_cast<double4*>(base + kidx) = make_double4(v.x, v.y, v.z, v.w);
+  } else {
+    *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b)) = make_double2(v.x, v.y);
+    *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1)) = make_double2(v.z, v.w);
+  }
+}
+
 // One workgroup = one task; wave w of the workgroup = message w of the task (records padded to K per task).
 //   * accumulate tasks (postorder, several children into one receiver block): every wave computes its
 //     message and divides; waves > 0 hand their delta to wave 0 through LDS; wave 0 adds the deltas in the
 //     reference's order and stores the receiver block once;
 //   * reuse (preorder, one sender, several children): the providing wave computes the marginal once and
 //     hands it to the others through LDS; every wave divides by its own sepset and updates its own receiver.
+// BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
+template <bool BS>
 __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry* __restrict__ recs, int K,
                                                        unsigned long long seq_base,
                                                        unsigned long long stop_below) {
@@ -138,6 +173,8 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
   const int a = lane & 7, b = lane >> 3;
+  const bool up = a <= b;                          // this lane's block is stored in BS16
+  const int kidx = (b * (b + 1) / 2 + a) * 4;      // its offset inside a packed symmetric tile
   const FEntry en = recs[(int64_t)blockIdx.x * K + wave];
   const unsigned long long failkey = S.fail[site];
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
@@ -156,34 +193,35 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   double* __restrict__ to = pool + en.to_off;
   double* __restrict__ res = rpool + en.res_off;
   const int mt = en.mt, up0 = en.up0;
-  const int64_t so = 2 * a + P * (2 * b);
-  const int64_t tO = (up0 + 2 * a) + (int64_t)mt * (up0 + 2 * b);
+  // offsets inside the sepset / receiver / residual records
+  const bool tpk = BS && (mt == 16 || mt == 32);                                  // receiver record is packed
+  const int sepH = BS ? bs16::kH16 : P * P, sepG = has_block ? (BS ? bs16::kG16 : P * P + P) : 0;
+  const int64_t tJ0 = tpk ? ((mt == 32 && up0 == P) ? bs16::kT11 : bs16::kT00) : (up0 + (int64_t)mt * up0);
+  const int64_t tH0 = (tpk ? (mt == 16 ? bs16::kH16 : bs16::kH32) : (int64_t)mt * mt) + up0;
+  const int64_t tG0 = tpk ? (mt == 16 ? bs16::kG16 : bs16::kG32) : (int64_t)mt * mt + mt;
 
-  double mJ[2][2] = {{0, 0}, {0, 0}}, mh[2] = {0, 0}, gmsg = 0.0;
-  double tJ[2][2] = {{0, 0}, {0, 0}}, th[2] = {0, 0}, tg = 0.0;
-  double2 s0 = make_double2(0.0, 0.0), s1 = s0, sh = s0;
+  Blk mJ{0, 0, 0, 0}, tJ{0, 0, 0, 0}, sJ{0, 0, 0, 0};
+  double mh[2] = {0, 0}, gmsg = 0.0, th[2] = {0, 0}, tg = 0.0;
+  double2 sh = make_double2(0.0, 0.0);
   double sg = 0.0;
   int info = 0;
   if (state == 1) {
     const int poisoned = S.poison[(int64_t)site * S.n_clusters + en.from_b];
     // ---- every load of this message is issued before any arithmetic
     if (has_block) {
-      s0 = *reinterpret_cast<const double2*>(sep + so);
-      s1 = *reinterpret_cast<const double2*>(sep + so + P);
-      if (b == 0) sh = *reinterpret_cast<const double2*>(sep + P * P + 2 * a);
+      sJ = load_blk<BS>(sep, P, a, b, up, kidx);
+      if (b == 0) sh = *reinterpret_cast<const double2*>(sep + sepH + 2 * a);
     }
-    sg = sep[(int)en.s * en.s + en.s];
+    sg = sep[sepG];
     if (own) {
       if (accum || has_block) {
-        const double2 t0 = *reinterpret_cast<const double2*>(to + tO);
-        const double2 t1 = *reinterpret_cast<const double2*>(to + tO + mt);
-        tJ[0][0] = t0.x; tJ[1][0] = t0.y; tJ[0][1] = t1.x; tJ[1][1] = t1.y;
+        tJ = load_blk<BS>(to + tJ0, mt, a, b, up, kidx);
         if (b == 0) {
-          const double2 t2 = *reinterpret_cast<const double2*>(to + (int64_t)mt * mt + up0 + 2 * a);
+          const double2 t2 = *reinterpret_cast<const double2*>(to + tH0 + 2 * a);
           th[0] = t2.x; th[1] = t2.y;
         }
       }
-      tg = to[(int64_t)mt * mt + mt];
+      tg = to[tG0];
     }
     if (provider) {
       const double* __restrict__ from = pool + en.from_off;
@@ -191,27 +229,38 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
         gmsg = from[0];  // a constant factor
       } else if (en.mf == P && has_block) {
         // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
-        const double2 c0 = *reinterpret_cast<const double2*>(from + so);
-        const double2 c1 = *reinterpret_cast<const double2*>(from + so + P);
-        const double2 ch = *reinterpret_cast<const double2*>(from + P * P + 2 * a);
-        mJ[0][0] = c0.x; mJ[1][0] = c0.y; mJ[0][1] = c1.x; mJ[1][1] = c1.y;
+        mJ = load_blk<BS>(from, P, a, b, up, kidx);
+        const double2 ch = *reinterpret_cast<const double2*>(from + (BS ? bs16::kH16 : P * P) + 2 * a);
         mh[0] = ch.x; mh[1] = ch.y;
-        gmsg = from[P * P + P];
+        gmsg = from[BS ? bs16::kG16 : P * P + P];
       } else {
         Frag f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f.w[i][j] = 0.0;
         if (en.mf == P) {
           // everything is integrated (dimension-0 sepset): the 16 x 16 precision is the integrated block
-          const double2 v0 = *reinterpret_cast<const double2*>(from + so);
-          const double2 v1 = *reinterpret_cast<const double2*>(from + so + P);
-          const double2 vh = *reinterpret_cast<const double2*>(from + P * P + 2 * a);
-          f.w[0][0] = v0.x; f.w[1][0] = v0.y; f.w[0][1] = v1.x; f.w[1][1] = v1.y;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f.w[2][j] = 0.0; f.w[3][j] = 0.0;
-            if (j >= 2) { f.w[0][j] = 0.0; f.w[1][j] = 0.0; }
-          }
+          const Blk v = load_blk<BS>(from, P, a, b, up, kidx);
+          const double2 vh = *reinterpret_cast<const double2*>(from + (BS ? bs16::kH16 : P * P) + 2 * a);
+          f.w[0][0] = v.x; f.w[1][0] = v.y; f.w[0][1] = v.z; f.w[1][1] = v.w;
           f.h[0] = vh.x; f.h[1] = vh.y; f.h[2] = 0.0; f.h[3] = 0.0;
-          gmsg = from[P * P + P];
+          gmsg = from[BS ? bs16::kG16 : P * P + P];
+        } else if constexpr (BS) {
+          // 32-dim sender, packed: tiles T00 | T10 | T11.  integrated block = tile 0 (postorder, keep0 = 16)
+          // or tile 1 (preorder, keep0 = 0)
+          const bool itrail = en.keep0 == 0;
+          const Blk ii = load_blk<true>(from + (itrail ? bs16::kT11 : bs16::kT00), P, a, b, up, kidx);
+          const Blk ss = load_blk<true>(from + (itrail ? bs16::kT00 : bs16::kT11), P, a, b, up, kidx);
+          // J_SI block (rows of S = my a, cols of I = my b): block (a, b) of T10, or block (b, a) transposed
+          const double4 t = *reinterpret_cast<const double4*>(from + bs16::kT10 + (itrail ? (b + 8 * a) : (a + 8 * b)) * 4);
+          f.w[0][0] = ii.x; f.w[1][0] = ii.y; f.w[0][1] = ii.z; f.w[1][1] = ii.w;
+          f.w[2][2] = ss.x; f.w[3][2] = ss.y; f.w[2][3] = ss.z; f.w[3][3] = ss.w;
+          f.w[2][0] = t.x; f.w[3][0] = itrail ? t.z : t.y; f.w[2][1] = itrail ? t.y : t.z; f.w[3][1] = t.w;
+          const double2 hi = *reinterpret_cast<const double2*>(from + bs16::kH32 + (itrail ? P : 0) + 2 * a);
+          const double2 hs = *reinterpret_cast<const double2*>(from + bs16::kH32 + (itrail ? 0 : P) + 2 * a);
+          f.h[0] = hi.x; f.h[1] = hi.y; f.h[2] = hs.x; f.h[3] = hs.y;
+          gmsg = from[bs16::kG32];
         } else {
           // logical index = original index rotated so that the integrated block comes first
           const int rot = (en.keep0 == 0) ? P : 0;
@@ -223,8 +272,6 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
             if (j < 2) {
               const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
               f.w[0][j] = v.x; f.w[1][j] = v.y;
-            } else {
-              f.w[0][j] = 0.0; f.w[1][j] = 0.0;
             }
             const double2 u = *reinterpret_cast<const double2*>(from + r1 + co);
             f.w[2][j] = u.x; f.w[3][j] = u.y;
@@ -234,28 +281,37 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
           f.h[0] = v.x; f.h[1] = v.y; f.h[2] = u.x; f.h[3] = u.y;
           gmsg = from[32 * 32 + 32];
         }
-        // "fake" message: J_I, J_SI, h_I all ~ 0 (src/beliefupdates.jl:62-66), tested on the raw values
-        bool nz = fabs(f.h[0]) > PGBP_EPS || fabs(f.h[1]) > PGBP_EPS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nz |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
-        if (__any(nz)) {
-          // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
+        // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
+        // (in BS16 the lanes a > b hold nothing yet: all four of their entries come from lane (b, a))
+        {
           const int tl = a * 8 + b;  // lane holding the transposed 2 x 2 block
           const double t00 = __shfl(f.w[0][0], tl), t01 = __shfl(f.w[1][0], tl);
           const double t10 = __shfl(f.w[0][1], tl), t11 = __shfl(f.w[1][1], tl);
+          // the "fake"-message test below must see the RAW lower triangle in the plain layout
+          bool nzraw = false;
+          if constexpr (!BS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) nzraw |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
+          }
           if (2 * a + 0 > 2 * b + 0) f.w[0][0] = t00;
           if (2 * a + 0 > 2 * b + 1) f.w[0][1] = t01;
           if (2 * a + 1 > 2 * b + 0) f.w[1][0] = t10;
           if (2 * a + 1 > 2 * b + 1) f.w[1][1] = t11;
-          double mant = 1.0, quad = 0.0;
-          int expo = 0;
-          info = eliminate2<0>(f, a, b, col, mant, expo, quad);
-          if (info == 0) {
-            const double logdet = log(mant) + (double)expo * PGBP_LN2;
-            gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
+          // "fake" message: J_I, J_SI, h_I all ~ 0 (src/beliefupdates.jl:62-66)
+          bool nz = nzraw || fabs(f.h[0]) > PGBP_EPS || fabs(f.h[1]) > PGBP_EPS;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nz |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
+          if (__any(nz)) {
+            double mant = 1.0, quad = 0.0;
+            int expo = 0;
+            info = eliminate2<0>(f, a, b, col, mant, expo, quad);
+            if (info == 0) {
+              const double logdet = log(mant) + (double)expo * PGBP_LN2;
+              gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
+            }
           }
         }
-        mJ[0][0] = f.w[2][2]; mJ[1][0] = f.w[3][2]; mJ[0][1] = f.w[2][3]; mJ[1][1] = f.w[3][3];
+        mJ = Blk{f.w[2][2], f.w[3][2], f.w[2][3], f.w[3][3]};
         mh[0] = f.h[2]; mh[1] = f.h[3];
       }
     }
@@ -266,7 +322,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     // hand the marginal over to the waves that reuse it
     if (provider && en.valid && !accum) {
       if (state == 1) {
-        *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(mJ[0][0], mJ[1][0], mJ[0][1], mJ[1][1]);
+        *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(mJ.x, mJ.y, mJ.z, mJ.w);
         if (b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(mh[0], mh[1]);
       }
       if (lane == 0) {
@@ -280,7 +336,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
       const int pst = (int)src[kSlotStatus];
       if (pst == 1) {
         const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
-        mJ[0][0] = v.x; mJ[1][0] = v.y; mJ[0][1] = v.z; mJ[1][1] = v.w;
+        mJ = Blk{v.x, v.y, v.z, v.w};
         if (b == 0) {
           const double2 u = *reinterpret_cast<const double2*>(src + kSlotH + 2 * a);
           mh[0] = u.x; mh[1] = u.y;
@@ -292,27 +348,28 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     }
   }
   // ---- divide! (src/beliefupdates.jl:579-587): every wave for its own sepset
-  double d00 = 0.0, d10 = 0.0, d01 = 0.0, d11 = 0.0, dh0 = 0.0, dh1 = 0.0, dg = 0.0;
+  Blk dJ{0, 0, 0, 0};
+  double dh0 = 0.0, dh1 = 0.0, dg = 0.0;
   if (state == 1) {
     double maxJ = 0.0, maxh = 0.0;
     if (has_block) {
-      d00 = mJ[0][0] - s0.x; d10 = mJ[1][0] - s0.y; d01 = mJ[0][1] - s1.x; d11 = mJ[1][1] - s1.y;
-      *reinterpret_cast<double2*>(sep + so) = make_double2(mJ[0][0], mJ[1][0]);
-      *reinterpret_cast<double2*>(sep + so + P) = make_double2(mJ[0][1], mJ[1][1]);
-      *reinterpret_cast<double2*>(res + so) = make_double2(d00, d10);
-      *reinterpret_cast<double2*>(res + so + P) = make_double2(d01, d11);
-      maxJ = fmax(fmax(fabs(d00), fabs(d10)), fmax(fabs(d01), fabs(d11)));
-      if (d00 != d00 || d10 != d10 || d01 != d01 || d11 != d11) maxJ = INFINITY;
+      dJ = Blk{mJ.x - sJ.x, mJ.y - sJ.y, mJ.z - sJ.z, mJ.w - sJ.w};
+      store_blk<BS>(sep, P, a, b, up, kidx, mJ);
+      store_blk<BS>(res, P, a, b, up, kidx, dJ);
+      if (!BS || up) {
+        maxJ = fmax(fmax(fabs(dJ.x), fabs(dJ.y)), fmax(fabs(dJ.z), fabs(dJ.w)));
+        if (dJ.x != dJ.x || dJ.y != dJ.y || dJ.z != dJ.z || dJ.w != dJ.w) maxJ = INFINITY;
+      }
       if (b == 0) {
         dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
-        *reinterpret_cast<double2*>(sep + P * P + 2 * a) = make_double2(mh[0], mh[1]);
-        *reinterpret_cast<double2*>(res + P * P + 2 * a) = make_double2(dh0, dh1);
+        *reinterpret_cast<double2*>(sep + sepH + 2 * a) = make_double2(mh[0], mh[1]);
+        *reinterpret_cast<double2*>(res + (BS ? bs16::kResH : P * P) + 2 * a) = make_double2(dh0, dh1);
         maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
       }
     }
     dg = gmsg - sg;
     if (lane == 0) {
-      sep[(int)en.s * en.s + en.s] = gmsg;
+      sep[sepG] = gmsg;
       S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
     }
     if (S.update_resnorm) {
@@ -336,7 +393,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     // waves > 0 publish their delta; wave 0 adds them in the reference's order
     if (wave > 0) {
       if (state == 1) {
-        *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(d00, d10, d01, d11);
+        *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(dJ.x, dJ.y, dJ.z, dJ.w);
         if (b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(dh0, dh1);
       }
       if (lane == 0) {
@@ -346,14 +403,14 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     }
     __syncthreads();
     if (wave == 0 && state == 1) {
-      tJ[0][0] += d00; tJ[1][0] += d10; tJ[0][1] += d01; tJ[1][1] += d11;
+      tJ = Blk{tJ.x + dJ.x, tJ.y + dJ.y, tJ.z + dJ.z, tJ.w + dJ.w};
       th[0] += dh0; th[1] += dh1;
       tg += dg;
       for (int w = 1; w < K; ++w) {
         const double* src = fast_lds + w * kSlotDoubles;
         if ((int)src[kSlotStatus] != 1) break;  // the reference stops at the first failing message
         const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
-        tJ[0][0] += v.x; tJ[1][0] += v.y; tJ[0][1] += v.z; tJ[1][1] += v.w;
+        tJ = Blk{tJ.x + v.x, tJ.y + v.y, tJ.z + v.z, tJ.w + v.w};
         if (b == 0) {
           const double2 u = *reinterpret_cast<const double2*>(src + kSlotH + 2 * a);
           th[0] += u.x; th[1] += u.y;
@@ -362,26 +419,29 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
       }
     }
   } else if (state == 1) {
-    tJ[0][0] += d00; tJ[1][0] += d10; tJ[0][1] += d01; tJ[1][1] += d11;
+    tJ = Blk{tJ.x + dJ.x, tJ.y + dJ.y, tJ.z + dJ.z, tJ.w + dJ.w};
     th[0] += dh0; th[1] += dh1;
     tg += dg;
   }
   if (own && state == 1) {
     if (accum || has_block) {
-      *reinterpret_cast<double2*>(to + tO) = make_double2(tJ[0][0], tJ[1][0]);
-      *reinterpret_cast<double2*>(to + tO + mt) = make_double2(tJ[0][1], tJ[1][1]);
-      if (b == 0) *reinterpret_cast<double2*>(to + (int64_t)mt * mt + up0 + 2 * a) = make_double2(th[0], th[1]);
+      store_blk<BS>(to + tJ0, mt, a, b, up, kidx, tJ);
+      if (b == 0) *reinterpret_cast<double2*>(to + tH0 + 2 * a) = make_double2(th[0], th[1]);
     }
-    if (lane == 0) to[(int64_t)mt * mt + mt] = tg;
+    if (lane == 0) to[tG0] = tg;
   }
 }
 
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(bp_level_fast16, dim3(ntasks, n_sites), dim3(kWave * K),
-                     sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K, st, S, d_recs, K, seq_base,
-                     stop_below);
+  const size_t lds = sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K;
+  if (S.bs16)
+    hipLaunchKernelGGL(bp_level_fast16<true>, dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K, seq_base,
+                       stop_below);
+  else
+    hipLaunchKernelGGL(bp_level_fast16<false>, dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
+                       seq_base, stop_below);
 }
 
 }  // namespace pgbp

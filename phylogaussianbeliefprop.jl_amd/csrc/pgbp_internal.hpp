@@ -87,6 +87,7 @@ struct Plan {
   std::vector<Tree> trees;
   int32_t max_dim = 0;
   int32_t fast_p = 0;  // sepset dimension the register-resident kernel is instantiated for (0: none)
+  bool all_fast = false;  // every task of every scheduled traversal runs on the register-resident kernel
   std::string err;
 
   int32_t n_beliefs() const { return n_clusters + n_sepsets; }

@@ -10,6 +10,7 @@
 // Handles any belief dimension <= PGBP_MAX_DIM and arbitrary (ragged) scope index maps.
 #include <hip/hip_runtime.h>
 
+#include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
 
 namespace pgbp {
@@ -217,7 +218,7 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2
 __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict__ pool_all, int64_t pool_stride,
-                                                       int64_t rec_off, int m, double* __restrict__ mu,
+                                                       int64_t rec_off, int m, int bs, double* __restrict__ mu,
                                                        int mu_stride, double* __restrict__ norm,
                                                        int32_t* __restrict__ info_out) {
   const int lane = threadIdx.x;
@@ -225,17 +226,24 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
   const double* __restrict__ rec = pool_all + (int64_t)site * pool_stride + rec_off;
   double* W = lds + kPermDoubles;
   const int ld = (m + 1) | 1;
-  const double g = rec[(int64_t)m * m + m];
+  const bool packed = bs && bs16::applies(m);
+  const double g = packed ? rec[bs16::g_off(m)] : rec[(int64_t)m * m + m];
   bool nz = false;
   for (int idx = lane; idx < m * m; idx += kWave) {
     const int j = idx / m, i = idx - j * m;
-    const double raw = rec[idx];
-    nz |= raw != 0.0;
-    // PDMat(Symmetric(J)): read the upper triangle
-    W[i * ld + j] = (i <= j) ? raw : rec[j + (int64_t)i * m];
+    if (packed) {
+      const double v = rec[bs16::J_off(m, i, j)];  // symmetric by construction
+      nz |= v != 0.0;
+      W[i * ld + j] = v;
+    } else {
+      const double raw = rec[idx];
+      nz |= raw != 0.0;
+      // PDMat(Symmetric(J)): read the upper triangle
+      W[i * ld + j] = (i <= j) ? raw : rec[j + (int64_t)i * m];
+    }
   }
   for (int i = lane; i < m; i += kWave) {
-    const double hv = rec[(int64_t)m * m + i];
+    const double hv = packed ? rec[bs16::h_off(m, i)] : rec[(int64_t)m * m + i];
     nz |= hv != 0.0;
     W[i * ld + m] = hv;
   }
@@ -275,10 +283,95 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
   }
 }
 
-void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, double* d_mu, int mu_stride,
-                      double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
+void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, double* d_mu,
+                      int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
   hipLaunchKernelGGL(integrate_kernel, dim3(n_sites), dim3(kWave), generic_lds_bytes(m), st, pool, pool_stride,
-                     rec_off, m, d_mu, mu_stride, d_norm, d_info);
+                     rec_off, m, bs16, d_mu, mu_stride, d_norm, d_info);
+}
+
+// ---- BS16 <-> plain, in place, one workgroup per record (pgbp_bs16.hpp)
+__global__ __launch_bounds__(256) void convert_layout_kernel(double* __restrict__ pool, int64_t stride,
+                                                             const int64_t* __restrict__ off,
+                                                             const int32_t* __restrict__ dim, int n_records,
+                                                             int to_bs16, int is_residual) {
+  __shared__ double buf[32 * 32 + 32 + 1];
+  const int site = blockIdx.y;
+  for (int r = blockIdx.x; r < n_records; r += gridDim.x) {
+    const int m = dim[r];
+    if (!bs16::applies(m) || (is_residual && m != 16)) continue;  // uniform per workgroup
+    double* __restrict__ rec = pool + (int64_t)site * stride + off[r];
+    const int tail = is_residual ? m : m + 1;  // h (and g) after J
+    const int plain_len = m * m + tail;
+    const int packed_len = (m == 16 ? bs16::kSym : bs16::kH32) + tail;
+    const int src_len = to_bs16 ? plain_len : packed_len;
+    __syncthreads();
+    for (int t = threadIdx.x; t < src_len; t += blockDim.x) buf[t] = rec[t];
+    __syncthreads();
+    if (to_bs16) {
+      for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+        const int c = idx / m, rr = idx - c * m;
+        if (bs16::canonical(m, rr, c)) rec[bs16::J_off(m, rr, c)] = buf[idx];
+      }
+      const int hb = m == 16 ? bs16::kSym : bs16::kH32;
+      for (int t = threadIdx.x; t < tail; t += blockDim.x) rec[hb + t] = buf[m * m + t];
+    } else {
+      const int hb = m == 16 ? bs16::kSym : bs16::kH32;
+      for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+        const int c = idx / m, rr = idx - c * m;
+        rec[idx] = buf[bs16::J_off(m, rr, c)];
+      }
+      for (int t = threadIdx.x; t < tail; t += blockDim.x) rec[m * m + t] = buf[hb + t];
+    }
+  }
+}
+
+void launch_convert_layout(double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim, int n_records,
+                           int n_sites, int to_bs16, int is_residual, hipStream_t st) {
+  if (n_records <= 0) return;
+  const int gx = n_records < 65535 ? n_records : 65535;
+  hipLaunchKernelGGL(convert_layout_kernel, dim3(gx, n_sites), dim3(256), 0, st, pool, stride, d_off, d_dim,
+                     n_records, to_bs16, is_residual);
+}
+
+__global__ __launch_bounds__(256) void check_symmetry_kernel(const double* __restrict__ pool, int64_t stride,
+                                                             const int64_t* __restrict__ off,
+                                                             const int32_t* __restrict__ dim, int n_records,
+                                                             int32_t* __restrict__ flag) {
+  __shared__ double red[2][4];
+  const int site = blockIdx.y;
+  for (int r = blockIdx.x; r < n_records; r += gridDim.x) {
+    const int m = dim[r];
+    if (!bs16::applies(m)) continue;
+    const double* __restrict__ rec = pool + (int64_t)site * stride + off[r];
+    double asym = 0.0, mx = 0.0;
+    for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+      const int c = idx / m, rr = idx - c * m;
+      const double v = rec[idx];
+      mx = fmax(mx, fabs(v));
+      if (rr > c) {
+        const double d = fabs(v - rec[c + rr * m]);
+        asym = (d != d) ? INFINITY : fmax(asym, d);
+      }
+    }
+    asym = wave_max(asym);
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = asym; red[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double A = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+      const double M = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+      if (!(A <= 1e-10 * M)) atomicOr(flag, 1);
+    }
+  }
+}
+
+void launch_check_symmetry(const double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim,
+                           int n_records, int n_sites, int32_t* d_flag, hipStream_t st) {
+  if (n_records <= 0) return;
+  const int gx = n_records < 65535 ? n_records : 65535;
+  hipLaunchKernelGGL(check_symmetry_kernel, dim3(gx, n_sites), dim3(256), 0, st, pool, stride, d_off, d_dim,
+                     n_records, d_flag);
 }
 
 // ---- record gather/scatter between the ABI's packed layout and the padded device records

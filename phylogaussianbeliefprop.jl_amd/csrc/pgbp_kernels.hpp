@@ -25,6 +25,7 @@ struct DevState {
   int32_t n_msgs;
   int32_t update_resnorm;
   double atol;
+  int32_t bs16;  // beliefs of dimension 16 / 32 and residuals of 16-dim sepsets are in the BS16 layout
 };
 
 size_t generic_lds_bytes(int max_mf);
@@ -37,8 +38,16 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
 
-void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, double* d_mu, int mu_stride,
-                      double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
+void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, double* d_mu,
+                      int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
+
+// In-place layout conversion of the records listed by (d_off, d_dim): to_bs16 != 0: plain -> BS16, else back.
+// is_residual: records are [dJ | dh] (no g).  One workgroup per record.
+void launch_convert_layout(double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim, int n_records,
+                           int n_sites, int to_bs16, int is_residual, hipStream_t st);
+// d_flag[0] |= 1 if some record's J is not symmetric to 1e-10 * max|J| (plain layout)
+void launch_check_symmetry(const double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim,
+                           int n_records, int n_sites, int32_t* d_flag, hipStream_t st);
 
 // dst[site*dst_stride + dst_off[r] + t] = src[site*src_stride + src_off[r] + t], t < src_off'[r+1]-..: record copy
 void launch_records(const double* src, int64_t src_stride, const int64_t* d_src_off, double* dst, int64_t dst_stride,

@@ -426,6 +426,11 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
     build_traversals(p, T);
   }
   p.trees.swap(trees);
+  p.all_fast = !p.trees.empty();
+  for (const Tree& t : p.trees)
+    for (const Traversal* tr : {&t.post, &t.pre})
+      for (size_t L = 0; L + 1 < tr->level_off.size(); ++L)
+        if (tr->level_nfast[L] != tr->level_off[L + 1] - tr->level_off[L]) p.all_fast = false;
   return PGBP_OK;
 }
 

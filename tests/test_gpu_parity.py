@@ -328,3 +328,43 @@ def test_run_to_run_bitwise_deterministic(P):
         assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
         outs.append(cgb._packed.copy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_bs16_layout_roundtrip_and_asymmetric_fallback(P):
+    """The symmetric block-packed device layout (pgbp_bs16.hpp) is an internal detail: (i) beliefs uploaded,
+    calibrated (register-resident kernel in BS16) and downloaded agree with the oracle -- covered by every
+    p = 16 test above; (ii) a download straight after an upload returns the input bit-for-bit for symmetric
+    input; (iii) input that is NOT symmetric keeps the plain layout (the reference reads upper(J_I) and J_SI,
+    src/beliefupdates.jl:59,68) and still matches the oracle, which follows the reference's reads exactly."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(123)
+    tr = S.random_tree(40, rng)
+    p = 16
+    R = S.random_rate_matrix(p, rng)
+    R = (R + R.T) / 2
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    # make every J exactly symmetric (np.linalg.inv does not guarantee it)
+    for i in range(prob.nclusters):
+        m = int(prob.dims[i]); o = prob.packed_off[i]
+        J = packed[o:o + m * m].reshape(m, m, order="F")
+        packed[o:o + m * m] = ((J + J.T) / 2).reshape(-1, order="F")
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    cgb.set_schedule(prob.schedule)
+    assert P.propagate_1traversal_postorder_(cgb, None, None, *prob.schedule[0], sync=False)   # device now in BS16
+    cgb.init_beliefs_reset_fromfactors_(sync=True)                                               # back to plain on pull
+    assert np.array_equal(cgb._packed[0], packed)                                                # (ii) bit-exact
+    # (iii) asymmetric input: perturb the LOWER triangle of one internal clique's integrated block
+    pa, ch = prob.schedule[0]
+    snd = next(int(c) for c in ch if prob.dims[c] == 2 * p)
+    o = prob.packed_off[snd]
+    packed2 = packed.copy()
+    J = packed2[o:o + 4 * p * p].reshape(2 * p, 2 * p, order="F")
+    J[3, 1] += 0.37          # below the diagonal of J_I: the reference never reads it
+    cgb2 = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed2)
+    ocgb = oracle_cgb_from_problem(prob, packed2, p)
+    assert P.calibrate_(cgb2, prob.schedule, 2)[0] and OC.calibrate(ocgb, [oracle_schedule(prob)], 2)[0]
+    assert_beliefs_close(cgb2, ocgb)
+    ll = cgb2.integratebelief_(prob.root_cluster)[1]
+    assert rel_close(ll, S.bm_loglik_pruning(tr, R, np.zeros(p), X))   # the perturbation is invisible to the path
