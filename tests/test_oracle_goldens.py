@@ -240,3 +240,24 @@ def test_iscalibrated_residnorm_rule():
     assert not OB.iscalibrated_residnorm_update(r)
     e = OB.MessageResidual(0)
     assert e.iscalibrated_resid and e.kldiv == 0.0 and OB.iscalibrated_residnorm_update(e)
+
+
+def test_calibration_bethe_loopy_level1():
+    """test/test_calibration.jl:79-106: loopy BP on the Bethe cluster graph of a level-1 network, two
+    spanning trees, calibrate!(cgb, sched, 20; auto=true) converges; posterior mean at I3.  (The reference
+    regularises the beliefs first -- a transformation that preserves the graphical model; without it the
+    same fixed point is reached here, at the iteration the reference's own comment quotes: ':101 iter 5, sch 1'.)"""
+    g = G["calibration_bethe_level1"]
+    net = ON.read_newick(g["net"])
+    model = make_model(g["model"])
+    cg = OCG.bethe(net)
+    cgb = oracle_setup(net, cg, model, [g["y"]], g["taxa"])
+    sched = OCG.spanningtrees_clusterlist(cg, net)
+    assert len(sched) >= 2     # loopy: one spanning tree cannot cover every edge
+    log = []
+    assert OC.calibrate(cgb, sched, g["niter"], auto=True, info=True, log=log) == (True, True)
+    assert log[-1] == ("info", "calibration reached: iteration 5, schedule tree 1")
+    i3 = next(i for i, n in enumerate(net.vec_node) if not n.leaf and net.root in net.parents(n))
+    ind = cgb.clusterindex(net.vec_node[i3].name)
+    mu, _ = cgb.integratebelief(ind)
+    assert close(mu[-1], g["posterior_mean_I3"], rtol=g["rtol"])
