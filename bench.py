@@ -206,7 +206,7 @@ def main():
             "value": value, "unit": "messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg3: homogeneous BM, {args.traits} traits, {args.ntips}-tip random "
+            "config": {"workload": f"{'cfg3' if (args.traits, args.ntips, args.graph) == (16, 50000, 'cliquetree') else 'custom'}: homogeneous BM, {args.traits} traits, {args.ntips}-tip random "
                                    f"bifurcating tree (seed {args.seed}), {args.graph}, fixed root",
                        "clusters": int(prob.nclusters), "sepsets": int(len(prob.dims) - prob.nclusters),
                        "messages_per_step": int(msgs_per_cal), "tree_depth": int(tr.depth().max()),

@@ -40,12 +40,19 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
                                                  double& quad) {
   logdet = 0.0;
   quad = 0.0;
+  double mant = 1.0;
+  int expo = 0;
   for (int k = 0; k < ni; ++k) {
     const double d = W[k * ld + k];
     if (!(d > 0.0)) return k + 1;
-    const double rd = 1.0 / d;
+    double rd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + 2 Newton steps: ~1 ulp, half the latency of a division
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
     const double hk = W[k * ld + mf];
-    logdet += log(d);
+    int ex;
+    mant *= frexp(d, &ex);  // log det as mantissa product + exponent sum: one log per message
+    expo += ex;
+    if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
     quad += hk * hk * rd;
     const int nc = mf - k;      // columns k+1 .. mf (the last one is h)
     const int nr = mf - 1 - k;  // rows k+1 .. mf-1
@@ -56,6 +63,7 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
     if (jj < nc) {
       const int j = k + 1 + jj;
       const double pkj = W[k * ld + j];
+#pragma unroll 4
       for (int ii = i0; ii < nr; ii += R) {
         const int i = k + 1 + ii;
         W[i * ld + j] -= (W[i * ld + k] * rd) * pkj;
@@ -63,6 +71,7 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
     }
     __syncthreads();
   }
+  logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
   return 0;
 }
 
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
         const int i = lane & (L - 1);
         if (i < mf) {
           const int pi = perm[i];
+#pragma unroll 4
           for (int j = lane / L; j < mf; j += R) W[i * ld + j] = from[pi + (int64_t)perm[j] * mf];
           if (lane / L == 0) W[i * ld + mf] = from[(int64_t)mf * mf + pi];
         }
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
       const int a = lane & (L - 1);
       if (a < s) {
         const int ua = up[a];
+#pragma unroll 4
         for (int b = lane / L; b < s; b += R) {
           const double msg = W[(ni + a) * ld + ni + b];
           const int64_t o = a + (int64_t)b * s;
