@@ -20,7 +20,9 @@ def per_kernel(path, counter):
     d = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            d.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = name.split("<")[0]
+            d.setdefault(name, []).append(float(r["Counter_Value"]))
     return d
 
 
