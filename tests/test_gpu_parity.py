@@ -430,3 +430,76 @@ def test_cfg4_univariate_ou_sites(P):
     assert not info.any()
     for s in range(ns):
         assert rel_close(norm[s], dense[s]), (s, norm[s], dense[s])
+
+
+def test_multi_site_p16_bs16(P):
+    """n_sites > 1 with the register-resident kernel and the BS16 layout (grid.y = site): every site equals
+    its single-site run bit for bit, and its log-likelihood equals the independent pruning value."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(31)
+    tr = S.random_tree(45, rng)
+    p, ns = 16, 3
+    prob = S.cliquetree_of_tree(tr, p)
+    R = S.random_rate_matrix(p, rng)
+    R = (R + R.T) / 2
+    packs, lls = [], []
+    for s in range(ns):
+        mu = rng.standard_normal(p)
+        X = S.simulate_bm(tr, R, mu, rng)
+        packs.append(S.bm_factors_cliquetree(tr, prob, R, mu, X))
+        lls.append(S.bm_loglik_pruning(tr, R, mu, X))
+    big = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                           np.stack(packs), n_sites=ns)
+    assert P.calibrate_(big, prob.schedule, 2) == (True, True)
+    _, norm, info = big.integratebelief_(prob.root_cluster, all_sites=True)
+    assert not info.any()
+    for s in range(ns):
+        assert rel_close(norm[s], lls[s])
+        single = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off,
+                                                  prob.scope_idx, packs[s])
+        assert P.calibrate_(single, prob.schedule, 2) == (True, True)
+        assert np.array_equal(single._packed[0], big._packed[s])
+    # per-site results of a failure in ONE site: the others are unaffected
+    pa, ch = prob.schedule[0]
+    snd = next(int(c) for c in ch if prob.dims[c] == 2 * p)
+    bad = np.stack(packs).copy()
+    bad[1, prob.packed_off[snd]] = -1e9
+    eng = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, bad,
+                                           n_sites=ns)
+    eng.site = 1
+    assert P.calibrate_(eng, prob.schedule, 2, verbose=False) == (False, False)
+    res = eng.last_results
+    assert [res[s].succ for s in range(ns)] == [1, 0, 1] and res[1].fail_info == 1
+    assert res[0].iscal == 1 and res[2].iscal == 1
+    assert np.array_equal(eng._packed[0], big._packed[0]) and np.array_equal(eng._packed[2], big._packed[2])
+
+
+def test_single_belief_access_and_set(P):
+    """pgbp_get_belief / pgbp_set_belief (reading b[i] after calibration, editing one factor) across the
+    internal layout switches."""
+    import ctypes as C
+    from pgbp_amd import _lib as L
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(8)
+    tr = S.random_tree(20, rng)
+    p = 16
+    prob = S.cliquetree_of_tree(tr, p)
+    R = S.random_rate_matrix(p, rng); R = (R + R.T) / 2
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    assert P.calibrate_(cgb, prob.schedule, 1, sync=False)[0]          # device in BS16 now
+    lib = P.load()
+    i = int(np.argmax(prob.dims[:prob.nclusters]))
+    m = int(prob.dims[i])
+    rec = np.zeros(m * m + m + 1)
+    assert lib.pgbp_get_belief(cgb._eng, 0, i, L.f64p(rec)) == 0        # converts back to the ABI layout
+    cgb.pull()
+    assert np.array_equal(rec, cgb._packed[0, prob.packed_off[i]:prob.packed_off[i + 1]])
+    J = rec[:m * m].reshape(m, m, order="F")
+    assert np.allclose(J, J.T, rtol=0, atol=1e-9 * np.abs(J).max())
+    rec2 = rec.copy(); rec2[-1] += 1.5                                   # g += 1.5 on one belief
+    assert lib.pgbp_set_belief(cgb._eng, 0, i, L.f64p(rec2)) == 0
+    n0 = cgb.integratebelief_(i)[1]
+    cgb.pull()
+    assert cgb._packed[0, prob.packed_off[i + 1] - 1] == rec2[-1]
