@@ -44,7 +44,7 @@ def build_workload(ntips, p, seed, graph):
         prob = S.bethe_of_tree(tr, p)
         packed = S.bm_factors_bethe(tr, prob, R, mu, X)
     ll_check = S.bm_loglik_pruning(tr, R, mu, X)
-    return tr, prob, packed, ll_check
+    return tr, prob, packed, ll_check, (R, mu, X)
 
 
 def cpu_baseline(prob, packed, budget_s=20.0):
@@ -145,7 +145,7 @@ def main():
     from pgbp_amd import _lib as L
     lib = pgbp_amd.load()
 
-    tr, prob, packed, ll_check = build_workload(args.ntips, args.traits, args.seed + rank, args.graph)
+    tr, prob, packed, ll_check, (R, mu, X) = build_workload(args.ntips, args.traits, args.seed + rank, args.graph)
     cgb = pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off,
                                                   prob.scope_idx, packed, device=local_rank)
     cgb.set_schedule(prob.schedule)
@@ -190,10 +190,23 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- secondary metric: log-likelihood evaluations / s (reset from factors + postorder + integrate)
+        # ---- secondary metric: log-likelihood evaluations / s = the body of score(theta)
+        # (src/calibration.jl:195-221): assignfactors! ON THE DEVICE from (R^-1, log det R, mu), postorder
+        # traversal, root integratebelief!; only the parameters and the result cross the bus.
+        from pgbp_amd import synth as S
         ms = C.c_float()
-        check(lib.pgbp_time_enqueued(eng, 1, max(3, args.steps // 2), 1, C.byref(opts), C.byref(ms)))
-        ll_evals = max(3, args.steps // 2) / (ms.value * 1e-3)
+        nll = max(3, args.steps // 2)
+        cgb.bm_tree_setup(*S.bm_tree_table(tr, prob), X)
+        cgb.assignfactors_bm_(R, mu)
+        check(lib.pgbp_time_enqueued(eng, 2, nll, 1, C.byref(opts), C.byref(ms)))
+        ll_evals = nll / (ms.value * 1e-3)
+        check(lib.pgbp_fetch_loglik(eng, L.f64p(norm), L.i32p(info)))
+        rel3 = abs(norm[0] - ll_check) / max(1.0, abs(ll_check))
+        if not (info[0] == 0 and rel3 <= 1e-8) and not skip_parity:
+            raise SystemExit(f"device-fill loglik parity failed: {norm[0]!r} vs {ll_check!r}")
+        # same without the fill (factors copied from the resident factor pool)
+        check(lib.pgbp_time_enqueued(eng, 1, nll, 1, C.byref(opts), C.byref(ms)))
+        ll_evals_nofill = nll / (ms.value * 1e-3)
         # ---- roofline of the dominant kernel: HIP events around every message-level launch
         nl = C.c_int32()
         reps = max(2, min(5, args.steps))
@@ -212,7 +225,7 @@ def main():
                        "messages_per_step": int(msgs_per_cal), "tree_depth": int(tr.depth().max()),
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
             "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel), "parity_skipped": skip_parity,
-            "ll_evals_per_s": ll_evals,
+            "ll_evals_per_s": ll_evals, "ll_evals_per_s_without_factor_fill": ll_evals_nofill,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc or {}).get("hbm_bytes_per_launch"),

@@ -161,6 +161,34 @@ int  pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_r
  * An all-zero belief gives mu = Inf, norm = g (src/beliefupdates.jl:189-191). */
 int  pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int32_t* info);
 
+/* ---- factor assignment on the device (first "next" row: SURVEY.md section 8(f)-1) ------------ */
+/* assignfactors! (src/beliefs.jl:786-861) for a homogeneous Brownian motion with full rate matrix
+ * (MvFullBrownianMotion: factor_treeedge src/evomodels/homogeneousbrownianmotion.jl:262-282,
+ * absorbleaf!/absorbevidence! src/beliefupdates.jl:210-274) on a TREE with complete tip data and a fixed
+ * root, when every cluster holds at most one node family {child, parent} (clique tree or Bethe graph of a
+ * tree).  The static part is given once; every later call only moves the p*p + p + 1 model parameters. */
+typedef struct pgbp_bm_tree {
+  int32_t p;               /* traits */
+  int32_t n_rows;          /* rows of `data` per site */
+  const int32_t* kind;     /* [n_clusters] factor of the cluster:
+                                0 edge child->parent, both in scope            J = [j -j; -j j], j = R^-1 / t
+                                1 edge whose parent is the fixed root          mu absorbed on the parent's variables
+                                2 edge whose child is a tip with data          data absorbed on the child's variables
+                                3 tip attached to the fixed root               constant
+                               -1 no factor (belief = 1), e.g. Bethe variable clusters */
+  const double* length;    /* [n_clusters] branch length t > 0 (ignored for kind -1) */
+  const int32_t* data_row; /* [n_clusters] row of the tip's data (kinds 2, 3), else -1 */
+  const double* data;      /* [n_sites][n_rows][p] tip data, host pointer */
+} pgbp_bm_tree;
+int  pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t);
+/* Fill every cluster belief AND the factors from (R^-1, log det R, mu), set sepsets to 1, reset the
+ * calibration flags: init_beliefs_reset! + the factor loop of assignfactors! + what ClusterGraphBelief /
+ * init_messagecalibrationflags_reset! do around it (src/calibration.jl:205-209).
+ * Rinv: p*p (column-major, symmetric), mu: p.  per_site != 0: one parameter set per site
+ * (Rinv [n_sites][p*p], logdetR [n_sites], mu [n_sites][p]), else one shared set.  Asynchronous. */
+int  pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double* logdetR, const double* mu,
+                                int32_t per_site);
+
 /* ---- device-side access for benchmarking / zero-copy callers ----------------------------- */
 /* Enqueue `reps` full calibrate iterations (all trees, post+pre, flag reduction) without any host
  * synchronisation; the caller brackets with pgbp_sync. Resets beliefs from factors before each
@@ -171,6 +199,9 @@ int  pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, co
  * per-site norms stay on the device until pgbp_fetch_loglik. */
 int  pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts);
 int  pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info);
+/* The whole body of score(theta) (src/calibration.jl:195-221) on the device: pgbp_bm_tree_assignfactors with
+ * the parameters uploaded by the LAST pgbp_bm_tree_assignfactors call, postorder of tree 0, root integrate. */
+int  pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts);
 int  pgbp_sync(pgbp_engine* e);
 /* Time `reps` repetitions of the enqueued work with HIP events on the engine's stream; returns the
  * total milliseconds in *ms_total and, per kernel family, accumulated device time is NOT measured here

@@ -28,6 +28,12 @@ class Desc(C.Structure):
                 ("n_sites", C.c_int32), ("device", C.c_int32)]
 
 
+class BmTree(C.Structure):
+    _fields_ = [("p", C.c_int32), ("n_rows", C.c_int32), ("kind", C.POINTER(C.c_int32)),
+                ("length", C.POINTER(C.c_double)), ("data_row", C.POINTER(C.c_int32)),
+                ("data", C.POINTER(C.c_double))]
+
+
 class Opts(C.Structure):
     _fields_ = [("auto_stop", C.c_int32), ("update_residualnorm", C.c_int32),
                 ("update_residualkldiv", C.c_int32), ("reserved", C.c_int32), ("atol", C.c_double)]
@@ -73,6 +79,9 @@ SYMBOLS = {
     "pgbp_traverse": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
     "pgbp_calibrate": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
     "pgbp_integrate": (C.c_int, [_P, C.c_int32, _F64P, _F64P, _I32P]),
+    "pgbp_bm_tree_setup": (C.c_int, [_P, C.POINTER(BmTree)]),
+    "pgbp_bm_tree_assignfactors": (C.c_int, [_P, _F64P, _F64P, _F64P, C.c_int32]),
+    "pgbp_enqueue_loglik_bm": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_enqueue_calibrate": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
     "pgbp_enqueue_loglik": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),

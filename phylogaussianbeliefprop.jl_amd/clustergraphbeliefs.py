@@ -297,6 +297,37 @@ class ClusterGraphBelief:
                 return j
         raise ValueError("no sepset with a single node")
 
+    # ------------------------------------------------------------------ device factor assignment
+    def bm_tree_setup(self, kind, length, data_row, data):
+        """Static part of assignfactors! for a homogeneous BM on a tree (include/pgbp.h: pgbp_bm_tree);
+        data: [n_sites, n_rows, p] (or [n_rows, p] for one site) tip data indexed by data_row."""
+        data = np.ascontiguousarray(np.asarray(data, np.float64))
+        if data.ndim == 2:
+            data = data[None]
+        assert data.shape[0] == self.n_sites
+        self._bm = dict(kind=np.ascontiguousarray(kind, np.int32), length=np.ascontiguousarray(length, np.float64),
+                        row=np.ascontiguousarray(data_row, np.int32), data=data)
+        t = L.BmTree(int(data.shape[2]), int(data.shape[1]), L.i32p(self._bm["kind"]), L.f64p(self._bm["length"]),
+                     L.i32p(self._bm["row"]), L.f64p(data))
+        _check(self._lib.pgbp_bm_tree_setup(self._eng, C.byref(t)), self._eng)
+        self._bm_p = int(data.shape[2])
+
+    def assignfactors_bm_(self, R, mu, sync=False):
+        """assignfactors!(beliefs, MvFullBrownianMotion(R, mu), ...) (src/beliefs.jl:786-861) on the device:
+        only R^-1, log det R and mu cross the bus.  R: [p, p] or [n_sites, p, p]; mu: [p] or [n_sites, p]."""
+        R = np.asarray(R, np.float64)
+        mu = np.asarray(mu, np.float64)
+        per_site = R.ndim == 3
+        Rs = R if per_site else R[None]
+        Rinv = np.ascontiguousarray(np.stack([np.linalg.inv((r + r.T) / 2) for r in Rs]))
+        Rinv = np.ascontiguousarray((Rinv + np.transpose(Rinv, (0, 2, 1))) / 2)
+        logdet = np.ascontiguousarray([np.linalg.slogdet(r)[1] for r in Rs], np.float64)
+        mus = np.ascontiguousarray(mu if mu.ndim == 2 else np.broadcast_to(mu, (len(Rs), self._bm_p)).copy())
+        _check(self._lib.pgbp_bm_tree_assignfactors(self._eng, L.f64p(Rinv), L.f64p(logdet), L.f64p(mus),
+                                                    int(per_site)), self._eng)
+        if sync:
+            self.pull()
+
     def traffic_model(self):
         b = C.c_double()
         n = C.c_int64()

@@ -59,6 +59,10 @@ struct pgbp_engine {
   Entry* d_one_entry = nullptr;
   std::vector<DevTraversal> dpost, dpre;
   bool have_factors = false;
+  // pgbp_bm_tree: static description + last parameters of the device factor fill
+  int32_t bm_p = 0, bm_rows = 0, bm_per_site = 0;
+  int32_t *d_bm_kind = nullptr, *d_bm_row = nullptr;
+  double *d_bm_length = nullptr, *d_bm_data = nullptr, *d_bm_Rinv = nullptr, *d_bm_logdet = nullptr, *d_bm_mu = nullptr;
   std::string err;
 
   int fail(int code, const std::string& msg) {
@@ -254,7 +258,8 @@ void pgbp_destroy(pgbp_engine* e) {
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
                   (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_bdim, (void*)e->d_rdim,
-                  (void*)e->d_symflag})
+                  (void*)e->d_symflag, (void*)e->d_bm_kind, (void*)e->d_bm_row, (void*)e->d_bm_length,
+                  (void*)e->d_bm_data, (void*)e->d_bm_Rinv, (void*)e->d_bm_logdet, (void*)e->d_bm_mu})
     if (p) (void)hipFree(p);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
@@ -659,6 +664,89 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
   return PGBP_OK;
 }
 
+// ---- device factor assignment (homogeneous BM on a tree) ----------------------------------------
+
+int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
+  if (!e || !t || !t->kind || !t->length || !t->data_row || t->p <= 0 || t->p > PGBP_MAX_DIM || t->n_rows < 0)
+    return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  const int nc = p.n_clusters;
+  // the cluster dimensions must be what the factor kinds imply
+  for (int c = 0; c < nc; ++c) {
+    const int k = t->kind[c];
+    const int want = k == 0 ? 2 * t->p : (k == 1 || k == 2) ? t->p : (k == 3 ? 0 : p.dims[c]);
+    if (k < -1 || k > 3 || p.dims[c] != want || (k >= 0 && !(t->length[c] > 0.0)) ||
+        (k >= 2 && (t->data_row[c] < 0 || t->data_row[c] >= t->n_rows)))
+      return e->fail(PGBP_ERR_INVALID, "pgbp_bm_tree_setup: cluster " + std::to_string(c) + ": kind, dimension, branch length or data row inconsistent");
+  }
+  if (t->n_rows > 0 && !t->data) return e->fail(PGBP_ERR_INVALID, "pgbp_bm_tree_setup: data missing");
+  for (void* q : {(void*)e->d_bm_kind, (void*)e->d_bm_row, (void*)e->d_bm_length, (void*)e->d_bm_data, (void*)e->d_bm_Rinv,
+                  (void*)e->d_bm_logdet, (void*)e->d_bm_mu})
+    if (q) (void)hipFree(q);
+  e->d_bm_kind = e->d_bm_row = nullptr;
+  e->d_bm_length = e->d_bm_data = e->d_bm_Rinv = e->d_bm_logdet = e->d_bm_mu = nullptr;
+  int rc;
+  if ((rc = upload(e, &e->d_bm_kind, std::vector<int32_t>(t->kind, t->kind + nc)))) return rc;
+  if ((rc = upload(e, &e->d_bm_row, std::vector<int32_t>(t->data_row, t->data_row + nc)))) return rc;
+  if ((rc = upload(e, &e->d_bm_length, std::vector<double>(t->length, t->length + nc)))) return rc;
+  const size_t nd = (size_t)p.n_sites * t->n_rows * t->p;
+  if ((rc = dev_alloc(e, &e->d_bm_data, nd))) return rc;
+  if (nd) HIPCHK(e, hipMemcpy(e->d_bm_data, t->data, nd * sizeof(double), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(e, &e->d_bm_Rinv, (size_t)p.n_sites * t->p * t->p))) return rc;
+  if ((rc = dev_alloc(e, &e->d_bm_logdet, (size_t)p.n_sites))) return rc;
+  if ((rc = dev_alloc(e, &e->d_bm_mu, (size_t)p.n_sites * t->p))) return rc;
+  e->bm_p = t->p;
+  e->bm_rows = t->n_rows;
+  return PGBP_OK;
+}
+
+static int bm_fill_async(pgbp_engine* e) {
+  const Plan& p = e->plan;
+  launch_bm_tree_fill(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, e->d_bm_kind,
+                      e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv, e->d_bm_logdet,
+                      e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.n_clusters, p.n_sites, e->st);
+  launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
+                      p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
+  e->have_factors = true;
+  return PGBP_OK;
+}
+
+int pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double* logdetR, const double* mu,
+                               int32_t per_site) {
+  if (!e || !Rinv || !logdetR || !mu) return PGBP_ERR_INVALID;
+  if (!e->d_bm_kind) return e->fail(PGBP_ERR_STATE, "pgbp_bm_tree_assignfactors: call pgbp_bm_tree_setup first");
+  const size_t n = per_site ? (size_t)e->plan.n_sites : 1, pp = (size_t)e->bm_p;
+  HIPCHK(e, hipMemcpyAsync(e->d_bm_Rinv, Rinv, n * pp * pp * sizeof(double), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipMemcpyAsync(e->d_bm_logdet, logdetR, n * sizeof(double), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipMemcpyAsync(e->d_bm_mu, mu, n * pp * sizeof(double), hipMemcpyHostToDevice, e->st));
+  e->bm_per_site = per_site ? 1 : 0;
+  // R^-1 is symmetric and the fill writes symmetric blocks: the layout the traversals want can be kept
+  e->sym_known = true;
+  e->sym_ok = true;
+  return bm_fill_async(e);
+}
+
+int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  if (!e->d_bm_kind) return e->fail(PGBP_ERR_STATE, "pgbp_enqueue_loglik_bm: call pgbp_bm_tree_setup / assignfactors first");
+  if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  DevState S = dev_state(e, opts);
+  const Plan& p = e->plan;
+  for (int r = 0; r < reps; ++r) {
+    if ((rc = bm_fill_async(e))) return rc;                      // assignfactors!        calibration.jl:205
+    enqueue_traversal(e, S, 0, 0, 0);                            // postorder             :210
+    const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
+    launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, nullptr,
+                     std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);  // :212
+  }
+  return PGBP_OK;
+}
+
 // ---- benchmarking / zero-copy entry points ---------------------------------------------------
 
 static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_each,
@@ -740,7 +828,8 @@ int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset
   HIPCHK(e, hipEventCreate(&b));
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipEventRecord(a, e->st));
-  int rc = kind == 0 ? pgbp_enqueue_calibrate(e, reps, reset_each, opts) : pgbp_enqueue_loglik(e, reps, opts);
+  int rc = kind == 0 ? pgbp_enqueue_calibrate(e, reps, reset_each, opts)
+                     : (kind == 2 ? pgbp_enqueue_loglik_bm(e, reps, opts) : pgbp_enqueue_loglik(e, reps, opts));
   if (rc == PGBP_OK) {
     HIPCHK(e, hipEventRecord(b, e->st));
     HIPCHK(e, hipEventSynchronize(b));

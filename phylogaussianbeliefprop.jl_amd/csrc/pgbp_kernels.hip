@@ -444,6 +444,94 @@ void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites
                      reinterpret_cast<double2*>(dst), dst_stride / 2, n / 2);
 }
 
+// assignfactors! for MvFullBrownianMotion on a tree, complete data, fixed root (include/pgbp.h: pgbp_bm_tree).
+//   factor_treeedge (src/evomodels/homogeneousbrownianmotion.jl:262-282): J = [j -j; -j j], j = R^-1 / t, h = 0,
+//     g = g0 - p log(t) / 2,  g0 = -(p log 2pi + log det R) / 2
+//   absorbevidence! (src/beliefupdates.jl:210-231) on the child's (tip data y) or the parent's (fixed root mu)
+//     variables: g += h_a'y - y'J_aa y / 2, h_k -= J_ka y, J <- J_kk
+__global__ __launch_bounds__(256) void bm_tree_fill_kernel(double* __restrict__ pool, int64_t pool_stride,
+                                                           double* __restrict__ fpool, int64_t fpool_stride,
+                                                           const int64_t* __restrict__ boff,
+                                                           const int32_t* __restrict__ dim,
+                                                           const int32_t* __restrict__ kind,
+                                                           const double* __restrict__ length,
+                                                           const int32_t* __restrict__ row,
+                                                           const double* __restrict__ data, int n_rows, int p,
+                                                           const double* __restrict__ Rinv_all,
+                                                           const double* __restrict__ logdetR_all,
+                                                           const double* __restrict__ mu_all, int per_site, int bs,
+                                                           int n_clusters) {
+  __shared__ double v[PGBP_MAX_DIM];   // the vector absorbed (y - or mu): R^-1 v / t
+  __shared__ double jv[PGBP_MAX_DIM];
+  const int site = blockIdx.y;
+  const double* __restrict__ Rinv = Rinv_all + (per_site ? (int64_t)site * p * p : 0);
+  const double* __restrict__ mu = mu_all + (per_site ? (int64_t)site * p : 0);
+  const double logdetR = logdetR_all[per_site ? site : 0];
+  for (int c = blockIdx.x; c < n_clusters; c += gridDim.x) {
+    const int k = kind[c], m = dim[c];
+    double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[c];
+    double* __restrict__ frec = fpool + (int64_t)site * fpool_stride + boff[c];
+    const bool packed = bs && bs16::applies(m);
+    const int len = packed ? (m == 16 ? bs16::kLen16 : bs16::kLen32) : m * m + m + 1;
+    __syncthreads();
+    if (k < 0) {  // no factor: the constant function 1
+      for (int t = threadIdx.x; t < len; t += blockDim.x) { rec[t] = 0.0; frec[t] = 0.0; }
+      continue;
+    }
+    const double it = 1.0 / length[c];
+    double g = -0.5 * ((double)p * PGBP_LOG2PI + logdetR) - 0.5 * (double)p * log(length[c]);
+    // absorbed vector(s): kinds 1 (mu on the parent), 2 (y on the child), 3 (y - mu: both)
+    if (k >= 1) {
+      const double* __restrict__ y = (k >= 2) ? data + ((int64_t)site * n_rows + row[c]) * p : mu;
+      for (int t = threadIdx.x; t < p; t += blockDim.x) v[t] = (k == 3) ? y[t] - mu[t] : y[t];
+      __syncthreads();
+      for (int t = threadIdx.x; t < p; t += blockDim.x) {
+        double acc = 0.0;
+        for (int u = 0; u < p; ++u) acc += Rinv[t + (int64_t)u * p] * v[u];
+        jv[t] = acc * it;
+      }
+      __syncthreads();
+      double q = 0.0;
+      for (int u = 0; u < p; ++u) q += jv[u] * v[u];
+      g -= 0.5 * q;
+    }
+    // J: kind 0: 2p x 2p [j -j; -j j]; kinds 1, 2: p x p block j; kind 3: nothing
+    if (k <= 2) {
+      for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+        const int cc = idx / m, rr = idx - cc * m;
+        const double j = Rinv[(rr % p) + (int64_t)(cc % p) * p] * it;
+        const double val = ((rr < p) == (cc < p)) ? j : -j;   // m == p: always +j
+        if (packed) {
+          if (bs16::canonical(m, rr, cc)) { rec[bs16::J_off(m, rr, cc)] = val; frec[bs16::J_off(m, rr, cc)] = val; }
+        } else {
+          rec[idx] = val; frec[idx] = val;
+        }
+      }
+      for (int t = threadIdx.x; t < m; t += blockDim.x) {
+        // h_k -= J_ka v with J_ka = -j: h = +j v on the kept block (kinds 1, 2); 0 for kind 0
+        const double hv = (k == 0) ? 0.0 : jv[t];
+        const int o = packed ? bs16::h_off(m, t) : m * m + t;
+        rec[o] = hv; frec[o] = hv;
+      }
+    }
+    if (threadIdx.x == 0) {
+      const int o = packed ? bs16::g_off(m) : m * m + m;
+      rec[o] = g; frec[o] = g;
+    }
+  }
+}
+
+void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
+                         const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
+                         const double* d_data, int n_rows, int p, const double* d_Rinv, const double* d_logdetR,
+                         const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
+  if (n_clusters <= 0) return;
+  const int gx = n_clusters < 65535 ? n_clusters : 65535;
+  hipLaunchKernelGGL(bm_tree_fill_kernel, dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool, fpool_stride,
+                     d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, p, d_Rinv, d_logdetR, d_mu, per_site, bs16,
+                     n_clusters);
+}
+
 // init_messagecalibrationflags_reset! (src/beliefs.jl:973-979): empty messages stay calibrated
 __global__ void reset_flags_kernel(const MsgDesc* __restrict__ msgs, int32_t* __restrict__ flags,
                                    double* __restrict__ kldiv, int n_msgs, int reset_kl) {

@@ -57,6 +57,13 @@ void launch_copy_strided(const double* src, int64_t src_stride, double* dst, int
                          int n_sites, hipStream_t st);
 void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites, hipStream_t st);
 
+// assignfactors! for a homogeneous BM on a tree (pgbp_bm_tree of include/pgbp.h): writes the cluster record into
+// `pool` and `fpool` (current layout), one workgroup per (cluster, site)
+void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
+                         const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
+                         const double* d_data, int n_rows, int p, const double* d_Rinv, const double* d_logdetR,
+                         const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st);
+
 void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int n_msgs, int n_sites, int reset_kl,
                         hipStream_t st);
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st);

@@ -290,6 +290,24 @@ def bm_factors_cliquetree(tree: Tree, prob: Problem, R: np.ndarray, mu: np.ndarr
     return packed
 
 
+def bm_tree_table(tree: Tree, prob: Problem):
+    """Static description for the DEVICE factor fill (include/pgbp.h: pgbp_bm_tree): per cluster the kind of
+    its node-family factor, the branch length and the data row (= node index) of a tip.  Works for
+    cliquetree_of_tree and bethe_of_tree problems (variable clusters get kind -1)."""
+    N = tree.nnodes
+    c = np.arange(1, N)
+    leaf, pa_root = tree.is_leaf[c], tree.parent[c] == 0
+    kind = np.where(~leaf & ~pa_root, 0, np.where(~leaf & pa_root, 1, np.where(leaf & ~pa_root, 2, 3))).astype(np.int32)
+    length = tree.length[c].astype(np.float64)
+    row = np.where(leaf, c, -1).astype(np.int32)
+    extra = prob.nclusters - (N - 1)
+    if extra > 0:  # Bethe variable clusters
+        kind = np.concatenate([kind, np.full(extra, -1, np.int32)])
+        length = np.concatenate([length, np.ones(extra)])
+        row = np.concatenate([row, np.full(extra, -1, np.int32)])
+    return kind, length, row
+
+
 def bm_loglik_pruning(tree: Tree, R: np.ndarray, mu: np.ndarray, Y: np.ndarray) -> float:
     """Independent O(n p^3) check: Felsenstein-style pruning for BM with a fixed root
     (no shared code with the engine): each subtree is summarised as N(x_hat, v R) x const."""

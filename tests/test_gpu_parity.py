@@ -503,3 +503,41 @@ def test_single_belief_access_and_set(P):
     n0 = cgb.integratebelief_(i)[1]
     cgb.pull()
     assert cgb._packed[0, prob.packed_off[i + 1] - 1] == rec2[-1]
+
+
+@pytest.mark.parametrize("graph,ntips,p", [("cliquetree", 30, 16), ("cliquetree", 25, 3), ("bethe", 20, 4),
+                                           ("cliquetree", 2, 16), ("cliquetree", 3, 1)])
+def test_device_factor_fill_bm_tree(P, graph, ntips, p):
+    """pgbp_bm_tree_assignfactors (assignfactors! on the device) == the host fill that
+    tests/test_plan_cpu.py pins against the oracle's assignfactors! restatement; a second parameter set is
+    evaluated without re-uploading anything but (R^-1, log det R, mu)."""
+    import ctypes as C
+    from pgbp_amd import _lib as L
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(500 + ntips + p)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng); R = (R + R.T) / 2
+    mu = rng.standard_normal(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    prob = S.cliquetree_of_tree(tr, p) if graph == "cliquetree" else S.bethe_of_tree(tr, p)
+    fill = S.bm_factors_cliquetree if graph == "cliquetree" else S.bm_factors_bethe
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                           np.zeros(int(prob.packed_off[-1])))
+    cgb.set_schedule(prob.schedule)
+    cgb.bm_tree_setup(*S.bm_tree_table(tr, prob), X)
+    for (R_, mu_) in ((R, mu), (2.0 * R + 0.3 * np.eye(p), mu + 0.5)):
+        cgb.assignfactors_bm_(R_, mu_, sync=True)
+        ref = fill(tr, prob, R_, mu_, X)
+        scale = max(1.0, np.abs(ref).max())
+        assert np.max(np.abs(cgb._packed[0] - ref)) <= 1e-12 * scale
+        # the whole score(theta) body on the device: fill + postorder + root integrate
+        lib = P.load()
+        o = cgb._opts()
+        assert lib.pgbp_enqueue_loglik_bm(cgb._eng, 2, C.byref(o)) == 0
+        norm = np.zeros(1); info = np.zeros(1, np.int32)
+        assert lib.pgbp_fetch_loglik(cgb._eng, L.f64p(norm), L.i32p(info)) == 0
+        assert info[0] == 0 and rel_close(norm[0], S.bm_loglik_pruning(tr, R_, mu_, X))
+        # and a full calibration from the device-filled factors
+        cgb.assignfactors_bm_(R_, mu_)
+        assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
+        assert rel_close(cgb.integratebelief_(prob.root_cluster)[1], S.bm_loglik_pruning(tr, R_, mu_, X))
