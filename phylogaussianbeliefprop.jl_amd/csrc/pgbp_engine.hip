@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -116,6 +117,7 @@ DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
   S.update_resnorm = o ? o->update_residualnorm : 1;
   S.atol = o ? o->atol : 1e-5;
   S.bs16 = e->layout_bs16 ? 1 : 0;
+  S.fast_p = e->plan.fast_p;
   return S;
 }
 
@@ -136,8 +138,8 @@ int ensure_layout(pgbp_engine* e, bool want_bs16) {
   if (want_bs16) {
     if (!e->sym_known) {
       HIPCHK(e, hipMemsetAsync(e->d_symflag, 0, sizeof(int32_t), e->st));
-      launch_check_symmetry(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_beliefs(), p.n_sites, e->d_symflag, e->st);
-      launch_check_symmetry(e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters, p.n_sites, e->d_symflag, e->st);
+      launch_check_symmetry(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_beliefs(), p.n_sites, e->d_symflag, p.fast_p, e->st);
+      launch_check_symmetry(e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters, p.n_sites, e->d_symflag, p.fast_p, e->st);
       int32_t flag = 0;
       HIPCHK(e, hipMemcpyAsync(&flag, e->d_symflag, sizeof(flag), hipMemcpyDeviceToHost, e->st));
       HIPCHK(e, hipStreamSynchronize(e->st));
@@ -147,15 +149,18 @@ int ensure_layout(pgbp_engine* e, bool want_bs16) {
     if (!e->sym_ok) return PGBP_OK;  // stay plain: exact reference semantics for asymmetric input
   }
   const int to = want_bs16 ? 1 : 0;
-  launch_convert_layout(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_beliefs(), p.n_sites, to, 0, e->st);
-  launch_convert_layout(e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters, p.n_sites, to, 0, e->st);
-  launch_convert_layout(e->d_rpool, p.rpool_stride(), e->d_roff, e->d_rdim, p.n_msgs(), p.n_sites, to, 1, e->st);
+  launch_convert_layout(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_beliefs(), p.n_sites, to, 0, p.fast_p, e->st);
+  launch_convert_layout(e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters, p.n_sites, to, 0, p.fast_p, e->st);
+  launch_convert_layout(e->d_rpool, p.rpool_stride(), e->d_roff, e->d_rdim, p.n_msgs(), p.n_sites, to, 1, p.fast_p, e->st);
   e->layout_bs16 = want_bs16;
   return PGBP_OK;
 }
 
 // layout wanted by the traversals of the current schedule
-bool want_bs16(const pgbp_engine* e) { return e->plan.all_fast && e->plan.fast_p == 16; }
+bool want_bs16(const pgbp_engine* e) {
+  static const bool disabled = getenv("PGBP_DISABLE_BS16") != nullptr;  // A/B and debugging aid
+  return !disabled && e->plan.all_fast && e->plan.fast_p > 0;
+}
 
 void free_traversals(pgbp_engine* e) {
   for (auto* v : {&e->dpost, &e->dpre}) {
@@ -645,7 +650,7 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
   if (belief < 0 || belief >= p.n_beliefs()) return e->fail(PGBP_ERR_INVALID, "belief index out of range");
   const int m = p.dims[belief];
   const int ns = p.n_sites;
-  launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], m, e->layout_bs16 ? 1 : 0, mu ? e->d_mu : nullptr,
+  launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], m, e->layout_bs16 ? 1 : 0, p.fast_p, mu ? e->d_mu : nullptr,
                    std::max(1, p.max_dim), e->d_norm, e->d_info, ns, e->st);
   HIPCHK(e, hipMemcpyAsync(norm, e->d_norm, sizeof(double) * ns, hipMemcpyDeviceToHost, e->st));
   std::vector<double> mus;
@@ -704,7 +709,7 @@ static int bm_fill_async(pgbp_engine* e) {
   const Plan& p = e->plan;
   launch_bm_tree_fill(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, e->d_bm_kind,
                       e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv, e->d_bm_logdet,
-                      e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.n_clusters, p.n_sites, e->st);
+                      e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.fast_p, p.n_clusters, p.n_sites, e->st);
   launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                       p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
@@ -741,7 +746,7 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
     if ((rc = bm_fill_async(e))) return rc;                      // assignfactors!        calibration.jl:205
     enqueue_traversal(e, S, 0, 0, 0);                            // postorder             :210
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
-    launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, nullptr,
+    launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, p.fast_p, nullptr,
                      std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);  // :212
   }
   return PGBP_OK;
@@ -785,7 +790,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
   enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
-  launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, nullptr,
+  launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, p.fast_p, nullptr,
                    std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);         // :212
   return PGBP_OK;
 }

@@ -31,7 +31,6 @@ namespace pgbp {
 
 namespace {
 
-constexpr int P = 16;
 
 struct Frag {
   double w[4][4];  // w[i][j] = W[R(i)][C(j)]; w[0..1][2..3] (integrated rows x kept cols) is never used
@@ -68,13 +67,13 @@ __device__ __forceinline__ void wave_sync_lds() {
 constexpr int kColStride = 10;                       // doubles per owner-lane slot (80 B: conflict-free b128 reads)
 constexpr int kColDoubles = 8 * kColStride + 4;      // + h_2R, h_2R+1
 
-template <int R>
-__device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, double* __restrict__ col, double& mant,
-                                          int& expo, double& quad) {
+template <int P, int R>
+__device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, const bool act, double* __restrict__ col,
+                                          double& mant, int& expo, double& quad) {
   if constexpr (R == P / 2) {
     return 0;
   } else {
-    if (b == R) {
+    if (act && b == R) {
       double* dst = col + a * kColStride;
       *reinterpret_cast<double4*>(dst) = make_double4(f.w[0][0], f.w[1][0], f.w[2][0], f.w[3][0]);
       *reinterpret_cast<double4*>(dst + 4) = make_double4(f.w[0][1], f.w[1][1], f.w[2][1], f.w[3][1]);
@@ -115,7 +114,7 @@ __device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, dou
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
-    return eliminate2<R + 1>(f, a, b, col, mant, expo, quad);
+    return eliminate2<P, R + 1>(f, a, b, act, col, mant, expo, quad);
   }
 }
 
@@ -148,11 +147,11 @@ __device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld,
   return r;
 }
 template <bool BS>
-__device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int a, int b, bool up, int kidx,
+__device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int a, int b, bool up, bool act, int kidx,
                                           const Blk& v) {
   if constexpr (BS) {
     if (up) *reinterpret_cast<double4*>(base + kidx) = make_double4(v.x, v.y, v.z, v.w);
-  } else {
+  } else if (act) {
     *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b)) = make_double2(v.x, v.y);
     *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1)) = make_double2(v.z, v.w);
   }
@@ -165,15 +164,17 @@ __device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int
 //   * reuse (preorder, one sender, several children): the providing wave computes the marginal once and
 //     hands it to the others through LDS; every wave divides by its own sepset and updates its own receiver.
 // BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
-template <bool BS>
+template <int P, bool BS>
 __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry* __restrict__ recs, int K,
                                                        unsigned long long seq_base,
                                                        unsigned long long stop_below) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
-  const int a = lane & 7, b = lane >> 3;
-  const bool up = a <= b;                          // this lane's block is stored in BS16
+  constexpr int G = P / 2;                         // lane grid G x G (all 64 lanes for P = 16)
+  const bool act = lane < G * G;                   // lanes beyond the grid shadow lane (0, 0) and never store
+  const int a = act ? lane % G : 0, b = act ? lane / G : 0;
+  const bool up = act && a <= b;                   // this lane's block is stored in the packed layout
   const int kidx = (b * (b + 1) / 2 + a) * 4;      // its offset inside a packed symmetric tile
   const FEntry en = recs[(int64_t)blockIdx.x * K + wave];
   const unsigned long long failkey = S.fail[site];
@@ -194,11 +195,11 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   double* __restrict__ res = rpool + en.res_off;
   const int mt = en.mt, up0 = en.up0;
   // offsets inside the sepset / receiver / residual records
-  const bool tpk = BS && (mt == 16 || mt == 32);                                  // receiver record is packed
-  const int sepH = BS ? bs16::kH16 : P * P, sepG = has_block ? (BS ? bs16::kG16 : P * P + P) : 0;
-  const int64_t tJ0 = tpk ? ((mt == 32 && up0 == P) ? bs16::kT11 : bs16::kT00) : (up0 + (int64_t)mt * up0);
-  const int64_t tH0 = (tpk ? (mt == 16 ? bs16::kH16 : bs16::kH32) : (int64_t)mt * mt) + up0;
-  const int64_t tG0 = tpk ? (mt == 16 ? bs16::kG16 : bs16::kG32) : (int64_t)mt * mt + mt;
+  const bool tpk = BS && (mt == P || mt == 2 * P);                                // receiver record is packed
+  const int sepH = BS ? bs16::h1(P) : P * P, sepG = has_block ? (BS ? bs16::g1(P) : P * P + P) : 0;
+  const int64_t tJ0 = tpk ? ((mt == 2 * P && up0 == P) ? bs16::t11(P) : 0) : (up0 + (int64_t)mt * up0);
+  const int64_t tH0 = (tpk ? (mt == P ? bs16::h1(P) : bs16::h2(P)) : (int64_t)mt * mt) + up0;
+  const int64_t tG0 = tpk ? (mt == P ? bs16::g1(P) : bs16::g2(P)) : (int64_t)mt * mt + mt;
 
   Blk mJ{0, 0, 0, 0}, tJ{0, 0, 0, 0}, sJ{0, 0, 0, 0};
   double mh[2] = {0, 0}, gmsg = 0.0, th[2] = {0, 0}, tg = 0.0;
@@ -230,9 +231,9 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
       } else if (en.mf == P && has_block) {
         // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
         mJ = load_blk<BS>(from, P, a, b, up, kidx);
-        const double2 ch = *reinterpret_cast<const double2*>(from + (BS ? bs16::kH16 : P * P) + 2 * a);
+        const double2 ch = *reinterpret_cast<const double2*>(from + (BS ? bs16::h1(P) : P * P) + 2 * a);
         mh[0] = ch.x; mh[1] = ch.y;
-        gmsg = from[BS ? bs16::kG16 : P * P + P];
+        gmsg = from[BS ? bs16::g1(P) : P * P + P];
       } else {
         Frag f;
 #pragma unroll
@@ -242,33 +243,33 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
         if (en.mf == P) {
           // everything is integrated (dimension-0 sepset): the 16 x 16 precision is the integrated block
           const Blk v = load_blk<BS>(from, P, a, b, up, kidx);
-          const double2 vh = *reinterpret_cast<const double2*>(from + (BS ? bs16::kH16 : P * P) + 2 * a);
+          const double2 vh = *reinterpret_cast<const double2*>(from + (BS ? bs16::h1(P) : P * P) + 2 * a);
           f.w[0][0] = v.x; f.w[1][0] = v.y; f.w[0][1] = v.z; f.w[1][1] = v.w;
           f.h[0] = vh.x; f.h[1] = vh.y; f.h[2] = 0.0; f.h[3] = 0.0;
-          gmsg = from[BS ? bs16::kG16 : P * P + P];
+          gmsg = from[BS ? bs16::g1(P) : P * P + P];
         } else if constexpr (BS) {
           // 32-dim sender, packed: tiles T00 | T10 | T11.  integrated block = tile 0 (postorder, keep0 = 16)
           // or tile 1 (preorder, keep0 = 0)
           const bool itrail = en.keep0 == 0;
-          const Blk ii = load_blk<true>(from + (itrail ? bs16::kT11 : bs16::kT00), P, a, b, up, kidx);
-          const Blk ss = load_blk<true>(from + (itrail ? bs16::kT00 : bs16::kT11), P, a, b, up, kidx);
+          const Blk ii = load_blk<true>(from + (itrail ? bs16::t11(P) : 0), P, a, b, up, kidx);
+          const Blk ss = load_blk<true>(from + (itrail ? 0 : bs16::t11(P)), P, a, b, up, kidx);
           // J_SI block (rows of S = my a, cols of I = my b): block (a, b) of T10, or block (b, a) transposed
-          const double4 t = *reinterpret_cast<const double4*>(from + bs16::kT10 + (itrail ? (b + 8 * a) : (a + 8 * b)) * 4);
+          const double4 t = *reinterpret_cast<const double4*>(from + bs16::t10(P) + (itrail ? (b + G * a) : (a + G * b)) * 4);
           f.w[0][0] = ii.x; f.w[1][0] = ii.y; f.w[0][1] = ii.z; f.w[1][1] = ii.w;
           f.w[2][2] = ss.x; f.w[3][2] = ss.y; f.w[2][3] = ss.z; f.w[3][3] = ss.w;
           f.w[2][0] = t.x; f.w[3][0] = itrail ? t.z : t.y; f.w[2][1] = itrail ? t.y : t.z; f.w[3][1] = t.w;
-          const double2 hi = *reinterpret_cast<const double2*>(from + bs16::kH32 + (itrail ? P : 0) + 2 * a);
-          const double2 hs = *reinterpret_cast<const double2*>(from + bs16::kH32 + (itrail ? 0 : P) + 2 * a);
+          const double2 hi = *reinterpret_cast<const double2*>(from + bs16::h2(P) + (itrail ? P : 0) + 2 * a);
+          const double2 hs = *reinterpret_cast<const double2*>(from + bs16::h2(P) + (itrail ? 0 : P) + 2 * a);
           f.h[0] = hi.x; f.h[1] = hi.y; f.h[2] = hs.x; f.h[3] = hs.y;
-          gmsg = from[bs16::kG32];
+          gmsg = from[bs16::g2(P)];
         } else {
           // logical index = original index rotated so that the integrated block comes first
           const int rot = (en.keep0 == 0) ? P : 0;
-          const int r0 = (2 * a + rot) & 31, r1 = (2 * a + P + rot) & 31;
+          const int r0 = (2 * a + rot) & (2 * P - 1), r1 = (2 * a + P + rot) & (2 * P - 1);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int cl = 2 * b + (j & 1) + (j >> 1) * P;  // logical column C_b(j)
-            const int64_t co = (int64_t)((cl + rot) & 31) * 32;
+            const int64_t co = (int64_t)((cl + rot) & (2 * P - 1)) * (2 * P);
             if (j < 2) {
               const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
               f.w[0][j] = v.x; f.w[1][j] = v.y;
@@ -276,15 +277,15 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
             const double2 u = *reinterpret_cast<const double2*>(from + r1 + co);
             f.w[2][j] = u.x; f.w[3][j] = u.y;
           }
-          const double2 v = *reinterpret_cast<const double2*>(from + 32 * 32 + r0);
-          const double2 u = *reinterpret_cast<const double2*>(from + 32 * 32 + r1);
+          const double2 v = *reinterpret_cast<const double2*>(from + 4 * P * P + r0);
+          const double2 u = *reinterpret_cast<const double2*>(from + 4 * P * P + r1);
           f.h[0] = v.x; f.h[1] = v.y; f.h[2] = u.x; f.h[3] = u.y;
-          gmsg = from[32 * 32 + 32];
+          gmsg = from[4 * P * P + 2 * P];
         }
         // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
         // (in BS16 the lanes a > b hold nothing yet: all four of their entries come from lane (b, a))
         {
-          const int tl = a * 8 + b;  // lane holding the transposed 2 x 2 block
+          const int tl = a * G + b;  // lane holding the transposed 2 x 2 block
           const double t00 = __shfl(f.w[0][0], tl), t01 = __shfl(f.w[1][0], tl);
           const double t10 = __shfl(f.w[0][1], tl), t11 = __shfl(f.w[1][1], tl);
           // the "fake"-message test below must see the RAW lower triangle in the plain layout
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
           if (__any(nz)) {
             double mant = 1.0, quad = 0.0;
             int expo = 0;
-            info = eliminate2<0>(f, a, b, col, mant, expo, quad);
+            info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
             if (info == 0) {
               const double logdet = log(mant) + (double)expo * PGBP_LN2;
               gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     if (provider && en.valid && !accum) {
       if (state == 1) {
         *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(mJ.x, mJ.y, mJ.z, mJ.w);
-        if (b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(mh[0], mh[1]);
+        if (act && b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(mh[0], mh[1]);
       }
       if (lane == 0) {
         slot[kSlotG] = gmsg;
@@ -354,16 +355,16 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     double maxJ = 0.0, maxh = 0.0;
     if (has_block) {
       dJ = Blk{mJ.x - sJ.x, mJ.y - sJ.y, mJ.z - sJ.z, mJ.w - sJ.w};
-      store_blk<BS>(sep, P, a, b, up, kidx, mJ);
-      store_blk<BS>(res, P, a, b, up, kidx, dJ);
-      if (!BS || up) {
+      store_blk<BS>(sep, P, a, b, up, act, kidx, mJ);
+      store_blk<BS>(res, P, a, b, up, act, kidx, dJ);
+      if (BS ? up : act) {
         maxJ = fmax(fmax(fabs(dJ.x), fabs(dJ.y)), fmax(fabs(dJ.z), fabs(dJ.w)));
         if (dJ.x != dJ.x || dJ.y != dJ.y || dJ.z != dJ.z || dJ.w != dJ.w) maxJ = INFINITY;
       }
-      if (b == 0) {
+      if (act && b == 0) {
         dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
         *reinterpret_cast<double2*>(sep + sepH + 2 * a) = make_double2(mh[0], mh[1]);
-        *reinterpret_cast<double2*>(res + (BS ? bs16::kResH : P * P) + 2 * a) = make_double2(dh0, dh1);
+        *reinterpret_cast<double2*>(res + (BS ? bs16::h1(P) : P * P) + 2 * a) = make_double2(dh0, dh1);
         maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
       }
     }
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     if (wave > 0) {
       if (state == 1) {
         *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(dJ.x, dJ.y, dJ.z, dJ.w);
-        if (b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(dh0, dh1);
+        if (act && b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(dh0, dh1);
       }
       if (lane == 0) {
         slot[kSlotG] = dg;
@@ -425,23 +426,36 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   }
   if (own && state == 1) {
     if (accum || has_block) {
-      store_blk<BS>(to + tJ0, mt, a, b, up, kidx, tJ);
-      if (b == 0) *reinterpret_cast<double2*>(to + tH0 + 2 * a) = make_double2(th[0], th[1]);
+      store_blk<BS>(to + tJ0, mt, a, b, up, act, kidx, tJ);
+      if (act && b == 0) *reinterpret_cast<double2*>(to + tH0 + 2 * a) = make_double2(th[0], th[1]);
     }
     if (lane == 0) to[tG0] = tg;
   }
 }
 
+template <int P>
+static void launch_fast_p(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
+                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
+  const size_t lds = sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K;
+  if (S.bs16)
+    hipLaunchKernelGGL((bp_level_fast16<P, true>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
+                       seq_base, stop_below);
+  else
+    hipLaunchKernelGGL((bp_level_fast16<P, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
+                       seq_base, stop_below);
+}
+
+// The kernel is instantiated for sepsets of dimension 16 (all 64 lanes), 8 (16 lanes) and 4 (4 lanes); the
+// small-P instances trade lane utilisation for the same per-level latency (one wave per message).
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
-  const size_t lds = sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K;
-  if (S.bs16)
-    hipLaunchKernelGGL(bp_level_fast16<true>, dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K, seq_base,
-                       stop_below);
-  else
-    hipLaunchKernelGGL(bp_level_fast16<false>, dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
-                       seq_base, stop_below);
+  switch (S.fast_p) {
+    case 16: launch_fast_p<16>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 8: launch_fast_p<8>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 4: launch_fast_p<4>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    default: break;  // the planner never marks a task fast for another P
+  }
 }
 
 }  // namespace pgbp

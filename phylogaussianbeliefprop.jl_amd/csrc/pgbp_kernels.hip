@@ -229,7 +229,8 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2
 __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict__ pool_all, int64_t pool_stride,
-                                                       int64_t rec_off, int m, int bs, double* __restrict__ mu,
+                                                       int64_t rec_off, int m, int bs, int fp,
+                                                       double* __restrict__ mu,
                                                        int mu_stride, double* __restrict__ norm,
                                                        int32_t* __restrict__ info_out) {
   const int lane = threadIdx.x;
@@ -237,13 +238,13 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
   const double* __restrict__ rec = pool_all + (int64_t)site * pool_stride + rec_off;
   double* W = lds + kPermDoubles;
   const int ld = (m + 1) | 1;
-  const bool packed = bs && bs16::applies(m);
-  const double g = packed ? rec[bs16::g_off(m)] : rec[(int64_t)m * m + m];
+  const bool packed = bs && bs16::applies(m, fp);
+  const double g = packed ? rec[bs16::g_off(m, fp)] : rec[(int64_t)m * m + m];
   bool nz = false;
   for (int idx = lane; idx < m * m; idx += kWave) {
     const int j = idx / m, i = idx - j * m;
     if (packed) {
-      const double v = rec[bs16::J_off(m, i, j)];  // symmetric by construction
+      const double v = rec[bs16::J_off(m, i, j, fp)];  // symmetric by construction
       nz |= v != 0.0;
       W[i * ld + j] = v;
     } else {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
     }
   }
   for (int i = lane; i < m; i += kWave) {
-    const double hv = packed ? rec[bs16::h_off(m, i)] : rec[(int64_t)m * m + i];
+    const double hv = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
     nz |= hv != 0.0;
     W[i * ld + m] = hv;
   }
@@ -294,26 +295,27 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
   }
 }
 
-void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, double* d_mu,
-                      int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
+void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
+                      double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
   hipLaunchKernelGGL(integrate_kernel, dim3(n_sites), dim3(kWave), generic_lds_bytes(m), st, pool, pool_stride,
-                     rec_off, m, bs16, d_mu, mu_stride, d_norm, d_info);
+                     rec_off, m, bs16, fast_p, d_mu, mu_stride, d_norm, d_info);
 }
 
 // ---- BS16 <-> plain, in place, one workgroup per record (pgbp_bs16.hpp)
 __global__ __launch_bounds__(256) void convert_layout_kernel(double* __restrict__ pool, int64_t stride,
                                                              const int64_t* __restrict__ off,
                                                              const int32_t* __restrict__ dim, int n_records,
-                                                             int to_bs16, int is_residual) {
+                                                             int to_bs16, int is_residual, int fp) {
   __shared__ double buf[32 * 32 + 32 + 1];
   const int site = blockIdx.y;
   for (int r = blockIdx.x; r < n_records; r += gridDim.x) {
     const int m = dim[r];
-    if (!bs16::applies(m) || (is_residual && m != 16)) continue;  // uniform per workgroup
+    if (!bs16::applies(m, fp) || (is_residual && m != fp)) continue;  // uniform per workgroup
     double* __restrict__ rec = pool + (int64_t)site * stride + off[r];
     const int tail = is_residual ? m : m + 1;  // h (and g) after J
     const int plain_len = m * m + tail;
-    const int packed_len = (m == 16 ? bs16::kSym : bs16::kH32) + tail;
+    const int hb = m == fp ? bs16::h1(fp) : bs16::h2(fp);  // where h starts in the packed record
+    const int packed_len = hb + tail;
     const int src_len = to_bs16 ? plain_len : packed_len;
     __syncthreads();
     for (int t = threadIdx.x; t < src_len; t += blockDim.x) buf[t] = rec[t];
@@ -321,15 +323,13 @@ __global__ __launch_bounds__(256) void convert_layout_kernel(double* __restrict_
     if (to_bs16) {
       for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
         const int c = idx / m, rr = idx - c * m;
-        if (bs16::canonical(m, rr, c)) rec[bs16::J_off(m, rr, c)] = buf[idx];
+        if (bs16::canonical(m, rr, c, fp)) rec[bs16::J_off(m, rr, c, fp)] = buf[idx];
       }
-      const int hb = m == 16 ? bs16::kSym : bs16::kH32;
       for (int t = threadIdx.x; t < tail; t += blockDim.x) rec[hb + t] = buf[m * m + t];
     } else {
-      const int hb = m == 16 ? bs16::kSym : bs16::kH32;
       for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
         const int c = idx / m, rr = idx - c * m;
-        rec[idx] = buf[bs16::J_off(m, rr, c)];
+        rec[idx] = buf[bs16::J_off(m, rr, c, fp)];
       }
       for (int t = threadIdx.x; t < tail; t += blockDim.x) rec[m * m + t] = buf[hb + t];
     }
@@ -337,22 +337,22 @@ __global__ __launch_bounds__(256) void convert_layout_kernel(double* __restrict_
 }
 
 void launch_convert_layout(double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim, int n_records,
-                           int n_sites, int to_bs16, int is_residual, hipStream_t st) {
+                           int n_sites, int to_bs16, int is_residual, int fast_p, hipStream_t st) {
   if (n_records <= 0) return;
   const int gx = n_records < 65535 ? n_records : 65535;
   hipLaunchKernelGGL(convert_layout_kernel, dim3(gx, n_sites), dim3(256), 0, st, pool, stride, d_off, d_dim,
-                     n_records, to_bs16, is_residual);
+                     n_records, to_bs16, is_residual, fast_p);
 }
 
 __global__ __launch_bounds__(256) void check_symmetry_kernel(const double* __restrict__ pool, int64_t stride,
                                                              const int64_t* __restrict__ off,
                                                              const int32_t* __restrict__ dim, int n_records,
-                                                             int32_t* __restrict__ flag) {
+                                                             int32_t* __restrict__ flag, int fp) {
   __shared__ double red[2][4];
   const int site = blockIdx.y;
   for (int r = blockIdx.x; r < n_records; r += gridDim.x) {
     const int m = dim[r];
-    if (!bs16::applies(m)) continue;
+    if (!bs16::applies(m, fp)) continue;
     const double* __restrict__ rec = pool + (int64_t)site * stride + off[r];
     double asym = 0.0, mx = 0.0;
     for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
@@ -378,11 +378,11 @@ __global__ __launch_bounds__(256) void check_symmetry_kernel(const double* __res
 }
 
 void launch_check_symmetry(const double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim,
-                           int n_records, int n_sites, int32_t* d_flag, hipStream_t st) {
+                           int n_records, int n_sites, int32_t* d_flag, int fast_p, hipStream_t st) {
   if (n_records <= 0) return;
   const int gx = n_records < 65535 ? n_records : 65535;
   hipLaunchKernelGGL(check_symmetry_kernel, dim3(gx, n_sites), dim3(256), 0, st, pool, stride, d_off, d_dim,
-                     n_records, d_flag);
+                     n_records, d_flag, fast_p);
 }
 
 // ---- record gather/scatter between the ABI's packed layout and the padded device records
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void bm_tree_fill_kernel(double* __restrict__ 
                                                            const double* __restrict__ Rinv_all,
                                                            const double* __restrict__ logdetR_all,
                                                            const double* __restrict__ mu_all, int per_site, int bs,
-                                                           int n_clusters) {
+                                                           int fp, int n_clusters) {
   __shared__ double v[PGBP_MAX_DIM];   // the vector absorbed (y - or mu): R^-1 v / t
   __shared__ double jv[PGBP_MAX_DIM];
   const int site = blockIdx.y;
@@ -471,8 +471,8 @@ __global__ __launch_bounds__(256) void bm_tree_fill_kernel(double* __restrict__ 
     const int k = kind[c], m = dim[c];
     double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[c];
     double* __restrict__ frec = fpool + (int64_t)site * fpool_stride + boff[c];
-    const bool packed = bs && bs16::applies(m);
-    const int len = packed ? (m == 16 ? bs16::kLen16 : bs16::kLen32) : m * m + m + 1;
+    const bool packed = bs && bs16::applies(m, fp);
+    const int len = packed ? bs16::rec_len(m, fp) : m * m + m + 1;
     __syncthreads();
     if (k < 0) {  // no factor: the constant function 1
       for (int t = threadIdx.x; t < len; t += blockDim.x) { rec[t] = 0.0; frec[t] = 0.0; }
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void bm_tree_fill_kernel(double* __restrict__ 
         const double j = Rinv[(rr % p) + (int64_t)(cc % p) * p] * it;
         const double val = ((rr < p) == (cc < p)) ? j : -j;   // m == p: always +j
         if (packed) {
-          if (bs16::canonical(m, rr, cc)) { rec[bs16::J_off(m, rr, cc)] = val; frec[bs16::J_off(m, rr, cc)] = val; }
+          if (bs16::canonical(m, rr, cc, fp)) { rec[bs16::J_off(m, rr, cc, fp)] = val; frec[bs16::J_off(m, rr, cc, fp)] = val; }
         } else {
           rec[idx] = val; frec[idx] = val;
         }
@@ -510,12 +510,12 @@ __global__ __launch_bounds__(256) void bm_tree_fill_kernel(double* __restrict__ 
       for (int t = threadIdx.x; t < m; t += blockDim.x) {
         // h_k -= J_ka v with J_ka = -j: h = +j v on the kept block (kinds 1, 2); 0 for kind 0
         const double hv = (k == 0) ? 0.0 : jv[t];
-        const int o = packed ? bs16::h_off(m, t) : m * m + t;
+        const int o = packed ? bs16::h_off(m, t, fp) : m * m + t;
         rec[o] = hv; frec[o] = hv;
       }
     }
     if (threadIdx.x == 0) {
-      const int o = packed ? bs16::g_off(m) : m * m + m;
+      const int o = packed ? bs16::g_off(m, fp) : m * m + m;
       rec[o] = g; frec[o] = g;
     }
   }
@@ -524,12 +524,13 @@ __global__ __launch_bounds__(256) void bm_tree_fill_kernel(double* __restrict__ 
 void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
                          const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
                          const double* d_data, int n_rows, int p, const double* d_Rinv, const double* d_logdetR,
-                         const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
+                         const double* d_mu, int per_site, int bs16, int fast_p, int n_clusters, int n_sites,
+                         hipStream_t st) {
   if (n_clusters <= 0) return;
   const int gx = n_clusters < 65535 ? n_clusters : 65535;
   hipLaunchKernelGGL(bm_tree_fill_kernel, dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool, fpool_stride,
                      d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, p, d_Rinv, d_logdetR, d_mu, per_site, bs16,
-                     n_clusters);
+                     fast_p, n_clusters);
 }
 
 // init_messagecalibrationflags_reset! (src/beliefs.jl:973-979): empty messages stay calibrated

@@ -25,7 +25,8 @@ struct DevState {
   int32_t n_msgs;
   int32_t update_resnorm;
   double atol;
-  int32_t bs16;  // beliefs of dimension 16 / 32 and residuals of 16-dim sepsets are in the BS16 layout
+  int32_t bs16;    // beliefs of dimension P / 2P and residuals of P-dim sepsets are in the packed layout
+  int32_t fast_p;  // P: sepset dimension of the register-resident kernel (16, 8 or 4; 0: none)
 };
 
 size_t generic_lds_bytes(int max_mf);
@@ -38,16 +39,16 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
 
-void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, double* d_mu,
-                      int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
+void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
+                      double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
 
 // In-place layout conversion of the records listed by (d_off, d_dim): to_bs16 != 0: plain -> BS16, else back.
 // is_residual: records are [dJ | dh] (no g).  One workgroup per record.
 void launch_convert_layout(double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim, int n_records,
-                           int n_sites, int to_bs16, int is_residual, hipStream_t st);
+                           int n_sites, int to_bs16, int is_residual, int fast_p, hipStream_t st);
 // d_flag[0] |= 1 if some record's J is not symmetric to 1e-10 * max|J| (plain layout)
 void launch_check_symmetry(const double* pool, int64_t stride, const int64_t* d_off, const int32_t* d_dim,
-                           int n_records, int n_sites, int32_t* d_flag, hipStream_t st);
+                           int n_records, int n_sites, int32_t* d_flag, int fast_p, hipStream_t st);
 
 // dst[site*dst_stride + dst_off[r] + t] = src[site*src_stride + src_off[r] + t], t < src_off'[r+1]-..: record copy
 void launch_records(const double* src, int64_t src_stride, const int64_t* d_src_off, double* dst, int64_t dst_stride,
@@ -62,7 +63,8 @@ void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites
 void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
                          const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
                          const double* d_data, int n_rows, int p, const double* d_Rinv, const double* d_logdetR,
-                         const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st);
+                         const double* d_mu, int per_site, int bs16, int fast_p, int n_clusters, int n_sites,
+                         hipStream_t st);
 
 void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int n_msgs, int n_sites, int reset_kl,
                         hipStream_t st);

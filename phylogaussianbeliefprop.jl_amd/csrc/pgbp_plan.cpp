@@ -136,10 +136,19 @@ int plan_build(Plan& p, const pgbp_desc* d) {
     }
   }
   p.trees.clear();
-  // the register-resident kernel exists for sepsets of dimension 16 (pgbp_fast.hip)
+  // the register-resident kernel is instantiated for sepsets of dimension 16, 8 and 4 (pgbp_fast.hip): pick
+  // the dimension most sepsets have
   p.fast_p = 0;
-  for (int k = 0; k < p.n_sepsets; ++k)
-    if (p.dims[p.n_clusters + k] == 16) p.fast_p = 16;
+  {
+    int cnt[3] = {0, 0, 0};
+    const int cand[3] = {16, 8, 4};
+    for (int k = 0; k < p.n_sepsets; ++k)
+      for (int q = 0; q < 3; ++q)
+        if (p.dims[p.n_clusters + k] == cand[q]) ++cnt[q];
+    int best = 0;
+    for (int q = 0; q < 3; ++q)
+      if (cnt[q] > best) { best = cnt[q]; p.fast_p = cand[q]; }
+  }
   return PGBP_OK;
 }
 

@@ -62,7 +62,8 @@ def _traversal(lib, pl, tree, d):
 
 
 @pytest.mark.parametrize("ntips,p,kind", [(2, 1, "random"), (3, 2, "random"), (40, 3, "random"), (500, 2, "random"),
-                                          (30, 2, "caterpillar"), (60, 16, "random"), (70, 16, "poly6")])
+                                          (30, 2, "caterpillar"), (60, 16, "random"), (70, 16, "poly6"),
+                                          (50, 8, "random"), (45, 4, "random")])
 def test_level_schedule_invariants(ntips, p, kind):
     rng = np.random.default_rng(ntips)
     if kind == "random":
@@ -112,8 +113,8 @@ def test_level_schedule_invariants(ntips, p, kind):
             nf = np.zeros(len(lo) - 1, np.int32)
             assert lib.pgbp_plan_level_nfast(pl, 0, d, L.i32p(nf)) == 0
             assert 0 <= nf[Lv] <= lo[Lv + 1] - lo[Lv]
-            if p == 16 and kind == "random" and ntips > 3:
-                assert nf[Lv] == lo[Lv + 1] - lo[Lv]            # a 16-trait bifurcating tree is all fast-class
+            if p in (4, 8, 16) and kind == "random" and ntips > 3:
+                assert nf[Lv] == lo[Lv + 1] - lo[Lv]            # a 4/8/16-trait bifurcating tree is all fast-class
             assert not (targets & senders)                      # no cluster both read and written in a level
         # dependencies: postorder: a child's incoming messages precede its outgoing one
         child_edge = {int(c): i for i, c in enumerate(ch)}
