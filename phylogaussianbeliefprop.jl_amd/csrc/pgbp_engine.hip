@@ -209,8 +209,11 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
     const int nf = tr.level_nfast[L];
     launch_level_fast16(S, d.d_fentries + tr.level_fbase[L], tr.level_fk[L], nf, e->plan.n_sites, seq_base,
                         stop_below, e->st);
-    launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
-                         tr.max_mf, e->st);
+    if (e->plan.max_dim <= 2 && e->plan.n_sites >= 8)  // many tiny problems: lanes = sites
+      launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->st);
+    else
+      launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
+                           tr.max_mf, e->st);
     launches += (nf > 0) + (nt - nf > 0);
   }
   if (ev) {

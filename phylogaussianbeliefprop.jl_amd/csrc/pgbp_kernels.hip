@@ -213,6 +213,131 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Univariate / tiny beliefs (every dimension <= 2): ONE THREAD per (site, task), lanes = sites.
+// The message descriptors are wave-uniform (scalar loads); each lane reads its own site's records.  This is the
+// batch-of-independent-sites case (cfg4: thousands of univariate problems on one tree), where a wavefront per
+// message would leave 63 of 64 lanes idle.  Same semantics as bp_level_generic (src/beliefupdates.jl:55-83,
+// 483-488, 579-587, src/beliefs.jl:994-1003), closed forms for m_f <= 2.
+__global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* __restrict__ task_off,
+                                                    const Entry* __restrict__ entries, int task0, int n_sites,
+                                                    unsigned long long seq_base, unsigned long long stop_below) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  const int task = task0 + blockIdx.x;
+  double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
+  double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  const int e0 = task_off[task], e1 = task_off[task + 1];
+  double mJ[4] = {0, 0, 0, 0}, mh[2] = {0, 0}, gmsg = 0.0;  // message (s <= 2), column-major
+  for (int e = e0; e < e1; ++e) {
+    const Entry en = entries[e];
+    const MsgDesc m = S.msgs[en.msg];
+    if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
+      S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+      return;
+    }
+    const int mf = m.mf, s = m.s, mt = m.mt, ni = m.ni;
+    if (!en.reuse) {
+      const double* __restrict__ from = pool + m.from_off;
+      double J[4] = {0, 0, 0, 0}, h[2] = {0, 0};
+      for (int t = 0; t < mf * mf; ++t) J[t] = from[t];
+      for (int t = 0; t < mf; ++t) h[t] = from[mf * mf + t];
+      gmsg = from[mf * mf + mf];
+      int keep[2] = {0, 0}, integ[2] = {0, 0};
+      for (int t = 0; t < s; ++t) keep[t] = S.idx[m.keep_map + t];
+      for (int t = 0; t < ni; ++t) integ[t] = S.idx[m.int_map + t];
+      for (int b = 0; b < s; ++b) {
+        mh[b] = h[keep[b]];
+        for (int a = 0; a < s; ++a) mJ[a + b * s] = J[keep[a] + keep[b] * mf];
+      }
+      if (ni > 0) {
+        // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
+        bool nz = false;
+        for (int b = 0; b < ni; ++b) {
+          nz |= fabs(h[integ[b]]) > PGBP_EPS;
+          for (int a = 0; a < ni; ++a) nz |= fabs(J[integ[a] + integ[b] * mf]) > PGBP_EPS;
+          for (int a = 0; a < s; ++a) nz |= fabs(J[keep[a] + integ[b] * mf]) > PGBP_EPS;
+        }
+        if (nz) {
+          int info = 0;
+          // Cholesky of Symmetric(J_I) (upper triangle), ni <= 2
+          const double d0 = J[integ[0] + integ[0] * mf];
+          double u01 = 0.0, d1 = 1.0;
+          if (!(d0 > 0.0)) info = 1;
+          if (!info && ni == 2) {
+            u01 = J[integ[0] + integ[1] * mf];              // upper entry (row integ[0] < integ[1])
+            d1 = J[integ[1] + integ[1] * mf] - u01 * u01 / d0;
+            if (!(d1 > 0.0)) info = 2;
+          }
+          if (info) {
+            S.status[(int64_t)site * S.n_msgs + en.msg] = info;
+            S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+            atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
+            return;
+          }
+          // forward substitution with L = U': y = L^-1 [h_I | J_IS columns]
+          const double y0 = h[integ[0]];
+          const double y1 = ni == 2 ? h[integ[1]] - u01 / d0 * y0 : 0.0;
+          double quad = y0 * y0 / d0 + (ni == 2 ? y1 * y1 / d1 : 0.0);
+          const double logdet = log(d0) + (ni == 2 ? log(d1) : 0.0);
+          // z_a = L^-1 J_SI[a, :]' (per kept variable a); message J -= z_a . z_b (D^-1 weighted), h -= z_a . y
+          double z0[2] = {0, 0}, z1[2] = {0, 0};
+          for (int a = 0; a < s; ++a) {
+            z0[a] = J[keep[a] + integ[0] * mf];
+            z1[a] = ni == 2 ? J[keep[a] + integ[1] * mf] - u01 / d0 * z0[a] : 0.0;
+          }
+          for (int b = 0; b < s; ++b) {
+            mh[b] -= z0[b] * y0 / d0 + (ni == 2 ? z1[b] * y1 / d1 : 0.0);
+            for (int a = 0; a < s; ++a) mJ[a + b * s] -= z0[a] * z0[b] / d0 + (ni == 2 ? z1[a] * z1[b] / d1 : 0.0);
+          }
+          gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
+        }
+      }
+    }
+    // ---- divide! and mult!
+    double* __restrict__ sep = pool + m.sep_off;
+    double* __restrict__ to = pool + m.to_off;
+    double* __restrict__ res = rpool + m.res_off;
+    int up[2] = {0, 0};
+    for (int t = 0; t < s; ++t) up[t] = S.idx[m.up_map + t];
+    double maxJ = 0.0, maxh = 0.0;
+    for (int b = 0; b < s; ++b) {
+      for (int a = 0; a < s; ++a) {
+        const int o = a + b * s;
+        const double dJ = mJ[o] - sep[o];
+        sep[o] = mJ[o];
+        res[o] = dJ;
+        to[up[a] + up[b] * mt] += dJ;
+        maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+      }
+      const int o = s * s + b;
+      const double dh = mh[b] - sep[o];
+      sep[o] = mh[b];
+      res[o] = dh;
+      to[mt * mt + up[b]] += dh;
+      maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
+    }
+    const int og = s * s + s;
+    const double dg = gmsg - sep[og];
+    sep[og] = gmsg;
+    to[mt * mt + mt] += dg;
+    S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
+    if (S.update_resnorm) {
+      const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+      S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
+    }
+  }
+}
+
+void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
+  if (ntasks <= 0) return;
+  const int bs = n_sites >= 256 ? 256 : 64;
+  hipLaunchKernelGGL(bp_level_uni, dim3(ntasks, (n_sites + bs - 1) / bs), dim3(bs), 0, st, S, d_task_off, d_entries,
+                     task0, n_sites, seq_base, stop_below);
+}
+
 size_t generic_lds_bytes(int max_mf) {
   const int mf = max_mf < 1 ? 1 : max_mf;
   const int ld = (mf + 1) | 1;

@@ -35,6 +35,10 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
                           int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
                           hipStream_t st);
 
+// thread-per-(site, task) kernel for graphs whose beliefs all have dimension <= 2 (univariate batches)
+void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
+
 // register-resident kernel for sepsets of dimension 16 (pgbp_fast.hip)
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);

@@ -349,6 +349,51 @@ def bm_loglik_pruning(tree: Tree, R: np.ndarray, mu: np.ndarray, Y: np.ndarray) 
     return float(lg[0] - 0.5 * (p * LOG2PI + p * np.log(v0) + logdetR + (d @ Rinv @ d) / v0))
 
 
+def simulate_bm_uni_sites(tree: Tree, sigma2: np.ndarray, mu: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """Univariate BM at every node for many independent sites at once: (n_sites, N)."""
+    ns = len(sigma2)
+    z = rng.standard_normal((ns, tree.nnodes)) * np.sqrt(sigma2)[:, None] * np.sqrt(tree.length)[None, :]
+    x = np.empty((ns, tree.nnodes))
+    x[:, 0] = mu
+    for i in range(1, tree.nnodes):
+        x[:, i] = x[:, tree.parent[i]] + z[:, i]
+    return x
+
+
+def bm_loglik_pruning_uni_sites(tree: Tree, sigma2: np.ndarray, mu: np.ndarray, X: np.ndarray) -> np.ndarray:
+    """bm_loglik_pruning for univariate sites, vectorised over sites: (n_sites,) log-likelihoods."""
+    N = tree.nnodes
+    ns = X.shape[0]
+    xh = np.where(tree.is_leaf[None, :], X, 0.0)
+    v = np.zeros(N)
+    lg = np.zeros((ns, N))
+    prec = np.zeros(N)
+    wsum = np.zeros((ns, N))
+    first = np.ones(N, dtype=bool)
+    logs2 = np.log(sigma2)
+    for i in range(N - 1, 0, -1):
+        if not tree.is_leaf[i]:
+            v[i] = 1.0 / prec[i]
+            xh[:, i] = wsum[:, i] * v[i]
+        pa = tree.parent[i]
+        vi = v[i] + tree.length[i]
+        if first[pa]:
+            first[pa] = False
+            prec[pa] = 1.0 / vi
+            wsum[:, pa] = xh[:, i] / vi
+            lg[:, pa] += lg[:, i]
+        else:
+            m_old = wsum[:, pa] / prec[pa]
+            s2 = 1.0 / prec[pa] + vi
+            d = xh[:, i] - m_old
+            lg[:, pa] += lg[:, i] - 0.5 * (LOG2PI + np.log(s2) + logs2 + d * d / (sigma2 * s2))
+            prec[pa] += 1.0 / vi
+            wsum[:, pa] += xh[:, i] / vi
+    v0 = 1.0 / prec[0]
+    d = wsum[:, 0] * v0 - mu
+    return lg[:, 0] - 0.5 * (LOG2PI + np.log(v0) + logs2 + d * d / (sigma2 * v0))
+
+
 def bethe_of_tree(tree: Tree, p: int) -> Problem:
     """Bethe cluster graph of a tree (src/clustergraph.jl:473-527): factor cluster {c, parent(c)}
     for every non-root node (ids 0..N-2, as in the clique tree) then one variable cluster {v} for

@@ -51,3 +51,50 @@ def test_single_rank_path():
     dt = bench.timed_region(lambda: time.sleep(0.01), None, lambda: None)
     assert 0.01 <= dt < 0.5
     assert bench.whole_job_rate(10, 2, 1, 2.0) == 10.0
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import pgbp_amd  # noqa: F401  (host-side helpers only)
+    from pgbp_amd.sharding import gather_sites, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 11                                  # uneven split: 6 + 5
+    lo, hi = shard_range(n_total, rank, world)
+    local = np.arange(lo, hi, dtype=np.float64) * 1.5 - 3.0   # stands for this rank's per-site log-likelihoods
+    full = gather_sites(local, n_total, dist, device="cpu")
+    q.put((rank, (lo, hi), full.tolist()))
+    dist.destroy_process_group()
+
+
+def test_site_sharding_gather_two_ranks():
+    """The N > 1 data path of the site-sharded configuration (cfg4): contiguous shards, one all-gather."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1] == (0, 6) and out[1][1] == (6, 11)
+    expect = (np.arange(11) * 1.5 - 3.0).tolist()
+    assert out[0][2] == expect and out[1][2] == expect
+
+
+def test_shard_range_properties():
+    sys.path.insert(0, ROOT)
+    import pgbp_amd  # noqa: F401
+    from pgbp_amd.sharding import shard_range
+    for n in (0, 1, 7, 1000):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1

@@ -401,8 +401,10 @@ def test_loopy_bethe_multi_tree_schedule(P, caplog):
 
 def test_cfg4_univariate_ou_sites(P):
     """cfg4-shaped case at test size: independent univariate OU problems (different alpha, sigma2, theta and
-    data per site) on one tree = one engine with n_sites replicas; each site's log-likelihood against the
-    oracle's dense-MVN likelihood (recipe of test/test_evomodels.jl:121-167)."""
+    data per site) on one tree = one engine with n_sites replicas (thread-per-site kernel bp_level_uni when
+    n_sites >= 8, wavefront kernel below); each site's log-likelihood against the oracle's dense-MVN likelihood
+    (recipe of test/test_evomodels.jl:121-167), calibrated beliefs and flags against the oracle, and a
+    non-positive-definite failure confined to its site."""
     from pgbp_amd import synth as S
     from oracle import densemvn as OD
     from oracle import models as OM
@@ -416,22 +418,46 @@ def test_cfg4_univariate_ou_sites(P):
     clusters = [(str(i), [int(a), int(b)]) for i, (a, b) in enumerate(prob.cluster_nodes)]
     edges = [(int(a), int(b), [int(prob.sepset_nodes[k])]) for k, (a, b) in enumerate(prob.sepset_clusters)]
     cg = OB.ClusterGraph(clusters, edges, "cliquetree")
-    ns = 6
-    packs, dense = [], []
-    for s in range(ns):
-        model = OM.UnivariateOrnsteinUhlenbeck(rng.uniform(0.5, 2), rng.uniform(0.1, 1), rng.normal(), rng.normal(), 0.0)
-        y = [float(v) for v in rng.normal(size=len(taxa))]
-        ocgb = oracle_setup(net, cg, model, [y], taxa)
-        assert [b.dimension for b in ocgb.belief] == prob.dims.tolist()
-        packs.append(pack_oracle(ocgb, prob))
-        dense.append(OD.loglik(net, model, [y], taxa))
-    eng = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
-                                           np.stack(packs), n_sites=ns)
-    assert P.propagate_1traversal_postorder_(eng, None, None, *prob.schedule[0])
-    mu, norm, info = eng.integratebelief_(prob.root_cluster, all_sites=True)
-    assert not info.any()
-    for s in range(ns):
-        assert rel_close(norm[s], dense[s]), (s, norm[s], dense[s])
+    spt = ([str(x) for x in prob.schedule[0][0]], [str(x) for x in prob.schedule[0][1]],
+           prob.schedule[0][0].tolist(), prob.schedule[0][1].tolist())
+    for ns in (3, 11):   # 3: wavefront-per-message kernel; 11: thread-per-site kernel
+        packs, dense, ocgbs = [], [], []
+        for s in range(ns):
+            model = OM.UnivariateOrnsteinUhlenbeck(rng.uniform(0.5, 2), rng.uniform(0.1, 1), rng.normal(), rng.normal(), 0.0)
+            y = [float(v) for v in rng.normal(size=len(taxa))]
+            ocgb = oracle_setup(net, cg, model, [y], taxa)
+            assert [b.dimension for b in ocgb.belief] == prob.dims.tolist()
+            packs.append(pack_oracle(ocgb, prob))
+            dense.append(OD.loglik(net, model, [y], taxa))
+            ocgbs.append(ocgb)
+        eng = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                               np.stack(packs), n_sites=ns)
+        assert P.propagate_1traversal_postorder_(eng, None, None, *prob.schedule[0])
+        mu, norm, info = eng.integratebelief_(prob.root_cluster, all_sites=True)
+        assert not info.any()
+        for s in range(ns):
+            assert rel_close(norm[s], dense[s]), (ns, s, norm[s], dense[s])
+        # full calibration of every site against the oracle
+        eng.init_beliefs_reset_fromfactors_()
+        eng.init_messagecalibrationflags_reset_()
+        assert P.calibrate_(eng, prob.schedule, 2) == (True, True)
+        for s in (0, ns - 1):
+            ocgbs[s].init_beliefs_reset_fromfactors()
+            assert OC.calibrate(ocgbs[s], [spt], 2) == (True, True)
+            ref = pack_oracle(ocgbs[s], prob)
+            assert np.allclose(eng._packed[s], ref, rtol=1e-8, atol=1e-8)
+        # failure confined to one site
+        bad = np.stack(packs).copy()
+        pa, ch = prob.schedule[0]
+        snd = next(int(c) for c in ch if prob.dims[c] == 2)
+        bad[ns - 2, prob.packed_off[snd]] = -5.0
+        eng2 = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, bad,
+                                                n_sites=ns)
+        eng2.site = ns - 2
+        assert P.calibrate_(eng2, prob.schedule, 1, verbose=False) == (False, False)
+        res = eng2.last_results
+        assert [res[s].succ for s in range(ns)] == [int(s != ns - 2) for s in range(ns)]
+        assert res[ns - 2].fail_info == 1 and res[ns - 2].fail_dir == 0
 
 
 def test_multi_site_p16_bs16(P):
