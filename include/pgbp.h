@@ -161,6 +161,14 @@ int  pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_r
  * An all-zero belief gives mu = Inf, norm = g (src/beliefupdates.jl:189-191). */
 int  pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int32_t* info);
 
+/* ---- scores (second "next" row: SURVEY.md section 8(f)-2) -------------------------------------- */
+/* free_energy(beliefs) (src/score.jl:162-182) for every site: out3[3*site + {0,1,2}] = (average energy,
+ * approximate entropy, free energy = energy - entropy); factored_energy (src/score.jl:151-154) = the same
+ * with the third value negated (the log-likelihood on a calibrated clique tree).  Uses the factors
+ * (ClusterGraphBelief.factor) and the current beliefs.  info[site] (may be NULL) = 0, or 1-based index of the
+ * first belief whose precision is not positive definite (its terms are NaN; the reference throws there). */
+int  pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info);
+
 /* ---- factor assignment on the device (first "next" row: SURVEY.md section 8(f)-1) ------------ */
 /* assignfactors! (src/beliefs.jl:786-861) for a homogeneous Brownian motion with full rate matrix
  * (MvFullBrownianMotion: factor_treeedge src/evomodels/homogeneousbrownianmotion.jl:262-282,

@@ -358,3 +358,76 @@ def propagate_belief(cluster_to: CanonicalBelief, sepset: CanonicalBelief,
     residual.dh[:] = dh
     residual.dJ[:] = dJ
     return None
+
+
+# ---------------------------------------------------------------------------
+# scores: src/score.jl (the loopy-BP objective; exact on a calibrated clique tree)
+# ---------------------------------------------------------------------------
+
+def entropy(J):
+    """src/score.jl:58-66: entropy of N(., J^-1); 0 for an empty J."""
+    J = np.atleast_2d(np.asarray(J, dtype=float))
+    n = J.shape[1]
+    if n == 0 or J.size == 0:
+        return 0.0
+    S = np.triu(J) + np.triu(J, 1).T  # Symmetric(J): upper triangle
+    sign, ld = np.linalg.slogdet(S)
+    if sign <= 0:
+        raise np.linalg.LinAlgError("entropy: J is not positive definite")
+    return (n * (bu.LOG2PI + 1.0) - ld) / 2.0
+
+
+def average_energy(Jr, hr, Jt, ht, gt):
+    """src/score.jl:105-117: E_r[-log C(x; Jt, ht, gt)] with r = N(Jr^-1 hr, Jr^-1)."""
+    Jt = np.atleast_2d(np.asarray(Jt, dtype=float))
+    if Jt.size == 0:
+        return -float(gt)
+    Jr = np.asarray(Jr, dtype=float)
+    S = np.triu(Jr) + np.triu(Jr, 1).T
+    L = np.linalg.cholesky(S)  # raises if not PD
+    mu = np.linalg.solve(S, np.asarray(hr, dtype=float))
+    return (float(np.trace(np.linalg.solve(S, Jt))) + float(mu @ Jt @ mu)) / 2.0 - float(np.asarray(ht) @ mu) - float(gt)
+
+
+def free_energy(cgb: "ClusterGraphBelief"):
+    """src/score.jl:162-182: (average energy, approximate entropy, free energy)."""
+    b = cgb.belief
+    nclu = cgb.nclusters
+    ave, ent = 0.0, 0.0
+    for i in range(nclu):
+        fh, fJ, fg = cgb.factor[i]
+        if fJ.size == 0:
+            ave -= float(fg[0])
+        else:
+            ave += average_energy(b[i].J, b[i].h, fJ, fh, fg[0])
+            ent += entropy(b[i].J)
+    for i in range(nclu, len(b)):
+        ent -= entropy(b[i].J)
+    return ave, ent, ave - ent
+
+
+def factored_energy(cgb: "ClusterGraphBelief"):
+    """src/score.jl:151-154."""
+    a, e, f = free_energy(cgb)
+    return a, e, -f
+
+
+def residual_kldiv(res: MessageResidual, sep: CanonicalBelief, atol=1e-5):
+    """src/beliefs.jl:1060-1075: KL(message || previous sepset belief); updates res.kldiv / iscalibrated_kl."""
+    if sep.J.size == 0:
+        return True
+    try:
+        J0 = np.triu(sep.J) + np.triu(sep.J, 1).T
+        np.linalg.cholesky(J0)
+        mu0 = np.linalg.solve(J0, sep.h)
+        J1f = sep.J - res.dJ
+        J1 = np.triu(J1f) + np.triu(J1f, 1).T
+        np.linalg.cholesky(J1)
+        mu1 = np.linalg.solve(J1, sep.h - res.dh)
+    except np.linalg.LinAlgError:
+        return False
+    d = mu1 - mu0
+    res.kldiv = (-float(np.trace(np.linalg.solve(J0, res.dJ))) + float(d @ J1 @ d)
+                 + np.linalg.slogdet(J0)[1] - np.linalg.slogdet(J1)[1]) / 2.0
+    res.iscalibrated_kl = abs(res.kldiv) <= atol
+    return res.iscalibrated_kl

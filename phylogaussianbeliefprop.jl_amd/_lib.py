@@ -79,6 +79,7 @@ SYMBOLS = {
     "pgbp_traverse": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
     "pgbp_calibrate": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
     "pgbp_integrate": (C.c_int, [_P, C.c_int32, _F64P, _F64P, _I32P]),
+    "pgbp_free_energy": (C.c_int, [_P, _F64P, _I32P]),
     "pgbp_bm_tree_setup": (C.c_int, [_P, C.POINTER(BmTree)]),
     "pgbp_bm_tree_assignfactors": (C.c_int, [_P, _F64P, _F64P, _F64P, C.c_int32]),
     "pgbp_enqueue_loglik_bm": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),

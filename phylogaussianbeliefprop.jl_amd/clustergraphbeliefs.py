@@ -297,6 +297,23 @@ class ClusterGraphBelief:
                 return j
         raise ValueError("no sepset with a single node")
 
+    # ------------------------------------------------------------------ scores (src/score.jl)
+    def free_energy(self, all_sites=False):
+        """free_energy(beliefs) (src/score.jl:162-182): (average energy, approximate entropy, free energy)."""
+        out = np.zeros((self.n_sites, 3))
+        info = np.zeros(self.n_sites, dtype=np.int32)
+        _check(self._lib.pgbp_free_energy(self._eng, L.f64p(out), L.i32p(info)), self._eng)
+        if all_sites:
+            return out, info
+        if info[self.site]:
+            raise np.linalg.LinAlgError(f"PosDefException: belief {info[self.site] - 1} is not positive definite")
+        return tuple(float(x) for x in out[self.site])
+
+    def factored_energy(self):
+        """factored_energy(beliefs) (src/score.jl:151-154): third value = -free energy."""
+        a, e, f = self.free_energy()
+        return (a, e, -f)
+
     # ------------------------------------------------------------------ device factor assignment
     def bm_tree_setup(self, kind, length, data_row, data):
         """Static part of assignfactors! for a homogeneous BM on a tree (include/pgbp.h: pgbp_bm_tree);

@@ -672,6 +672,36 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
   return PGBP_OK;
 }
 
+// ---- scores ---------------------------------------------------------------------------------------------
+
+int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
+  if (!e || !out3) return PGBP_ERR_INVALID;
+  if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "pgbp_free_energy: no factors (pgbp_set_beliefs with snapshot, or pgbp_init_factors_frombeliefs)");
+  const Plan& p = e->plan;
+  const int ns = p.n_sites;
+  double *d_contrib = nullptr, *d_out = nullptr;
+  int32_t* d_inf = nullptr;
+  int rc;
+  if ((rc = dev_alloc(e, &d_contrib, (size_t)2 * ns * p.n_beliefs()))) return rc;
+  if ((rc = dev_alloc(e, &d_out, (size_t)3 * ns))) { (void)hipFree(d_contrib); return rc; }
+  if ((rc = dev_alloc(e, &d_inf, (size_t)ns))) { (void)hipFree(d_contrib); (void)hipFree(d_out); return rc; }
+  std::vector<int32_t> inf(ns, 0x7fffffff);
+  hipError_t herr = hipMemcpyAsync(d_inf, inf.data(), sizeof(int32_t) * ns, hipMemcpyHostToDevice, e->st);
+  if (herr == hipSuccess) {
+    launch_free_energy(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters,
+                       p.n_beliefs(), p.max_dim, e->layout_bs16 ? 1 : 0, p.fast_p, d_contrib, d_out, d_inf, ns, e->st);
+    herr = hipMemcpyAsync(out3, d_out, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost, e->st);
+  }
+  if (herr == hipSuccess) herr = hipMemcpyAsync(inf.data(), d_inf, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st);
+  if (herr == hipSuccess) herr = hipStreamSynchronize(e->st);
+  if (herr == hipSuccess) herr = hipGetLastError();
+  (void)hipFree(d_contrib); (void)hipFree(d_out); (void)hipFree(d_inf);
+  if (herr != hipSuccess) return e->fail(PGBP_ERR_HIP, std::string("pgbp_free_energy: ") + hipGetErrorString(herr));
+  if (info)
+    for (int s = 0; s < ns; ++s) info[s] = inf[s] == 0x7fffffff ? 0 : inf[s];
+  return PGBP_OK;
+}
+
 // ---- device factor assignment (homogeneous BM on a tree) ----------------------------------------
 
 int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {

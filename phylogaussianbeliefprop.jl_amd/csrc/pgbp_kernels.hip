@@ -510,6 +510,137 @@ void launch_check_symmetry(const double* pool, int64_t stride, const int64_t* d_
                      n_records, d_flag, fast_p);
 }
 
+// ---- free_energy / factored_energy (src/score.jl:105-182): one wavefront per belief ------------------------
+// cluster i (factor (J_t, h_t, g_t), belief (J, h)):  average energy = (tr(J^-1 J_t) + mu'J_t mu)/2 - h_t'mu - g_t,
+//   entropy = (m (log 2pi + 1) - log det J) / 2, mu = J^-1 h;  sepset: -entropy.
+// Gauss-Jordan on the augmented system [J | J_t | h] in LDS (pivots = Cholesky pivots of Symmetric(J)).
+// contrib[site][belief] = (energy term, entropy term); summed per site by free_energy_reduce_kernel in a
+// fixed order (deterministic).  info[site] = smallest 1-based belief index whose J is not positive definite.
+__device__ __forceinline__ double fe_elem(const double* __restrict__ rec, int m, bool packed, int fp, int i, int j) {
+  return packed ? rec[bs16::J_off(m, i, j, fp)] : rec[(i <= j) ? i + (int64_t)j * m : j + (int64_t)i * m];
+}
+
+__global__ __launch_bounds__(64) void free_energy_kernel(const double* __restrict__ pool, int64_t pool_stride,
+                                                         const double* __restrict__ fpool, int64_t fpool_stride,
+                                                         const int64_t* __restrict__ boff,
+                                                         const int32_t* __restrict__ dim, int n_clusters,
+                                                         int n_beliefs, int bs, int fp,
+                                                         double2* __restrict__ contrib, int32_t* __restrict__ info) {
+  const int lane = threadIdx.x, b = blockIdx.x, site = blockIdx.y;
+  const int m = dim[b];
+  const bool is_cluster = b < n_clusters;
+  const double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[b];
+  const double* __restrict__ frec = fpool + (int64_t)site * fpool_stride + (is_cluster ? boff[b] : 0);
+  double2* out = contrib + (int64_t)site * n_beliefs + b;
+  if (m == 0) {
+    // empty J: -g_t for a cluster (src/score.jl:170-171), entropy 0 for a sepset
+    if (lane == 0) *out = make_double2(is_cluster ? -frec[0] : 0.0, 0.0);
+    return;
+  }
+  const bool packed = bs && bs16::applies(m, fp);
+  const int nrhs = is_cluster ? m + 1 : 0;
+  const int nc = m + nrhs;
+  const int ld = nc | 1;
+  double* W = lds;
+  for (int idx = lane; idx < m * m; idx += kWave) {
+    const int j = idx / m, i = idx - j * m;
+    W[i * ld + j] = fe_elem(rec, m, packed, fp, i, j);  // Symmetric(J): upper triangle
+    if (is_cluster) W[i * ld + m + j] = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
+  }
+  if (is_cluster)
+    for (int i = lane; i < m; i += kWave) W[i * ld + 2 * m] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
+  __syncthreads();
+  double mant = 1.0;
+  int expo = 0;
+  for (int k = 0; k < m; ++k) {
+    const double d = W[k * ld + k];
+    if (!(d > 0.0)) {
+      if (lane == 0) { atomicMin(&info[site], b + 1); *out = make_double2(NAN, NAN); }
+      return;
+    }
+    int ex;
+    mant *= frexp(d, &ex);
+    expo += ex;
+    if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
+    const double rd = 1.0 / d;
+    __syncthreads();
+    for (int j = k + 1 + lane; j < nc; j += kWave) W[k * ld + j] *= rd;  // normalise the pivot row
+    __syncthreads();
+    // eliminate column k from every other row (columns > k only: the rest is never read again)
+    const int ncol = nc - (k + 1);
+    if (ncol > 0) {
+      for (int idx = lane; idx < (m - 1) * ncol; idx += kWave) {
+        int i = idx / ncol;
+        const int j = k + 1 + (idx - i * ncol);
+        if (i >= k) ++i;
+        W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
+      }
+    }
+    __syncthreads();
+  }
+  const double logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
+  const double ent = 0.5 * ((double)m * (PGBP_LOG2PI + 1.0) - logdet);
+  if (!is_cluster) {
+    if (lane == 0) *out = make_double2(0.0, -ent);
+    return;
+  }
+  // right block now holds J^-1 J_t (columns m .. 2m-1) and mu = J^-1 h (column 2m)
+  double acc = 0.0;
+  for (int i = lane; i < m; i += kWave) acc += 0.5 * W[i * ld + m + i];  // tr(J^-1 J_t) / 2
+  for (int idx = lane; idx < m * m; idx += kWave) {
+    const int j = idx / m, i = idx - j * m;
+    const double jt = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
+    acc += 0.5 * W[i * ld + 2 * m] * jt * W[j * ld + 2 * m];             // mu'J_t mu / 2
+  }
+  for (int i = lane; i < m; i += kWave)
+    acc -= (packed ? frec[bs16::h_off(m, i, fp)] : frec[(int64_t)m * m + i]) * W[i * ld + 2 * m];  // - h_t'mu
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) *out = make_double2(acc - (packed ? frec[bs16::g_off(m, fp)] : frec[(int64_t)m * m + m]), ent);
+}
+
+__global__ __launch_bounds__(256) void free_energy_reduce_kernel(const double2* __restrict__ contrib, int n_beliefs,
+                                                                 double* __restrict__ out3) {
+  __shared__ double sa[256], se[256];
+  const int site = blockIdx.x;
+  double a = 0.0, e = 0.0;
+  for (int b = threadIdx.x; b < n_beliefs; b += blockDim.x) {  // fixed assignment -> deterministic sums
+    const double2 c = contrib[(int64_t)site * n_beliefs + b];
+    a += c.x;
+    e += c.y;
+  }
+  sa[threadIdx.x] = a;
+  se[threadIdx.x] = e;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) { sa[threadIdx.x] += sa[threadIdx.x + s2]; se[threadIdx.x] += se[threadIdx.x + s2]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out3[3 * site + 0] = sa[0];
+    out3[3 * site + 1] = se[0];
+    out3[3 * site + 2] = sa[0] - se[0];
+  }
+}
+
+void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
+                        const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
+                        int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st) {
+  const int mm = max_dim < 1 ? 1 : max_dim;
+  const size_t ldsb = sizeof(double) * (size_t)mm * (size_t)((2 * mm + 1) | 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(free_energy_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(free_energy_kernel, dim3(n_beliefs, n_sites), dim3(kWave), ldsb, st, pool, pool_stride, fpool,
+                     fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p,
+                     reinterpret_cast<double2*>(d_contrib), d_info);
+  hipLaunchKernelGGL(free_energy_reduce_kernel, dim3(n_sites), dim3(256), 0, st,
+                     reinterpret_cast<const double2*>(d_contrib), n_beliefs, d_out3);
+}
+
 // ---- record gather/scatter between the ABI's packed layout and the padded device records
 __global__ void records_kernel(const double* __restrict__ src, int64_t src_stride,
                                const int64_t* __restrict__ src_off, double* __restrict__ dst, int64_t dst_stride,

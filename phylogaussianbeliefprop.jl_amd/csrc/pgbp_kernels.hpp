@@ -70,6 +70,12 @@ void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64
                          const double* d_mu, int per_site, int bs16, int fast_p, int n_clusters, int n_sites,
                          hipStream_t st);
 
+// free_energy (src/score.jl:162-182): per-belief terms + deterministic per-site sum -> out3[site] =
+// (average energy, approximate entropy, free energy); info[site] (preset to INT_MAX) = first non-PD belief + 1
+void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
+                        const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
+                        int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st);
+
 void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int n_msgs, int n_sites, int reset_kl,
                         hipStream_t st);
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st);

@@ -570,3 +570,51 @@ def test_device_factor_fill_bm_tree(P, graph, ntips, p):
         cgb.assignfactors_bm_(R_, mu_)
         assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
         assert rel_close(cgb.integratebelief_(prob.root_cluster)[1], S.bm_loglik_pruning(tr, R_, mu_, X))
+
+
+def test_free_energy_goldens_and_oracle(P):
+    """factored_energy / free_energy (src/score.jl:151-182) on the device: test/test_calibration.jl:59
+    (factored energy == log-likelihood on the calibrated clique tree), docs getting_started.md:288-291,
+    and the oracle's restatement on a loopy (approximate) Bethe graph and on a BS-layout 16-trait tree."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(g["model"]), [g["y"]], g["taxa"])
+    assert P.calibrate_(pcgb, [spt])[0] and OC.calibrate(ocgb, [spt])[0]
+    fe = pcgb.factored_energy()
+    assert rel_close(fe[2], g["ll_every_belief"])
+    for x, y in zip(fe, OB.factored_energy(ocgb)):
+        assert rel_close(x, y)
+    g = G["doctest_lazaridis"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(g["model"]), [g["x"]], g["taxa"])
+    assert P.calibrate_(pcgb, [spt])[0]
+    assert abs(pcgb.factored_energy()[2] - g["factored_energy"]) <= 1e-10 * abs(g["factored_energy"])
+    # loopy Bethe: an approximation, compared with the oracle
+    g = G["calibration_bethe_level1"]
+    net = ON.read_newick(g["net"])
+    cg = OCG.bethe(net)
+    sched = OCG.spanningtrees_clusterlist(cg, net)
+    ocgb, pcgb = build_both(P, net, cg, make_model(g["model"]), [g["y"]], g["taxa"])
+    assert P.calibrate_(pcgb, sched, 20, auto=True)[0] and OC.calibrate(ocgb, sched, 20, auto=True)[0]
+    for x, y in zip(pcgb.free_energy(), OB.free_energy(ocgb)):
+        assert rel_close(x, y)
+    # 16-trait tree (packed layout on the device)
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(77)
+    tr = S.random_tree(30, rng)
+    p = 16
+    R = S.random_rate_matrix(p, rng); R = (R + R.T) / 2
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    assert P.calibrate_(cgb, prob.schedule, 1, sync=False)[0]
+    assert rel_close(cgb.factored_energy()[2], S.bm_loglik_pruning(tr, R, np.zeros(p), X))
+    # before calibration the sepset beliefs are not normalisable: reported, not crashed
+    cgb.init_beliefs_reset_fromfactors_(sync=False)
+    out, info = cgb.free_energy(all_sites=True)
+    assert info[0] > 0

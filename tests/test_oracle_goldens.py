@@ -156,6 +156,7 @@ def test_calibration_cliquetree_level1():
     for i in range(len(cgb.belief)):
         _, ll = cgb.integratebelief(i)
         assert close(ll, g["ll_every_belief"])
+    assert close(OB.factored_energy(cgb)[2], g["ll_every_belief"])   # test/test_calibration.jl:59
     root_ind = next(i for i, be in enumerate(cgb.belief) if 1 in be.nodelabel)
     mu, _ = cgb.integratebelief(root_ind)
     assert close(mu[-1], g["posterior_root_mean"], rtol=g["rtol_posterior"])
@@ -200,6 +201,8 @@ def test_doctest_lazaridis():
     for i in range(len(cgb.belief)):
         assert close(cgb.integratebelief(i)[1], g["ll"])
     assert close(OD.loglik(net, model, tbl, g["taxa"]), g["ll"])
+    # docs/src/man/getting_started.md:288-291: "both approaches return the same value, modulo rounding error"
+    assert close(OB.factored_energy(cgb)[2], g["factored_energy"], rtol=1e-12)
 
 
 def test_bpposdef_exception_text():
@@ -261,3 +264,14 @@ def test_calibration_bethe_loopy_level1():
     ind = cgb.clusterindex(net.vec_node[i3].name)
     mu, _ = cgb.integratebelief(ind)
     assert close(mu[-1], g["posterior_mean_I3"], rtol=g["rtol"])
+
+
+def test_residual_kldiv_golden():
+    """test/test_calibration.jl:13-33 (value from R rags2ridges::KLdiv)."""
+    g = G["residual_kldiv"]
+    res = OB.MessageResidual(2)
+    res.dJ[:] = np.array(g["dJ"]); res.dh[:] = np.array(g["dh"])
+    sep = OB.CanonicalBelief([1, 2], 1, np.ones((1, 2), bool), OB.SEPSET, ("A", "B"))
+    sep.J[:] = np.array(g["sepJ"]); sep.h[:] = np.array(g["seph"])
+    OB.residual_kldiv(res, sep)
+    assert close(res.kldiv, g["kldiv"], rtol=g["rtol"])
