@@ -213,7 +213,7 @@ int  pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts)
 int  pgbp_sync(pgbp_engine* e);
 /* Time `reps` repetitions of the enqueued work with HIP events on the engine's stream; returns the
  * total milliseconds in *ms_total and, per kernel family, accumulated device time is NOT measured here
- * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik. */
+ * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik, 2 = loglik_bm (with the device factor fill). */
 int  pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each,
                         const pgbp_opts* opts, float* ms_total);
 /* Time only the message-kernel launches of `reps` calibrate iterations (reset from factors before each):

@@ -487,21 +487,26 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
                       const int32_t* ch_j) {
   if (!e) return PGBP_ERR_INVALID;
   int rc = plan_set_schedule(e->plan, n_trees, tree_off, pa_j, ch_j);
-  if (rc) return e->fail(rc, e->plan.err);
+  if (rc) return e->fail(rc, e->plan.err);  // the previous schedule (if any) stays in force
   HIPCHK(e, hipStreamSynchronize(e->st));
   free_traversals(e);
   e->dpost.resize(n_trees);
   e->dpre.resize(n_trees);
-  for (int t = 0; t < n_trees; ++t) {
-    for (int dir = 0; dir < 2; ++dir) {
+  for (int t = 0; t < n_trees && rc == PGBP_OK; ++t) {
+    for (int dir = 0; dir < 2 && rc == PGBP_OK; ++dir) {
       const Traversal& tr = dir == 0 ? e->plan.trees[t].post : e->plan.trees[t].pre;
       DevTraversal& d = dir == 0 ? e->dpost[t] : e->dpre[t];
-      if ((rc = upload(e, &d.d_task_off, tr.task_off))) return rc;
-      if ((rc = upload(e, &d.d_entries, tr.entries))) return rc;
-      if ((rc = upload(e, &d.d_fentries, tr.fentries))) return rc;
+      if ((rc = upload(e, &d.d_task_off, tr.task_off))) break;
+      if ((rc = upload(e, &d.d_entries, tr.entries))) break;
+      rc = upload(e, &d.d_fentries, tr.fentries);
     }
   }
-  return PGBP_OK;
+  if (rc) {  // out of device memory half way: leave the engine without a schedule rather than with half of one
+    free_traversals(e);
+    e->plan.trees.clear();
+    e->plan.all_fast = false;
+  }
+  return rc;
 }
 
 int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from, const pgbp_opts* opts,
@@ -600,6 +605,13 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   if ((rc = need_schedule(e, 0))) return rc;
   const Plan& p = e->plan;
   const int ns = p.n_sites, nt = (int)p.trees.size();
+  if (niter == 0) {  // the loop of src/calibration.jl:46 does not run: (succ, iscal) = (false, false)
+    for (int s = 0; s < ns; ++s) {
+      std::memset(&results[s], 0, sizeof(pgbp_result));
+      results[s].fail_edge = -1;
+    }
+    return PGBP_OK;
+  }
   const bool auto_stop = opts && opts->auto_stop;
   const int64_t n_pairs_max = (int64_t)niter * nt;
   if (n_pairs_max > e->hist_cap) {
@@ -860,7 +872,7 @@ int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
 
 int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each, const pgbp_opts* opts,
                        float* ms_total) {
-  if (!e || !ms_total) return PGBP_ERR_INVALID;
+  if (!e || !ms_total || kind < 0 || kind > 2) return PGBP_ERR_INVALID;
   hipEvent_t a, b;
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));

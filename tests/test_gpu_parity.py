@@ -618,3 +618,36 @@ def test_free_energy_goldens_and_oracle(P):
     cgb.init_beliefs_reset_fromfactors_(sync=False)
     out, info = cgb.free_energy(all_sites=True)
     assert info[0] > 0
+
+
+def test_api_edge_cases(P):
+    """niter = 0 returns (false, false) like the reference's empty loop (src/calibration.jl:45-59); a bad
+    schedule is refused and the previous one stays in force; calls out of order fail with a message."""
+    import ctypes as C
+    from pgbp_amd import _lib as L
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(2)
+    tr = S.random_tree(12, rng)
+    p = 2
+    prob = S.cliquetree_of_tree(tr, p)
+    R = S.random_rate_matrix(p, rng)
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    lib = P.load()
+    res = (L.Result * 1)()
+    o = cgb._opts()
+    assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o), res) == L.ERR_STATE       # no schedule yet
+    assert b"pgbp_set_schedule" in lib.pgbp_last_error(cgb._eng)
+    assert P.calibrate_(cgb, prob.schedule, 0) == (False, False)
+    assert np.array_equal(cgb._packed[0], packed)                                  # nothing ran
+    pa, ch = prob.schedule[0]
+    bad = (pa.copy(), ch.copy()); bad[1][-1] = bad[1][0]
+    with pytest.raises(P.PgbpError) as ei:
+        cgb.set_schedule([bad])
+    assert ei.value.code == L.ERR_NOT_TREE
+    cgb._schedule = None
+    assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
+    assert rel_close(cgb.integratebelief_(prob.root_cluster)[1], S.bm_loglik_pruning(tr, R, np.zeros(p), X))
+    o2 = cgb._opts(update_residualkldiv=True)
+    assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o2), res) == L.ERR_INVALID      # refused explicitly
