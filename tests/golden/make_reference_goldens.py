@@ -83,6 +83,24 @@ G["calibration_bethe_level1"] = {
     "niter": 20, "posterior_mean_I3": 0.21511454631828986, "rtol": 1e-5,
     "comment": "I3 = the internal child of the root (see the rerooting comment :85-92)"}
 
+G["calibration_level3_joingraph"] = {
+    "cite": "test/test_calibration.jl:131-185",
+    "net": "((#H1:0.1::0.4,#H2:0.1::0.4)I1:1.0,(((A:1.0)#H1:0.1::0.6,#H3:0.1::0.4)#H2:0.1::0.6,(B:1.0)#H3:0.1::0.6)I2:1.0)I3;",
+    "taxa": ["A", "B"], "y1": [2.11, 2.15], "y2": [30.0, None],
+    "model_improper": {"kind": "MvFullBM", "R": [[1, 0.5], [0.5, 1]], "mu": [0, 0], "v": [["inf", 0], [0, "inf"]]},
+    "norm_improper": -1.390595772423,
+    "comment": "the reference's comments give the same numbers from a clique tree (:150-160): the join-graph(3) "
+               "run converges to the exact values, so any exact cluster graph pins them",
+    "posterior_means_improper": {"I1": [2.121105154896223, 30.005552577448075],
+                                 "I2": [2.1360649504455984, 30.013032475222563],
+                                 "I3": [2.128585052670943, 30.00929252633547],
+                                 "H1": [2.125583120364, 30.007791560181964],
+                                 "H2": [2.129918967774073, 30.009959483886966]},
+    "model_fixed": {"kind": "MvFullBM", "R": [[1, 0.5], [0.5, 1]], "mu": [2.128585052670943, 30.00929252633547]},
+    "norm_fixed": -3.3498677834866997,
+    "posterior_means_fixed": {"I1": [2.121105154896223, 30.005552577448075],
+                              "I2": [2.1360649504455984, 30.013032475222563]}}
+
 G["bpposdef_message"] = {
     "cite": "test/test_calibration.jl:6-12",
     "msg": "belief 1, integrate 3,4", "info": 1,

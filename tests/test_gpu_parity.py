@@ -651,3 +651,30 @@ def test_api_edge_cases(P):
     assert rel_close(cgb.integratebelief_(prob.root_cluster)[1], S.bm_loglik_pruning(tr, R, np.zeros(p), X))
     o2 = cgb._opts(update_residualkldiv=True)
     assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o2), res) == L.ERR_INVALID      # refused explicitly
+
+
+@pytest.mark.parametrize("variant", ["improper", "fixed"])
+def test_calibration_level3_network(P, variant):
+    """test/test_calibration.jl:131-185 on the device (generic kernel: hybrid-node clusters of 3 nodes, ragged
+    scopes from a missing value, improper or fixed root): normalisation constant at every belief, posterior means."""
+    g = G["calibration_level3_joingraph"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(g["model_" + variant]), [g["y1"], g["y2"]], g["taxa"])
+    assert P.calibrate_(pcgb, [spt])[0] and OC.calibrate(ocgb, [spt])[0]
+    assert_beliefs_close(pcgb, ocgb)
+    seen = {}
+    for i, be in enumerate(ocgb.belief):
+        if be.dimension == 0:
+            continue
+        mu, norm = pcgb.integratebelief_(i)
+        assert abs(norm - g["norm_" + variant]) <= 1e-9 * abs(g["norm_" + variant])
+        k = 0
+        for col, lab in enumerate(be.nodelabel):
+            d = int(be.inscope[:, col].sum())
+            if d == be.ntraits:
+                seen.setdefault(net.vec_node[lab - 1].name, mu[k:k + d])
+            k += d
+    for name, m in g["posterior_means_" + variant].items():
+        assert np.allclose(seen[name], m, rtol=1.5e-8, atol=0), name

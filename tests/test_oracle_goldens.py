@@ -275,3 +275,42 @@ def test_residual_kldiv_golden():
     sep.J[:] = np.array(g["sepJ"]); sep.h[:] = np.array(g["seph"])
     OB.residual_kldiv(res, sep)
     assert close(res.kldiv, g["kldiv"], rtol=g["rtol"])
+
+
+def _node_means(cgb, net, integrate):
+    """posterior mean of every in-scope node, read from the first belief that contains it"""
+    out = {}
+    for i, be in enumerate(cgb.belief):
+        if be.dimension == 0:
+            continue
+        mu, _ = integrate(i)
+        k = 0
+        for col, lab in enumerate(be.nodelabel):
+            d = int(be.inscope[:, col].sum())
+            name = net.vec_node[lab - 1].name
+            if d == be.ntraits and name not in out:
+                out[name] = np.array(mu[k:k + d])
+            k += d
+    return out
+
+
+@pytest.mark.parametrize("variant", ["improper", "fixed"])
+def test_calibration_level3_network(variant):
+    """test/test_calibration.jl:131-185: level-3 network (3 stacked hybrids), 2 traits, one missing value,
+    MvFullBM with improper / fixed root: normalisation constant and posterior means.  The reference gets these
+    from a join-graph(3) loopy run AND (in its comments) from a clique tree; an exact cluster graph pins them."""
+    g = G["calibration_level3_joingraph"]
+    net = ON.read_newick(g["net"])
+    model = make_model(g["model_" + variant])
+    tbl = [g["y1"], g["y2"]]
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, model, tbl, g["taxa"])
+    assert OC.calibrate(cgb, [spt])[0]
+    for i, be in enumerate(cgb.belief):
+        if be.dimension:
+            assert close(cgb.integratebelief(i)[1], g["norm_" + variant], rtol=1e-9)
+    means = _node_means(cgb, net, cgb.integratebelief)
+    for name, m in g["posterior_means_" + variant].items():
+        assert np.allclose(means[name], m, rtol=1.5e-8, atol=0), (name, means[name], m)
+    assert close(OD.loglik(net, model, tbl, g["taxa"]), g["norm_" + variant], rtol=1e-9)
