@@ -66,7 +66,7 @@ typedef struct pgbp_desc {
 typedef struct pgbp_opts {
   int32_t auto_stop;           /* auto */
   int32_t update_residualnorm; /* default 1 */
-  int32_t update_residualkldiv;/* must be 0 (off by default in the reference: src/calibration.jl:43) */
+  int32_t update_residualkldiv;/* default 0 (src/calibration.jl:43); 1: residual_kldiv! after every message */
   int32_t reserved;
   double  atol;                /* 1e-5 */
 } pgbp_opts;
@@ -138,8 +138,10 @@ int  pgbp_reset_from_factors(pgbp_engine* e);
 /* init_messagecalibrationflags_reset!(beliefs, reset_kl) (src/clustergraphbeliefs.jl:146-150) */
 int  pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl);
 /* MessageResidual fields of every directed message, site-major: dJ,dh packed (pgbp_residual_size
- * doubles per site), iscalibrated_resid flags and kldiv (n_messages per site). Any pointer may be NULL. */
-int  pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv);
+ * doubles per site), iscalibrated_resid flags, kldiv and iscalibrated_kl flags (n_messages per site).
+ * Any pointer may be NULL. */
+int  pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv,
+                        int32_t* iscalibrated_kl);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 int  pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off,
@@ -149,6 +151,16 @@ int  pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off,
  * exception "returned not thrown"); `sepset` is a belief index (>= n_clusters). */
 int  pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from,
                     const pgbp_opts* opts, int32_t* info);
+/* residual_kldiv!(messageresidual[(to, from)], sepset) (src/beliefs.jl:1060-1075) for every site, for the
+ * message last sent from cluster_from to cluster_to: updates that residual's kldiv and iscalibrated_kl
+ * (left alone if the sepset belief, or the one before the message, is not positive definite).
+ * iscalibrated_kl[n_sites] (may be NULL) receives the flag. */
+int  pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from,
+                         const pgbp_opts* opts, int32_t* iscalibrated_kl);
+/* regularizebeliefs_bycluster!(beliefs, clustergraph) (src/clustergraphbeliefs.jl:235-275) on the device:
+ * per cluster eps = max(eps(Float64), max|J|); +eps on the cluster's diagonal at the scope of each
+ * incident sepset, and on the sepset's diagonal.  Asynchronous on the engine's stream. */
+int  pgbp_regularize_bycluster(pgbp_engine* e);
 /* propagate_1traversal_postorder! / _preorder! (src/calibration.jl:111-161), dir 0 / 1.
  * results[n_sites]: succ, fail_* filled. */
 int  pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* opts, pgbp_result* results);

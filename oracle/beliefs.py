@@ -420,6 +420,7 @@ def residual_kldiv(res: MessageResidual, sep: CanonicalBelief, atol=1e-5):
         J0 = np.triu(sep.J) + np.triu(sep.J, 1).T
         np.linalg.cholesky(J0)
         mu0 = np.linalg.solve(J0, sep.h)
+        sep.mu = mu0  # side product of getcholesky_μ! (src/score.jl:32-36)
         J1f = sep.J - res.dJ
         J1 = np.triu(J1f) + np.triu(J1f, 1).T
         np.linalg.cholesky(J1)
@@ -431,3 +432,114 @@ def residual_kldiv(res: MessageResidual, sep: CanonicalBelief, atol=1e-5):
                  + np.linalg.slogdet(J0)[1] - np.linalg.slogdet(J1)[1]) / 2.0
     res.iscalibrated_kl = abs(res.kldiv) <= atol
     return res.iscalibrated_kl
+
+
+# ---------------------------------------------------------------------------
+# regularisation: src/clustergraphbeliefs.jl:235-403 (graph walks on the host + diagonal updates)
+# ---------------------------------------------------------------------------
+
+def _neighbors(cgb: "ClusterGraphBelief"):
+    """cluster index -> [(neighbor cluster index, sepset belief index)] in sepset order"""
+    nb = {i: [] for i in range(cgb.nclusters)}
+    for j in range(cgb.nclusters, len(cgb.belief)):
+        a, c = (cgb.cdict[l] for l in cgb.belief[j].metadata)
+        nb[a].append((c, j))
+        nb[c].append((a, j))
+    return nb
+
+
+def regularizebeliefs_1clustersepset(cluster: CanonicalBelief, sepset: CanonicalBelief, eps):
+    """src/clustergraphbeliefs.jl:264-275."""
+    upind = scopeindex(sepset, cluster)
+    if upind.size == 0:
+        return
+    cluster.J[upind, upind] += eps
+    sepset.J[np.diag_indices_from(sepset.J)] += eps
+
+
+def regularizebeliefs_bycluster(cgb: "ClusterGraphBelief"):
+    """src/clustergraphbeliefs.jl:235-249."""
+    nb = _neighbors(cgb)
+    for ci in range(cgb.nclusters):
+        cl = cgb.belief[ci]
+        eps = max(bu.EPS, float(np.max(np.abs(cl.J))) if cl.J.size else 0.0)
+        for (_, sj) in nb[ci]:
+            regularizebeliefs_1clustersepset(cl, cgb.belief[sj], eps)
+
+
+def regularizebeliefs_onschedule(cgb: "ClusterGraphBelief"):
+    """src/clustergraphbeliefs.jl:376-403: default messages eps*I, then real messages, cluster by cluster."""
+    nb = _neighbors(cgb)
+    sent = set()
+    eps0 = float(np.sqrt(bu.EPS))
+    labels = [b.metadata for b in cgb.belief[:cgb.nclusters]]
+    for ci in range(cgb.nclusters):
+        cl = cgb.belief[ci]
+        eps = max(float(np.max(np.abs(cl.J))) if cl.J.size else 0.0, eps0)
+        tosend = []
+        for (ni, sj) in nb[ci]:
+            if (ni, ci) not in sent:
+                regularizebeliefs_1clustersepset(cl, cgb.belief[sj], eps)
+                sent.add((ni, ci))
+            if (ci, ni) not in sent:
+                tosend.append((ni, sj))
+                sent.add((ci, ni))
+        for (ni, sj) in tosend:
+            propagate_belief(cgb.belief[ni], cgb.belief[sj], cl, cgb.messageresidual[(labels[ni], labels[ci])])
+
+
+def scopeindex_node(node_lab: int, sep: CanonicalBelief, clu: CanonicalBelief):
+    """src/beliefs.jl:418-436: (ind_in_sepset, ind_in_cluster) of the node's traits shared by both scopes."""
+    if node_lab not in sep.nodelabel:
+        raise ValueError(f"{node_lab} not in sepset")
+    if node_lab not in clu.nodelabel:
+        raise ValueError(f"{node_lab} not in cluster")
+    s_j, c_j = sep.nodelabel.index(node_lab), clu.nodelabel.index(node_lab)
+    s_node = sep.inscope[:, s_j]
+    if np.any(s_node & ~clu.inscope[:, c_j]):
+        raise ValueError(f"some traits are in sepset's but not in cluster's scope for node {node_lab}")
+    s_insc = np.zeros_like(sep.inscope)
+    s_insc[:, s_j] = s_node
+    c_insc = np.zeros_like(clu.inscope)
+    c_insc[:, c_j] = s_node
+    ind_sep = np.nonzero(s_insc.T.reshape(-1)[sep.inscope.T.reshape(-1)])[0]
+    ind_clu = np.nonzero(c_insc.T.reshape(-1)[clu.inscope.T.reshape(-1)])[0]
+    return ind_sep, ind_clu
+
+
+def regularizebeliefs_bynodesubtree(cgb: "ClusterGraphBelief"):
+    """src/clustergraphbeliefs.jl:306-340.  For each node: the clusters and sepsets holding it form a tree
+    (running intersection); rooted at the cluster of largest first preorder index, every non-root cluster
+    and the sepset to its parent get +eps on the node's shared traits."""
+    nc = cgb.nclusters
+    b = cgb.belief
+    sep_ends = [tuple(cgb.cdict[l] for l in b[j].metadata) for j in range(nc, len(b))]
+    nodes = sorted({v for i in range(nc) for v in b[i].nodelabel})
+    for v in nodes:
+        cl = [i for i in range(nc) if v in b[i].nodelabel]
+        if len(cl) <= 1:
+            continue
+        ed = [(a, c, nc + k) for k, (a, c) in enumerate(sep_ends) if v in b[nc + k].nodelabel]
+        if len(ed) != len(cl) - 1:
+            raise ValueError(f"running intersection violated for node / variable {v}")
+        root = max(cl, key=lambda i: b[i].nodelabel[0])
+        eps = bu.EPS
+        for i in cl:
+            eps = max(eps, float(np.max(np.abs(b[i].J))))
+        nbr = {i: [] for i in cl}
+        for (a, c, j) in ed:
+            nbr[a].append((c, j))
+            nbr[c].append((a, j))
+        seen, stack = {root}, [root]
+        while stack:
+            p = stack.pop()
+            for (c, j) in nbr[p]:
+                if c in seen:
+                    continue
+                seen.add(c)
+                stack.append(c)
+                s_ind, c_ind = scopeindex_node(v, b[j], b[c])
+                b[c].J[c_ind, c_ind] += eps
+                b[j].J[s_ind, s_ind] += eps
+        if len(seen) != len(cl):
+            raise ValueError(f"running intersection violated for node / variable {v}")

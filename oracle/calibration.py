@@ -13,7 +13,8 @@ from . import beliefs as B
 
 
 def propagate_1traversal_postorder(cgb: B.ClusterGraphBelief, pa_lab, ch_lab, pa_j, ch_j,
-                                   verbose=True, update_residualnorm=True, log: List[str] = None):
+                                   verbose=True, update_residualnorm=True, log: List[str] = None,
+                                   update_residualkldiv=False):
     """src/calibration.jl:111-135."""
     b, mr = cgb.belief, cgb.messageresidual
     for i in reversed(range(len(pa_lab))):
@@ -23,6 +24,8 @@ def propagate_1traversal_postorder(cgb: B.ClusterGraphBelief, pa_lab, ch_lab, pa
         if flag is None:
             if update_residualnorm:
                 B.iscalibrated_residnorm_update(mrss)
+            if update_residualkldiv:
+                B.residual_kldiv(mrss, sepset)
         else:
             if verbose and log is not None:
                 log.append(("error", flag.msg))
@@ -32,7 +35,8 @@ def propagate_1traversal_postorder(cgb: B.ClusterGraphBelief, pa_lab, ch_lab, pa
 
 
 def propagate_1traversal_preorder(cgb: B.ClusterGraphBelief, pa_lab, ch_lab, pa_j, ch_j,
-                                  verbose=True, update_residualnorm=True, log: List[str] = None):
+                                  verbose=True, update_residualnorm=True, log: List[str] = None,
+                                   update_residualkldiv=False):
     """src/calibration.jl:137-161."""
     b, mr = cgb.belief, cgb.messageresidual
     for i in range(len(pa_lab)):
@@ -42,6 +46,8 @@ def propagate_1traversal_preorder(cgb: B.ClusterGraphBelief, pa_lab, ch_lab, pa_
         if flag is None:
             if update_residualnorm:
                 B.iscalibrated_residnorm_update(mrss)
+            if update_residualkldiv:
+                B.residual_kldiv(mrss, sepset)
         else:
             if verbose and log is not None:
                 log.append(("error", flag.msg))
@@ -50,23 +56,23 @@ def propagate_1traversal_preorder(cgb: B.ClusterGraphBelief, pa_lab, ch_lab, pa_
     return True
 
 
-def calibrate_tree(cgb, spt, verbose=True, up_resnorm=True, log=None):
+def calibrate_tree(cgb, spt, verbose=True, up_resnorm=True, log=None, up_reskldiv=False):
     """src/calibration.jl:72-84."""
-    possucc = propagate_1traversal_postorder(cgb, *spt, verbose, up_resnorm, log)
-    presucc = propagate_1traversal_preorder(cgb, *spt, verbose, up_resnorm, log)
+    possucc = propagate_1traversal_postorder(cgb, *spt, verbose, up_resnorm, log, up_reskldiv)
+    presucc = propagate_1traversal_preorder(cgb, *spt, verbose, up_resnorm, log, up_reskldiv)
     if not (possucc and presucc):
         return (False, False)
     return (True, cgb.iscalibrated_residnorm())
 
 
 def calibrate(cgb, schedule, niter=1, auto=False, info=False, verbose=True,
-              update_residualnorm=True, log=None):
+              update_residualnorm=True, log=None, update_residualkldiv=False):
     """src/calibration.jl:35-60.  `log` collects (level, text) tuples for the
     @info/@error lines."""
     succ, iscal = False, False
     for i in range(1, niter + 1):
         for j, spt in enumerate(schedule, start=1):
-            succ, iscal = calibrate_tree(cgb, spt, verbose, update_residualnorm, log)
+            succ, iscal = calibrate_tree(cgb, spt, verbose, update_residualnorm, log, update_residualkldiv)
             if not succ:
                 if info and log is not None:
                     log.append(("info", f"propagation failed: iteration {i}, schedule tree {j}"))

@@ -9,9 +9,12 @@ from .beliefs import CanonicalBelief, MessageResidual, bclustertype, bsepsettype
 from .beliefupdates import BPPosDefException, integratebelief_, propagate_belief_
 from .calibration import calibrate_, propagate_1traversal_postorder_, propagate_1traversal_preorder_
 from .clustergraphbeliefs import ClusterGraphBelief
+from .regularization import (regularizebeliefs_bycluster_, regularizebeliefs_bynodesubtree_,
+                             regularizebeliefs_onschedule_)
 
 __all__ = [
     "CanonicalBelief", "MessageResidual", "ClusterGraphBelief", "BPPosDefException", "scopeindex",
     "bclustertype", "bsepsettype", "calibrate_", "propagate_1traversal_postorder_",
-    "propagate_1traversal_preorder_", "propagate_belief_", "integratebelief_", "load", "LIB_PATH", "PgbpError",
+    "propagate_1traversal_preorder_", "propagate_belief_", "regularizebeliefs_bycluster_",
+    "regularizebeliefs_bynodesubtree_", "regularizebeliefs_onschedule_", "integratebelief_", "load", "LIB_PATH", "PgbpError",
 ]

@@ -73,7 +73,9 @@ SYMBOLS = {
     "pgbp_init_factors_frombeliefs": (C.c_int, [_P]),
     "pgbp_reset_from_factors": (C.c_int, [_P]),
     "pgbp_reset_flags": (C.c_int, [_P, C.c_int32]),
-    "pgbp_get_residuals": (C.c_int, [_P, _F64P, _I32P, _F64P]),
+    "pgbp_get_residuals": (C.c_int, [_P, _F64P, _I32P, _F64P, _I32P]),
+    "pgbp_residual_kldiv": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Opts), _I32P]),
+    "pgbp_regularize_bycluster": (C.c_int, [_P]),
     "pgbp_set_schedule": (C.c_int, [_P, C.c_int32, _I32P, _I32P, _I32P]),
     "pgbp_propagate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Opts), _I32P]),
     "pgbp_traverse": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),

@@ -73,3 +73,7 @@ class MessageResidual:
     @property
     def kldiv(self):
         return float(self._o._kldiv()[self._d])
+
+    @property
+    def iscalibrated_kl(self):
+        return bool(self._o._klflags()[self._d])

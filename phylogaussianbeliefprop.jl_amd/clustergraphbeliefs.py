@@ -121,6 +121,7 @@ class ClusterGraphBelief:
         self._res = None
         self._flg = None
         self._kl = None
+        self._klflg = None
         self._schedule = None
         self.site = 0  # which site the belief views / residual views show
         self.belief = _BeliefList(self)
@@ -165,8 +166,9 @@ class ClusterGraphBelief:
         self._res = np.zeros((self.n_sites, max(1, int(self._roff[-1]))))
         self._flg = np.zeros((self.n_sites, max(1, nm)), dtype=np.int32)
         self._kl = np.zeros((self.n_sites, max(1, nm)))
-        _check(self._lib.pgbp_get_residuals(self._eng, L.f64p(self._res), L.i32p(self._flg), L.f64p(self._kl)),
-               self._eng)
+        self._klflg = np.zeros((self.n_sites, max(1, nm)), dtype=np.int32)
+        _check(self._lib.pgbp_get_residuals(self._eng, L.f64p(self._res), L.i32p(self._flg), L.f64p(self._kl),
+                                            L.i32p(self._klflg)), self._eng)
 
     def _residual_record(self, d):
         if self._res is None:
@@ -182,6 +184,23 @@ class ClusterGraphBelief:
         if self._kl is None:
             self.pull()
         return self._kl[self.site]
+
+    def _klflags(self):
+        if getattr(self, "_klflg", None) is None:
+            self.pull()
+        return self._klflg[self.site]
+
+    def residual_kldiv_(self, cluster_to, sepset, cluster_from, atol=1e-5):
+        """residual_kldiv!(messageresidual[(to, from)], sepset) (src/beliefs.jl:1060-1075) on belief indices:
+        updates kldiv / iscalibrated_kl of that residual on the device and returns the flag."""
+        out = np.zeros(self.n_sites, dtype=np.int32)
+        o = self._opts(atol=atol)
+        _check(self._lib.pgbp_residual_kldiv(self._eng, int(cluster_to), int(sepset), int(cluster_from), C.byref(o),
+                                             L.i32p(out)), self._eng)
+        self.pull()
+        if int(self._dims[sepset]) == 0:
+            return True
+        return bool(out[self.site])
 
     def _msg_id(self, receiver, sender):
         for k in range(self.nsepsets):
@@ -266,7 +285,7 @@ class ClusterGraphBelief:
     def init_messagecalibrationflags_reset_(self, reset_kl=True):
         """init_messagecalibrationflags_reset! (src/clustergraphbeliefs.jl:146-150)."""
         _check(self._lib.pgbp_reset_flags(self._eng, int(reset_kl)), self._eng)
-        self._flg = None
+        self._flg = self._kl = self._klflg = None
 
     def iscalibrated_residnorm(self):
         """iscalibrated_residnorm(beliefs) (src/clustergraphbeliefs.jl:168-169)."""

@@ -39,6 +39,11 @@ struct pgbp_engine {
   int32_t* d_flags = nullptr;
   int32_t* d_status = nullptr;
   double* d_kldiv = nullptr;
+  int32_t* d_klflags = nullptr;     // [n_sites][n_msgs] iscalibrated_kl
+  int32_t* d_nb_off = nullptr;      // [n_clusters+1] -> d_nb_msg: the messages each cluster sends (regularisers)
+  int32_t* d_nb_msg = nullptr;
+  int32_t* d_sepcl = nullptr;       // [2*n_sepsets] sepset -> its two clusters
+  double* d_eps = nullptr;          // [n_sites][n_clusters] regularisation scratch
   unsigned long long* d_fail = nullptr;
   int32_t* d_poison = nullptr;      // [n_sites][n_clusters]
   int32_t* d_iscal = nullptr;       // [n_sites]
@@ -54,6 +59,7 @@ struct pgbp_engine {
   int32_t* d_bdim = nullptr;        // [n_beliefs] dims (layout conversion)
   int32_t* d_rdim = nullptr;        // [n_msgs] sepset dim of every directed message
   int32_t* d_symflag = nullptr;     // != 0: some precision matrix is not symmetric
+  int32_t max_s = 0;                // largest sepset dimension
   bool layout_bs16 = false;         // current device layout of 16/32-dim beliefs and 16-dim residuals
   bool sym_known = false, sym_ok = false;
   int32_t* d_one_task_off = nullptr;  // single-message task for pgbp_propagate
@@ -174,8 +180,7 @@ void free_traversals(pgbp_engine* e) {
 }
 
 int check_opts(pgbp_engine* e, const pgbp_opts* o) {
-  if (o && o->update_residualkldiv)
-    return e->fail(PGBP_ERR_INVALID, "update_residualkldiv is not supported (off by default in the reference)");
+  if (o && !(o->atol >= 0.0)) return e->fail(PGBP_ERR_INVALID, "pgbp_opts.atol must be >= 0");
   return PGBP_OK;
 }
 
@@ -187,7 +192,8 @@ unsigned long long seq_stride(const pgbp_engine* e) {
 
 // enqueue one traversal: one launch per level
 void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, unsigned long long pair_index,
-                       std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev = nullptr, int* n_launches = nullptr) {
+                       std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev = nullptr, int* n_launches = nullptr,
+                       bool kl = false) {
   const Tree& T = e->plan.trees[tree];
   const Traversal& tr = dir == 0 ? T.post : T.pre;
   const DevTraversal& d = dir == 0 ? e->dpost[tree] : e->dpre[tree];
@@ -215,6 +221,11 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
       launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, e->st);
     launches += (nf > 0) + (nt - nf > 0);
+    if (kl) {  // residual_kldiv! right after the messages of the level (src/calibration.jl:128,154)
+      const int e0 = tr.task_off[t0], e1 = tr.task_off[t0 + nt];
+      launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, e->max_s, e->d_kldiv, e->d_klflags, e->plan.n_sites,
+                            stop_below, e->st);
+    }
   }
   if (ev) {
     (void)hipEventRecord(b, e->st);
@@ -261,7 +272,7 @@ void pgbp_destroy(pgbp_engine* e) {
   (void)hipSetDevice(e->plan.device);
   free_traversals(e);
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
-                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_fail, (void*)e->d_poison,
+                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_fail, (void*)e->d_poison,
                   (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
@@ -313,6 +324,24 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   if ((rc = dev_alloc(e, &e->d_flags, ns * nm))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_status, ns * nm))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_kldiv, ns * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_klflags, ns * nm))) return bail(rc);
+  {
+    std::vector<int32_t> nb_off(p.n_clusters + 1, 0), nb_msg(nm);
+    for (int k = 0; k < p.n_sepsets; ++k) {
+      ++nb_off[p.sepset_clusters[2 * k] + 1];
+      ++nb_off[p.sepset_clusters[2 * k + 1] + 1];
+    }
+    for (int c = 0; c < p.n_clusters; ++c) nb_off[c + 1] += nb_off[c];
+    std::vector<int32_t> fill(nb_off.begin(), nb_off.end() - 1);
+    for (int k = 0; k < p.n_sepsets; ++k) {  // message 2k is received by cluster a (sent by b), 2k+1 the reverse
+      nb_msg[fill[p.sepset_clusters[2 * k]]++] = 2 * k + 1;
+      nb_msg[fill[p.sepset_clusters[2 * k + 1]]++] = 2 * k;
+    }
+    if ((rc = upload(e, &e->d_nb_off, nb_off))) return bail(rc);
+    if ((rc = upload(e, &e->d_nb_msg, nb_msg))) return bail(rc);
+    if ((rc = upload(e, &e->d_sepcl, p.sepset_clusters))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_eps, ns * (size_t)std::max(1, p.n_clusters)))) return bail(rc);
+  }
   if ((rc = dev_alloc(e, &e->d_fail, ns))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_poison, ns * (size_t)p.n_clusters))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_iscal, ns))) return bail(rc);
@@ -326,6 +355,7 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   {
     std::vector<int32_t> rdim(nm);
     for (size_t d = 0; d < nm; ++d) rdim[d] = p.dims[p.n_clusters + d / 2];
+    for (int32_t v : rdim) e->max_s = std::max(e->max_s, v);
     if ((rc = upload(e, &e->d_bdim, p.dims))) return bail(rc);
     if ((rc = upload(e, &e->d_rdim, rdim))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_symflag, 1))) return bail(rc);
@@ -343,7 +373,7 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
     e->err = "hipMemsetAsync failed";
     return bail(PGBP_ERR_HIP);
   }
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, (int)nm, p.n_sites, 1, e->st);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, (int)nm, p.n_sites, 1, e->st);
   if (hipStreamSynchronize(e->st) != hipSuccess) {
     e->err = "initialisation kernels failed";
     return bail(PGBP_ERR_HIP);
@@ -454,11 +484,12 @@ int pgbp_reset_from_factors(pgbp_engine* e) {
 
 int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
   if (!e) return PGBP_ERR_INVALID;
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st);
   return pgbp_sync(e);
 }
 
-int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv) {
+int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv,
+                       int32_t* iscalibrated_kl) {
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   if (packed) {
@@ -480,6 +511,8 @@ int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_res
   if (iscalibrated_resid)
     HIPCHK(e, hipMemcpyAsync(iscalibrated_resid, e->d_flags, sizeof(int32_t) * ns * nm, hipMemcpyDeviceToHost, e->st));
   if (kldiv) HIPCHK(e, hipMemcpyAsync(kldiv, e->d_kldiv, sizeof(double) * ns * nm, hipMemcpyDeviceToHost, e->st));
+  if (iscalibrated_kl)
+    HIPCHK(e, hipMemcpyAsync(iscalibrated_kl, e->d_klflags, sizeof(int32_t) * ns * nm, hipMemcpyDeviceToHost, e->st));
   return pgbp_sync(e);
 }
 
@@ -543,6 +576,51 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   return PGBP_OK;
 }
 
+int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from, const pgbp_opts* opts,
+                        int32_t* iscalibrated_kl) {
+  if (!e) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  const int k = sepset - p.n_clusters;
+  if (k < 0 || k >= p.n_sepsets) return e->fail(PGBP_ERR_INVALID, "pgbp_residual_kldiv: not a sepset index");
+  const int a = p.sepset_clusters[2 * k], b = p.sepset_clusters[2 * k + 1];
+  int dir;
+  if (cluster_to == a && cluster_from == b)
+    dir = 0;
+  else if (cluster_to == b && cluster_from == a)
+    dir = 1;
+  else
+    return e->fail(PGBP_ERR_INVALID, "pgbp_residual_kldiv: the sepset does not connect these two clusters");
+  Entry en{2 * k + dir, 0, 0, 0};
+  HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
+  DevState S = dev_state(e, opts);
+  // a standalone call always computes (stop_below = 0; the status of the last attempt of this message still gates)
+  launch_residual_kldiv(S, e->d_one_entry, 0, 1, e->max_s, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st);
+  if (iscalibrated_kl) {
+    std::vector<int32_t> all((size_t)p.n_sites * std::max(1, p.n_msgs()));
+    HIPCHK(e, hipMemcpyAsync(all.data(), e->d_klflags, sizeof(int32_t) * (size_t)p.n_sites * p.n_msgs(),
+                             hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    for (int s = 0; s < p.n_sites; ++s) iscalibrated_kl[s] = all[(size_t)s * p.n_msgs() + en.msg];
+  }
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());
+  return PGBP_OK;
+}
+
+int pgbp_regularize_bycluster(pgbp_engine* e) {
+  if (!e) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  int rc = ensure_layout(e, false);
+  if (rc) return rc;
+  launch_regularize_bycluster(e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, e->d_nb_off, e->d_nb_msg, e->d_msgs,
+                              e->d_idx, e->d_sepcl, e->d_eps, p.n_clusters, p.n_sepsets, p.n_sites, e->st);
+  e->sym_known = false;
+  HIPCHK(e, hipGetLastError());
+  return PGBP_OK;
+}
+
 static int need_schedule(pgbp_engine* e, int tree) {
   if (e->plan.trees.empty()) return e->fail(PGBP_ERR_STATE, "no schedule: call pgbp_set_schedule first");
   if (tree < 0 || tree >= (int)e->plan.trees.size()) return e->fail(PGBP_ERR_INVALID, "schedule tree index out of range");
@@ -593,7 +671,7 @@ int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* op
   if ((rc = reset_fail(e))) return rc;
   if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
   DevState S = dev_state(e, opts);
-  enqueue_traversal(e, S, tree, dir, (unsigned long long)tree);
+  enqueue_traversal(e, S, tree, dir, (unsigned long long)tree, nullptr, nullptr, opts && opts->update_residualkldiv);
   launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
   return collect_results(e, results, nullptr, 0);
 }
@@ -613,6 +691,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
     return PGBP_OK;
   }
   const bool auto_stop = opts && opts->auto_stop;
+  const bool kl = opts && opts->update_residualkldiv;
   const int64_t n_pairs_max = (int64_t)niter * nt;
   if (n_pairs_max > e->hist_cap) {
     if (e->d_iscal_hist) (void)hipFree(e->d_iscal_hist);
@@ -632,8 +711,8 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   for (int i = 0; i < niter && !stop; ++i) {
     for (int j = 0; j < nt && !stop; ++j) {
       const unsigned long long pair = (unsigned long long)i * nt + j;
-      enqueue_traversal(e, S, j, 0, pair);
-      enqueue_traversal(e, S, j, 1, pair);
+      enqueue_traversal(e, S, j, 0, pair, nullptr, nullptr, kl);
+      enqueue_traversal(e, S, j, 1, pair, nullptr, nullptr, kl);
       launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st);
       ++pairs_done;
       if (auto_stop) {
@@ -757,7 +836,7 @@ static int bm_fill_async(pgbp_engine* e) {
                       e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.fast_p, p.n_clusters, p.n_sites, e->st);
   launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                       p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
   e->have_factors = true;
   return PGBP_OK;
 }
@@ -805,7 +884,7 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
   if (reset_each) {
     int rc = reset_from_factors_async(e);
     if (rc) return rc;
-    launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
+    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
   }
   for (int j = 0; j < (int)p.trees.size(); ++j) {
     enqueue_traversal(e, S, j, 0, (unsigned long long)j, ev, n_launches);
@@ -832,7 +911,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
   const Plan& p = e->plan;
   int rc = reset_from_factors_async(e);
   if (rc) return rc;
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
   enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
   launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, p.fast_p, nullptr,

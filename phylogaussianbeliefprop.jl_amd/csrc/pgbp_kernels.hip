@@ -520,6 +520,39 @@ __device__ __forceinline__ double fe_elem(const double* __restrict__ rec, int m,
   return packed ? rec[bs16::J_off(m, i, j, fp)] : rec[(i <= j) ? i + (int64_t)j * m : j + (int64_t)i * m];
 }
 
+// Gauss-Jordan on the m x nc augmented system W = [A | B] (row stride ld) held in LDS, by ONE wavefront:
+// on return the right block holds A^-1 B and logdet = log det A.  Pivots are the Cholesky pivots of A
+// (no pivoting); returns false (uniformly) as soon as a pivot is not positive, i.e. A is not positive definite.
+__device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int ld, int lane, double& logdet) {
+  double mant = 1.0;
+  int expo = 0;
+  for (int k = 0; k < m; ++k) {
+    const double d = W[k * ld + k];
+    if (!(d > 0.0)) return false;
+    int ex;
+    mant *= frexp(d, &ex);
+    expo += ex;
+    if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
+    const double rd = 1.0 / d;
+    __syncthreads();
+    for (int j = k + 1 + lane; j < nc; j += kWave) W[k * ld + j] *= rd;  // normalise the pivot row
+    __syncthreads();
+    // eliminate column k from every other row (columns > k only: the rest is never read again)
+    const int ncol = nc - (k + 1);
+    if (ncol > 0) {
+      for (int idx = lane; idx < (m - 1) * ncol; idx += kWave) {
+        int i = idx / ncol;
+        const int j = k + 1 + (idx - i * ncol);
+        if (i >= k) ++i;
+        W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
+      }
+    }
+    __syncthreads();
+  }
+  logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
+  return true;
+}
+
 __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restrict__ pool, int64_t pool_stride,
                                                          const double* __restrict__ fpool, int64_t fpool_stride,
                                                          const int64_t* __restrict__ boff,
@@ -550,35 +583,11 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
   if (is_cluster)
     for (int i = lane; i < m; i += kWave) W[i * ld + 2 * m] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
   __syncthreads();
-  double mant = 1.0;
-  int expo = 0;
-  for (int k = 0; k < m; ++k) {
-    const double d = W[k * ld + k];
-    if (!(d > 0.0)) {
-      if (lane == 0) { atomicMin(&info[site], b + 1); *out = make_double2(NAN, NAN); }
-      return;
-    }
-    int ex;
-    mant *= frexp(d, &ex);
-    expo += ex;
-    if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
-    const double rd = 1.0 / d;
-    __syncthreads();
-    for (int j = k + 1 + lane; j < nc; j += kWave) W[k * ld + j] *= rd;  // normalise the pivot row
-    __syncthreads();
-    // eliminate column k from every other row (columns > k only: the rest is never read again)
-    const int ncol = nc - (k + 1);
-    if (ncol > 0) {
-      for (int idx = lane; idx < (m - 1) * ncol; idx += kWave) {
-        int i = idx / ncol;
-        const int j = k + 1 + (idx - i * ncol);
-        if (i >= k) ++i;
-        W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
-      }
-    }
-    __syncthreads();
+  double logdet;
+  if (!gauss_jordan_spd(W, m, nc, ld, lane, logdet)) {
+    if (lane == 0) { atomicMin(&info[site], b + 1); *out = make_double2(NAN, NAN); }
+    return;
   }
-  const double logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
   const double ent = 0.5 * ((double)m * (PGBP_LOG2PI + 1.0) - logdet);
   if (!is_cluster) {
     if (lane == 0) *out = make_double2(0.0, -ent);
@@ -641,6 +650,171 @@ void launch_free_energy(const double* pool, int64_t pool_stride, const double* f
                      reinterpret_cast<const double2*>(d_contrib), n_beliefs, d_out3);
 }
 
+static int grid_for(int64_t n, int n_sites) {
+  int64_t g = (n + 255) / 256;
+  const int64_t cap = n_sites >= 8 ? 256 : 2048;  // ~8 blocks per CU in total
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---- residual_kldiv! (src/beliefs.jl:1060-1075): one wavefront per message of a level ---------------------
+// Runs right after the level's message kernels: the sepset holds the message just sent (J0, h0), the residual
+// (dJ, dh) = after - before, so the belief before is (J1, h1) = (J0 - dJ, h0 - dh).
+//   kl = ( -tr(J0^-1 dJ) + (mu1-mu0)' J1 (mu1-mu0) + logdet J0 - logdet J1 ) / 2
+// If J0 or J1 is not positive definite nothing is written (the reference returns false and leaves kldiv and
+// the flag alone).  Messages that did not run (failed / downstream of a failure) are skipped.
+__global__ __launch_bounds__(64) void residual_kldiv_kernel(DevState S, const Entry* __restrict__ entries, int e0,
+                                                            double* __restrict__ kldiv, int32_t* __restrict__ klflags,
+                                                            unsigned long long stop_below) {
+  const int lane = threadIdx.x, site = blockIdx.y;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  const int msg = entries[e0 + blockIdx.x].msg;
+  const MsgDesc m = S.msgs[msg];
+  const int s = m.s;
+  if (s == 0) return;  // empty message: calibrated from birth
+  if (S.status[(int64_t)site * S.n_msgs + msg] != 0) return;
+  if (S.poison[(int64_t)site * S.n_clusters + m.from_b] || S.poison[(int64_t)site * S.n_clusters + m.to_b]) return;
+  const double* __restrict__ sep = S.pool + (int64_t)site * S.pool_stride + m.sep_off;
+  const double* __restrict__ res = S.rpool + (int64_t)site * S.rpool_stride + m.res_off;
+  const bool packed = S.bs16 && bs16::applies(s, S.fast_p);
+  const int fp = S.fast_p;
+  auto Jm = [&](int i, int j) {  // Symmetric(J0): upper triangle
+    return packed ? sep[bs16::J_off(s, i, j, fp)] : sep[(i <= j) ? i + (int64_t)j * s : j + (int64_t)i * s];
+  };
+  auto dJ = [&](int i, int j) { return packed ? res[bs16::J_off(s, i, j, fp)] : res[i + (int64_t)j * s]; };
+  auto J1u = [&](int i, int j) {  // Symmetric(J0 .- dJ)
+    const int a = i <= j ? i : j, b = i <= j ? j : i;
+    return packed ? sep[bs16::J_off(s, a, b, fp)] - res[bs16::J_off(s, a, b, fp)]
+                  : sep[a + (int64_t)b * s] - res[a + (int64_t)b * s];
+  };
+  auto hm = [&](int i) { return packed ? sep[bs16::h_off(s, i, fp)] : sep[(int64_t)s * s + i]; };
+  auto dh = [&](int i) { return packed ? res[bs16::h_off(s, i, fp)] : res[(int64_t)s * s + i]; };
+
+  const int nc0 = 2 * s + 1, ld0 = nc0 | 1;
+  double* W = lds;
+  double* vec = lds + (size_t)s * ld0;  // mu0, later mu1 - mu0
+  for (int idx = lane; idx < s * s; idx += kWave) {
+    const int j = idx / s, i = idx - j * s;
+    W[i * ld0 + j] = Jm(i, j);
+    W[i * ld0 + s + j] = dJ(i, j);
+  }
+  for (int i = lane; i < s; i += kWave) W[i * ld0 + 2 * s] = hm(i);
+  __syncthreads();
+  double logdet0, logdet1;
+  if (!gauss_jordan_spd(W, s, nc0, ld0, lane, logdet0)) return;
+  double tr = 0.0;
+  for (int i = lane; i < s; i += kWave) {
+    tr += W[i * ld0 + s + i];
+    vec[i] = W[i * ld0 + 2 * s];
+  }
+  __syncthreads();
+  const int nc1 = s + 1, ld1 = nc1 | 1;
+  for (int idx = lane; idx < s * s; idx += kWave) {
+    const int j = idx / s, i = idx - j * s;
+    W[i * ld1 + j] = J1u(i, j);
+  }
+  for (int i = lane; i < s; i += kWave) W[i * ld1 + s] = hm(i) - dh(i);
+  __syncthreads();
+  if (!gauss_jordan_spd(W, s, nc1, ld1, lane, logdet1)) return;
+  for (int i = lane; i < s; i += kWave) vec[i] = W[i * ld1 + s] - vec[i];
+  __syncthreads();
+  double quad = 0.0;
+  for (int idx = lane; idx < s * s; idx += kWave) {
+    const int j = idx / s, i = idx - j * s;
+    quad += vec[i] * J1u(i, j) * vec[j];
+  }
+  double acc = quad - tr;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    const double kl = 0.5 * (acc + logdet0 - logdet1);
+    kldiv[(int64_t)site * S.n_msgs + msg] = kl;
+    klflags[(int64_t)site * S.n_msgs + msg] = fabs(kl) <= S.atol ? 1 : 0;  // iscalibrated_kl! (src/beliefs.jl:1014-1016)
+  }
+}
+
+void launch_residual_kldiv(const DevState& S, const Entry* d_entries, int e0, int n_entries, int max_s, double* d_kldiv,
+                           int32_t* d_klflags, int n_sites, unsigned long long stop_below, hipStream_t st) {
+  if (n_entries <= 0 || max_s <= 0) return;
+  const size_t ldsb = sizeof(double) * ((size_t)max_s * (size_t)((2 * max_s + 1) | 1) + (size_t)max_s);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(residual_kldiv_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(residual_kldiv_kernel, dim3(n_entries, n_sites), dim3(kWave), ldsb, st, S, d_entries, e0, d_kldiv,
+                     d_klflags, stop_below);
+}
+
+// ---- regularizebeliefs_bycluster! (src/clustergraphbeliefs.jl:235-275) ------------------------------------
+// Pass 1, one wavefront per (cluster, site): eps = max(eps(T), max|J|) BEFORE any edit (only the cluster itself
+// edits its J), then for every incident sepset with a non-empty scope: J[i,i] += eps at the sepset's positions.
+// Pass 2, one thread per (sepset, site): diag(J_sepset) += eps of its two clusters, lower cluster index first
+// (the order of the reference's loop over labels).  The graphical model (product of cluster beliefs over
+// product of sepset beliefs) is unchanged.  Plain layout only (the engine converts before launching).
+__global__ __launch_bounds__(64) void regularize_cluster_kernel(double* __restrict__ pool, int64_t pool_stride,
+                                                                const int64_t* __restrict__ boff,
+                                                                const int32_t* __restrict__ dim,
+                                                                const int32_t* __restrict__ nb_off,
+                                                                const int32_t* __restrict__ nb_msg,
+                                                                const MsgDesc* __restrict__ msgs,
+                                                                const int32_t* __restrict__ idx,
+                                                                double* __restrict__ eps_out, int n_clusters) {
+  const int lane = threadIdx.x, c = blockIdx.x, site = blockIdx.y;
+  const int m = dim[c];
+  double* __restrict__ J = pool + (int64_t)site * pool_stride + boff[c];
+  double mx = PGBP_EPS;
+  for (int i = lane; i < m * m; i += kWave) mx = fmax(mx, fabs(J[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  if (lane == 0) eps_out[(int64_t)site * n_clusters + c] = mx;
+  __syncthreads();
+  for (int q = nb_off[c]; q < nb_off[c + 1]; ++q) {
+    // nb_msg[q]: the message this cluster SENDS through the sepset: keep_map = scopeindex(sepset, cluster)
+    const MsgDesc md = msgs[nb_msg[q]];
+    for (int t = lane; t < md.s; t += kWave) {
+      const int i = idx[md.keep_map + t];
+      J[i + (int64_t)i * m] += mx;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void regularize_sepset_kernel(double* __restrict__ pool, int64_t pool_stride,
+                                                                const int64_t* __restrict__ boff,
+                                                                const int32_t* __restrict__ dim,
+                                                                const int32_t* __restrict__ sepcl,
+                                                                const double* __restrict__ eps, int n_clusters,
+                                                                int n_sepsets) {
+  const int site = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_sepsets; k += gridDim.x * blockDim.x) {
+    const int s = dim[n_clusters + k];
+    if (s == 0) continue;
+    const int a = sepcl[2 * k], b = sepcl[2 * k + 1];
+    const double e1 = eps[(int64_t)site * n_clusters + (a < b ? a : b)];
+    const double e2 = eps[(int64_t)site * n_clusters + (a < b ? b : a)];
+    double* __restrict__ J = pool + (int64_t)site * pool_stride + boff[n_clusters + k];
+    for (int i = 0; i < s; ++i) {
+      double v = J[i + (int64_t)i * s];
+      v += e1;
+      v += e2;
+      J[i + (int64_t)i * s] = v;
+    }
+  }
+}
+
+void launch_regularize_bycluster(double* pool, int64_t pool_stride, const int64_t* d_boff, const int32_t* d_dim,
+                                 const int32_t* d_nb_off, const int32_t* d_nb_msg, const MsgDesc* d_msgs,
+                                 const int32_t* d_idx, const int32_t* d_sepcl, double* d_eps, int n_clusters,
+                                 int n_sepsets, int n_sites, hipStream_t st) {
+  if (n_clusters <= 0) return;
+  hipLaunchKernelGGL(regularize_cluster_kernel, dim3(n_clusters, n_sites), dim3(kWave), 0, st, pool, pool_stride, d_boff,
+                     d_dim, d_nb_off, d_nb_msg, d_msgs, d_idx, d_eps, n_clusters);
+  if (n_sepsets <= 0) return;
+  hipLaunchKernelGGL(regularize_sepset_kernel, dim3(grid_for(n_sepsets, n_sites), n_sites), dim3(256), 0, st, pool,
+                     pool_stride, d_boff, d_dim, d_sepcl, d_eps, n_clusters, n_sepsets);
+}
+
 // ---- record gather/scatter between the ABI's packed layout and the padded device records
 __global__ void records_kernel(const double* __restrict__ src, int64_t src_stride,
                                const int64_t* __restrict__ src_off, double* __restrict__ dst, int64_t dst_stride,
@@ -677,12 +851,6 @@ __global__ void zero_strided_kernel(double2* __restrict__ dst, int64_t dst_strid
   double2* __restrict__ d = dst + (int64_t)site * dst_stride2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
     d[i] = make_double2(0.0, 0.0);
-}
-
-static int grid_for(int64_t n, int n_sites) {
-  int64_t g = (n + 255) / 256;
-  const int64_t cap = n_sites >= 8 ? 256 : 2048;  // ~8 blocks per CU in total
-  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 // all strides / offsets / counts are multiples of 2 doubles (records are padded to 16)
@@ -791,11 +959,13 @@ void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64
 
 // init_messagecalibrationflags_reset! (src/beliefs.jl:973-979): empty messages stay calibrated
 __global__ void reset_flags_kernel(const MsgDesc* __restrict__ msgs, int32_t* __restrict__ flags,
-                                   double* __restrict__ kldiv, int n_msgs, int reset_kl) {
+                                   int32_t* __restrict__ klflags, double* __restrict__ kldiv, int n_msgs,
+                                   int reset_kl) {
   const int site = blockIdx.y;
   for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < n_msgs; d += gridDim.x * blockDim.x) {
     const bool empty = msgs[d].s == 0;
     flags[(int64_t)site * n_msgs + d] = empty ? 1 : 0;
+    klflags[(int64_t)site * n_msgs + d] = empty ? 1 : 0;
     if (empty)
       kldiv[(int64_t)site * n_msgs + d] = 0.0;
     else if (reset_kl)
@@ -803,11 +973,11 @@ __global__ void reset_flags_kernel(const MsgDesc* __restrict__ msgs, int32_t* __
   }
 }
 
-void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, double* kldiv, int n_msgs, int n_sites, int reset_kl,
-                        hipStream_t st) {
+void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, int32_t* klflags, double* kldiv, int n_msgs, int n_sites,
+                        int reset_kl, hipStream_t st) {
   if (n_msgs <= 0) return;
   hipLaunchKernelGGL(reset_flags_kernel, dim3(grid_for(n_msgs, n_sites), n_sites), dim3(256), 0, st, msgs, flags,
-                     kldiv, n_msgs, reset_kl);
+                     klflags, kldiv, n_msgs, reset_kl);
 }
 
 // iscalibrated_residnorm(beliefs) = all flags (src/clustergraphbeliefs.jl:168-169).

@@ -82,7 +82,7 @@ function pull!(o::DeviceClusterGraphBelief)
     nm = 2 * (length(o.cgb.belief) - o.cgb.nclusters)
     rs = Int(@ccall LIB.pgbp_residual_size(o.handle::Ptr{Cvoid})::Int64)
     res = zeros(max(rs, 1)); flags = zeros(Int32, max(nm, 1))
-    check(o.handle, @ccall LIB.pgbp_get_residuals(o.handle::Ptr{Cvoid}, res::Ptr{Float64}, flags::Ptr{Int32}, C_NULL::Ptr{Float64})::Cint)
+    check(o.handle, @ccall LIB.pgbp_get_residuals(o.handle::Ptr{Cvoid}, res::Ptr{Float64}, flags::Ptr{Int32}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Int32})::Cint)
     p = 0
     for (k, j) in enumerate((o.cgb.nclusters+1):length(o.cgb.belief)), (dir, key) in enumerate((o.cgb.belief[j].metadata, reverse(o.cgb.belief[j].metadata)))
         mr = o.cgb.messageresidual[key]; s = length(mr.Δh)       # key = (receiver, sender)

@@ -649,7 +649,7 @@ def test_api_edge_cases(P):
     cgb._schedule = None
     assert P.calibrate_(cgb, prob.schedule, 2) == (True, True)
     assert rel_close(cgb.integratebelief_(prob.root_cluster)[1], S.bm_loglik_pruning(tr, R, np.zeros(p), X))
-    o2 = cgb._opts(update_residualkldiv=True)
+    o2 = cgb._opts(atol=-1.0)
     assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o2), res) == L.ERR_INVALID      # refused explicitly
 
 
@@ -678,3 +678,193 @@ def test_calibration_level3_network(P, variant):
             k += d
     for name, m in g["posterior_means_" + variant].items():
         assert np.allclose(seen[name], m, rtol=1.5e-8, atol=0), name
+
+
+# ----------------------------------------------------------------------------- KL residuals, regularisers
+
+def _kl_state(cgb, keys):
+    return (np.array([cgb.messageresidual[k].kldiv for k in keys]),
+            np.array([cgb.messageresidual[k].iscalibrated_kl for k in keys]))
+
+
+def test_residual_kldiv_golden(P):
+    """test/test_calibration.jl:13-33 on the device: a message with nothing to integrate turns the sepset
+    (J, h) = ((1/3)[2 -1; -1 2], (1/3)[2, -1]) into (I, [0, 1]); residual_kldiv! = 1.215973 (R: rags2ridges::KLdiv)."""
+    g = G["residual_kldiv"]
+    dims = np.array([2, 2, 2], np.int32)
+    off = np.array([0, 7, 14, 21])
+    packed = np.zeros(21)
+    packed[7:11] = np.eye(2).reshape(-1)
+    packed[11:13] = [0.0, 1.0]
+    packed[14:18] = (np.array([[2.0, -1.0], [-1.0, 2.0]]) / 3).reshape(-1)
+    packed[18:20] = np.array([2.0, -1.0]) / 3
+    cgb = P.ClusterGraphBelief.from_arrays(dims, [0, 1], [0, 2, 4], [0, 1, 0, 1], packed)
+    assert cgb.messageresidual[(0, 1)].kldiv == -1.0 and not cgb.messageresidual[(0, 1)].iscalibrated_kl
+    assert P.propagate_belief_(cgb, 0, 2, 1) is None
+    mr = cgb.messageresidual[(0, 1)]
+    assert np.allclose(mr.dJ, np.ones((2, 2)) / 3, rtol=1e-14) and np.allclose(mr.dh, np.array([-2.0, 4.0]) / 3, rtol=1e-14)
+    assert cgb.residual_kldiv_(0, 2, 1) is False
+    assert abs(mr.kldiv - g["kldiv"]) <= g["rtol"] * g["kldiv"]
+    assert not mr.iscalibrated_kl
+    assert cgb.messageresidual[(1, 0)].kldiv == -1.0          # the other direction was not touched
+    # exact value: ( tr(J1 J0^-1) - p + (mu1-mu0)'J1(mu1-mu0) + log det J0 - log det J1 ) / 2
+    J1 = np.array([[2.0, -1.0], [-1.0, 2.0]]) / 3
+    d = np.array([1.0, 0.0]) - np.array([0.0, 1.0])
+    exact = 0.5 * (np.trace(J1) - 2 + d @ J1 @ d - np.log(np.linalg.det(J1)))
+    assert abs(mr.kldiv - exact) <= 1e-13 * abs(exact)
+    # resending the same message: KL = 0, flag true
+    assert P.propagate_belief_(cgb, 0, 2, 1) is None
+    assert cgb.residual_kldiv_(0, 2, 1) is True and abs(mr.kldiv) <= 1e-14 and mr.iscalibrated_kl
+    # a sepset that is not positive definite: nothing is updated, false (src/beliefs.jl:1063-1066)
+    cgb.belief[2].J[0, 0] = -1.0
+    cgb.push()
+    cgb.init_messagecalibrationflags_reset_()
+    assert cgb.residual_kldiv_(0, 2, 1) is False and cgb.messageresidual[(0, 1)].kldiv == -1.0
+
+
+@pytest.mark.parametrize("ntips,p,nsites", [(40, 3, 1), (60, 16, 1), (50, 8, 3), (30, 1, 1), (25, 32, 1)])
+def test_residual_kldiv_during_calibration(P, ntips, p, nsites):
+    """calibrate!(...; update_residualkldiv=true) (src/calibration.jl:128,154): kldiv and iscalibrated_kl of every
+    directed message against the oracle after 1 and after 2 iterations (p = 16: BS16 layout of sepsets and
+    residuals; p = 32: generic kernel).  Tolerance: 1e-8 relative (1e-8 absolute once the KL is ~0)."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(77 * p + ntips)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    mu = rng.standard_normal(p)
+    prob = S.cliquetree_of_tree(tr, p)
+    sites = [S.bm_factors_cliquetree(tr, prob, R, mu, S.simulate_bm(tr, R, mu, rng)) for _ in range(nsites)]
+    pcgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                            np.stack(sites), n_sites=nsites)
+    spt = oracle_schedule(prob)
+    keys = [(int(a), int(c)) for a, c in prob.sepset_clusters] + [(int(c), int(a)) for a, c in prob.sepset_clusters]
+    ocgbs = [oracle_cgb_from_problem(prob, sites[s], p) for s in range(nsites)]
+    for it in range(2):
+        assert P.calibrate_(pcgb, prob.schedule, 1, update_residualkldiv=True)[0]
+        for s in range(nsites):
+            assert OC.calibrate(ocgbs[s], [spt], 1, update_residualkldiv=True)[0]
+            pcgb.site = s
+            pk, pf = _kl_state(pcgb, keys)
+            ok, of = _kl_state(ocgbs[s], keys)
+            assert np.all(np.abs(pk - ok) <= 1e-8 * np.maximum(1.0, np.abs(ok))), (it, s, np.abs(pk - ok).max())
+            # flags agree wherever the KL is not within rounding of the 1e-5 threshold
+            clear = np.abs(np.abs(ok) - 1e-5) > 1e-7
+            assert np.array_equal(pf[clear], of[clear])
+            if it == 0:
+                assert np.any(ok == -1.0) and np.any(ok > 1e-5)   # postorder: sepsets were improper before
+            else:
+                assert np.all(np.abs(pk) <= 1e-8) and pf.all()
+        pcgb.site = 0
+    # reset_kl semantics (src/beliefs.jl:973-979)
+    pcgb.init_messagecalibrationflags_reset_(reset_kl=False)
+    pk, pf = _kl_state(pcgb, keys)
+    nonempty = np.array([prob.dims[prob.nclusters + k] > 0 for k in range(len(prob.sepset_clusters))] * 2)
+    assert not pf[nonempty].any() and pf[~nonempty].all() and np.all(np.abs(pk) <= 1e-8)
+    pcgb.init_messagecalibrationflags_reset_(reset_kl=True)
+    pk = _kl_state(pcgb, keys)[0]
+    assert np.all(pk[nonempty] == -1.0) and np.all(pk[~nonempty] == 0.0)
+
+
+def test_regularize_bycluster_device(P):
+    """regularizebeliefs_bycluster! (src/clustergraphbeliefs.jl:235-275) on the device: the edited beliefs are
+    bit-identical to the oracle's (same eps, same order of additions); test/test_calibration.jl:72-76: the
+    clique-tree log-likelihood is unchanged ("graph invariant was preserved")."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = build_both(P, net, ct, make_model(g["model"]), [g["y"]], g["taxa"])
+    P.regularizebeliefs_bycluster_(pcgb, ct)
+    OB.regularizebeliefs_bycluster(ocgb)
+    for pb, ob in zip(pcgb.belief, ocgb.belief):
+        assert np.array_equal(pb.J, ob.J) and np.array_equal(pb.h, ob.h) and pb.g[0] == ob.g[0]
+    assert P.calibrate_(pcgb, [spt])[0] and OC.calibrate(ocgb, [spt])[0]
+    assert_beliefs_close(pcgb, ocgb)
+    for i in range(len(ocgb.belief)):
+        assert rel_close(pcgb.integratebelief_(i)[1], g["ll_every_belief"])
+
+
+@pytest.mark.parametrize("p,nsites", [(16, 1), (8, 2), (3, 1)])
+def test_regularize_bycluster_tree_layouts(P, p, nsites):
+    """Device regulariser on clique trees of random trees, including the BS16-resident state (p = 16 / 8: the
+    engine converts to the plain layout, edits, and the next calibration converts back): bit-identical edits,
+    log-likelihood unchanged."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(4242 + p)
+    tr = S.random_tree(70, rng)
+    R = S.random_rate_matrix(p, rng)
+    mu = rng.standard_normal(p)
+    prob = S.cliquetree_of_tree(tr, p)
+    Xs = [S.simulate_bm(tr, R, mu, rng) for _ in range(nsites)]
+    sites = [S.bm_factors_cliquetree(tr, prob, R, mu, X) for X in Xs]
+    pcgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                            np.stack(sites), n_sites=nsites)
+    assert P.calibrate_(pcgb, prob.schedule, 1)[0]           # puts the state in its fast layout
+    pcgb.init_beliefs_reset_fromfactors_()
+    P.regularizebeliefs_bycluster_(pcgb)
+    for s in range(nsites):
+        ocgb = oracle_cgb_from_problem(prob, sites[s], p)
+        OB.regularizebeliefs_bycluster(ocgb)
+        ref = pack_oracle(ocgb, prob)
+        if p == 3:
+            assert np.array_equal(pcgb._packed[s], ref)
+        else:
+            # the symmetric block-packed layout keeps one representative of every (i,j)/(j,i) pair: the rounding
+            # asymmetry of the input precision (~1e-17 relative) does not survive the round trip
+            assert np.allclose(pcgb._packed[s], ref, rtol=1e-13, atol=0.0)
+            d = prob.packed_off
+            for i in range(0, len(prob.dims), 7):      # diagonals (where eps lands) are exact
+                m = int(prob.dims[i])
+                Jp = pcgb._packed[s][d[i]:d[i] + m * m].reshape(m, m)
+                assert np.array_equal(np.diag(Jp), np.diag(ref[d[i]:d[i] + m * m].reshape(m, m)))
+    assert P.calibrate_(pcgb, prob.schedule, 1)[0]
+    for s in range(nsites):
+        pcgb.site = s
+        ll = pcgb.integratebelief_(prob.root_cluster, all_sites=False)[1]
+        assert rel_close(ll, S.bm_loglik_pruning(tr, R, mu, Xs[s]))
+    pcgb.site = 0
+
+
+def test_regularize_onschedule_bethe_pipeline(P, caplog):
+    """test/test_calibration.jl:94-105 end to end on the device: regularizebeliefs_onschedule! (default messages
+    on the host, real messages through pgbp_propagate), then calibrate!(cgb, sched, 20; auto=true):
+    "calibration reached: iteration 5, schedule tree 1", posterior mean at I3; beliefs against the oracle."""
+    g = G["calibration_bethe_level1"]
+    net = ON.read_newick(g["net"])
+    cg = OCG.bethe(net)
+    sched = OCG.spanningtrees_clusterlist(cg, net)
+    ocgb, pcgb = build_both(P, net, cg, make_model(g["model"]), [g["y"]], g["taxa"])
+    P.regularizebeliefs_onschedule_(pcgb, cg)
+    OB.regularizebeliefs_onschedule(ocgb)
+    assert_beliefs_close(pcgb, ocgb)
+    with caplog.at_level(logging.INFO, logger="PhyloGaussianBeliefProp"):
+        assert P.calibrate_(pcgb, sched, g["niter"], auto=True, info=True) == (True, True)
+    assert "calibration reached: iteration 5, schedule tree 1" in caplog.text
+    assert OC.calibrate(ocgb, sched, g["niter"], auto=True) == (True, True)
+    assert_beliefs_close(pcgb, ocgb)
+    i3 = next(i for i, n in enumerate(net.vec_node) if not n.leaf and net.root in net.parents(n))
+    mu, _ = pcgb.integratebelief_(pcgb.clusterindex(net.vec_node[i3].name))
+    assert abs(mu[-1] - g["posterior_mean_I3"]) <= g["rtol"] * abs(g["posterior_mean_I3"])
+    # the regularised loopy graph has proper beliefs: the free energy is finite and matches the oracle
+    fe = pcgb.free_energy()
+    ofe = OB.free_energy(ocgb)
+    assert all(rel_close(a, b) for a, b in zip(fe, ofe))
+
+
+def test_regularize_bynodesubtree(P):
+    """regularizebeliefs_bynodesubtree! (src/clustergraphbeliefs.jl:306-340) against the oracle on the level-1
+    clique tree (test/test_calibration.jl:67-71) and on its Bethe cluster graph; the clique-tree likelihood
+    is unchanged."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    for cg in (OCG.cliquetree(net), OCG.bethe(net)):
+        ocgb, pcgb = build_both(P, net, cg, make_model(g["model"]), [g["y"]], g["taxa"])
+        P.regularizebeliefs_bynodesubtree_(pcgb, cg)
+        OB.regularizebeliefs_bynodesubtree(ocgb)
+        for pb, ob in zip(pcgb.belief, ocgb.belief):
+            assert np.array_equal(pb.J, ob.J)
+        if cg.method != "Bethe":
+            spt = OCG.spanningtree_clusterlist(cg, OCG.default_rootcluster(cg, net))
+            assert P.calibrate_(pcgb, [spt])[0]
+            for i in range(len(ocgb.belief)):
+                assert rel_close(pcgb.integratebelief_(i)[1], g["ll_every_belief"])

@@ -314,3 +314,59 @@ def test_calibration_level3_network(variant):
     for name, m in g["posterior_means_" + variant].items():
         assert np.allclose(means[name], m, rtol=1.5e-8, atol=0), (name, means[name], m)
     assert close(OD.loglik(net, model, tbl, g["taxa"]), g["norm_" + variant], rtol=1e-9)
+
+
+@pytest.mark.parametrize("regul", ["bynodesubtree", "bycluster", "onschedule"])
+def test_regularization_preserves_cliquetree_loglik(regul):
+    """test/test_calibration.jl:66-77: after init_beliefs_reset_fromfactors!, regularize, calibrate on the
+    clique tree: the log-likelihood is the un-regularised golden ("graph invariant was preserved")."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, make_model(g["model"]), [g["y"]], g["taxa"])
+    before = [b.J.copy() for b in cgb.belief]
+    getattr(OB, "regularizebeliefs_" + regul)(cgb)
+    assert any(not np.array_equal(a, b.J) for a, b in zip(before, cgb.belief))   # something was regularised
+    assert OC.calibrate(cgb, [spt])[0]
+    for i in range(len(cgb.belief)):
+        assert close(cgb.integratebelief(i)[1], g["ll_every_belief"], rtol=1e-9)
+
+
+def test_regularize_onschedule_bethe_golden():
+    """test/test_calibration.jl:94-105: the reference's own pipeline -- regularizebeliefs_onschedule!, then
+    calibrate!(cgb, sched, 20; auto=true): ':102 Calibration detected: iter 5, sch 1', posterior mean at I3."""
+    g = G["calibration_bethe_level1"]
+    net = ON.read_newick(g["net"])
+    cg = OCG.bethe(net)
+    cgb = oracle_setup(net, cg, make_model(g["model"]), [g["y"]], g["taxa"])
+    OB.regularizebeliefs_onschedule(cgb)
+    # every cluster belief is now non-degenerate (the point of the regularisation)
+    for b in cgb.belief[:cgb.nclusters]:
+        assert np.all(np.linalg.eigvalsh(b.J) > 0)
+    log = []
+    sched = OCG.spanningtrees_clusterlist(cg, net)
+    assert OC.calibrate(cgb, sched, g["niter"], auto=True, info=True, log=log) == (True, True)
+    assert log[-1] == ("info", "calibration reached: iteration 5, schedule tree 1")
+    i3 = next(i for i, n in enumerate(net.vec_node) if not n.leaf and net.root in net.parents(n))
+    mu, _ = cgb.integratebelief(cgb.clusterindex(net.vec_node[i3].name))
+    assert close(mu[-1], g["posterior_mean_I3"], rtol=g["rtol"])
+
+
+def test_residual_kldiv_during_calibration():
+    """src/calibration.jl:128,154 (update_residualkldiv=true): on a tree, the second iteration resends the same
+    messages: every KL divergence is 0 and every iscalibrated_kl flag true; after the first iteration the
+    postorder messages (sepsets were 0 = improper before) are left at their initial -1 / false."""
+    g = G["calibration_cliquetree_level1"]
+    net = ON.read_newick(g["net"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    cgb = oracle_setup(net, ct, make_model(g["model"]), [g["y"]], g["taxa"])
+    assert OC.calibrate(cgb, [spt], 1, update_residualkldiv=True)[0]
+    pa, ch = spt[0], spt[1]
+    for p, c in zip(pa, ch):
+        assert cgb.messageresidual[(p, c)].kldiv == -1.0 and not cgb.messageresidual[(p, c)].iscalibrated_kl
+        assert cgb.messageresidual[(c, p)].kldiv > 1e-5 and not cgb.messageresidual[(c, p)].iscalibrated_kl
+    assert OC.calibrate(cgb, [spt], 1, update_residualkldiv=True) == (True, True)
+    for mr in cgb.messageresidual.values():
+        assert abs(mr.kldiv) < 1e-10 and mr.iscalibrated_kl
