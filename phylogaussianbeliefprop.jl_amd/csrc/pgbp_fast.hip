@@ -25,6 +25,34 @@
 
 namespace pgbp {
 
+#ifdef PGBP_TRACE
+// experiment-only instrumentation (tools/, never in the shipped build): per-phase timestamps of wave 0 of
+// single-task launches
+constexpr unsigned int kTraceCap = 1u << 19;
+__device__ unsigned long long g_trace[kTraceCap][10];
+__device__ unsigned int g_trace_n;
+__device__ unsigned int g_trace_all;  // 0: wave 0 of single-task launches only; 1: every wave of every launch
+__device__ unsigned int g_trace_base;  // first slot of the running launch (advanced by trace_advance between launches)
+__global__ void trace_advance(unsigned int n) {
+  if (g_trace_all) { g_trace_base += n; g_trace_n = g_trace_base; }
+}
+__device__ __forceinline__ unsigned long long trace_vgpr(unsigned long long t) {
+  unsigned int lo = (unsigned int)t, hi = (unsigned int)(t >> 32);
+  asm("" : "+v"(lo), "+v"(hi));
+  return ((unsigned long long)hi << 32) | lo;
+}
+#ifdef PGBP_TRACE_LIGHT  // start / end / hardware id only: must not change the kernel's register budget
+#define PGBP_TR(i) do { } while (0)
+#define PGBP_TR_NOWAIT(i) do { } while (0)
+#else
+#define PGBP_TR(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); tr[i] = trace_vgpr(__builtin_amdgcn_s_memtime()); } while (0)
+#define PGBP_TR_NOWAIT(i) do { tr[i] = trace_vgpr(__builtin_amdgcn_s_memtime()); } while (0)
+#endif
+#else
+#define PGBP_TR(i) do { } while (0)
+#define PGBP_TR_NOWAIT(i) do { } while (0)
+#endif
+
 #define PGBP_LOG2PI 1.8378770664093454835606594728112
 #define PGBP_LN2 0.69314718055994530941723212145818
 #define PGBP_EPS 2.220446049250313e-16
@@ -41,12 +69,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
 }
 
 // Wave-synchronous exchange through LDS: the hardware executes a wave's DS instructions in order, but the
@@ -165,9 +187,33 @@ __device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int
 //     hands it to the others through LDS; every wave divides by its own sepset and updates its own receiver.
 // BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
 template <int P, bool BS>
-__global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry* __restrict__ recs, int K,
-                                                       unsigned long long seq_base,
-                                                       unsigned long long stop_below) {
+#ifdef PGBP_TRACE_LIGHT
+__attribute__((amdgpu_waves_per_eu(4, 4)))  // keep the production kernel's occupancy despite the extra live values
+#endif
+__global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEntry* __restrict__ recs_arg, int K_arg,
+                                                       unsigned long long seq_base_arg,
+                                                       unsigned long long stop_below_arg) {
+  // The 0x90-byte kernarg segment spans three cache lines and the compiler fetches arguments one group at a
+  // time, each a dependent round trip on the critical path of a narrow level.  Pinning the plain scalars of
+  // all three lines in SGPRs here makes ONE batch of scalar loads touch every line; the pointer arguments are
+  // left alone (an asm operand would cost them their global-address-space provenance) and hit the scalar cache.
+#if defined(PGBP_TRACE) && !defined(PGBP_TRACE_LIGHT)
+  unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool trace_on = g_trace_all != 0 || (gridDim.x == 1 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0);
+  tr[8] = trace_vgpr(__builtin_amdgcn_s_memrealtime());
+  PGBP_TR_NOWAIT(0);
+#endif
+  DevState S = S_arg;
+  const FEntry* __restrict__ recs = recs_arg;
+  int K = K_arg;
+  unsigned long long seq_base = seq_base_arg, stop_below = stop_below_arg;
+  {
+    unsigned long long atol_bits = __double_as_longlong(S.atol);
+    asm("; kernel arguments resident"
+        : "+s"(S.pool_stride), "+s"(S.rpool_stride), "+s"(S.n_clusters), "+s"(S.n_msgs), "+s"(S.update_resnorm),
+          "+s"(atol_bits), "+s"(K), "+s"(seq_base), "+s"(stop_below));
+    S.atol = __longlong_as_double(atol_bits);
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
@@ -176,13 +222,42 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   const int a = act ? lane % G : 0, b = act ? lane / G : 0;
   const bool up = act && a <= b;                   // this lane's block is stored in the packed layout
   const int kidx = (b * (b + 1) / 2 + a) * 4;      // its offset inside a packed symmetric tile
-  const FEntry en = recs[(int64_t)blockIdx.x * K + wave];
-  const unsigned long long failkey = S.fail[site];
+  // The whole 64-byte record and the site's fail key are fetched by ONE batch of scalar loads and pinned in
+  // SGPRs here: left to itself the compiler sinks them into the branches that use them, and the wave then
+  // pays a dependent memory round trip per field group (valid -> fail key -> offsets -> ...).
+  FEntry en;
+  unsigned long long failkey;
+#if defined(PGBP_TRACE) && !defined(PGBP_TRACE_LIGHT)
+  en = recs[(int64_t)blockIdx.x * K + wave];  // (the timestamp reads defeat the scalar-load pinning below)
+  failkey = S.fail[site];
+#else
+  {
+    const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs + ((int64_t)blockIdx.x * K + wave));
+    uint4 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
+    failkey = S.fail[site];
+    unsigned int fl = (unsigned int)failkey, fh = (unsigned int)(failkey >> 32);
+    asm("; record + fail key resident"
+                 : "+s"(q0.x), "+s"(q0.y), "+s"(q0.z), "+s"(q0.w), "+s"(q1.x), "+s"(q1.y), "+s"(q1.z), "+s"(q1.w),
+                   "+s"(q2.x), "+s"(q2.y), "+s"(q2.z), "+s"(q2.w), "+s"(q3.x), "+s"(q3.y), "+s"(q3.z), "+s"(q3.w),
+                   "+s"(fl), "+s"(fh));
+    const uint4 q[4] = {q0, q1, q2, q3};
+    __builtin_memcpy(&en, q, sizeof(FEntry));
+    failkey = ((unsigned long long)fh << 32) | fl;
+  }
+#endif
+#ifdef PGBP_TRACE_LIGHT
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();  // after the pinned scalar loads (see above)
+#endif
+  PGBP_TR(1);
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   double* slot = fast_lds + wave * kSlotDoubles;
   double* col = fast_lds + K * kSlotDoubles + wave * kColDoubles;  // private strip of this wave
 
+  // A padding record (tasks are padded to the K of their launch) outside an accumulate task has nothing to hand
+  // over: its wave ends here and gives its slot and registers back.  The workgroup's barriers wait only for the
+  // surviving waves (S_BARRIER semantics of the ISA).
+  if (!en.valid && !(en.mode & kFAccum)) return;
   // state 0: nothing to do / stopped; 1: message available; 2: failed (not PD); 3: sender poisoned
   int state = (en.valid && !((failkey >> kInfoBits) < stop_below)) ? 1 : 0;
   const bool has_block = en.s > 0;                // the message has a J/h part
@@ -208,32 +283,38 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
   int info = 0;
   if (state == 1) {
     const int poisoned = S.poison[(int64_t)site * S.n_clusters + en.from_b];
-    // ---- every load of this message is issued before any arithmetic
-    if (has_block) {
-      sJ = load_blk<BS>(sep, P, a, b, up, kidx);
-      if (b == 0) sh = *reinterpret_cast<const double2*>(sep + sepH + 2 * a);
-    }
-    sg = sep[sepG];
-    if (own) {
-      if (accum || has_block) {
-        tJ = load_blk<BS>(to + tJ0, mt, a, b, up, kidx);
-        if (b == 0) {
-          const double2 t2 = *reinterpret_cast<const double2*>(to + tH0 + 2 * a);
-          th[0] = t2.x; th[1] = t2.y;
-        }
+    // ---- every load of this message is issued before any arithmetic; the sender (the largest operand and
+    // the one the elimination waits for) goes first, the sepset and the receiver block right behind it
+    auto load_sep_to = [&]() {
+      if (has_block) {
+        sJ = load_blk<BS>(sep, P, a, b, up, kidx);
+        if (b == 0) sh = *reinterpret_cast<const double2*>(sep + sepH + 2 * a);
       }
-      tg = to[tG0];
-    }
+      sg = sep[sepG];
+      if (own) {
+        if (accum || has_block) {
+          tJ = load_blk<BS>(to + tJ0, mt, a, b, up, kidx);
+          if (b == 0) {
+            const double2 t2 = *reinterpret_cast<const double2*>(to + tH0 + 2 * a);
+            th[0] = t2.x; th[1] = t2.y;
+          }
+        }
+        tg = to[tG0];
+      }
+    };
+    if (!provider) load_sep_to();
     if (provider) {
       const double* __restrict__ from = pool + en.from_off;
       if (en.mf == 0) {
         gmsg = from[0];  // a constant factor
+        load_sep_to();
       } else if (en.mf == P && has_block) {
         // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
         mJ = load_blk<BS>(from, P, a, b, up, kidx);
         const double2 ch = *reinterpret_cast<const double2*>(from + (BS ? bs16::h1(P) : P * P) + 2 * a);
         mh[0] = ch.x; mh[1] = ch.y;
         gmsg = from[BS ? bs16::g1(P) : P * P + P];
+        load_sep_to();
       } else {
         Frag f;
 #pragma unroll
@@ -282,6 +363,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
           f.h[0] = v.x; f.h[1] = v.y; f.h[2] = u.x; f.h[3] = u.y;
           gmsg = from[4 * P * P + 2 * P];
         }
+        load_sep_to();
         // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
         // (in BS16 the lanes a > b hold nothing yet: all four of their entries come from lane (b, a))
         {
@@ -305,7 +387,9 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
           if (__any(nz)) {
             double mant = 1.0, quad = 0.0;
             int expo = 0;
+            PGBP_TR(2);
             info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
+            PGBP_TR_NOWAIT(3);
             if (info == 0) {
               const double logdet = log(mant) + (double)expo * PGBP_LN2;
               gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
@@ -348,6 +432,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
       }
     }
   }
+  PGBP_TR_NOWAIT(4);
   // ---- divide! (src/beliefupdates.jl:579-587): every wave for its own sepset
   Blk dJ{0, 0, 0, 0};
   double dh0 = 0.0, dh1 = 0.0, dg = 0.0;
@@ -375,11 +460,11 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     }
     if (S.update_resnorm) {
       // iscalibrated_residnorm! (src/beliefs.jl:994-1003); an empty message is calibrated
-      maxJ = wave_max_f64(maxJ);
-      maxh = wave_max_f64(maxh);
-      if (lane == 0)
-        S.flags[(int64_t)site * S.n_msgs + en.msg] =
-            (!has_block || (maxh / sqrt((double)P) <= S.atol && maxJ / sqrt((double)P * (double)P) <= S.atol)) ? 1 : 0;
+      // x -> fl(x / c) is monotone, so "max over the wave, divide, compare" equals "every lane divides and
+      // compares its own maximum": one ballot instead of two 6-step wave reductions on the critical path
+      const bool lane_ok = maxh / sqrt((double)P) <= S.atol && maxJ / sqrt((double)P * (double)P) <= S.atol;
+      const bool all_ok = __all(lane_ok);
+      if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = (!has_block || all_ok) ? 1 : 0;
     }
   } else if (state >= 2 && lane == 0) {
     // not positive definite, or downstream of a failure: nothing of this message is applied
@@ -431,6 +516,38 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S, const FEntry*
     }
     if (lane == 0) to[tG0] = tg;
   }
+#ifdef PGBP_TRACE_LIGHT
+  {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+    const unsigned int slot = g_trace_base + blockIdx.x * K + (threadIdx.x >> 6);
+    if (g_trace_all && lane == 0 && slot < kTraceCap) {
+      const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      g_trace[slot][0] = ((unsigned long long)xcc << 32) | hw;
+      g_trace[slot][7] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
+      g_trace[slot][8] = t_start;
+      g_trace[slot][9] = t_end;
+    }
+  }
+#elif defined(PGBP_TRACE)
+  PGBP_TR_NOWAIT(5);
+  PGBP_TR(6);  // all stores acknowledged
+  tr[9] = trace_vgpr(__builtin_amdgcn_s_memrealtime());
+  if (trace_on && lane == 0) {
+    const unsigned int slot = g_trace_all ? g_trace_base + blockIdx.x * K + (threadIdx.x >> 6) : atomicAdd(&g_trace_n, 1u);
+    if (slot < kTraceCap) {
+      // marks 0 and 7 carry identification in full-trace mode: grid size / workgroup, hardware ids
+      tr[7] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
+      const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      const unsigned long long t0 = tr[0];
+      for (int i = 1; i < 7; ++i) g_trace[slot][i] = tr[i] - t0;
+      g_trace[slot][0] = ((unsigned long long)xcc << 32) | hw;
+      g_trace[slot][7] = tr[7];
+      g_trace[slot][8] = tr[8];
+      g_trace[slot][9] = tr[9];
+    }
+  }
+#endif
 }
 
 template <int P>
@@ -456,6 +573,27 @@ void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int nta
     case 4: launch_fast_p<4>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
     default: break;  // the planner never marks a task fast for another P
   }
+#ifdef PGBP_TRACE
+  hipLaunchKernelGGL(trace_advance, dim3(1), dim3(1), 0, st, (unsigned int)(ntasks * K));
+#endif
 }
 
 }  // namespace pgbp
+
+#ifdef PGBP_TRACE
+extern "C" int pgbp_debug_trace_mode(unsigned int all) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_trace_all), &all, sizeof(all)) == hipSuccess ? 0 : 1;
+}
+extern "C" int pgbp_debug_trace(unsigned long long* out, unsigned int cap, unsigned int* n, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return 4;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(pgbp::g_trace_n), sizeof(unsigned int)) != hipSuccess) return 1;
+  const unsigned int k = *n < cap ? *n : cap;
+  if (k && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgbp::g_trace), sizeof(unsigned long long) * (size_t)k * 10) != hipSuccess) return 2;
+  if (reset) {
+    unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_trace_n), &z, sizeof(z)) != hipSuccess) return 3;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_trace_base), &z, sizeof(z)) != hipSuccess) return 3;
+  }
+  return 0;
+}
+#endif
