@@ -868,3 +868,53 @@ def test_regularize_bynodesubtree(P):
             assert P.calibrate_(pcgb, [spt])[0]
             for i in range(len(ocgb.belief)):
                 assert rel_close(pcgb.integratebelief_(i)[1], g["ll_every_belief"])
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configurations at full size
+
+@pytest.mark.parametrize("ntips,p,graph", [(50000, 16, "cliquetree"), (10000, 8, "bethe")],
+                         ids=["cfg3_50k_p16_cliquetree", "cfg2_10k_p8_bethe"])
+def test_full_size_config_against_c_oracle(P, ntips, p, graph):
+    """BASELINE.json configs[2] (the headline) and configs[1] at their full sizes: every calibrated belief, every
+    residual flag and the log-likelihood against the plain-C sequential engine of the oracle (reference message order;
+    itself pinned to the numpy restatement in tests/test_oracle_c.py), plus the properties that do not depend on size:
+    the likelihood equals the independent pruning algorithm's, every belief integrates to it, and a further
+    calibration leaves the calibrated state where it is.  Tolerances: 1e-8 relative (log-likelihood), 1e-8 * max|.| per
+    belief."""
+    from oracle import cengine
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(3)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    mu = np.zeros(p)
+    X = S.simulate_bm(tr, R, mu, rng)
+    if graph == "cliquetree":
+        prob = S.cliquetree_of_tree(tr, p)
+        packed = S.bm_factors_cliquetree(tr, prob, R, mu, X)
+    else:
+        prob = S.bethe_of_tree(tr, p)
+        packed = S.bm_factors_bethe(tr, prob, R, mu, X)
+    ll_ref = S.bm_loglik_pruning(tr, R, mu, X)
+    pcgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    eng = cengine.Engine(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    pa, ch = prob.schedule[0]
+    assert P.calibrate_(pcgb, prob.schedule, 2) == (True, True)
+    assert eng.calibrate(pa, ch, 2, return_iscal=True) == (True, True)
+    got, ref = pcgb._packed[0], eng.packed()
+    off = prob.packed_off
+    worst = 0.0
+    for i in range(len(prob.dims)):
+        a, b = got[off[i]:off[i + 1]], ref[off[i]:off[i + 1]]
+        if a.size:
+            worst = max(worst, float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b)))))
+    assert worst <= 1e-8, worst
+    _, flags = eng.residuals()
+    assert np.array_equal(pcgb._flags().astype(bool), flags.astype(bool))
+    ll = pcgb.integratebelief_(prob.root_cluster)[1]
+    assert rel_close(ll, ll_ref) and rel_close(ll, eng.integrate(prob.root_cluster)[1])
+    for i in np.random.default_rng(1).choice(len(prob.dims), size=64, replace=False):
+        if prob.dims[i] > 0:
+            assert rel_close(pcgb.integratebelief_(int(i))[1], ll_ref)
+    before = got.copy()
+    assert P.calibrate_(pcgb, prob.schedule, 1) == (True, True)     # idempotent on a calibrated clique tree
+    assert np.max(np.abs(pcgb._packed[0] - before)) <= 1e-9 * max(1.0, float(np.max(np.abs(before))))
