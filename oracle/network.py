@@ -248,3 +248,84 @@ def random_tree_newick(ntips: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> 
         new = f"({a}:{la:.6f},{b}:{lb:.6f})n{k}"
         parts = [p for t, p in enumerate(parts) if t not in (i, j)] + [new]
     return parts[0] + ";"
+
+
+def random_network(ntips: int, nhybrids: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> Network:
+    """Random rooted network for the cfg5-shaped tests: a random bifurcating tree (uniform
+    random joins, edge lengths U(lo, hi)) plus `nhybrids` reticulations, each inside the two child edges of its own
+    internal node w, so that the blobs are edge-disjoint and the network has a small level:
+      * triangle: x splits w->c1, hybrid y splits w->c2, minor edge x->y;
+      * 4-cycle:  x splits w->c1, hybrid y splits a child edge of c2, minor edge x->y (c2 then hosts no blob itself).
+    Minor inheritance gamma ~ U(0.1, 0.5); every edge length > 0 (no degenerate hybrids)."""
+    nodes: List[Node] = []
+    edges: List[Edge] = []
+
+    def new_node(name="", leaf=False):
+        n = Node(name=name, leaf=leaf)
+        nodes.append(n)
+        return n
+
+    def new_edge(pa, ch, length, gamma=1.0, hybrid=False):
+        e = Edge(number=len(edges) + 1, parent=pa, child=ch, length=float(length), gamma=float(gamma), hybrid=hybrid)
+        edges.append(e)
+        pa.edges.append(e)
+        ch.edges.append(e)
+        return e
+
+    parts = [new_node(f"t{i+1}", leaf=True) for i in range(ntips)]
+    while len(parts) > 1:
+        i, j = sorted(int(x) for x in rng.choice(len(parts), size=2, replace=False))
+        a, b = parts[i], parts[j]
+        w = new_node()
+        new_edge(w, a, rng.uniform(lo, hi))
+        new_edge(w, b, rng.uniform(lo, hi))
+        parts = [p for t, p in enumerate(parts) if t not in (i, j)] + [w]
+    root = parts[0]
+
+    def child_edges(n):
+        return [e for e in n.edges if e.parent is n]
+
+    def split(e, frac, hybrid_node):
+        """insert a node on edge e at fraction `frac` from the parent; returns it"""
+        m = new_node()
+        m.hybrid = hybrid_node
+        ch = e.child
+        full = e.length
+        e.child.edges.remove(e)
+        e.child = m
+        e.length = full * frac
+        m.edges.append(e)
+        new_edge(m, ch, full * (1.0 - frac))
+        return m
+
+    internal = [n for n in nodes if not n.leaf]
+    order = rng.permutation(len(internal))
+    blocked = set()
+    made = 0
+    for k in order:
+        if made >= nhybrids:
+            break
+        w = internal[int(k)]
+        if id(w) in blocked:
+            continue
+        ce = child_edges(w)
+        if len(ce) != 2:
+            continue
+        if rng.random() < 0.5:
+            ce = ce[::-1]
+        e1, e2 = ce
+        c2 = e2.child
+        target = e2
+        if (not c2.leaf) and id(c2) not in blocked and rng.random() < 0.5 and len(child_edges(c2)) == 2:
+            target = child_edges(c2)[int(rng.integers(2))]      # 4-cycle through c2
+            blocked.add(id(c2))
+        x = split(e1, rng.uniform(0.3, 0.7), False)
+        y = split(target, rng.uniform(0.3, 0.7), True)
+        g = rng.uniform(0.1, 0.5)
+        major = [e for e in y.edges if e.child is y][0]
+        major.gamma = 1.0 - g
+        major.hybrid = True
+        new_edge(x, y, rng.uniform(0.05, 0.3), gamma=g, hybrid=True)
+        blocked.add(id(w))
+        made += 1
+    return Network(root, nodes, edges)

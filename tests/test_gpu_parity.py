@@ -17,6 +17,7 @@ from helpers import (goldens, make_model, oracle_cgb_from_problem, oracle_schedu
 from oracle import beliefs as OB
 from oracle import calibration as OC
 from oracle import clustergraph as OCG
+from oracle import models as OM
 from oracle import network as ON
 
 pytestmark = pytest.mark.gpu
@@ -918,3 +919,63 @@ def test_full_size_config_against_c_oracle(P, ntips, p, graph):
     before = got.copy()
     assert P.calibrate_(pcgb, prob.schedule, 1) == (True, True)     # idempotent on a calibrated clique tree
     assert np.max(np.abs(pcgb._packed[0] - before)) <= 1e-9 * max(1.0, float(np.max(np.abs(before))))
+
+
+@pytest.mark.parametrize("ntips,nhyb,python_bp", [(400, 80, True), (1500, 300, False)], ids=["400tips_80hybrids", "1500tips_300hybrids"])
+def test_cfg5_shaped_loopy_network(P, caplog, ntips, nhyb, python_bp):
+    """BASELINE.json configs[4] at test size: heterogeneous BM (3 painted rates, 4 traits) on a random network with
+    reticulations (triangles and 4-cycles, gamma ~ U(0.1, 0.5), no zero-length edges), loopy cluster graph (Bethe:
+    hybrid families of dimension 12 on the generic kernel, tree edges and variable clusters on the P = 4 fast
+    instance), regularizebeliefs_bycluster! on the device, calibrate!(beliefs, schedule, 100; auto=true) over the
+    spanning-tree schedule of spanningtrees_clusterlist.  Checked against the plain-C sequential engine (and, at the
+    small size, the numpy restatement): same iteration / schedule tree at which calibration is detected, calibrated
+    beliefs to 1e-8 * max|.|, and the free energy of the fixed point."""
+    from oracle import cengine
+    rng = np.random.default_rng(5)
+    net = ON.random_network(ntips, nhyb, rng)
+    p = 4
+    rates = [np.eye(p) * s + 0.3 * s for s in (0.5, 1.0, 2.0)]
+    colors = {e.number: 1 + int(rng.integers(3)) for e in net.edges}
+    model = OM.HeterogeneousBrownianMotion(rates, colors, np.zeros(p))
+    taxa = net.tip_names
+    tbl = [list(rng.normal(size=len(taxa))) for _ in range(p)]
+    cg = OCG.bethe(net)
+    sched = OCG.spanningtrees_clusterlist(cg, net)
+    assert len(sched) >= 2                                   # loopy
+    ocgb, pcgb = build_both(P, net, cg, model, tbl, taxa)
+    P.regularizebeliefs_bycluster_(pcgb, cg)
+    OB.regularizebeliefs_bycluster(ocgb)
+    for pb, ob in zip(pcgb.belief, ocgb.belief):
+        assert np.array_equal(pb.J, ob.J)
+    eng = cengine.Engine(pcgb._dims, pcgb._sepcl.reshape(-1), pcgb._scope_off, pcgb._scope_idx, pcgb._packed[0].copy())
+    reached = None
+    for it in range(1, 101):
+        for j, spt in enumerate(sched, start=1):
+            succ, iscal = eng.calibrate(spt[2], spt[3], 1, return_iscal=True)
+            assert succ
+            if iscal:
+                reached = (it, j)
+                break
+        if reached:
+            break
+    assert reached is not None and reached[0] > 2            # genuinely iterative
+    with caplog.at_level(logging.INFO, logger="PhyloGaussianBeliefProp"):
+        assert P.calibrate_(pcgb, sched, 100, auto=True, info=True) == (True, True)
+    r = pcgb.last_results[0]
+    assert (r.iter_reached, r.tree_reached) == reached
+    assert f"calibration reached: iteration {reached[0]}, schedule tree {reached[1]}" in caplog.text
+    got, ref = pcgb._packed[0], eng.packed()
+    off = pcgb._poff
+    worst = 0.0
+    for i in range(len(pcgb._dims)):
+        a, b = got[off[i]:off[i + 1]], ref[off[i]:off[i + 1]]
+        if a.size:
+            worst = max(worst, float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b)))))
+    assert worst <= 1e-8, worst
+    if python_bp:
+        olog = []
+        assert OC.calibrate(ocgb, sched, 100, auto=True, info=True, log=olog) == (True, True)
+        assert olog[-1] == ("info", f"calibration reached: iteration {reached[0]}, schedule tree {reached[1]}")
+        assert_beliefs_close(pcgb, ocgb)
+        fe, ofe = pcgb.free_energy(), OB.free_energy(ocgb)
+        assert all(rel_close(a, b) for a, b in zip(fe, ofe))
