@@ -237,7 +237,11 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
 int reset_from_factors_async(pgbp_engine* e) {
   if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "no factors: call pgbp_set_beliefs(snapshot) or pgbp_init_factors_frombeliefs first");
   const Plan& p = e->plan;
-  launch_copy_strided(e->d_fpool, p.cluster_stride(), e->d_pool, p.pool_stride(), p.cluster_stride(), p.n_sites, e->st);
+  if (e->layout_bs16)  // packed records use about half of their slots: copy what is in use
+    launch_copy_records(e->d_fpool, p.cluster_stride(), e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_clusters, 1,
+                        p.fast_p, p.n_sites, e->st);
+  else
+    launch_copy_strided(e->d_fpool, p.cluster_stride(), e->d_pool, p.pool_stride(), p.cluster_stride(), p.n_sites, e->st);
   launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                       p.n_sites, e->st);
   return PGBP_OK;
@@ -829,15 +833,27 @@ int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
   return PGBP_OK;
 }
 
-static int bm_fill_async(pgbp_engine* e) {
+// also_factors: assignfactors! followed by init_factors_frombeliefs! (what the callers of the optimisers do once);
+// without it only the beliefs are written, as in the body of score() (src/calibration.jl:205-209).
+static int bm_fill_async(pgbp_engine* e, bool also_factors) {
   const Plan& p = e->plan;
-  launch_bm_tree_fill(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, e->d_bm_kind,
-                      e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv, e->d_bm_logdet,
-                      e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.fast_p, p.n_clusters, p.n_sites, e->st);
+  double* fp = also_factors ? e->d_fpool : nullptr;
+  bool done = false;
+  if (e->bm_p == p.fast_p)  // lane-blocked instance: every cluster has dimension 0, p or 2p (checked at setup)
+    done = launch_bm_tree_fill_fast(e->d_pool, p.pool_stride(), fp, p.cluster_stride(), e->d_boff, e->d_bdim, e->d_bm_kind,
+                                    e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv,
+                                    e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.n_clusters,
+                                    p.n_sites, e->st);
+  if (!done) {
+    launch_bm_tree_fill(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, e->d_bm_kind,
+                        e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv, e->d_bm_logdet,
+                        e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.fast_p, p.n_clusters, p.n_sites, e->st);
+    also_factors = true;  // the general kernel always writes both
+  }
   launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                       p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
-  e->have_factors = true;
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st);
+  if (also_factors) e->have_factors = true;
   return PGBP_OK;
 }
 
@@ -853,7 +869,7 @@ int pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double*
   // R^-1 is symmetric and the fill writes symmetric blocks: the layout the traversals want can be kept
   e->sym_known = true;
   e->sym_ok = true;
-  return bm_fill_async(e);
+  return bm_fill_async(e, true);
 }
 
 int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
@@ -867,7 +883,7 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
   DevState S = dev_state(e, opts);
   const Plan& p = e->plan;
   for (int r = 0; r < reps; ++r) {
-    if ((rc = bm_fill_async(e))) return rc;                      // assignfactors!        calibration.jl:205
+    if ((rc = bm_fill_async(e, false))) return rc;               // assignfactors!        calibration.jl:205-209
     enqueue_traversal(e, S, 0, 0, 0);                            // postorder             :210
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
     launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, p.fast_p, nullptr,

@@ -20,6 +20,8 @@
 // log det J_I is accumulated as mantissa product + exponent sum (one log per message).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
 
@@ -560,6 +562,130 @@ static void launch_fast_p(const DevState& S, const FEntry* d_recs, int K, int nt
   else
     hipLaunchKernelGGL((bp_level_fast16<P, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
                        seq_base, stop_below);
+}
+
+// ---- assignfactors! for MvFullBrownianMotion on a tree (pgbp_bm_tree of include/pgbp.h), lane-blocked ---------------
+// One wavefront per cluster, same lane geometry as the message kernel: lane (a, b) holds the 2 x 2 block
+// R^-1[2a..2a+1][2b..2b+1] for the whole launch and writes it, scaled by 1/t and signed, into the tiles of the record
+// (32-byte stores, whole lines), h = R^-1 v / t by a butterfly over b, g from v'R^-1 v / t by a butterfly over a.
+// Formulas: pgbp_kernels.hip, bm_tree_fill_kernel (the general-dimension version of the same fill).
+template <int P, bool BS>
+__global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ pool, int64_t pool_stride,
+                                                         double* __restrict__ fpool, int64_t fpool_stride,
+                                                         const int64_t* __restrict__ boff,
+                                                         const int32_t* __restrict__ dim,
+                                                         const int32_t* __restrict__ kind,
+                                                         const double* __restrict__ length,
+                                                         const int32_t* __restrict__ row,
+                                                         const double* __restrict__ data, int n_rows,
+                                                         const double* __restrict__ Rinv_all,
+                                                         const double* __restrict__ logdetR_all,
+                                                         const double* __restrict__ mu_all, int per_site, int n_clusters) {
+  constexpr int G = P / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, site = blockIdx.y;
+  const bool act = lane < G * G;
+  const int a = act ? lane % G : 0, b = act ? lane / G : 0;
+  const bool up = act && a <= b;
+  const int kidx = (b * (b + 1) / 2 + a) * 4;
+  const double* __restrict__ Rinv = Rinv_all + (per_site ? (int64_t)site * P * P : 0);
+  const double* __restrict__ mu = mu_all + (per_site ? (int64_t)site * P : 0);
+  const double g_base = -0.5 * ((double)P * PGBP_LOG2PI + logdetR_all[per_site ? site : 0]);
+  const double2 c0 = *reinterpret_cast<const double2*>(Rinv + 2 * a + P * (2 * b));
+  const double2 c1 = *reinterpret_cast<const double2*>(Rinv + 2 * a + P * (2 * b + 1));
+  const Blk Rb{c0.x, c0.y, c1.x, c1.y};
+  for (int c = blockIdx.x * 4 + wave; c < n_clusters; c += gridDim.x * 4) {
+    const int k = kind[c], m = dim[c];
+    double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[c];
+    double* __restrict__ frec = fpool ? fpool + (int64_t)site * fpool_stride + boff[c] : nullptr;
+    if (k < 0) {  // no factor: the constant function 1
+      const int len = (BS && bs16::applies(m, P)) ? bs16::rec_len(m, P) : m * m + m + 1;
+      for (int t = lane; t < len; t += kWave) {
+        rec[t] = 0.0;
+        if (frec) frec[t] = 0.0;
+      }
+      continue;
+    }
+    const double tlen = length[c], it = 1.0 / tlen;
+    double g = g_base - 0.5 * (double)P * log(tlen);
+    double jv0 = 0.0, jv1 = 0.0;
+    if (k >= 1) {
+      // absorbed vector v: mu on the parent (1), the tip's data on the child (2), their difference (3)
+      const double* __restrict__ y = (k >= 2) ? data + ((int64_t)site * n_rows + row[c]) * P : mu;
+      double vb0 = y[2 * b], vb1 = y[2 * b + 1], va0 = y[2 * a], va1 = y[2 * a + 1];
+      if (k == 3) { vb0 -= mu[2 * b]; vb1 -= mu[2 * b + 1]; va0 -= mu[2 * a]; va1 -= mu[2 * a + 1]; }
+      double p0 = act ? fma(Rb.x, vb0, Rb.z * vb1) : 0.0, p1 = act ? fma(Rb.y, vb0, Rb.w * vb1) : 0.0;
+#pragma unroll
+      for (int o = G; o < G * G; o <<= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+      jv0 = p0 * it;
+      jv1 = p1 * it;
+      double q = act ? fma(jv0, va0, jv1 * va1) : 0.0;
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) q += __shfl_xor(q, o);
+      g -= 0.5 * q;
+    }
+    const Blk Jp{Rb.x * it, Rb.y * it, Rb.z * it, Rb.w * it}, Jm{-Jp.x, -Jp.y, -Jp.z, -Jp.w};
+    for (int which = 0; which < (frec ? 2 : 1); ++which) {
+      double* __restrict__ r = which ? frec : rec;
+      if (k == 0) {  // 2P x 2P: [j -j; -j j], h = 0
+        if constexpr (BS) {
+          store_blk<true>(r, P, a, b, up, act, kidx, Jp);
+          store_blk<true>(r + bs16::t11(P), P, a, b, up, act, kidx, Jp);
+          if (act) *reinterpret_cast<double4*>(r + bs16::t10(P) + (a + G * b) * 4) = make_double4(Jm.x, Jm.y, Jm.z, Jm.w);
+          if (act && b == 0) {
+            *reinterpret_cast<double2*>(r + bs16::h2(P) + 2 * a) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(r + bs16::h2(P) + P + 2 * a) = make_double2(0.0, 0.0);
+          }
+          if (lane == 0) r[bs16::g2(P)] = g;
+        } else {
+          store_blk<false>(r, 2 * P, a, b, up, act, kidx, Jp);
+          store_blk<false>(r + P, 2 * P, a, b, up, act, kidx, Jm);
+          store_blk<false>(r + (int64_t)2 * P * P, 2 * P, a, b, up, act, kidx, Jm);
+          store_blk<false>(r + (int64_t)2 * P * P + P, 2 * P, a, b, up, act, kidx, Jp);
+          if (act && b == 0) {
+            *reinterpret_cast<double2*>(r + 4 * P * P + 2 * a) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(r + 4 * P * P + P + 2 * a) = make_double2(0.0, 0.0);
+          }
+          if (lane == 0) r[4 * P * P + 2 * P] = g;
+        }
+      } else if (k <= 2) {  // P x P block j on the kept variables, h = +j v
+        store_blk<BS>(r, P, a, b, up, act, kidx, Jp);
+        if (act && b == 0) *reinterpret_cast<double2*>(r + (BS ? bs16::h1(P) : P * P) + 2 * a) = make_double2(jv0, jv1);
+        if (lane == 0) r[BS ? bs16::g1(P) : P * P + P] = g;
+      } else {  // everything absorbed: a constant
+        if (lane == 0) r[0] = g;
+      }
+    }
+  }
+}
+
+template <int P>
+static void launch_fill_p(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
+                          const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
+                          const double* d_data, int n_rows, const double* d_Rinv, const double* d_logdetR,
+                          const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
+  const int gx = std::min((n_clusters + 3) / 4, 16384);
+  if (bs16)
+    hipLaunchKernelGGL((bm_tree_fill_fast<P, true>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
+                       fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
+                       per_site, n_clusters);
+  else
+    hipLaunchKernelGGL((bm_tree_fill_fast<P, false>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
+                       fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
+                       per_site, n_clusters);
+}
+
+bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride,
+                              const int64_t* d_boff, const int32_t* d_dim, const int32_t* d_kind, const double* d_length,
+                              const int32_t* d_row, const double* d_data, int n_rows, int p, const double* d_Rinv,
+                              const double* d_logdetR, const double* d_mu, int per_site, int bs16, int n_clusters,
+                              int n_sites, hipStream_t st) {
+  if (n_clusters <= 0) return true;
+  switch (p) {
+    case 16: launch_fill_p<16>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st); return true;
+    case 8: launch_fill_p<8>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st); return true;
+    case 4: launch_fill_p<4>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st); return true;
+    default: return false;
+  }
 }
 
 // The kernel is instantiated for sepsets of dimension 16 (all 64 lanes), 8 (16 lanes) and 4 (4 lanes); the

@@ -10,6 +10,8 @@
 // Handles any belief dimension <= PGBP_MAX_DIM and arbitrary (ragged) scope index maps.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
 
@@ -851,6 +853,31 @@ __global__ void zero_strided_kernel(double2* __restrict__ dst, int64_t dst_strid
   double2* __restrict__ d = dst + (int64_t)site * dst_stride2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
     d[i] = make_double2(0.0, 0.0);
+}
+
+// Record-aware copy (reset from factors in the BS16 layout): a packed record fills only the first ~55 % of its slot
+// (577 of 1057 doubles for a 32-dim belief); one wavefront per record copies the part in use, in 16-byte pieces
+// (slots start on 128-byte lines; the tail beyond the record is padding either way).
+__global__ __launch_bounds__(256) void copy_records_kernel(const double* __restrict__ src, int64_t src_stride,
+                                                           double* __restrict__ dst, int64_t dst_stride,
+                                                           const int64_t* __restrict__ boff,
+                                                           const int32_t* __restrict__ dim, int n_records, int bs, int fp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, site = blockIdx.y;
+  for (int r = blockIdx.x * 4 + wave; r < n_records; r += gridDim.x * 4) {
+    const int m = dim[r];
+    const int len = (bs && bs16::applies(m, fp)) ? bs16::rec_len(m, fp) : m * m + m + 1;
+    const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src + (int64_t)site * src_stride + boff[r]);
+    double2* __restrict__ d2 = reinterpret_cast<double2*>(dst + (int64_t)site * dst_stride + boff[r]);
+    for (int t = lane; t < (len + 1) / 2; t += kWave) d2[t] = s2[t];
+  }
+}
+
+void launch_copy_records(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, const int64_t* d_boff,
+                         const int32_t* d_dim, int n_records, int bs16, int fast_p, int n_sites, hipStream_t st) {
+  if (n_records <= 0) return;
+  const int gx = std::min((n_records + 3) / 4, 16384);
+  hipLaunchKernelGGL(copy_records_kernel, dim3(gx, n_sites), dim3(256), 0, st, src, src_stride, dst, dst_stride, d_boff,
+                     d_dim, n_records, bs16, fast_p);
 }
 
 // all strides / offsets / counts are multiples of 2 doubles (records are padded to 16)

@@ -61,6 +61,9 @@ void launch_records(const double* src, int64_t src_stride, const int64_t* d_src_
 void launch_copy_strided(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, int64_t n,
                          int n_sites, hipStream_t st);
 void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites, hipStream_t st);
+// record-aware copy: only the part of each record slot that the current layout uses (pgbp_kernels.hip)
+void launch_copy_records(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, const int64_t* d_boff,
+                         const int32_t* d_dim, int n_records, int bs16, int fast_p, int n_sites, hipStream_t st);
 
 // assignfactors! for a homogeneous BM on a tree (pgbp_bm_tree of include/pgbp.h): writes the cluster record into
 // `pool` and `fpool` (current layout), one workgroup per (cluster, site)
@@ -72,6 +75,15 @@ void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64
 
 // free_energy (src/score.jl:162-182): per-belief terms + deterministic per-site sum -> out3[site] =
 // (average energy, approximate entropy, free energy); info[site] (preset to INT_MAX) = first non-PD belief + 1
+// lane-blocked version of the same fill (pgbp_fast.hip) for p = 16 / 8 / 4 when every cluster has dimension 0, p or 2p
+// as its kind implies; fpool may be null (beliefs only: the score() body of src/calibration.jl:205 does not touch the
+// factors).  Returns false if p has no instance.
+bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride,
+                              const int64_t* d_boff, const int32_t* d_dim, const int32_t* d_kind, const double* d_length,
+                              const int32_t* d_row, const double* d_data, int n_rows, int p, const double* d_Rinv,
+                              const double* d_logdetR, const double* d_mu, int per_site, int bs16, int n_clusters,
+                              int n_sites, hipStream_t st);
+
 void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
                         const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
                         int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st);
