@@ -6,10 +6,11 @@ traffic of the message kernel.
 
 gfx950 corrections (same guide): counters are in KiB; FETCH_SIZE reports exactly 1/2 of the bytes of a
 16-B-per-lane coalesced read -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  The correction is
-re-validated inside the same run on `copy_strided_kernel`, whose byte count is known exactly
-(cluster part of the belief pool, read once and written once).
+re-validated inside the same run on the reset-from-factors copy kernel, whose byte count is known exactly
+(the cluster records, read once and written once: `copy_strided_kernel` in the plain layout,
+`copy_records_kernel` -- only the part of each slot in use -- in the packed layout).
 
-usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel]
 """
 import csv
 import json
@@ -28,10 +29,11 @@ def per_kernel(path, counter):
 
 def main():
     f_csv, w_csv, copy_bytes, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+    ck = "pgbp::" + (sys.argv[5] if len(sys.argv) > 5 else "copy_strided_kernel")
     F = per_kernel(f_csv, "FETCH_SIZE")
     W = per_kernel(w_csv, "WRITE_SIZE")
-    cal_f = 2.0 * 1024 * sum(F["pgbp::copy_strided_kernel"]) / len(F["pgbp::copy_strided_kernel"])
-    cal_w = 1024 * sum(W["pgbp::copy_strided_kernel"]) / len(W["pgbp::copy_strided_kernel"])
+    cal_f = 2.0 * 1024 * sum(F[ck]) / len(F[ck])
+    cal_w = 1024 * sum(W[ck]) / len(W[ck])
     k = "pgbp::bp_level_fast16"
     n = len(F[k])
     fetch = 2.0 * 1024 * sum(F[k])
@@ -41,7 +43,7 @@ def main():
         "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / len(W[k]),
         "hbm_bytes_per_launch": fetch / n + write / len(W[k]),
         "corrections": "KiB units; FETCH_SIZE x2 (16-B/lane reads on gfx950); WRITE_SIZE exact",
-        "calibration_copy_kernel": {"known_bytes_each_way": copy_bytes, "fetch_corrected": cal_f, "write": cal_w,
+        "calibration_copy_kernel": {"kernel": ck, "known_bytes_each_way": copy_bytes, "fetch_corrected": cal_f, "write": cal_w,
                                     "fetch_ratio": cal_f / copy_bytes, "write_ratio": cal_w / copy_bytes},
         "note": "average over every bp_level_fast16 launch of one bench.py run (postorder and preorder levels)",
     }
