@@ -60,6 +60,9 @@ struct pgbp_engine {
   int32_t* d_rdim = nullptr;        // [n_msgs] sepset dim of every directed message
   int32_t* d_symflag = nullptr;     // != 0: some precision matrix is not symmetric
   int32_t max_s = 0;                // largest sepset dimension
+  // site-minor copies of the pools (univariate batches: every dimension <= 2), allocated at first use
+  double *d_pool_sm = nullptr, *d_fpool_sm = nullptr, *d_rpool_sm = nullptr;
+  bool layout_sm = false;           // the live state is in the site-minor buffers
   bool layout_bs16 = false;         // current device layout of 16/32-dim beliefs and 16-dim residuals
   bool sym_known = false, sym_ok = false;
   int32_t* d_one_task_off = nullptr;  // single-message task for pgbp_propagate
@@ -124,6 +127,14 @@ DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
   S.atol = o ? o->atol : 1e-5;
   S.bs16 = e->layout_bs16 ? 1 : 0;
   S.fast_p = e->plan.fast_p;
+  S.sm = e->layout_sm ? 1 : 0;
+  S.n_sites = e->plan.n_sites;
+  S.packed_off = e->d_packed_off;
+  S.rpacked_off = e->d_rpacked_off;
+  if (e->layout_sm) {
+    S.pool = e->d_pool_sm;
+    S.rpool = e->d_rpool_sm;
+  }
   return S;
 }
 
@@ -138,8 +149,38 @@ int reset_fail(pgbp_engine* e) {
 // residual between plain (ABI order, what the generic kernel and all transfers use) and BS16 (symmetric
 // block-packed, what the register-resident kernel streams).  plain -> BS16 keeps the upper triangle, so it
 // is only taken when every precision matrix is symmetric (checked once per upload).
-int ensure_layout(pgbp_engine* e, bool want_bs16) {
+// Site-minor layout of univariate batches (DevState::sm): the state moves between the plain pools and the site-minor
+// buffers as a whole; only the traversals of bp_level_uni, the root integrate, reset-from-factors and the univariate
+// factor fill work on the site-minor buffers, every other entry point asks for the plain layout first.
+int ensure_site_minor(pgbp_engine* e, bool want) {
   const Plan& p = e->plan;
+  if (want == e->layout_sm) return PGBP_OK;
+  const size_t ns = (size_t)p.n_sites;
+  if (want && !e->d_pool_sm) {
+    int rc;
+    if ((rc = dev_alloc(e, &e->d_pool_sm, ns * (size_t)p.packed_off.back()))) return rc;
+    if ((rc = dev_alloc(e, &e->d_fpool_sm, ns * (size_t)p.packed_off[p.n_clusters]))) return rc;
+    if ((rc = dev_alloc(e, &e->d_rpool_sm, ns * (size_t)p.rpacked_off.back()))) return rc;
+  }
+  const int to = want ? 1 : 0;
+  launch_site_minor(e->d_pool, p.pool_stride(), e->d_pool_sm, e->d_boff, e->d_packed_off, p.n_beliefs(), p.n_sites, to, e->st);
+  launch_site_minor(e->d_fpool, p.cluster_stride(), e->d_fpool_sm, e->d_boff, e->d_packed_off, p.n_clusters, p.n_sites, to, e->st);
+  launch_site_minor(e->d_rpool, p.rpool_stride(), e->d_rpool_sm, e->d_roff, e->d_rpacked_off, p.n_msgs(), p.n_sites, to, e->st);
+  e->layout_sm = want;
+  return PGBP_OK;
+}
+
+bool want_site_minor(const pgbp_engine* e) {
+  static const bool disabled = getenv("PGBP_DISABLE_SITE_MINOR") != nullptr;  // A/B and debugging aid
+  return !disabled && e->plan.max_dim <= 2 && e->plan.n_sites >= 64;
+}
+
+int ensure_layout(pgbp_engine* e, bool want_bs16, bool want_sm = false) {
+  const Plan& p = e->plan;
+  if (want_sm != e->layout_sm) {
+    const int rc = ensure_site_minor(e, want_sm);
+    if (rc) return rc;
+  }
   if (want_bs16 == e->layout_bs16) return PGBP_OK;
   if (want_bs16) {
     if (!e->sym_known) {
@@ -234,9 +275,26 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
   }
 }
 
+// integratebelief! of one belief in whatever layout the state is in
+void integrate_async(pgbp_engine* e, int belief, double* d_mu) {
+  const Plan& p = e->plan;
+  if (e->layout_sm)
+    launch_integrate_sm(e->d_pool_sm, p.packed_off[belief], p.dims[belief], d_mu, std::max(1, p.max_dim), e->d_norm,
+                        e->d_info, p.n_sites, e->st);
+  else
+    launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], p.dims[belief], e->layout_bs16 ? 1 : 0, p.fast_p, d_mu,
+                     std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);
+}
+
 int reset_from_factors_async(pgbp_engine* e) {
   if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "no factors: call pgbp_set_beliefs(snapshot) or pgbp_init_factors_frombeliefs first");
   const Plan& p = e->plan;
+  if (e->layout_sm) {  // cluster elements come first and are contiguous over sites
+    const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
+    HIPCHK(e, hipMemcpyAsync(e->d_pool_sm, e->d_fpool_sm, sizeof(double) * (size_t)nc, hipMemcpyDeviceToDevice, e->st));
+    HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));
+    return PGBP_OK;
+  }
   if (e->layout_bs16)  // packed records use about half of their slots: copy what is in use
     launch_copy_records(e->d_fpool, p.cluster_stride(), e->d_pool, p.pool_stride(), e->d_boff, e->d_bdim, p.n_clusters, 1,
                         p.fast_p, p.n_sites, e->st);
@@ -276,7 +334,7 @@ void pgbp_destroy(pgbp_engine* e) {
   (void)hipSetDevice(e->plan.device);
   free_traversals(e);
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
-                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_fail, (void*)e->d_poison,
+                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_fail, (void*)e->d_poison,
                   (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
@@ -399,8 +457,12 @@ int pgbp_sync(pgbp_engine* e) {
 int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
-  launch_copy_strided(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), p.cluster_stride(), p.n_sites,
-                      e->st);
+  if (e->layout_sm)
+    HIPCHK(e, hipMemcpyAsync(e->d_fpool_sm, e->d_pool_sm, sizeof(double) * (size_t)p.packed_off[p.n_clusters] * p.n_sites,
+                             hipMemcpyDeviceToDevice, e->st));
+  else
+    launch_copy_strided(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), p.cluster_stride(), p.n_sites,
+                        e->st);
   e->have_factors = true;
   return pgbp_sync(e);
 }
@@ -598,6 +660,7 @@ int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int3
     return e->fail(PGBP_ERR_INVALID, "pgbp_residual_kldiv: the sepset does not connect these two clusters");
   Entry en{2 * k + dir, 0, 0, 0};
   HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
+  if (e->layout_sm && (rc = ensure_site_minor(e, false))) return rc;
   DevState S = dev_state(e, opts);
   // a standalone call always computes (stop_below = 0; the status of the last attempt of this message still gates)
   launch_residual_kldiv(S, e->d_one_entry, 0, 1, e->max_s, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st);
@@ -673,7 +736,7 @@ int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* op
   if ((rc = need_schedule(e, tree))) return rc;
   const Plan& p = e->plan;
   if ((rc = reset_fail(e))) return rc;
-  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e) && !(opts && opts->update_residualkldiv)))) return rc;
   DevState S = dev_state(e, opts);
   enqueue_traversal(e, S, tree, dir, (unsigned long long)tree, nullptr, nullptr, opts && opts->update_residualkldiv);
   launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
@@ -706,7 +769,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   }
   if ((rc = reset_fail(e))) return rc;
   HIPCHK(e, hipMemsetAsync(e->d_iscal, 0, sizeof(int32_t) * ns, e->st));
-  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e) && !(opts && opts->update_residualkldiv)))) return rc;
   DevState S = dev_state(e, opts);
   int pairs_done = 0;
   bool stop = false;
@@ -748,8 +811,7 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
   if (belief < 0 || belief >= p.n_beliefs()) return e->fail(PGBP_ERR_INVALID, "belief index out of range");
   const int m = p.dims[belief];
   const int ns = p.n_sites;
-  launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], m, e->layout_bs16 ? 1 : 0, p.fast_p, mu ? e->d_mu : nullptr,
-                   std::max(1, p.max_dim), e->d_norm, e->d_info, ns, e->st);
+  integrate_async(e, belief, mu ? e->d_mu : nullptr);
   HIPCHK(e, hipMemcpyAsync(norm, e->d_norm, sizeof(double) * ns, hipMemcpyDeviceToHost, e->st));
   std::vector<double> mus;
   if (mu && m > 0) {
@@ -772,6 +834,10 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
 int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
   if (!e || !out3) return PGBP_ERR_INVALID;
   if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "pgbp_free_energy: no factors (pgbp_set_beliefs with snapshot, or pgbp_init_factors_frombeliefs)");
+  if (e->layout_sm) {
+    const int rc0 = ensure_site_minor(e, false);
+    if (rc0) return rc0;
+  }
   const Plan& p = e->plan;
   const int ns = p.n_sites;
   double *d_contrib = nullptr, *d_out = nullptr;
@@ -837,6 +903,20 @@ int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
 // without it only the beliefs are written, as in the body of score() (src/calibration.jl:205-209).
 static int bm_fill_async(pgbp_engine* e, bool also_factors) {
   const Plan& p = e->plan;
+  if (e->layout_sm && e->bm_p == 1) {  // univariate batch, site-minor state
+    launch_bm_tree_fill_uni_sm(e->d_pool_sm, also_factors ? e->d_fpool_sm : nullptr, e->d_packed_off, e->d_bdim,
+                               e->d_bm_kind, e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->d_bm_Rinv,
+                               e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, p.n_clusters, p.n_sites, e->st);
+    const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
+    HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
+    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st);
+    if (also_factors) e->have_factors = true;
+    return PGBP_OK;
+  }
+  if (e->layout_sm) {
+    const int rc0 = ensure_site_minor(e, false);
+    if (rc0) return rc0;
+  }
   double* fp = also_factors ? e->d_fpool : nullptr;
   bool done = false;
   if (e->bm_p == p.fast_p)  // lane-blocked instance: every cluster has dimension 0, p or 2p (checked at setup)
@@ -879,15 +959,14 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
   if ((rc = need_schedule(e, 0))) return rc;
   if (!e->d_bm_kind) return e->fail(PGBP_ERR_STATE, "pgbp_enqueue_loglik_bm: call pgbp_bm_tree_setup / assignfactors first");
   if ((rc = reset_fail(e))) return rc;
-  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
   DevState S = dev_state(e, opts);
   const Plan& p = e->plan;
   for (int r = 0; r < reps; ++r) {
     if ((rc = bm_fill_async(e, false))) return rc;               // assignfactors!        calibration.jl:205-209
     enqueue_traversal(e, S, 0, 0, 0);                            // postorder             :210
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
-    launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, p.fast_p, nullptr,
-                     std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);  // :212
+    integrate_async(e, root, nullptr);  // :212
   }
   return PGBP_OK;
 }
@@ -916,7 +995,7 @@ int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, con
   if (rc) return rc;
   if ((rc = need_schedule(e, 0))) return rc;
   if ((rc = reset_fail(e))) return rc;
-  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
   DevState S = dev_state(e, opts);
   for (int r = 0; r < reps; ++r)
     if ((rc = enqueue_calibrate_once(e, S, reset_each, nullptr))) return rc;
@@ -930,8 +1009,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
   enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
-  launch_integrate(e->d_pool, p.pool_stride(), p.boff[root], p.dims[root], e->layout_bs16 ? 1 : 0, p.fast_p, nullptr,
-                   std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);         // :212
+  integrate_async(e, root, nullptr);         // :212
   return PGBP_OK;
 }
 
@@ -941,7 +1019,7 @@ int pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
   if (rc) return rc;
   if ((rc = need_schedule(e, 0))) return rc;
   if ((rc = reset_fail(e))) return rc;
-  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
   DevState S = dev_state(e, opts);
   for (int r = 0; r < reps; ++r)
     if ((rc = enqueue_loglik_once(e, S))) return rc;
@@ -992,7 +1070,7 @@ int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opt
   if (rc) return rc;
   if ((rc = need_schedule(e, 0))) return rc;
   if ((rc = reset_fail(e))) return rc;
-  if ((rc = ensure_layout(e, want_bs16(e)))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
   DevState S = dev_state(e, opts);
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int launches = 0;

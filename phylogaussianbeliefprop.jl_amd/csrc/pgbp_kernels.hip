@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
 // batch-of-independent-sites case (cfg4: thousands of univariate problems on one tree), where a wavefront per
 // message would leave 63 of 64 lanes idle.  Same semantics as bp_level_generic (src/beliefupdates.jl:55-83,
 // 483-488, 579-587, src/beliefs.jl:994-1003), closed forms for m_f <= 2.
+template <bool SM>
 __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* __restrict__ task_off,
                                                     const Entry* __restrict__ entries, int task0, int n_sites,
                                                     unsigned long long seq_base, unsigned long long stop_below) {
@@ -230,6 +231,17 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
   const int task = task0 + blockIdx.x;
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  // element t of a belief / residual record: plain (this site's pool + padded offset) or site-minor (SM: lanes =
+  // consecutive sites read consecutive doubles)
+  const int64_t ns = S.n_sites;
+  auto bel = [&](int b, int64_t plain_off, int t) -> double* {
+    if constexpr (SM) return S.pool + (S.packed_off[b] + t) * ns + site;
+    else return pool + plain_off + t;
+  };
+  auto rsd = [&](int msg, int64_t plain_off, int t) -> double* {
+    if constexpr (SM) return S.rpool + (S.rpacked_off[msg] + t) * ns + site;
+    else return rpool + plain_off + t;
+  };
   const int e0 = task_off[task], e1 = task_off[task + 1];
   double mJ[4] = {0, 0, 0, 0}, mh[2] = {0, 0}, gmsg = 0.0;  // message (s <= 2), column-major
   for (int e = e0; e < e1; ++e) {
@@ -241,11 +253,10 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     }
     const int mf = m.mf, s = m.s, mt = m.mt, ni = m.ni;
     if (!en.reuse) {
-      const double* __restrict__ from = pool + m.from_off;
       double J[4] = {0, 0, 0, 0}, h[2] = {0, 0};
-      for (int t = 0; t < mf * mf; ++t) J[t] = from[t];
-      for (int t = 0; t < mf; ++t) h[t] = from[mf * mf + t];
-      gmsg = from[mf * mf + mf];
+      for (int t = 0; t < mf * mf; ++t) J[t] = *bel(m.from_b, m.from_off, t);
+      for (int t = 0; t < mf; ++t) h[t] = *bel(m.from_b, m.from_off, mf * mf + t);
+      gmsg = *bel(m.from_b, m.from_off, mf * mf + mf);
       int keep[2] = {0, 0}, integ[2] = {0, 0};
       for (int t = 0; t < s; ++t) keep[t] = S.idx[m.keep_map + t];
       for (int t = 0; t < ni; ++t) integ[t] = S.idx[m.int_map + t];
@@ -298,32 +309,32 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
       }
     }
     // ---- divide! and mult!
-    double* __restrict__ sep = pool + m.sep_off;
-    double* __restrict__ to = pool + m.to_off;
-    double* __restrict__ res = rpool + m.res_off;
+    auto sep = [&](int t) -> double& { return *bel(m.sep_b, m.sep_off, t); };
+    auto to = [&](int t) -> double& { return *bel(m.to_b, m.to_off, t); };
+    auto res = [&](int t) -> double& { return *rsd(en.msg, m.res_off, t); };
     int up[2] = {0, 0};
     for (int t = 0; t < s; ++t) up[t] = S.idx[m.up_map + t];
     double maxJ = 0.0, maxh = 0.0;
     for (int b = 0; b < s; ++b) {
       for (int a = 0; a < s; ++a) {
         const int o = a + b * s;
-        const double dJ = mJ[o] - sep[o];
-        sep[o] = mJ[o];
-        res[o] = dJ;
-        to[up[a] + up[b] * mt] += dJ;
+        const double dJ = mJ[o] - sep(o);
+        sep(o) = mJ[o];
+        res(o) = dJ;
+        to(up[a] + up[b] * mt) += dJ;
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
       const int o = s * s + b;
-      const double dh = mh[b] - sep[o];
-      sep[o] = mh[b];
-      res[o] = dh;
-      to[mt * mt + up[b]] += dh;
+      const double dh = mh[b] - sep(o);
+      sep(o) = mh[b];
+      res(o) = dh;
+      to(mt * mt + up[b]) += dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
     const int og = s * s + s;
-    const double dg = gmsg - sep[og];
-    sep[og] = gmsg;
-    to[mt * mt + mt] += dg;
+    const double dg = gmsg - sep(og);
+    sep(og) = gmsg;
+    to(mt * mt + mt) += dg;
     S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
     if (S.update_resnorm) {
       const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
@@ -336,8 +347,12 @@ void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry*
                       int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
   const int bs = n_sites >= 256 ? 256 : 64;
-  hipLaunchKernelGGL(bp_level_uni, dim3(ntasks, (n_sites + bs - 1) / bs), dim3(bs), 0, st, S, d_task_off, d_entries,
-                     task0, n_sites, seq_base, stop_below);
+  if (S.sm)
+    hipLaunchKernelGGL(bp_level_uni<true>, dim3(ntasks, (n_sites + bs - 1) / bs), dim3(bs), 0, st, S, d_task_off,
+                       d_entries, task0, n_sites, seq_base, stop_below);
+  else
+    hipLaunchKernelGGL(bp_level_uni<false>, dim3(ntasks, (n_sites + bs - 1) / bs), dim3(bs), 0, st, S, d_task_off,
+                       d_entries, task0, n_sites, seq_base, stop_below);
 }
 
 size_t generic_lds_bytes(int max_mf) {
@@ -878,6 +893,131 @@ void launch_copy_records(const double* src, int64_t src_stride, double* dst, int
   const int gx = std::min((n_records + 3) / 4, 16384);
   hipLaunchKernelGGL(copy_records_kernel, dim3(gx, n_sites), dim3(256), 0, st, src, src_stride, dst, dst_stride, d_boff,
                      d_dim, n_records, bs16, fast_p);
+}
+
+// ---- site-minor layout (univariate batches) ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void site_minor_kernel(double* __restrict__ plain, int64_t plain_stride,
+                                                         double* __restrict__ sm, const int64_t* __restrict__ off,
+                                                         const int64_t* __restrict__ poff, int n_records, int n_sites,
+                                                         int to_sm) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  for (int r = blockIdx.x; r < n_records; r += gridDim.x) {
+    const int64_t p0 = poff[r], len = poff[r + 1] - p0;
+    double* __restrict__ rec = plain + (int64_t)site * plain_stride + off[r];
+    for (int64_t t = 0; t < len; ++t) {
+      if (to_sm) sm[(p0 + t) * n_sites + site] = rec[t];
+      else rec[t] = sm[(p0 + t) * n_sites + site];
+    }
+  }
+}
+
+void launch_site_minor(double* plain, int64_t plain_stride, double* sm, const int64_t* d_off, const int64_t* d_poff,
+                       int n_records, int n_sites, int to_sm, hipStream_t st) {
+  if (n_records <= 0) return;
+  const int bs = n_sites >= 256 ? 256 : 64;
+  const int gx = n_records < 16384 ? n_records : 16384;
+  hipLaunchKernelGGL(site_minor_kernel, dim3(gx, (n_sites + bs - 1) / bs), dim3(bs), 0, st, plain, plain_stride, sm, d_off,
+                     d_poff, n_records, n_sites, to_sm);
+}
+
+// integratebelief(h, J, g) (src/beliefupdates.jl:187-200) for m <= 2, site-minor layout, one thread per site
+__global__ __launch_bounds__(256) void integrate_sm_kernel(const double* __restrict__ pool, int64_t p0, int m,
+                                                           double* __restrict__ mu, int mu_stride,
+                                                           double* __restrict__ norm, int32_t* __restrict__ info,
+                                                           int n_sites) {
+  const int site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  const int64_t ns = n_sites;
+  auto E = [&](int t) { return pool[(p0 + t) * ns + site]; };
+  double g = E(m * m + m);
+  int bad = 0;
+  double m0 = 0.0, m1 = 0.0, nrm = g;
+  if (m == 1) {
+    const double J = E(0), h = E(1);
+    if (J == 0.0 && h == 0.0) { m0 = INFINITY; }               // iszero(h) && iszero(J): (:189-191)
+    else if (!(J > 0.0)) bad = 1;
+    else { m0 = h / J; nrm = g + 0.5 * (PGBP_LOG2PI - log(J) + h * m0); }
+  } else if (m == 2) {
+    const double a = E(0), b = E(2), d = E(3), h0 = E(4), h1 = E(5);  // Symmetric(J): upper triangle
+    if (a == 0.0 && E(1) == 0.0 && b == 0.0 && d == 0.0 && h0 == 0.0 && h1 == 0.0) { m0 = m1 = INFINITY; }
+    else if (!(a > 0.0)) bad = 1;
+    else {
+      const double s = d - b * b / a;
+      if (!(s > 0.0)) bad = 2;
+      else {
+        m1 = (h1 - b / a * h0) / s;
+        m0 = (h0 - b * m1) / a;
+        nrm = g + 0.5 * (2.0 * PGBP_LOG2PI - (log(a) + log(s)) + h0 * m0 + h1 * m1);
+      }
+    }
+  }
+  if (mu) {
+    if (m >= 1) mu[(int64_t)site * mu_stride] = m0;
+    if (m >= 2) mu[(int64_t)site * mu_stride + 1] = m1;
+  }
+  norm[site] = bad ? NAN : nrm;
+  if (info) info[site] = bad;
+}
+
+void launch_integrate_sm(const double* pool_sm, int64_t packed_off_b, int m, double* d_mu, int mu_stride, double* d_norm,
+                         int32_t* d_info, int n_sites, hipStream_t st) {
+  hipLaunchKernelGGL(integrate_sm_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, st, pool_sm, packed_off_b, m, d_mu,
+                     mu_stride, d_norm, d_info, n_sites);
+}
+
+// assignfactors! for a univariate BM on a tree (formulas: bm_tree_fill_kernel below with p = 1), site-minor layout
+__global__ __launch_bounds__(256) void bm_tree_fill_uni_sm_kernel(double* __restrict__ pool, double* __restrict__ fpool,
+                                                                  const int64_t* __restrict__ poff,
+                                                                  const int32_t* __restrict__ dim,
+                                                                  const int32_t* __restrict__ kind,
+                                                                  const double* __restrict__ length,
+                                                                  const int32_t* __restrict__ row,
+                                                                  const double* __restrict__ data, int n_rows,
+                                                                  const double* __restrict__ Rinv_all,
+                                                                  const double* __restrict__ logdetR_all,
+                                                                  const double* __restrict__ mu_all, int per_site,
+                                                                  int n_clusters, int n_sites) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  const int64_t ns = n_sites;
+  const double rinv = Rinv_all[per_site ? site : 0], mu = mu_all[per_site ? site : 0];
+  const double g_base = -0.5 * (PGBP_LOG2PI + logdetR_all[per_site ? site : 0]);
+  for (int c = blockIdx.x; c < n_clusters; c += gridDim.x) {
+    const int k = kind[c], m = dim[c];
+    const int64_t p0 = poff[c];
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    int len = m * m + m + 1;
+    if (k >= 0) {
+      const double j = rinv / length[c];
+      double g = g_base - 0.5 * log(length[c]);
+      double x = 0.0;
+      if (k >= 1) {
+        x = (k >= 2) ? data[((int64_t)site * n_rows + row[c])] : mu;
+        if (k == 3) x -= mu;
+        g -= 0.5 * j * x * x;
+      }
+      if (k == 0) { v[0] = j; v[1] = -j; v[2] = -j; v[3] = j; v[6] = g; }
+      else if (k <= 2) { v[0] = j; v[1] = j * x; v[2] = g; }
+      else { v[0] = g; }
+    }
+    for (int t = 0; t < len; ++t) {
+      pool[(p0 + t) * ns + site] = v[t];
+      if (fpool) fpool[(p0 + t) * ns + site] = v[t];
+    }
+  }
+}
+
+void launch_bm_tree_fill_uni_sm(double* pool_sm, double* fpool_sm, const int64_t* d_poff, const int32_t* d_dim,
+                                const int32_t* d_kind, const double* d_length, const int32_t* d_row, const double* d_data,
+                                int n_rows, const double* d_Rinv, const double* d_logdetR, const double* d_mu, int per_site,
+                                int n_clusters, int n_sites, hipStream_t st) {
+  if (n_clusters <= 0) return;
+  const int bs = n_sites >= 256 ? 256 : 64;
+  const int gx = n_clusters < 16384 ? n_clusters : 16384;
+  hipLaunchKernelGGL(bm_tree_fill_uni_sm_kernel, dim3(gx, (n_sites + bs - 1) / bs), dim3(bs), 0, st, pool_sm, fpool_sm,
+                     d_poff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, n_clusters,
+                     n_sites);
 }
 
 // all strides / offsets / counts are multiples of 2 doubles (records are padded to 16)

@@ -27,6 +27,12 @@ struct DevState {
   double atol;
   int32_t bs16;    // beliefs of dimension P / 2P and residuals of P-dim sepsets are in the packed layout
   int32_t fast_p;  // P: sepset dimension of the register-resident kernel (16, 8 or 4; 0: none)
+  // site-minor layout (univariate batches, every dimension <= 2): element t of belief b of site s lives at
+  // pool[(packed_off[b] + t) * n_sites + s] (residuals: rpacked_off[msg]); pool / rpool then point at those buffers
+  int32_t sm;
+  int32_t n_sites;
+  const int64_t* packed_off;
+  const int64_t* rpacked_off;
 };
 
 size_t generic_lds_bytes(int max_mf);
@@ -61,6 +67,20 @@ void launch_records(const double* src, int64_t src_stride, const int64_t* d_src_
 void launch_copy_strided(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, int64_t n,
                          int n_sites, hipStream_t st);
 void launch_zero_strided(double* dst, int64_t dst_stride, int64_t n, int n_sites, hipStream_t st);
+
+// site-minor layout (DevState::sm): transposition of the records listed by (d_off: padded plain offsets, d_poff: packed
+// offsets) between plain[site * stride + off[r] + t] and sm[(poff[r] + t) * n_sites + site]; to_sm != 0: plain -> sm
+void launch_site_minor(double* plain, int64_t plain_stride, double* sm, const int64_t* d_off, const int64_t* d_poff,
+                       int n_records, int n_sites, int to_sm, hipStream_t st);
+// integratebelief! of one belief of dimension <= 2 in the site-minor layout, one thread per site
+void launch_integrate_sm(const double* pool_sm, int64_t packed_off_b, int m, double* d_mu, int mu_stride, double* d_norm,
+                         int32_t* d_info, int n_sites, hipStream_t st);
+// assignfactors! for a univariate BM on a tree (pgbp_bm_tree, p = 1) straight into the site-minor layout;
+// fpool_sm may be null (beliefs only)
+void launch_bm_tree_fill_uni_sm(double* pool_sm, double* fpool_sm, const int64_t* d_poff, const int32_t* d_dim,
+                                const int32_t* d_kind, const double* d_length, const int32_t* d_row, const double* d_data,
+                                int n_rows, const double* d_Rinv, const double* d_logdetR, const double* d_mu, int per_site,
+                                int n_clusters, int n_sites, hipStream_t st);
 // record-aware copy: only the part of each record slot that the current layout uses (pgbp_kernels.hip)
 void launch_copy_records(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, const int64_t* d_boff,
                          const int32_t* d_dim, int n_records, int bs16, int fast_p, int n_sites, hipStream_t st);

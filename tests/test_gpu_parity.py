@@ -421,7 +421,7 @@ def test_cfg4_univariate_ou_sites(P):
     cg = OB.ClusterGraph(clusters, edges, "cliquetree")
     spt = ([str(x) for x in prob.schedule[0][0]], [str(x) for x in prob.schedule[0][1]],
            prob.schedule[0][0].tolist(), prob.schedule[0][1].tolist())
-    for ns in (3, 11):   # 3: wavefront-per-message kernel; 11: thread-per-site kernel
+    for ns in (3, 11, 70):   # 3: wavefront-per-message kernel; 11: thread-per-site kernel; 70: + site-minor layout
         packs, dense, ocgbs = [], [], []
         for s in range(ns):
             model = OM.UnivariateOrnsteinUhlenbeck(rng.uniform(0.5, 2), rng.uniform(0.1, 1), rng.normal(), rng.normal(), 0.0)
@@ -459,6 +459,27 @@ def test_cfg4_univariate_ou_sites(P):
         res = eng2.last_results
         assert [res[s].succ for s in range(ns)] == [int(s != ns - 2) for s in range(ns)]
         assert res[ns - 2].fail_info == 1 and res[ns - 2].fail_dir == 0
+    # site-minor state (ns = 70): entry points that need the plain layout bring it back transparently
+    fe, feinfo = eng.free_energy(all_sites=True)
+    assert not feinfo.any() and all(rel_close(a, b) for a, b in zip(fe[ns - 1], OB.free_energy(ocgbs[ns - 1])))
+    assert P.calibrate_(eng, prob.schedule, 1) == (True, True)          # back to site-minor, state intact
+    assert np.allclose(eng._packed[ns - 1], pack_oracle(ocgbs[ns - 1], prob), rtol=1e-8, atol=1e-8)
+    # device factor fill straight into the site-minor state: univariate BM with one (sigma2, mu) per site
+    sig = rng.uniform(0.5, 2.0, size=ns)
+    mus = rng.normal(size=ns)
+    X = S.simulate_bm_uni_sites(tr, sig, mus, rng)
+    eng.bm_tree_setup(*S.bm_tree_table(tr, prob), X[:, :, None])
+    eng.assignfactors_bm_(sig[:, None, None], mus[:, None])
+    assert P.calibrate_(eng, prob.schedule, 1)[0]
+    ll = eng.integratebelief_(prob.root_cluster, all_sites=True)[1]
+    assert np.allclose(ll, S.bm_loglik_pruning_uni_sites(tr, sig, mus, X), rtol=1e-9, atol=0)
+    import ctypes as C
+    from pgbp_amd import _lib as L
+    o = eng._opts()
+    assert eng._lib.pgbp_enqueue_loglik_bm(eng._eng, 2, C.byref(o)) == 0      # fill + postorder + integrate, twice
+    norm, info = np.zeros(ns), np.zeros(ns, np.int32)
+    assert eng._lib.pgbp_fetch_loglik(eng._eng, L.f64p(norm), L.i32p(info)) == 0 and not info.any()
+    assert np.allclose(norm, ll, rtol=1e-12, atol=0)
 
 
 def test_multi_site_p16_bs16(P):
