@@ -62,6 +62,9 @@ struct pgbp_engine {
   int32_t max_s = 0;                // largest sepset dimension
   // site-minor copies of the pools (univariate batches: every dimension <= 2), allocated at first use
   double *d_pool_sm = nullptr, *d_fpool_sm = nullptr, *d_rpool_sm = nullptr;
+  // second copies of the per-message / per-cluster word arrays: a layout switch transposes into them and swaps
+  int32_t *d_flags_alt = nullptr, *d_status_alt = nullptr, *d_klflags_alt = nullptr, *d_poison_alt = nullptr;
+  double* d_kldiv_alt = nullptr;
   bool layout_sm = false;           // the live state is in the site-minor buffers
   bool layout_bs16 = false;         // current device layout of 16/32-dim beliefs and 16-dim residuals
   bool sym_known = false, sym_ok = false;
@@ -161,8 +164,25 @@ int ensure_site_minor(pgbp_engine* e, bool want) {
     if ((rc = dev_alloc(e, &e->d_pool_sm, ns * (size_t)p.packed_off.back()))) return rc;
     if ((rc = dev_alloc(e, &e->d_fpool_sm, ns * (size_t)p.packed_off[p.n_clusters]))) return rc;
     if ((rc = dev_alloc(e, &e->d_rpool_sm, ns * (size_t)p.rpacked_off.back()))) return rc;
+    const size_t nm = (size_t)p.n_msgs();
+    if ((rc = dev_alloc(e, &e->d_flags_alt, ns * nm))) return rc;
+    if ((rc = dev_alloc(e, &e->d_status_alt, ns * nm))) return rc;
+    if ((rc = dev_alloc(e, &e->d_klflags_alt, ns * nm))) return rc;
+    if ((rc = dev_alloc(e, &e->d_kldiv_alt, ns * nm))) return rc;
+    if ((rc = dev_alloc(e, &e->d_poison_alt, ns * (size_t)std::max(1, p.n_clusters)))) return rc;
   }
   const int to = want ? 1 : 0;
+  // flags, status, KL words and poison marks: [site][index] <-> [index][site]
+  launch_transpose_words_i32(e->d_flags, e->d_flags_alt, p.n_msgs(), p.n_sites, to, e->st);
+  launch_transpose_words_i32(e->d_status, e->d_status_alt, p.n_msgs(), p.n_sites, to, e->st);
+  launch_transpose_words_i32(e->d_klflags, e->d_klflags_alt, p.n_msgs(), p.n_sites, to, e->st);
+  launch_transpose_words_f64(e->d_kldiv, e->d_kldiv_alt, p.n_msgs(), p.n_sites, to, e->st);
+  launch_transpose_words_i32(e->d_poison, e->d_poison_alt, p.n_clusters, p.n_sites, to, e->st);
+  std::swap(e->d_flags, e->d_flags_alt);
+  std::swap(e->d_status, e->d_status_alt);
+  std::swap(e->d_klflags, e->d_klflags_alt);
+  std::swap(e->d_kldiv, e->d_kldiv_alt);
+  std::swap(e->d_poison, e->d_poison_alt);
   launch_site_minor(e->d_pool, p.pool_stride(), e->d_pool_sm, e->d_boff, e->d_packed_off, p.n_beliefs(), p.n_sites, to, e->st);
   launch_site_minor(e->d_fpool, p.cluster_stride(), e->d_fpool_sm, e->d_boff, e->d_packed_off, p.n_clusters, p.n_sites, to, e->st);
   launch_site_minor(e->d_rpool, p.rpool_stride(), e->d_rpool_sm, e->d_roff, e->d_rpacked_off, p.n_msgs(), p.n_sites, to, e->st);
@@ -334,7 +354,8 @@ void pgbp_destroy(pgbp_engine* e) {
   (void)hipSetDevice(e->plan.device);
   free_traversals(e);
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
-                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_fail, (void*)e->d_poison,
+                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_flags_alt, (void*)e->d_status_alt,
+                  (void*)e->d_klflags_alt, (void*)e->d_poison_alt, (void*)e->d_kldiv_alt, (void*)e->d_fail, (void*)e->d_poison,
                   (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
@@ -435,7 +456,7 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
     e->err = "hipMemsetAsync failed";
     return bail(PGBP_ERR_HIP);
   }
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, (int)nm, p.n_sites, 1, e->st);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, (int)nm, p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);
   if (hipStreamSynchronize(e->st) != hipSuccess) {
     e->err = "initialisation kernels failed";
     return bail(PGBP_ERR_HIP);
@@ -550,7 +571,7 @@ int pgbp_reset_from_factors(pgbp_engine* e) {
 
 int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
   if (!e) return PGBP_ERR_INVALID;
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st, e->layout_sm ? 1 : 0);
   return pgbp_sync(e);
 }
 
@@ -558,7 +579,7 @@ int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_res
                        int32_t* iscalibrated_kl) {
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
-  if (packed) {
+  if (packed || e->layout_sm) {  // the word arrays are transposed in the site-minor layout
     int rc0 = ensure_layout(e, false);
     if (rc0) return rc0;
   }
@@ -739,7 +760,7 @@ int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* op
   if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e) && !(opts && opts->update_residualkldiv)))) return rc;
   DevState S = dev_state(e, opts);
   enqueue_traversal(e, S, tree, dir, (unsigned long long)tree, nullptr, nullptr, opts && opts->update_residualkldiv);
-  launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
+  launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st, e->layout_sm ? 1 : 0);
   return collect_results(e, results, nullptr, 0);
 }
 
@@ -780,7 +801,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
       const unsigned long long pair = (unsigned long long)i * nt + j;
       enqueue_traversal(e, S, j, 0, pair, nullptr, nullptr, kl);
       enqueue_traversal(e, S, j, 1, pair, nullptr, nullptr, kl);
-      launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st);
+      launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st, e->layout_sm ? 1 : 0);
       ++pairs_done;
       if (auto_stop) {
         // `auto`: stop after the first tree at which calibration is reached (src/calibration.jl:53-56);
@@ -909,7 +930,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors) {
                                e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, p.n_clusters, p.n_sites, e->st);
     const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
     HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
-    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st);
+    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
     if (also_factors) e->have_factors = true;
     return PGBP_OK;
   }
@@ -932,7 +953,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors) {
   }
   launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                       p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
   if (also_factors) e->have_factors = true;
   return PGBP_OK;
 }
@@ -979,12 +1000,12 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
   if (reset_each) {
     int rc = reset_from_factors_async(e);
     if (rc) return rc;
-    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);
+    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);
   }
   for (int j = 0; j < (int)p.trees.size(); ++j) {
     enqueue_traversal(e, S, j, 0, (unsigned long long)j, ev, n_launches);
     enqueue_traversal(e, S, j, 1, (unsigned long long)j, ev, n_launches);
-    launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st);
+    launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st, e->layout_sm ? 1 : 0);
   }
   return PGBP_OK;
 }
@@ -1006,7 +1027,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
   const Plan& p = e->plan;
   int rc = reset_from_factors_async(e);
   if (rc) return rc;
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st);  // calibration.jl:209
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);  // calibration.jl:209
   enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
   integrate_async(e, root, nullptr);         // :212

@@ -238,6 +238,16 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     if constexpr (SM) return S.pool + (S.packed_off[b] + t) * ns + site;
     else return pool + plain_off + t;
   };
+  // per-message / per-cluster words (flags, status, poison): [site][index] in the plain layout, [index][site] in the
+  // site-minor one
+  auto mword = [&](int32_t* base, int msg) -> int32_t* {
+    if constexpr (SM) return base + (int64_t)msg * ns + site;
+    else return base + (int64_t)site * S.n_msgs + msg;
+  };
+  auto cword = [&](int32_t* base, int c) -> int32_t* {
+    if constexpr (SM) return base + (int64_t)c * ns + site;
+    else return base + (int64_t)site * S.n_clusters + c;
+  };
   auto rsd = [&](int msg, int64_t plain_off, int t) -> double* {
     if constexpr (SM) return S.rpool + (S.rpacked_off[msg] + t) * ns + site;
     else return rpool + plain_off + t;
@@ -247,8 +257,8 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
   for (int e = e0; e < e1; ++e) {
     const Entry en = entries[e];
     const MsgDesc m = S.msgs[en.msg];
-    if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
-      S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+    if (*cword(S.poison, m.from_b)) {
+      *cword(S.poison, m.to_b) = 1;
       return;
     }
     const int mf = m.mf, s = m.s, mt = m.mt, ni = m.ni;
@@ -284,8 +294,8 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
             if (!(d1 > 0.0)) info = 2;
           }
           if (info) {
-            S.status[(int64_t)site * S.n_msgs + en.msg] = info;
-            S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+            *mword(S.status, en.msg) = info;
+            *cword(S.poison, m.to_b) = 1;
             atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
             return;
           }
@@ -335,10 +345,10 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     const double dg = gmsg - sep(og);
     sep(og) = gmsg;
     to(mt * mt + mt) += dg;
-    S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
+    *mword(S.status, en.msg) = 0;
     if (S.update_resnorm) {
       const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
-      S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
+      *mword(S.flags, en.msg) = ok ? 1 : 0;
     }
   }
 }
@@ -1140,9 +1150,31 @@ __global__ void reset_flags_kernel(const MsgDesc* __restrict__ msgs, int32_t* __
   }
 }
 
+// the same on the site-minor arrays ([message][site]): threads = sites
+__global__ __launch_bounds__(256) void reset_flags_sm_kernel(const MsgDesc* __restrict__ msgs, int32_t* __restrict__ flags,
+                                                             int32_t* __restrict__ klflags, double* __restrict__ kldiv,
+                                                             int n_msgs, int n_sites, int reset_kl) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  for (int d = blockIdx.x; d < n_msgs; d += gridDim.x) {
+    const bool empty = msgs[d].s == 0;
+    const int64_t o = (int64_t)d * n_sites + site;
+    flags[o] = empty ? 1 : 0;
+    klflags[o] = empty ? 1 : 0;
+    if (empty) kldiv[o] = 0.0;
+    else if (reset_kl) kldiv[o] = -1.0;
+  }
+}
+
 void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, int32_t* klflags, double* kldiv, int n_msgs, int n_sites,
-                        int reset_kl, hipStream_t st) {
+                        int reset_kl, hipStream_t st, int sm) {
   if (n_msgs <= 0) return;
+  if (sm) {
+    const int bs = n_sites >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(reset_flags_sm_kernel, dim3(n_msgs < 4096 ? n_msgs : 4096, (n_sites + bs - 1) / bs), dim3(bs), 0, st,
+                       msgs, flags, klflags, kldiv, n_msgs, n_sites, reset_kl);
+    return;
+  }
   hipLaunchKernelGGL(reset_flags_kernel, dim3(grid_for(n_msgs, n_sites), n_sites), dim3(256), 0, st, msgs, flags,
                      klflags, kldiv, n_msgs, reset_kl);
 }
@@ -1158,11 +1190,54 @@ __global__ __launch_bounds__(256) void reduce_flags_kernel(const int32_t* __rest
   if (__any(bad) && (threadIdx.x & 63) == 0) iscal[site] = 0;
 }
 
-void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st) {
+// site-minor flags ([message][site]): threads = sites, each ANDs its column
+__global__ __launch_bounds__(256) void reduce_flags_sm_kernel(const int32_t* __restrict__ flags, int n_msgs, int n_sites,
+                                                              int32_t* __restrict__ iscal) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  int bad = 0;
+  for (int d = blockIdx.x; d < n_msgs; d += gridDim.x) bad |= (flags[(int64_t)d * n_sites + site] == 0);
+  if (bad) iscal[site] = 0;
+}
+
+void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st, int sm) {
   (void)hipMemsetAsync(d_iscal, 0x01, sizeof(int32_t) * (size_t)n_sites, st);
   if (n_msgs <= 0) return;
+  if (sm) {
+    const int bs = n_sites >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(reduce_flags_sm_kernel, dim3(n_msgs < 1024 ? n_msgs : 1024, (n_sites + bs - 1) / bs), dim3(bs), 0, st,
+                       flags, n_msgs, n_sites, d_iscal);
+    return;
+  }
   hipLaunchKernelGGL(reduce_flags_kernel, dim3(grid_for(n_msgs, n_sites), n_sites), dim3(256), 0, st, flags,
                      n_msgs, d_iscal);
+}
+
+// [n_sites][n] <-> [n][n_sites] transposition of the per-message / per-cluster word arrays (site-minor layout switch);
+// T = int32_t or double; to_sm != 0: src is [site][n]
+template <class T>
+__global__ __launch_bounds__(256) void transpose_words_kernel(const T* __restrict__ src, T* __restrict__ dst, int n,
+                                                              int n_sites, int to_sm) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  for (int d = blockIdx.x; d < n; d += gridDim.x) {
+    const int64_t a = (int64_t)site * n + d, b = (int64_t)d * n_sites + site;
+    if (to_sm) dst[b] = src[a];
+    else dst[a] = src[b];
+  }
+}
+
+void launch_transpose_words_i32(const int32_t* src, int32_t* dst, int n, int n_sites, int to_sm, hipStream_t st) {
+  if (n <= 0) return;
+  const int bs = n_sites >= 256 ? 256 : 64;
+  hipLaunchKernelGGL(transpose_words_kernel<int32_t>, dim3(n < 8192 ? n : 8192, (n_sites + bs - 1) / bs), dim3(bs), 0, st, src,
+                     dst, n, n_sites, to_sm);
+}
+void launch_transpose_words_f64(const double* src, double* dst, int n, int n_sites, int to_sm, hipStream_t st) {
+  if (n <= 0) return;
+  const int bs = n_sites >= 256 ? 256 : 64;
+  hipLaunchKernelGGL(transpose_words_kernel<double>, dim3(n < 8192 ? n : 8192, (n_sites + bs - 1) / bs), dim3(bs), 0, st, src,
+                     dst, n, n_sites, to_sm);
 }
 
 }  // namespace pgbp

@@ -108,8 +108,11 @@ void launch_free_energy(const double* pool, int64_t pool_stride, const double* f
                         const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
                         int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st);
 
+// sm != 0: the arrays are in the site-minor order [message][site]
 void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, int32_t* klflags, double* kldiv, int n_msgs, int n_sites,
-                        int reset_kl, hipStream_t st);
+                        int reset_kl, hipStream_t st, int sm = 0);
+void launch_transpose_words_i32(const int32_t* src, int32_t* dst, int n, int n_sites, int to_sm, hipStream_t st);
+void launch_transpose_words_f64(const double* src, double* dst, int n, int n_sites, int to_sm, hipStream_t st);
 
 // residual_kldiv! (src/beliefs.jl:1060-1075) for the messages entries[e0 .. e0+n_entries) just sent by a level
 void launch_residual_kldiv(const DevState& S, const Entry* d_entries, int e0, int n_entries, int max_s, double* d_kldiv,
@@ -120,6 +123,6 @@ void launch_regularize_bycluster(double* pool, int64_t pool_stride, const int64_
                                  const int32_t* d_nb_off, const int32_t* d_nb_msg, const MsgDesc* d_msgs,
                                  const int32_t* d_idx, const int32_t* d_sepcl, double* d_eps, int n_clusters,
                                  int n_sepsets, int n_sites, hipStream_t st);
-void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st);
+void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st, int sm = 0);
 
 }  // namespace pgbp
