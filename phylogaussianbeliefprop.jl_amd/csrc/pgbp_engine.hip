@@ -134,6 +134,7 @@ DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
   S.n_sites = e->plan.n_sites;
   S.packed_off = e->d_packed_off;
   S.rpacked_off = e->d_rpacked_off;
+  S.sep_zero = 0;
   if (e->layout_sm) {
     S.pool = e->d_pool_sm;
     S.rpool = e->d_rpool_sm;
@@ -224,6 +225,14 @@ int ensure_layout(pgbp_engine* e, bool want_bs16, bool want_sm = false) {
 }
 
 // layout wanted by the traversals of the current schedule
+// The postorder of tree 0 writes every sepset and, straight after a reset, would read only zeros from them: true when
+// that traversal runs entirely on the register-resident kernel (which honours DevState::sep_zero) and the schedule
+// tree spans every sepset (a clique tree, the Bethe graph of a tree).
+bool fresh_sepsets_shortcut(const pgbp_engine* e) {
+  const Plan& p = e->plan;
+  return !e->layout_sm && p.all_fast && !p.trees.empty() && (int)p.trees[0].pa.size() == p.n_sepsets;
+}
+
 bool want_bs16(const pgbp_engine* e) {
   static const bool disabled = getenv("PGBP_DISABLE_BS16") != nullptr;  // A/B and debugging aid
   return !disabled && e->plan.all_fast && e->plan.fast_p > 0;
@@ -306,7 +315,8 @@ void integrate_async(pgbp_engine* e, int belief, double* d_mu) {
                      std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);
 }
 
-int reset_from_factors_async(pgbp_engine* e) {
+// skip_sepsets: the caller's next traversal overwrites every sepset without reading it (DevState::sep_zero)
+int reset_from_factors_async(pgbp_engine* e, bool skip_sepsets = false) {
   if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "no factors: call pgbp_set_beliefs(snapshot) or pgbp_init_factors_frombeliefs first");
   const Plan& p = e->plan;
   if (e->layout_sm) {  // cluster elements come first and are contiguous over sites
@@ -320,8 +330,9 @@ int reset_from_factors_async(pgbp_engine* e) {
                         p.fast_p, p.n_sites, e->st);
   else
     launch_copy_strided(e->d_fpool, p.cluster_stride(), e->d_pool, p.pool_stride(), p.cluster_stride(), p.n_sites, e->st);
-  launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
-                      p.n_sites, e->st);
+  if (!skip_sepsets)
+    launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
+                        p.n_sites, e->st);
   return PGBP_OK;
 }
 
@@ -922,7 +933,7 @@ int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
 
 // also_factors: assignfactors! followed by init_factors_frombeliefs! (what the callers of the optimisers do once);
 // without it only the beliefs are written, as in the body of score() (src/calibration.jl:205-209).
-static int bm_fill_async(pgbp_engine* e, bool also_factors) {
+static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = false) {
   const Plan& p = e->plan;
   if (e->layout_sm && e->bm_p == 1) {  // univariate batch, site-minor state
     launch_bm_tree_fill_uni_sm(e->d_pool_sm, also_factors ? e->d_fpool_sm : nullptr, e->d_packed_off, e->d_bdim,
@@ -951,8 +962,9 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors) {
                         e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.fast_p, p.n_clusters, p.n_sites, e->st);
     also_factors = true;  // the general kernel always writes both
   }
-  launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
-                      p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
+  if (!skip_sepsets)
+    launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
+                        p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
   if (also_factors) e->have_factors = true;
   return PGBP_OK;
@@ -984,8 +996,10 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
   DevState S = dev_state(e, opts);
   const Plan& p = e->plan;
   for (int r = 0; r < reps; ++r) {
-    if ((rc = bm_fill_async(e, false))) return rc;               // assignfactors!        calibration.jl:205-209
-    enqueue_traversal(e, S, 0, 0, 0);                            // postorder             :210
+    DevState S1 = S;
+    S1.sep_zero = fresh_sepsets_shortcut(e) ? 1 : 0;
+    if ((rc = bm_fill_async(e, false, S1.sep_zero != 0))) return rc;   // assignfactors!        calibration.jl:205-209
+    enqueue_traversal(e, S1, 0, 0, 0);                           // postorder             :210
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
     integrate_async(e, root, nullptr);  // :212
   }
@@ -1023,9 +1037,11 @@ int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, con
   return PGBP_OK;
 }
 
-static int enqueue_loglik_once(pgbp_engine* e, const DevState& S) {
+static int enqueue_loglik_once(pgbp_engine* e, const DevState& S0) {
   const Plan& p = e->plan;
-  int rc = reset_from_factors_async(e);
+  DevState S = S0;
+  S.sep_zero = fresh_sepsets_shortcut(e) ? 1 : 0;
+  int rc = reset_from_factors_async(e, S.sep_zero != 0);
   if (rc) return rc;
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);  // calibration.jl:209
   enqueue_traversal(e, S, 0, 0, 0);                                                         // :210

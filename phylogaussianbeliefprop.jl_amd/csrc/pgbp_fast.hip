@@ -288,11 +288,13 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
     // ---- every load of this message is issued before any arithmetic; the sender (the largest operand and
     // the one the elimination waits for) goes first, the sepset and the receiver block right behind it
     auto load_sep_to = [&]() {
-      if (has_block) {
-        sJ = load_blk<BS>(sep, P, a, b, up, kidx);
-        if (b == 0) sh = *reinterpret_cast<const double2*>(sep + sepH + 2 * a);
+      if (!S.sep_zero) {
+        if (has_block) {
+          sJ = load_blk<BS>(sep, P, a, b, up, kidx);
+          if (b == 0) sh = *reinterpret_cast<const double2*>(sep + sepH + 2 * a);
+        }
+        sg = sep[sepG];
       }
-      sg = sep[sepG];
       if (own) {
         if (accum || has_block) {
           tJ = load_blk<BS>(to + tJ0, mt, a, b, up, kidx);
