@@ -350,11 +350,11 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
         } else {
           // logical index = original index rotated so that the integrated block comes first
           const int rot = (en.keep0 == 0) ? P : 0;
-          const int r0 = (2 * a + rot) & (2 * P - 1), r1 = (2 * a + P + rot) & (2 * P - 1);
+          const int r0 = (2 * a + rot) % (2 * P), r1 = (2 * a + P + rot) % (2 * P);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int cl = 2 * b + (j & 1) + (j >> 1) * P;  // logical column C_b(j)
-            const int64_t co = (int64_t)((cl + rot) & (2 * P - 1)) * (2 * P);
+            const int64_t co = (int64_t)((cl + rot) % (2 * P)) * (2 * P);
             if (j < 2) {
               const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
               f.w[0][j] = v.x; f.w[1][j] = v.y;
@@ -690,15 +690,20 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
   }
 }
 
-// The kernel is instantiated for sepsets of dimension 16 (all 64 lanes), 8 (16 lanes) and 4 (4 lanes); the
-// small-P instances trade lane utilisation for the same per-level latency (one wave per message).
+// The kernel is instantiated for every even sepset dimension P <= 16 ((P/2)^2 lanes: all 64 for P = 16, 16 for P = 8,
+// 1 for P = 2); the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
   switch (S.fast_p) {
     case 16: launch_fast_p<16>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 14: launch_fast_p<14>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 12: launch_fast_p<12>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 10: launch_fast_p<10>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
     case 8: launch_fast_p<8>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 6: launch_fast_p<6>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
     case 4: launch_fast_p<4>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 2: launch_fast_p<2>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
     default: break;  // the planner never marks a task fast for another P
   }
 #ifdef PGBP_TRACE

@@ -136,18 +136,18 @@ int plan_build(Plan& p, const pgbp_desc* d) {
     }
   }
   p.trees.clear();
-  // the register-resident kernel is instantiated for sepsets of dimension 16, 8 and 4 (pgbp_fast.hip): pick
-  // the dimension most sepsets have
+  // the register-resident kernel is instantiated for every even sepset dimension up to 16 (pgbp_fast.hip: 2 x 2 blocks
+  // per lane): pick the one most sepsets have
   p.fast_p = 0;
   {
-    int cnt[3] = {0, 0, 0};
-    const int cand[3] = {16, 8, 4};
-    for (int k = 0; k < p.n_sepsets; ++k)
-      for (int q = 0; q < 3; ++q)
-        if (p.dims[p.n_clusters + k] == cand[q]) ++cnt[q];
+    int cnt[17] = {0};
+    for (int k = 0; k < p.n_sepsets; ++k) {
+      const int s = p.dims[p.n_clusters + k];
+      if (s >= 2 && s <= 16 && s % 2 == 0) ++cnt[s];
+    }
     int best = 0;
-    for (int q = 0; q < 3; ++q)
-      if (cnt[q] > best) { best = cnt[q]; p.fast_p = cand[q]; }
+    for (int q = 16; q >= 2; q -= 2)
+      if (cnt[q] > best) { best = cnt[q]; p.fast_p = q; }
   }
   return PGBP_OK;
 }

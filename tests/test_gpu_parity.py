@@ -230,7 +230,10 @@ def test_auto_stop_and_info_log(P, caplog):
                                           (2, 16, "random"), (3, 16, "random"), (150, 16, "random"),
                                           (80, 16, "poly3"), (120, 16, "poly4"), (90, 16, "poly7"), (40, 3, "poly5"),
                                           (130, 8, "random"), (70, 8, "poly4"), (90, 4, "random"), (2, 8, "random"),
-                                          (3, 4, "random"), (40, 8, "caterpillar")])
+                                          (3, 4, "random"), (40, 8, "caterpillar"),
+                                          # every even trait count <= 16 has a register-resident instance
+                                          (50, 2, "random"), (45, 6, "random"), (35, 10, "poly3"), (40, 12, "random"),
+                                          (30, 14, "caterpillar"), (2, 6, "random"), (25, 5, "random"), (20, 7, "poly4")])
 def test_random_tree_cliquetree_vs_oracle(P, ntips, p, kind):
     from pgbp_amd import synth as S
     rng = np.random.default_rng(1000 * p + ntips)
@@ -557,7 +560,8 @@ def test_single_belief_access_and_set(P):
 
 @pytest.mark.parametrize("graph,ntips,p", [("cliquetree", 30, 16), ("cliquetree", 25, 3), ("bethe", 20, 4),
                                            ("cliquetree", 2, 16), ("cliquetree", 3, 1), ("bethe", 35, 8),
-                                           ("bethe", 30, 16), ("cliquetree", 40, 8)])
+                                           ("bethe", 30, 16), ("cliquetree", 40, 8), ("cliquetree", 30, 6),
+                                           ("bethe", 25, 12), ("cliquetree", 20, 2)])
 def test_device_factor_fill_bm_tree(P, graph, ntips, p):
     """pgbp_bm_tree_assignfactors (assignfactors! on the device) == the host fill that
     tests/test_plan_cpu.py pins against the oracle's assignfactors! restatement; a second parameter set is
