@@ -103,6 +103,31 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
       if (lane == 0) S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
       return;
     }
+    // sepset and receiver operands of this lane, requested BEFORE the gather / elimination so that their HBM latency
+    // runs beside it (small sepsets only: at most 4 (a, b) pairs per lane; larger ones are read after the elimination)
+    const bool pre = m.s > 0 && m.s <= 16;
+    double pre_sep[4] = {0, 0, 0, 0}, pre_to[4] = {0, 0, 0, 0}, pre_seph = 0.0, pre_toh = 0.0;
+    if (pre) {
+      const double* __restrict__ sep0 = pool + m.sep_off;
+      const double* __restrict__ to0 = pool + m.to_off;
+      const int32_t* __restrict__ up0 = S.idx + m.up_map;
+      const int s0 = m.s, L0 = pow2_at_least(s0), R0 = kWave / L0, a0 = lane & (L0 - 1);
+      if (a0 < s0) {
+        const int ua = up0[a0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int b = lane / L0 + q * R0;
+          if (b < s0) {
+            pre_sep[q] = sep0[a0 + (int64_t)b * s0];
+            pre_to[q] = to0[ua + (int64_t)up0[b] * m.mt];
+          }
+        }
+        if (lane / L0 == 0) {
+          pre_seph = sep0[(int64_t)s0 * s0 + a0];
+          pre_toh = to0[(int64_t)m.mt * m.mt + ua];
+        }
+      }
+    }
     if (!en.reuse) {
       const double* __restrict__ from = pool + m.from_off;
       mf = m.mf;
@@ -174,23 +199,39 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
       const int a = lane & (L - 1);
       if (a < s) {
         const int ua = up[a];
+        if (pre) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = lane / L + q * R;
+            if (b < s) {
+              const double msg = W[(ni + a) * ld + ni + b];
+              const int64_t o = a + (int64_t)b * s;
+              const double dJ = msg - pre_sep[q];
+              sep[o] = msg;
+              res[o] = dJ;
+              to[ua + (int64_t)up[b] * mt] = pre_to[q] + dJ;
+              maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+            }
+          }
+        } else {
 #pragma unroll 4
-        for (int b = lane / L; b < s; b += R) {
-          const double msg = W[(ni + a) * ld + ni + b];
-          const int64_t o = a + (int64_t)b * s;
-          const double dJ = msg - sep[o];
-          sep[o] = msg;
-          res[o] = dJ;
-          to[ua + (int64_t)up[b] * mt] += dJ;
-          maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+          for (int b = lane / L; b < s; b += R) {
+            const double msg = W[(ni + a) * ld + ni + b];
+            const int64_t o = a + (int64_t)b * s;
+            const double dJ = msg - sep[o];
+            sep[o] = msg;
+            res[o] = dJ;
+            to[ua + (int64_t)up[b] * mt] += dJ;
+            maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+          }
         }
         if (lane / L == 0) {
           const double msg = W[(ni + a) * ld + mf];
           const int64_t o = (int64_t)s * s + a;
-          const double dh = msg - sep[o];
+          const double dh = msg - (pre ? pre_seph : sep[o]);
           sep[o] = msg;
           res[o] = dh;
-          to[(int64_t)mt * mt + ua] += dh;
+          to[(int64_t)mt * mt + ua] = (pre ? pre_toh : to[(int64_t)mt * mt + ua]) + dh;
           maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
         }
       }
@@ -204,12 +245,10 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
     }
     if (S.update_resnorm) {
       // iscalibrated_residnorm!: max|dh|/sqrt(s) <= atol && max|dJ|/s <= atol (src/beliefs.jl:994-1003)
-      maxJ = wave_max(maxJ);
-      maxh = wave_max(maxh);
-      if (lane == 0) {
-        const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
-        S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
-      }
+      // x -> fl(x / c) is monotone: every lane tests its own maximum, one ballot instead of two wave reductions
+      const bool lane_ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+      const bool ok = __all(lane_ok);
+      if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
     }
     if (e + 1 < e1) __threadfence_block();  // next entry of the task may read-modify-write the same receiver
   }
