@@ -54,6 +54,7 @@ struct FEntry {
 static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
 constexpr int kFOwn = 1, kFAccum = 2;
 constexpr int kFastMaxWaves = 4;
+constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
 
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first

@@ -214,6 +214,16 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
         slow.push_back(t);
       }
     }
+    // A level that needs the generic kernel anyway and has too few fast-class tasks to fill the chip runs entirely on
+    // the generic kernel: one launch instead of two (a narrow level costs its slowest task plus a kernel boundary per
+    // launch: loopy cluster graphs of networks, where hybrid families sit beside tree-edge clusters in every level).
+    if (!slow.empty() && fast.size() < kMixedLevelFastMin) {
+      slow.insert(slow.end(), fast.begin(), fast.end());
+      std::sort(slow.begin(), slow.end());
+      fast.clear();
+      blk.clear();
+      K = 1;
+    }
     tr.level_nfast[L] = (int32_t)fast.size();
     tr.level_fbase[L] = (int64_t)tr.fentries.size();
     tr.level_fk[L] = K;
