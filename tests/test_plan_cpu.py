@@ -236,3 +236,35 @@ def test_synth_factors_match_oracle_assignfactors(ntips, p):
     dense = OD.loglik(net, model, tbl, taxa)
     assert abs(ll - dense) <= 1e-9 * max(1, abs(dense))
     assert abs(S.bm_loglik_pruning(tr, R, mu, X) - dense) <= 1e-9 * max(1, abs(dense))
+
+
+def test_mixed_level_goes_to_the_generic_kernel_whole():
+    """A level that needs the generic kernel anyway (a task with more than 4 messages: a 7-way polytomy) and has
+    fewer than 2048 fast-class tasks is planned as ONE generic launch (level_nfast = 0); levels made of fast-class
+    tasks only keep them all on the register-resident kernel; even trait counts <= 16 all have an instance."""
+    rng = np.random.default_rng(11)
+    tr = S.random_multifurcating_tree(300, 7, rng)
+    for p in (16, 6, 2):
+        prob = S.cliquetree_of_tree(tr, p)
+        lib, pl, code, keep = _plan(prob)
+        assert code == 0 and _set_sched(lib, pl, prob.schedule) == 0
+        saw_mixed = saw_fast = False
+        for d in (0, 1):
+            nl, nt, ne = C.c_int32(), C.c_int32(), C.c_int32()
+            assert lib.pgbp_plan_traversal_sizes(pl, 0, d, C.byref(nl), C.byref(nt), C.byref(ne)) == 0
+            lo = np.zeros(nl.value + 1, np.int32); to = np.zeros(nt.value + 1, np.int32)
+            em = np.zeros(ne.value, np.int32); ee = em.copy(); er = em.copy()
+            assert lib.pgbp_plan_traversal(pl, 0, d, L.i32p(lo), L.i32p(to), L.i32p(em), L.i32p(ee), L.i32p(er)) == 0
+            nf = np.zeros(nl.value, np.int32)
+            assert lib.pgbp_plan_level_nfast(pl, 0, d, L.i32p(nf)) == 0
+            for Lv in range(nl.value):
+                sizes = np.diff(to[lo[Lv]: lo[Lv + 1] + 1])
+                if (sizes > 4).any():
+                    assert nf[Lv] == 0
+                    saw_mixed = True
+                elif nf[Lv] == len(sizes):   # (a level may still hold a task the fast class does not cover, e.g. several
+                    saw_fast = True          # constant messages into one receiver: then it is generic as a whole, too)
+                else:
+                    assert nf[Lv] == 0
+        assert saw_mixed and saw_fast
+        lib.pgbp_plan_destroy(pl)
