@@ -41,7 +41,7 @@ enum pgbp_status {
   PGBP_ERR_INVALID = 1,    /* malformed description / argument (ErrorException in the reference: src/beliefs.jl:398-401) */
   PGBP_ERR_HIP = 2,        /* HIP runtime error */
   PGBP_ERR_NOT_TREE = 3,   /* a schedule entry is not a preorder edge list of a tree (src/clustergraph.jl:885-894) */
-  PGBP_ERR_TOO_LARGE = 4,  /* a belief dimension exceeds PGBP_MAX_DIM */
+  PGBP_ERR_TOO_LARGE = 4,  /* a belief dimension exceeds PGBP_MAX_DIM, or more than 65535 sites of dimension > 2 */
   PGBP_ERR_NO_DEVICE = 5,  /* no HIP device: the engine has no CPU path */
   PGBP_ERR_STATE = 6       /* call out of order (e.g. calibrate before set_schedule) */
 };

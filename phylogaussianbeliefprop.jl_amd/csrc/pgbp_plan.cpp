@@ -47,6 +47,12 @@ int plan_build(Plan& p, const pgbp_desc* d) {
             std::to_string(PGBP_MAX_DIM);
     return PGBP_ERR_TOO_LARGE;
   }
+  if (p.n_sites > 65535 && p.max_dim > 2) {
+    // the wavefront-per-message kernels put the site on grid.y (only the thread-per-site kernel of univariate batches,
+    // every dimension <= 2, has no such bound)
+    p.err = "n_sites = " + std::to_string(p.n_sites) + " exceeds 65535 (split the batch into several engines)";
+    return PGBP_ERR_TOO_LARGE;
+  }
   p.sepset_clusters.assign(d->sepset_clusters, d->sepset_clusters + 2 * (size_t)p.n_sepsets);
   p.scope_off.assign(d->scope_off, d->scope_off + 2 * (size_t)p.n_sepsets + 1);
   p.scope_idx.assign(d->scope_idx, d->scope_idx + (p.n_sepsets ? p.scope_off.back() : 0));

@@ -168,6 +168,12 @@ def test_plan_rejects_bad_input():
     p3 = S.cliquetree_of_tree(tr, 40)
     lib, pl, code, keep = _plan(p3)
     assert code == L.ERR_TOO_LARGE
+    # more sites than grid.y holds: refused for the wavefront-per-message kernels, fine for univariate batches
+    lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 2), n_sites=70000)
+    assert code == L.ERR_TOO_LARGE and b"65535" in lib.pgbp_plan_last_error(pl)
+    lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 1), n_sites=70000)
+    assert code == 0
+    lib.pgbp_plan_destroy(pl)
     lib.pgbp_plan_destroy(pl)
 
 
