@@ -174,7 +174,6 @@ def test_plan_rejects_bad_input():
     lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 1), n_sites=70000)
     assert code == 0
     lib.pgbp_plan_destroy(pl)
-    lib.pgbp_plan_destroy(pl)
 
 
 def test_no_cpu_fallback():
