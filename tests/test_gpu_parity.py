@@ -1004,3 +1004,24 @@ def test_cfg5_shaped_loopy_network(P, caplog, ntips, nhyb, python_bp):
         assert_beliefs_close(pcgb, ocgb)
         fe, ofe = pcgb.free_energy(), OB.free_energy(ocgb)
         assert all(rel_close(a, b) for a, b in zip(fe, ofe))
+
+
+def test_c_abi_example_runs(P):
+    """examples/c_abi_example.c: a plain-C host over include/pgbp.h (what any FFI binding does): two clusters, one
+    calibration, the log-likelihood of a two-node Gaussian chain against its closed form (exit code 0)."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(P.LIB_PATH)
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "ex")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "examples", "c_abi_example.c"), "-L", libdir, "-lpgbp", "-lm", "-o", exe])
+        env = dict(os.environ, LD_LIBRARY_PATH=libdir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+        out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (out.stdout, out.stderr)
+        assert "succ 1 iscal 1" in out.stdout

@@ -273,3 +273,18 @@ def test_mixed_level_goes_to_the_generic_kernel_whole():
                     assert nf[Lv] == 0
         assert saw_mixed and saw_fast
         lib.pgbp_plan_destroy(pl)
+
+
+def test_header_is_plain_c_and_example_links():
+    """include/pgbp.h is a C header (C99, -pedantic): a foreign-function binding needs nothing else; the C example
+    compiles and links against the built library (it runs in tests/test_gpu_parity.py)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                               os.path.join(ROOT, "examples", "c_abi_example.c"), "-o", os.path.join(td, "ex.o")])
+        libdir = os.path.dirname(pgbp_amd.LIB_PATH)
+        subprocess.check_call(["gcc", os.path.join(td, "ex.o"), "-L", libdir, "-lpgbp", "-lm", "-o", os.path.join(td, "ex")])
