@@ -8,6 +8,7 @@ from ._lib import LIB_PATH, PgbpError, load
 from .beliefs import CanonicalBelief, MessageResidual, bclustertype, bsepsettype, scopeindex
 from .beliefupdates import BPPosDefException, integratebelief_, propagate_belief_
 from .calibration import calibrate_, propagate_1traversal_postorder_, propagate_1traversal_preorder_
+from .clustergraph import default_rootcluster, spanningtree_clusterlist, spanningtrees_clusterlist
 from .clustergraphbeliefs import ClusterGraphBelief
 from .regularization import (regularizebeliefs_bycluster_, regularizebeliefs_bynodesubtree_,
                              regularizebeliefs_onschedule_)
@@ -16,5 +17,6 @@ __all__ = [
     "CanonicalBelief", "MessageResidual", "ClusterGraphBelief", "BPPosDefException", "scopeindex",
     "bclustertype", "bsepsettype", "calibrate_", "propagate_1traversal_postorder_",
     "propagate_1traversal_preorder_", "propagate_belief_", "regularizebeliefs_bycluster_",
-    "regularizebeliefs_bynodesubtree_", "regularizebeliefs_onschedule_", "integratebelief_", "load", "LIB_PATH", "PgbpError",
+    "regularizebeliefs_bynodesubtree_", "regularizebeliefs_onschedule_", "default_rootcluster",
+    "spanningtree_clusterlist", "spanningtrees_clusterlist", "integratebelief_", "load", "LIB_PATH", "PgbpError",
 ]

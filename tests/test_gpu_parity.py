@@ -967,6 +967,10 @@ def test_cfg5_shaped_loopy_network(P, caplog, ntips, nhyb, python_bp):
     cg = OCG.bethe(net)
     sched = OCG.spanningtrees_clusterlist(cg, net)
     assert len(sched) >= 2                                   # loopy
+    # the product's own schedule builder (host side, src/clustergraph.jl:908-937) gives the same trees
+    psched = P.spanningtrees_clusterlist(len(cg.clusters), [(a, b) for (a, b, _) in cg.edges], [c[1] for c in cg.clusters],
+                                         [n.leaf for n in net.vec_node], cg.labels)
+    assert [tuple(map(list, t)) for t in psched] == [tuple(map(list, t)) for t in sched]
     ocgb, pcgb = build_both(P, net, cg, model, tbl, taxa)
     P.regularizebeliefs_bycluster_(pcgb, cg)
     OB.regularizebeliefs_bycluster(ocgb)
@@ -985,7 +989,7 @@ def test_cfg5_shaped_loopy_network(P, caplog, ntips, nhyb, python_bp):
             break
     assert reached is not None and reached[0] > 2            # genuinely iterative
     with caplog.at_level(logging.INFO, logger="PhyloGaussianBeliefProp"):
-        assert P.calibrate_(pcgb, sched, 100, auto=True, info=True) == (True, True)
+        assert P.calibrate_(pcgb, psched, 100, auto=True, info=True) == (True, True)
     r = pcgb.last_results[0]
     assert (r.iter_reached, r.tree_reached) == reached
     assert f"calibration reached: iteration {reached[0]}, schedule tree {reached[1]}" in caplog.text

@@ -288,3 +288,35 @@ def test_header_is_plain_c_and_example_links():
                                os.path.join(ROOT, "examples", "c_abi_example.c"), "-o", os.path.join(td, "ex.o")])
         libdir = os.path.dirname(pgbp_amd.LIB_PATH)
         subprocess.check_call(["gcc", os.path.join(td, "ex.o"), "-L", libdir, "-lpgbp", "-lm", "-o", os.path.join(td, "ex")])
+
+
+def test_schedule_builders_match_the_oracle():
+    """The product's host-side spanningtree(s)_clusterlist / default_rootcluster (src/clustergraph.jl:885-937,
+    1022-1029) against the oracle's restatement (itself behind the golden loopy runs: "iteration 5, schedule tree 1")
+    on clique trees and Bethe graphs of random networks and on the reference's level-1 network."""
+    from oracle import clustergraph as OCG
+    from oracle import network as ON
+    from helpers import goldens
+    nets = [ON.read_newick(goldens()["calibration_bethe_level1"]["net"])]
+    rng = np.random.default_rng(8)
+    nets += [ON.random_network(40, 8, rng), ON.random_network(120, 40, rng)]
+    for net in nets:
+        is_leaf = [n.leaf for n in net.vec_node]
+        for cg in (OCG.bethe(net), OCG.cliquetree(net)):
+            nodes = [c[1] for c in cg.clusters]
+            edges = [(a, b) for (a, b, _) in cg.edges]
+            root = pgbp_amd.default_rootcluster(nodes, is_leaf)
+            assert root == OCG.default_rootcluster(cg, net)
+            got = pgbp_amd.spanningtree_clusterlist(len(nodes), edges, root, cg.labels)
+            ref = OCG.spanningtree_clusterlist(cg, root)
+            assert tuple(map(list, got)) == tuple(map(list, ref))
+            gots = pgbp_amd.spanningtrees_clusterlist(len(nodes), edges, nodes, is_leaf, cg.labels)
+            refs = OCG.spanningtrees_clusterlist(cg, net)
+            assert len(gots) == len(refs)
+            for g, r in zip(gots, refs):
+                assert tuple(map(list, g)) == tuple(map(list, r))
+            covered = set()
+            for g in gots:   # every edge is in some tree; each tree spans all clusters
+                assert len(g[2]) == len(nodes) - 1
+                covered |= {frozenset(e) for e in zip(g[2], g[3])}
+            assert covered == {frozenset(e) for e in edges}
