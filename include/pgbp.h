@@ -89,6 +89,7 @@ typedef struct pgbp_engine pgbp_engine; /* opaque: device-resident ClusterGraphB
 typedef struct pgbp_plan pgbp_plan;     /* opaque: host-only layout + level schedule (no GPU needed) */
 
 /* ---- host-only planning (no GPU): layout, message table, level schedule ------------- */
+/* On failure *out still receives a plan object that only carries the message for pgbp_plan_last_error; destroy it. */
 int  pgbp_plan_create(const pgbp_desc* desc, pgbp_plan** out);
 void pgbp_plan_destroy(pgbp_plan* p);
 /* schedule = vector of spanning trees, each the (pa_j, ch_j) index vectors of
