@@ -235,7 +235,7 @@ bool fresh_sepsets_shortcut(const pgbp_engine* e) {
 
 bool want_bs16(const pgbp_engine* e) {
   static const bool disabled = getenv("PGBP_DISABLE_BS16") != nullptr;  // A/B and debugging aid
-  return !disabled && e->plan.all_fast && e->plan.fast_p > 0;
+  return !disabled && e->plan.all_fast && e->plan.fast_p > 0 && e->plan.fast_p % 2 == 0;  // packed tiles: even P
 }
 
 void free_traversals(pgbp_engine* e) {

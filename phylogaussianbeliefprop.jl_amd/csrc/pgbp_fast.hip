@@ -155,14 +155,23 @@ struct Blk { double x, y, z, w; };
 // Load / store the lane's block of a 16 x 16 symmetric quantity (sepset J, residual dJ, receiver sub-block,
 // a 16-dim sender).  Plain layout: column-major with leading dimension ld, all 64 lanes (two double2).
 // BS16: packed upper blocks, lanes a <= b only (one double4), pgbp_bs16.hpp.
-template <bool BS>
-__device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld, int a, int b, bool up, int kidx) {
+// ODD (plain layout only): the quantity really is n x n with n = P - 1 odd; the lane grid is the one of P, index n is
+// a phantom (reads 0, is never stored), and the accesses are element-wise because rows no longer pair up on 16 bytes.
+template <bool BS, bool ODD = false>
+__device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld, int a, int b, bool up, int kidx,
+                                        int n = 0) {
   Blk r{0.0, 0.0, 0.0, 0.0};
   if constexpr (BS) {
     if (up) {
       const double4 v = *reinterpret_cast<const double4*>(base + kidx);
       r = Blk{v.x, v.y, v.z, v.w};
     }
+  } else if constexpr (ODD) {
+    const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
+    if (r0 < n && c0 < n) r.x = base[r0 + (int64_t)ld * c0];
+    if (r1 < n && c0 < n) r.y = base[r1 + (int64_t)ld * c0];
+    if (r0 < n && c1 < n) r.z = base[r0 + (int64_t)ld * c1];
+    if (r1 < n && c1 < n) r.w = base[r1 + (int64_t)ld * c1];
   } else {
     const double2 c0 = *reinterpret_cast<const double2*>(base + 2 * a + (int64_t)ld * (2 * b));
     const double2 c1 = *reinterpret_cast<const double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1));
@@ -170,14 +179,37 @@ __device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld,
   }
   return r;
 }
-template <bool BS>
+template <bool BS, bool ODD = false>
 __device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int a, int b, bool up, bool act, int kidx,
-                                          const Blk& v) {
+                                          const Blk& v, int n = 0) {
   if constexpr (BS) {
     if (up) *reinterpret_cast<double4*>(base + kidx) = make_double4(v.x, v.y, v.z, v.w);
+  } else if constexpr (ODD) {
+    if (act) {
+      const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
+      if (r0 < n && c0 < n) base[r0 + (int64_t)ld * c0] = v.x;
+      if (r1 < n && c0 < n) base[r1 + (int64_t)ld * c0] = v.y;
+      if (r0 < n && c1 < n) base[r0 + (int64_t)ld * c1] = v.z;
+      if (r1 < n && c1 < n) base[r1 + (int64_t)ld * c1] = v.w;
+    }
   } else if (act) {
     *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b)) = make_double2(v.x, v.y);
     *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1)) = make_double2(v.z, v.w);
+  }
+}
+// entries 2a, 2a+1 of a vector (h, dh)
+template <bool ODD>
+__device__ __forceinline__ double2 load_pair(const double* __restrict__ v, int a, int n) {
+  if constexpr (ODD) return make_double2(2 * a < n ? v[2 * a] : 0.0, 2 * a + 1 < n ? v[2 * a + 1] : 0.0);
+  else return *reinterpret_cast<const double2*>(v + 2 * a);
+}
+template <bool ODD>
+__device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double x, double y, int n) {
+  if constexpr (ODD) {
+    if (2 * a < n) v[2 * a] = x;
+    if (2 * a + 1 < n) v[2 * a + 1] = y;
+  } else {
+    *reinterpret_cast<double2*>(v + 2 * a) = make_double2(x, y);
   }
 }
 
@@ -188,7 +220,9 @@ __device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int
 //   * reuse (preorder, one sender, several children): the providing wave computes the marginal once and
 //     hands it to the others through LDS; every wave divides by its own sepset and updates its own receiver.
 // BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
-template <int P, bool BS>
+// ODD: the sepsets really have PR = P - 1 variables (an odd trait count): same lane grid, one phantom variable per
+// block, unit precision where it is integrated so that its pivot is 1 (log det and quadratic term unchanged).
+template <int P, bool BS, bool ODD>
 #ifdef PGBP_TRACE_LIGHT
 __attribute__((amdgpu_waves_per_eu(4, 4)))  // keep the production kernel's occupancy despite the extra live values
 #endif
@@ -219,6 +253,8 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
+  static_assert(!(ODD && BS), "odd dimensions run in the plain layout");
+  constexpr int PR = P - (ODD ? 1 : 0);            // the real sepset dimension
   constexpr int G = P / 2;                         // lane grid G x G (all 64 lanes for P = 16)
   const bool act = lane < G * G;                   // lanes beyond the grid shadow lane (0, 0) and never store
   const int a = act ? lane % G : 0, b = act ? lane / G : 0;
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
   const int mt = en.mt, up0 = en.up0;
   // offsets inside the sepset / receiver / residual records
   const bool tpk = BS && (mt == P || mt == 2 * P);                                // receiver record is packed
-  const int sepH = BS ? bs16::h1(P) : P * P, sepG = has_block ? (BS ? bs16::g1(P) : P * P + P) : 0;
+  const int sepH = BS ? bs16::h1(P) : PR * PR, sepG = has_block ? (BS ? bs16::g1(P) : PR * PR + PR) : 0;
   const int64_t tJ0 = tpk ? ((mt == 2 * P && up0 == P) ? bs16::t11(P) : 0) : (up0 + (int64_t)mt * up0);
   const int64_t tH0 = (tpk ? (mt == P ? bs16::h1(P) : bs16::h2(P)) : (int64_t)mt * mt) + up0;
   const int64_t tG0 = tpk ? (mt == P ? bs16::g1(P) : bs16::g2(P)) : (int64_t)mt * mt + mt;
@@ -290,16 +326,16 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
     auto load_sep_to = [&]() {
       if (!S.sep_zero) {
         if (has_block) {
-          sJ = load_blk<BS>(sep, P, a, b, up, kidx);
-          if (b == 0) sh = *reinterpret_cast<const double2*>(sep + sepH + 2 * a);
+          sJ = load_blk<BS, ODD>(sep, PR, a, b, up, kidx, PR);
+          if (b == 0) sh = load_pair<ODD>(sep + sepH, a, PR);
         }
         sg = sep[sepG];
       }
       if (own) {
         if (accum || has_block) {
-          tJ = load_blk<BS>(to + tJ0, mt, a, b, up, kidx);
+          tJ = load_blk<BS, ODD>(to + tJ0, mt, a, b, up, kidx, PR);
           if (b == 0) {
-            const double2 t2 = *reinterpret_cast<const double2*>(to + tH0 + 2 * a);
+            const double2 t2 = load_pair<ODD>(to + tH0, a, PR);
             th[0] = t2.x; th[1] = t2.y;
           }
         }
@@ -312,12 +348,12 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
       if (en.mf == 0) {
         gmsg = from[0];  // a constant factor
         load_sep_to();
-      } else if (en.mf == P && has_block) {
+      } else if (en.mf == PR && has_block) {
         // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
-        mJ = load_blk<BS>(from, P, a, b, up, kidx);
-        const double2 ch = *reinterpret_cast<const double2*>(from + (BS ? bs16::h1(P) : P * P) + 2 * a);
+        mJ = load_blk<BS, ODD>(from, PR, a, b, up, kidx, PR);
+        const double2 ch = load_pair<ODD>(from + (BS ? bs16::h1(P) : PR * PR), a, PR);
         mh[0] = ch.x; mh[1] = ch.y;
-        gmsg = from[BS ? bs16::g1(P) : P * P + P];
+        gmsg = from[BS ? bs16::g1(P) : PR * PR + PR];
         load_sep_to();
       } else {
         Frag f;
@@ -325,13 +361,38 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) f.w[i][j] = 0.0;
-        if (en.mf == P) {
+        if (en.mf == PR) {
           // everything is integrated (dimension-0 sepset): the 16 x 16 precision is the integrated block
-          const Blk v = load_blk<BS>(from, P, a, b, up, kidx);
-          const double2 vh = *reinterpret_cast<const double2*>(from + (BS ? bs16::h1(P) : P * P) + 2 * a);
+          const Blk v = load_blk<BS, ODD>(from, PR, a, b, up, kidx, PR);
+          const double2 vh = load_pair<ODD>(from + (BS ? bs16::h1(P) : PR * PR), a, PR);
           f.w[0][0] = v.x; f.w[1][0] = v.y; f.w[0][1] = v.z; f.w[1][1] = v.w;
+          if (ODD && a == G - 1 && b == G - 1) f.w[1][1] = 1.0;  // the phantom variable: decoupled, unit precision
           f.h[0] = vh.x; f.h[1] = vh.y; f.h[2] = 0.0; f.h[3] = 0.0;
-          gmsg = from[BS ? bs16::g1(P) : P * P + P];
+          gmsg = from[BS ? bs16::g1(P) : PR * PR + PR];
+        } else if constexpr (ODD) {
+          // 2 PR-dim sender, odd PR: logical index l in [0, 2P) (integrated block first) -> physical index, -1: phantom
+          const int rot = (en.keep0 == 0) ? PR : 0;
+          auto phys = [&](int l) -> int {
+            const int Kb = l >= P ? 1 : 0, i = l - Kb * P;
+            if (i >= PR) return -1;
+            const int q = Kb * PR + i + rot;
+            return q >= 2 * PR ? q - 2 * PR : q;
+          };
+          int pr[4], pc[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            pr[i] = phys((i & 1) + 2 * a + (i >> 1) * P);
+            pc[i] = phys((i & 1) + 2 * b + (i >> 1) * P);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (!(i < 2 && j >= 2) && pr[i] >= 0 && pc[j] >= 0) f.w[i][j] = from[pr[i] + (int64_t)pc[j] * (2 * PR)];
+          if (a == G - 1 && b == G - 1) f.w[1][1] = 1.0;  // the phantom integrated variable: decoupled, unit precision
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f.h[i] = pr[i] >= 0 ? from[4 * PR * PR + pr[i]] : 0.0;
+          gmsg = from[4 * PR * PR + 2 * PR];
         } else if constexpr (BS) {
           // 32-dim sender, packed: tiles T00 | T10 | T11.  integrated block = tile 0 (postorder, keep0 = 16)
           // or tile 1 (preorder, keep0 = 0)
@@ -396,7 +457,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
             PGBP_TR_NOWAIT(3);
             if (info == 0) {
               const double logdet = log(mant) + (double)expo * PGBP_LN2;
-              gmsg += 0.5 * ((double)P * PGBP_LOG2PI - logdet + quad);  // :81
+              gmsg += 0.5 * ((double)PR * PGBP_LOG2PI - logdet + quad);  // :81
             }
           }
         }
@@ -444,16 +505,16 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
     double maxJ = 0.0, maxh = 0.0;
     if (has_block) {
       dJ = Blk{mJ.x - sJ.x, mJ.y - sJ.y, mJ.z - sJ.z, mJ.w - sJ.w};
-      store_blk<BS>(sep, P, a, b, up, act, kidx, mJ);
-      store_blk<BS>(res, P, a, b, up, act, kidx, dJ);
+      store_blk<BS, ODD>(sep, PR, a, b, up, act, kidx, mJ, PR);
+      store_blk<BS, ODD>(res, PR, a, b, up, act, kidx, dJ, PR);
       if (BS ? up : act) {
         maxJ = fmax(fmax(fabs(dJ.x), fabs(dJ.y)), fmax(fabs(dJ.z), fabs(dJ.w)));
         if (dJ.x != dJ.x || dJ.y != dJ.y || dJ.z != dJ.z || dJ.w != dJ.w) maxJ = INFINITY;
       }
       if (act && b == 0) {
         dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
-        *reinterpret_cast<double2*>(sep + sepH + 2 * a) = make_double2(mh[0], mh[1]);
-        *reinterpret_cast<double2*>(res + (BS ? bs16::h1(P) : P * P) + 2 * a) = make_double2(dh0, dh1);
+        store_pair<ODD>(sep + sepH, a, mh[0], mh[1], PR);
+        store_pair<ODD>(res + (BS ? bs16::h1(P) : PR * PR), a, dh0, dh1, PR);
         maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
       }
     }
@@ -466,7 +527,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
       // iscalibrated_residnorm! (src/beliefs.jl:994-1003); an empty message is calibrated
       // x -> fl(x / c) is monotone, so "max over the wave, divide, compare" equals "every lane divides and
       // compares its own maximum": one ballot instead of two 6-step wave reductions on the critical path
-      const bool lane_ok = maxh / sqrt((double)P) <= S.atol && maxJ / sqrt((double)P * (double)P) <= S.atol;
+      const bool lane_ok = maxh / sqrt((double)PR) <= S.atol && maxJ / sqrt((double)PR * (double)PR) <= S.atol;
       const bool all_ok = __all(lane_ok);
       if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = (!has_block || all_ok) ? 1 : 0;
     }
@@ -515,8 +576,8 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
   }
   if (own && state == 1) {
     if (accum || has_block) {
-      store_blk<BS>(to + tJ0, mt, a, b, up, act, kidx, tJ);
-      if (act && b == 0) *reinterpret_cast<double2*>(to + tH0 + 2 * a) = make_double2(th[0], th[1]);
+      store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
+      if (act && b == 0) store_pair<ODD>(to + tH0, a, th[0], th[1], PR);
     }
     if (lane == 0) to[tG0] = tg;
   }
@@ -554,16 +615,19 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
 #endif
 }
 
-template <int P>
+template <int P, bool ODD>
 static void launch_fast_p(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                           unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   const size_t lds = sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K;
-  if (S.bs16)
-    hipLaunchKernelGGL((bp_level_fast16<P, true>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
-                       seq_base, stop_below);
-  else
-    hipLaunchKernelGGL((bp_level_fast16<P, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
-                       seq_base, stop_below);
+  if constexpr (!ODD) {
+    if (S.bs16) {
+      hipLaunchKernelGGL((bp_level_fast16<P, true, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
+                         seq_base, stop_below);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((bp_level_fast16<P, false, ODD>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
+                     seq_base, stop_below);
 }
 
 // ---- assignfactors! for MvFullBrownianMotion on a tree (pgbp_bm_tree of include/pgbp.h), lane-blocked ---------------
@@ -691,19 +755,27 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
 }
 
 // The kernel is instantiated for every even sepset dimension P <= 16 ((P/2)^2 lanes: all 64 for P = 16, 16 for P = 8,
-// 1 for P = 2); the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
+// 1 for P = 2), and each instance once more for the odd dimension P - 1 (plain layout, a phantom variable per block);
+// the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
   if (ntasks <= 0) return;
-  switch (S.fast_p) {
-    case 16: launch_fast_p<16>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 14: launch_fast_p<14>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 12: launch_fast_p<12>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 10: launch_fast_p<10>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 8: launch_fast_p<8>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 6: launch_fast_p<6>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 4: launch_fast_p<4>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 2: launch_fast_p<2>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+  switch (S.fast_p) {  // the real sepset dimension; odd ones run on the next even instance with a phantom variable
+    case 16: launch_fast_p<16, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 15: launch_fast_p<16, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 14: launch_fast_p<14, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 13: launch_fast_p<14, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 12: launch_fast_p<12, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 11: launch_fast_p<12, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 10: launch_fast_p<10, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 9: launch_fast_p<10, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 8: launch_fast_p<8, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 7: launch_fast_p<8, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 6: launch_fast_p<6, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 5: launch_fast_p<6, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 4: launch_fast_p<4, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 3: launch_fast_p<4, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 2: launch_fast_p<2, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
     default: break;  // the planner never marks a task fast for another P
   }
 #ifdef PGBP_TRACE

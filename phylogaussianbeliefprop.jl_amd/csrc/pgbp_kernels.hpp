@@ -26,7 +26,7 @@ struct DevState {
   int32_t update_resnorm;
   double atol;
   int32_t bs16;    // beliefs of dimension P / 2P and residuals of P-dim sepsets are in the packed layout
-  int32_t fast_p;  // P: sepset dimension of the register-resident kernel (an even number <= 16; 0: none)
+  int32_t fast_p;  // P: sepset dimension of the register-resident kernel (2 .. 16, the real dimension; 0: none)
   // site-minor layout (univariate batches, every dimension <= 2): element t of belief b of site s lives at
   // pool[(packed_off[b] + t) * n_sites + s] (residuals: rpacked_off[msg]); pool / rpool then point at those buffers
   int32_t sm;

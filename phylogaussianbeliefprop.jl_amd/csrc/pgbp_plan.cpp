@@ -142,17 +142,17 @@ int plan_build(Plan& p, const pgbp_desc* d) {
     }
   }
   p.trees.clear();
-  // the register-resident kernel is instantiated for every even sepset dimension up to 16 (pgbp_fast.hip: 2 x 2 blocks
-  // per lane): pick the one most sepsets have
+  // the register-resident kernel has an instance for every sepset dimension from 2 to 16 (pgbp_fast.hip: 2 x 2 blocks
+  // per lane; odd dimensions on the next even instance with a phantom variable): pick the one most sepsets have
   p.fast_p = 0;
   {
     int cnt[17] = {0};
     for (int k = 0; k < p.n_sepsets; ++k) {
       const int s = p.dims[p.n_clusters + k];
-      if (s >= 2 && s <= 16 && s % 2 == 0) ++cnt[s];
+      if (s >= 2 && s <= 16) ++cnt[s];
     }
     int best = 0;
-    for (int q = 16; q >= 2; q -= 2)
+    for (int q = 16; q >= 2; --q)
       if (cnt[q] > best) { best = cnt[q]; p.fast_p = q; }
   }
   return PGBP_OK;

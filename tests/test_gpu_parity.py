@@ -233,7 +233,10 @@ def test_auto_stop_and_info_log(P, caplog):
                                           (3, 4, "random"), (40, 8, "caterpillar"),
                                           # every even trait count <= 16 has a register-resident instance
                                           (50, 2, "random"), (45, 6, "random"), (35, 10, "poly3"), (40, 12, "random"),
-                                          (30, 14, "caterpillar"), (2, 6, "random"), (25, 5, "random"), (20, 7, "poly4")])
+                                          (30, 14, "caterpillar"), (2, 6, "random"), (25, 5, "random"), (20, 7, "poly4"),
+                                          # ... and every odd one the next even instance with a phantom variable
+                                          (60, 3, "random"), (45, 9, "random"), (40, 11, "poly3"), (35, 13, "caterpillar"),
+                                          (50, 15, "random"), (2, 15, "random"), (3, 9, "random"), (30, 15, "poly4")])
 def test_random_tree_cliquetree_vs_oracle(P, ntips, p, kind):
     from pgbp_amd import synth as S
     rng = np.random.default_rng(1000 * p + ntips)
