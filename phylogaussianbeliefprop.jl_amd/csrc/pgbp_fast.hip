@@ -635,7 +635,7 @@ static void launch_fast_p(const DevState& S, const FEntry* d_recs, int K, int nt
 // R^-1[2a..2a+1][2b..2b+1] for the whole launch and writes it, scaled by 1/t and signed, into the tiles of the record
 // (32-byte stores, whole lines), h = R^-1 v / t by a butterfly over b, g from v'R^-1 v / t by a butterfly over a.
 // Formulas: pgbp_kernels.hip, bm_tree_fill_kernel (the general-dimension version of the same fill).
-template <int P, bool BS>
+template <int P, bool BS, bool ODD>
 __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ pool, int64_t pool_stride,
                                                          double* __restrict__ fpool, int64_t fpool_stride,
                                                          const int64_t* __restrict__ boff,
@@ -647,18 +647,19 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
                                                          const double* __restrict__ Rinv_all,
                                                          const double* __restrict__ logdetR_all,
                                                          const double* __restrict__ mu_all, int per_site, int n_clusters) {
+  static_assert(!(ODD && BS), "odd dimensions are filled in the plain layout");
+  constexpr int PR = P - (ODD ? 1 : 0);  // the real trait count (ODD: the lane grid of P with a phantom index PR)
   constexpr int G = P / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, site = blockIdx.y;
   const bool act = lane < G * G;
   const int a = act ? lane % G : 0, b = act ? lane / G : 0;
   const bool up = act && a <= b;
   const int kidx = (b * (b + 1) / 2 + a) * 4;
-  const double* __restrict__ Rinv = Rinv_all + (per_site ? (int64_t)site * P * P : 0);
-  const double* __restrict__ mu = mu_all + (per_site ? (int64_t)site * P : 0);
-  const double g_base = -0.5 * ((double)P * PGBP_LOG2PI + logdetR_all[per_site ? site : 0]);
-  const double2 c0 = *reinterpret_cast<const double2*>(Rinv + 2 * a + P * (2 * b));
-  const double2 c1 = *reinterpret_cast<const double2*>(Rinv + 2 * a + P * (2 * b + 1));
-  const Blk Rb{c0.x, c0.y, c1.x, c1.y};
+  const double* __restrict__ Rinv = Rinv_all + (per_site ? (int64_t)site * PR * PR : 0);
+  const double* __restrict__ mu = mu_all + (per_site ? (int64_t)site * PR : 0);
+  const double g_base = -0.5 * ((double)PR * PGBP_LOG2PI + logdetR_all[per_site ? site : 0]);
+  const Blk Rb = load_blk<false, ODD>(Rinv, PR, a, b, up, kidx, PR);
+  auto vec = [&](const double* __restrict__ v, int i) { return (!ODD || i < PR) ? v[i] : 0.0; };
   for (int c = blockIdx.x * 4 + wave; c < n_clusters; c += gridDim.x * 4) {
     const int k = kind[c], m = dim[c];
     double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[c];
@@ -672,21 +673,24 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
       continue;
     }
     const double tlen = length[c], it = 1.0 / tlen;
-    double g = g_base - 0.5 * (double)P * log(tlen);
+    double g = g_base - 0.5 * (double)PR * log(tlen);
     double jv0 = 0.0, jv1 = 0.0;
     if (k >= 1) {
       // absorbed vector v: mu on the parent (1), the tip's data on the child (2), their difference (3)
-      const double* __restrict__ y = (k >= 2) ? data + ((int64_t)site * n_rows + row[c]) * P : mu;
-      double vb0 = y[2 * b], vb1 = y[2 * b + 1], va0 = y[2 * a], va1 = y[2 * a + 1];
-      if (k == 3) { vb0 -= mu[2 * b]; vb1 -= mu[2 * b + 1]; va0 -= mu[2 * a]; va1 -= mu[2 * a + 1]; }
-      double p0 = act ? fma(Rb.x, vb0, Rb.z * vb1) : 0.0, p1 = act ? fma(Rb.y, vb0, Rb.w * vb1) : 0.0;
+      const double* __restrict__ y = (k >= 2) ? data + ((int64_t)site * n_rows + row[c]) * PR : mu;
+      double vb0 = vec(y, 2 * b), vb1 = vec(y, 2 * b + 1), va0 = vec(y, 2 * a), va1 = vec(y, 2 * a + 1);
+      if (k == 3) { vb0 -= vec(mu, 2 * b); vb1 -= vec(mu, 2 * b + 1); va0 -= vec(mu, 2 * a); va1 -= vec(mu, 2 * a + 1); }
+      const double t0 = act ? fma(Rb.x, vb0, Rb.z * vb1) : 0.0, t1 = act ? fma(Rb.y, vb0, Rb.w * vb1) : 0.0;
+      // rows 2a, 2a+1 of R^-1 v: the sum over the G lanes (a, 0 .. G-1), in a fixed order (any G, not only powers of 2)
+      double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-      for (int o = G; o < G * G; o <<= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+      for (int bb = 0; bb < G; ++bb) { p0 += __shfl(t0, bb * G + a); p1 += __shfl(t1, bb * G + a); }
       jv0 = p0 * it;
       jv1 = p1 * it;
-      double q = act ? fma(jv0, va0, jv1 * va1) : 0.0;
+      const double qa = fma(jv0, va0, jv1 * va1);  // this lane's rows; the same on every lane of a given a
+      double q = 0.0;
 #pragma unroll
-      for (int o = 1; o < G; o <<= 1) q += __shfl_xor(q, o);
+      for (int aa = 0; aa < G; ++aa) q += __shfl(qa, aa);
       g -= 0.5 * q;
     }
     const Blk Jp{Rb.x * it, Rb.y * it, Rb.z * it, Rb.w * it}, Jm{-Jp.x, -Jp.y, -Jp.z, -Jp.w};
@@ -703,20 +707,20 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
           }
           if (lane == 0) r[bs16::g2(P)] = g;
         } else {
-          store_blk<false>(r, 2 * P, a, b, up, act, kidx, Jp);
-          store_blk<false>(r + P, 2 * P, a, b, up, act, kidx, Jm);
-          store_blk<false>(r + (int64_t)2 * P * P, 2 * P, a, b, up, act, kidx, Jm);
-          store_blk<false>(r + (int64_t)2 * P * P + P, 2 * P, a, b, up, act, kidx, Jp);
+          store_blk<false, ODD>(r, 2 * PR, a, b, up, act, kidx, Jp, PR);
+          store_blk<false, ODD>(r + PR, 2 * PR, a, b, up, act, kidx, Jm, PR);
+          store_blk<false, ODD>(r + (int64_t)2 * PR * PR, 2 * PR, a, b, up, act, kidx, Jm, PR);
+          store_blk<false, ODD>(r + (int64_t)2 * PR * PR + PR, 2 * PR, a, b, up, act, kidx, Jp, PR);
           if (act && b == 0) {
-            *reinterpret_cast<double2*>(r + 4 * P * P + 2 * a) = make_double2(0.0, 0.0);
-            *reinterpret_cast<double2*>(r + 4 * P * P + P + 2 * a) = make_double2(0.0, 0.0);
+            store_pair<ODD>(r + 4 * PR * PR, a, 0.0, 0.0, PR);
+            store_pair<ODD>(r + 4 * PR * PR + PR, a, 0.0, 0.0, PR);
           }
-          if (lane == 0) r[4 * P * P + 2 * P] = g;
+          if (lane == 0) r[4 * PR * PR + 2 * PR] = g;
         }
       } else if (k <= 2) {  // P x P block j on the kept variables, h = +j v
-        store_blk<BS>(r, P, a, b, up, act, kidx, Jp);
-        if (act && b == 0) *reinterpret_cast<double2*>(r + (BS ? bs16::h1(P) : P * P) + 2 * a) = make_double2(jv0, jv1);
-        if (lane == 0) r[BS ? bs16::g1(P) : P * P + P] = g;
+        store_blk<BS, ODD>(r, PR, a, b, up, act, kidx, Jp, PR);
+        if (act && b == 0) store_pair<ODD>(r + (BS ? bs16::h1(P) : PR * PR), a, jv0, jv1, PR);
+        if (lane == 0) r[BS ? bs16::g1(P) : PR * PR + PR] = g;
       } else {  // everything absorbed: a constant
         if (lane == 0) r[0] = g;
       }
@@ -724,20 +728,23 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
   }
 }
 
-template <int P>
+template <int P, bool ODD>
 static void launch_fill_p(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
                           const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
                           const double* d_data, int n_rows, const double* d_Rinv, const double* d_logdetR,
                           const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
   const int gx = std::min((n_clusters + 3) / 4, 16384);
-  if (bs16)
-    hipLaunchKernelGGL((bm_tree_fill_fast<P, true>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
-                       fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
-                       per_site, n_clusters);
-  else
-    hipLaunchKernelGGL((bm_tree_fill_fast<P, false>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
-                       fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
-                       per_site, n_clusters);
+  if constexpr (!ODD) {
+    if (bs16) {
+      hipLaunchKernelGGL((bm_tree_fill_fast<P, true, false>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
+                         fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
+                         per_site, n_clusters);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((bm_tree_fill_fast<P, false, ODD>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
+                     fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
+                     per_site, n_clusters);
 }
 
 bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride,
@@ -746,12 +753,29 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
                               const double* d_logdetR, const double* d_mu, int per_site, int bs16, int n_clusters,
                               int n_sites, hipStream_t st) {
   if (n_clusters <= 0) return true;
-  switch (p) {
-    case 16: launch_fill_p<16>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st); return true;
-    case 8: launch_fill_p<8>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st); return true;
-    case 4: launch_fill_p<4>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st); return true;
+#define PGBP_FILL(PP, OD)                                                                                              \
+  launch_fill_p<PP, OD>(pool, pool_stride, fpool, fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, \
+                        d_Rinv, d_logdetR, d_mu, per_site, bs16, n_clusters, n_sites, st);                             \
+  return true
+  switch (p) {  // the real trait count; odd ones on the next even lane grid
+    case 16: PGBP_FILL(16, false);
+    case 15: PGBP_FILL(16, true);
+    case 14: PGBP_FILL(14, false);
+    case 13: PGBP_FILL(14, true);
+    case 12: PGBP_FILL(12, false);
+    case 11: PGBP_FILL(12, true);
+    case 10: PGBP_FILL(10, false);
+    case 9: PGBP_FILL(10, true);
+    case 8: PGBP_FILL(8, false);
+    case 7: PGBP_FILL(8, true);
+    case 6: PGBP_FILL(6, false);
+    case 5: PGBP_FILL(6, true);
+    case 4: PGBP_FILL(4, false);
+    case 3: PGBP_FILL(4, true);
+    case 2: PGBP_FILL(2, false);
     default: return false;
   }
+#undef PGBP_FILL
 }
 
 // The kernel is instantiated for every even sepset dimension P <= 16 ((P/2)^2 lanes: all 64 for P = 16, 16 for P = 8,

@@ -98,7 +98,7 @@ void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64
 
 // free_energy (src/score.jl:162-182): per-belief terms + deterministic per-site sum -> out3[site] =
 // (average energy, approximate entropy, free energy); info[site] (preset to INT_MAX) = first non-PD belief + 1
-// lane-blocked version of the same fill (pgbp_fast.hip) for p = 16 / 8 / 4 when every cluster has dimension 0, p or 2p
+// lane-blocked version of the same fill (pgbp_fast.hip) for 2 <= p <= 16 when every cluster has dimension 0, p or 2p
 // as its kind implies; fpool may be null (beliefs only: the score() body of src/calibration.jl:205 does not touch the
 // factors).  Returns false if p has no instance.
 bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride,

@@ -564,7 +564,8 @@ def test_single_belief_access_and_set(P):
 @pytest.mark.parametrize("graph,ntips,p", [("cliquetree", 30, 16), ("cliquetree", 25, 3), ("bethe", 20, 4),
                                            ("cliquetree", 2, 16), ("cliquetree", 3, 1), ("bethe", 35, 8),
                                            ("bethe", 30, 16), ("cliquetree", 40, 8), ("cliquetree", 30, 6),
-                                           ("bethe", 25, 12), ("cliquetree", 20, 2)])
+                                           ("bethe", 25, 12), ("cliquetree", 20, 2), ("bethe", 20, 5),
+                                           ("cliquetree", 18, 15), ("cliquetree", 22, 9)])
 def test_device_factor_fill_bm_tree(P, graph, ntips, p):
     """pgbp_bm_tree_assignfactors (assignfactors! on the device) == the host fill that
     tests/test_plan_cpu.py pins against the oracle's assignfactors! restatement; a second parameter set is
