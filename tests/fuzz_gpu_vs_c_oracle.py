@@ -17,9 +17,8 @@ from oracle import cengine  # noqa: E402
 from pgbp_amd import synth as S  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def run(n_cases, seed):
+    """Returns (cases with an injected failure, worst relative belief error); asserts on any disagreement."""
     rng = np.random.default_rng(seed)
     worst = 0.0
     n_fail = 0
@@ -84,6 +83,13 @@ def main():
             assert np.array_equal(eng._flags().astype(bool), flags.astype(bool)), (case, s)
         assert got == (bool(eng.last_results[0].succ), bool(eng.last_results[0].iscal))
         del eng
+    return n_fail, worst
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    n_fail, worst = run(n_cases, seed)
     print(f"{n_cases} cases ok ({n_fail} with an injected failure reported identically), worst relative belief error {worst:.2e}")
 
 

@@ -1033,3 +1033,12 @@ def test_c_abi_example_runs(P):
         out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, (out.stdout, out.stderr)
         assert "succ 1 iscal 1" in out.stdout
+
+
+def test_differential_fuzz_against_c_oracle(P):
+    """A slice of tests/fuzz_gpu_vs_c_oracle.py in the suite: 150 random (tree shape, trait count 1..16, cluster graph,
+    sites, iterations) cases, a quarter of them with a non-positive-definite block injected into one site, against the
+    plain-C sequential engine: beliefs to 1e-8 * max|.|, flags, (succ, iscal), the first failure's (edge, dir, info)."""
+    import fuzz_gpu_vs_c_oracle as F
+    n_fail, worst = F.run(150, 2024)
+    assert n_fail >= 10 and worst <= 1e-8
