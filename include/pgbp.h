@@ -210,6 +210,60 @@ int  pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t);
 int  pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double* logdetR, const double* mu,
                                 int32_t per_site);
 
+/* ---- factor assignment on the device for every linear-Gaussian model of the reference, trees and networks ---- */
+/* assignfactors! (src/beliefs.jl:786-861) with complete tip data (no trait missing at any tip), all parent edges of
+ * positive length (no degenerate family): homogeneous / heterogeneous Brownian motion
+ * (src/evomodels/homogeneousbrownianmotion.jl:222-351, heterogeneousmodels.jl:110-150), Ornstein-Uhlenbeck
+ * (homogeneousornsteinuhlenbeck.jl:51-66), tree edges (factor_treeedge), hybrid nodes (factor_hybridnode,
+ * evomodels.jl:314-330), root prior (factor_root, evomodels.jl:377-396), leaf data and fixed-root mean absorbed
+ * (absorbleaf!, absorbevidence!: src/beliefupdates.jl:210-274).  Any cluster graph: a cluster may hold several
+ * families (clique trees of networks, join graphs); they are added in the order given, the reference's loop order.
+ * Static part (once): one entry per node family that carries a factor, in the order of the reference's loop
+ * `for (ni, ci) in enumerate(node2cluster)` (preorder node index); per parent, in the order of node2family[ni][2:end]. */
+typedef struct pgbp_lg_families {
+  int32_t p;                 /* traits */
+  int32_t n_families;
+  int32_t max_parents;       /* K >= 1: row length of the per-parent arrays */
+  int32_t n_rates;           /* number of p x p variance matrices in pgbp_lg_params.R */
+  int32_t n_rows;            /* rows of `data` per site */
+  const int32_t* cluster;    /* [n_families] node2cluster[ni] */
+  const int32_t* n_parents;  /* [n_families] 0: root prior, 1: tree edge, >= 2: hybrid node */
+  const int32_t* child_pos;  /* [n_families] position of the child's first variable in the cluster (its p traits are
+                                contiguous: complete data), or -1: a tip, its data row is absorbed */
+  const int32_t* data_row;   /* [n_families] row of the tip's data, else -1 */
+  const int32_t* parent_pos; /* [n_families * K] position of parent k's first variable, or -1: the fixed root, whose
+                                mean is absorbed */
+  const double* length;      /* [n_families * K] length of the parent edge, > 0 */
+  const double* gamma;       /* [n_families * K] inheritance of the parent edge (1 for a tree edge) */
+  const int32_t* color;      /* [n_families * K] index into R of the parent edge's variance rate (heterogeneous models:
+                                the edge's colour; homogeneous: 0).  Root prior family: entry [f*K] = index of the
+                                prior variance among R */
+  const double* data;        /* [n_sites][n_rows][p] tip data, host pointer */
+} pgbp_lg_families;
+int  pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f);
+
+enum pgbp_lg_model {
+  PGBP_LG_BM = 0,  /* X_child | parents ~ N(sum_k gamma_k X_k, sum_k gamma_k^2 t_k R[color_k]) */
+  PGBP_LG_OU = 1   /* a_k = exp(-alpha t_k): N(sum_k gamma_k (a_k X_k + (1 - a_k) theta), sum_k gamma_k^2 (1 - a_k^2) R[color_k]),
+                      R = stationary variance sigma2 / (2 alpha); the reference has p = 1 (UnivariateOrnsteinUhlenbeck) */
+};
+/* Model parameters: everything that changes between two likelihood evaluations.  per_site != 0: one set per site
+ * (R [n_sites][n_rates][p*p], alpha [n_sites], theta [n_sites][p], mu [n_sites][p]). */
+typedef struct pgbp_lg_params {
+  int32_t model;       /* enum pgbp_lg_model */
+  int32_t per_site;
+  const double* R;     /* [n_rates][p*p] column-major symmetric positive definite */
+  const double* alpha; /* OU: [1] */
+  const double* theta; /* OU: [p]; NULL for BM */
+  const double* mu;    /* [p] root mean (fixed root: the value absorbed; random root: the prior mean) */
+} pgbp_lg_params;
+/* init_beliefs_reset! + the factor loop of assignfactors! + init_factors_frombeliefs! + flag reset.  A variance
+ * sum_k vc_k R[color_k] that is not positive definite (the reference throws) makes that cluster's g NaN.  Asynchronous. */
+int  pgbp_lg_assignfactors(pgbp_engine* e, const pgbp_lg_params* m);
+/* The whole body of score(theta) (src/calibration.jl:195-221) on the device with the parameters of the LAST
+ * pgbp_lg_assignfactors call: factor fill (beliefs only), postorder of tree 0, root integrate. */
+int  pgbp_enqueue_loglik_lg(pgbp_engine* e, int32_t reps, const pgbp_opts* opts);
+
 /* ---- device-side access for benchmarking / zero-copy callers ----------------------------- */
 /* Enqueue `reps` full calibrate iterations (all trees, post+pre, flag reduction) without any host
  * synchronisation; the caller brackets with pgbp_sync. Resets beliefs from factors before each
@@ -226,7 +280,7 @@ int  pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts)
 int  pgbp_sync(pgbp_engine* e);
 /* Time `reps` repetitions of the enqueued work with HIP events on the engine's stream; returns the
  * total milliseconds in *ms_total and, per kernel family, accumulated device time is NOT measured here
- * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik, 2 = loglik_bm (with the device factor fill). */
+ * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik, 2 = loglik_bm, 3 = loglik_lg (2, 3: with the device factor fill). */
 int  pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each,
                         const pgbp_opts* opts, float* ms_total);
 /* Time only the message-kernel launches of `reps` calibrate iterations (reset from factors before each):

@@ -10,6 +10,7 @@ from .beliefupdates import BPPosDefException, integratebelief_, propagate_belief
 from .calibration import calibrate_, propagate_1traversal_postorder_, propagate_1traversal_preorder_
 from .clustergraph import default_rootcluster, spanningtree_clusterlist, spanningtrees_clusterlist
 from .clustergraphbeliefs import ClusterGraphBelief
+from .factors import lg_families
 from .regularization import (regularizebeliefs_bycluster_, regularizebeliefs_bynodesubtree_,
                              regularizebeliefs_onschedule_)
 
@@ -18,5 +19,5 @@ __all__ = [
     "bclustertype", "bsepsettype", "calibrate_", "propagate_1traversal_postorder_",
     "propagate_1traversal_preorder_", "propagate_belief_", "regularizebeliefs_bycluster_",
     "regularizebeliefs_bynodesubtree_", "regularizebeliefs_onschedule_", "default_rootcluster",
-    "spanningtree_clusterlist", "spanningtrees_clusterlist", "integratebelief_", "load", "LIB_PATH", "PgbpError",
+    "spanningtree_clusterlist", "spanningtrees_clusterlist", "integratebelief_", "lg_families", "load", "LIB_PATH", "PgbpError",
 ]

@@ -34,6 +34,22 @@ class BmTree(C.Structure):
                 ("data", C.POINTER(C.c_double))]
 
 
+class LgFamilies(C.Structure):
+    _fields_ = [("p", C.c_int32), ("n_families", C.c_int32), ("max_parents", C.c_int32), ("n_rates", C.c_int32),
+                ("n_rows", C.c_int32), ("cluster", C.POINTER(C.c_int32)), ("n_parents", C.POINTER(C.c_int32)),
+                ("child_pos", C.POINTER(C.c_int32)), ("data_row", C.POINTER(C.c_int32)),
+                ("parent_pos", C.POINTER(C.c_int32)), ("length", C.POINTER(C.c_double)),
+                ("gamma", C.POINTER(C.c_double)), ("color", C.POINTER(C.c_int32)), ("data", C.POINTER(C.c_double))]
+
+
+class LgParams(C.Structure):
+    _fields_ = [("model", C.c_int32), ("per_site", C.c_int32), ("R", C.POINTER(C.c_double)),
+                ("alpha", C.POINTER(C.c_double)), ("theta", C.POINTER(C.c_double)), ("mu", C.POINTER(C.c_double))]
+
+
+LG_BM, LG_OU = 0, 1
+
+
 class Opts(C.Structure):
     _fields_ = [("auto_stop", C.c_int32), ("update_residualnorm", C.c_int32),
                 ("update_residualkldiv", C.c_int32), ("reserved", C.c_int32), ("atol", C.c_double)]
@@ -85,6 +101,9 @@ SYMBOLS = {
     "pgbp_bm_tree_setup": (C.c_int, [_P, C.POINTER(BmTree)]),
     "pgbp_bm_tree_assignfactors": (C.c_int, [_P, _F64P, _F64P, _F64P, C.c_int32]),
     "pgbp_enqueue_loglik_bm": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_lg_setup": (C.c_int, [_P, C.POINTER(LgFamilies)]),
+    "pgbp_lg_assignfactors": (C.c_int, [_P, C.POINTER(LgParams)]),
+    "pgbp_enqueue_loglik_lg": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_enqueue_calibrate": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
     "pgbp_enqueue_loglik": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),

@@ -364,6 +364,59 @@ class ClusterGraphBelief:
         if sync:
             self.pull()
 
+    def lg_setup(self, fam, data):
+        """Static part of assignfactors! for any linear-Gaussian model (include/pgbp.h: pgbp_lg_families).
+        fam: the dictionary factors.lg_families(...) returns; data: [n_sites, n_rows, p] (or [n_rows, p]) tip data."""
+        data = np.ascontiguousarray(np.asarray(data, np.float64))
+        if data.ndim == 2:
+            data = data[None]
+        assert data.shape[0] == self.n_sites and data.shape[2] == fam["p"]
+        k = {n: np.ascontiguousarray(fam[n], np.int32) for n in ("cluster", "n_parents", "child_pos", "data_row",
+                                                                 "parent_pos", "color")}
+        k.update({n: np.ascontiguousarray(fam[n], np.float64) for n in ("length", "gamma")})
+        k["data"] = data
+        self._lg = k  # keep alive
+        nf = len(k["cluster"])
+        K = max(1, int(fam["max_parents"]))
+        for n in ("parent_pos", "color", "length", "gamma"):
+            assert k[n].size == nf * K, n
+        t = L.LgFamilies(int(fam["p"]), nf, K, int(fam["n_rates"]), int(data.shape[1]), L.i32p(k["cluster"]),
+                         L.i32p(k["n_parents"]), L.i32p(k["child_pos"]), L.i32p(k["data_row"]), L.i32p(k["parent_pos"]),
+                         L.f64p(k["length"]), L.f64p(k["gamma"]), L.i32p(k["color"]), L.f64p(data))
+        _check(self._lib.pgbp_lg_setup(self._eng, C.byref(t)), self._eng)
+        self._lg_p, self._lg_nrates = int(fam["p"]), int(fam["n_rates"])
+
+    def assignfactors_lg_(self, R, mu, model="bm", alpha=None, theta=None, sync=False):
+        """assignfactors!(beliefs, model, ...) (src/beliefs.jl:786-861) on the device for a Brownian motion
+        (homogeneous / heterogeneous: R = the variance rate(s)) or an Ornstein-Uhlenbeck process (R = stationary
+        variance), on the families given to lg_setup; only the model parameters cross the bus.
+        R: [n_rates, p, p] or, per site, [n_sites, n_rates, p, p]; mu / theta: [p] or [n_sites, p]; alpha: scalar or
+        [n_sites].  A random root's prior variance is one more entry of R (the root family's colour)."""
+        p, nr = self._lg_p, self._lg_nrates
+        R = np.asarray(R, np.float64)
+        per_site = R.ndim == 4
+        n = self.n_sites if per_site else 1
+        R = np.ascontiguousarray(R.reshape(n, nr, p, p).transpose(0, 1, 3, 2))  # column-major blocks
+        mu = np.ascontiguousarray(np.broadcast_to(np.asarray(mu, np.float64).reshape(-1, p), (n, p)))
+        ou = model == "ou"
+        al = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha if ou else 0.0, np.float64).reshape(-1), (n,)))
+        th = np.ascontiguousarray(np.broadcast_to(np.asarray(theta if ou else np.zeros(p), np.float64).reshape(-1, p), (n, p)))
+        m = L.LgParams(L.LG_OU if ou else L.LG_BM, int(per_site), L.f64p(R), L.f64p(al) if ou else None,
+                       L.f64p(th) if ou else None, L.f64p(mu))
+        _check(self._lib.pgbp_lg_assignfactors(self._eng, C.byref(m)), self._eng)
+        if sync:
+            self.pull()
+
+    def loglik_lg(self, reps=1):
+        """The body of score(theta) (src/calibration.jl:195-221) on the device with the parameters of the last
+        assignfactors_lg_: factor fill, postorder of schedule tree 0, root integrate.  Returns (loglik[n_sites], info)."""
+        o = self._opts()
+        _check(self._lib.pgbp_enqueue_loglik_lg(self._eng, int(reps), C.byref(o)), self._eng)
+        norm = np.zeros(self.n_sites)
+        info = np.zeros(self.n_sites, dtype=np.int32)
+        _check(self._lib.pgbp_fetch_loglik(self._eng, L.f64p(norm), L.i32p(info)), self._eng)
+        return norm, info
+
     def traffic_model(self):
         b = C.c_double()
         n = C.c_int64()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -76,6 +77,12 @@ struct pgbp_engine {
   int32_t bm_p = 0, bm_rows = 0, bm_per_site = 0;
   int32_t *d_bm_kind = nullptr, *d_bm_row = nullptr;
   double *d_bm_length = nullptr, *d_bm_data = nullptr, *d_bm_Rinv = nullptr, *d_bm_logdet = nullptr, *d_bm_mu = nullptr;
+  // pgbp_lg_families: static description + last parameters of the general linear-Gaussian factor fill
+  LgStatic lg{};                  // device pointers (owned: lg_bufs)
+  LgParams lgp{};
+  std::vector<void*> lg_bufs;
+  bool lg_ready = false, lg_have_params = false, lg_uni_ok = false;
+  double *d_lg_R = nullptr, *d_lg_alpha = nullptr, *d_lg_theta = nullptr, *d_lg_mu = nullptr;
   std::string err;
 
   int fail(int code, const std::string& msg) {
@@ -373,6 +380,10 @@ void pgbp_destroy(pgbp_engine* e) {
                   (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_bdim, (void*)e->d_rdim,
                   (void*)e->d_symflag, (void*)e->d_bm_kind, (void*)e->d_bm_row, (void*)e->d_bm_length,
                   (void*)e->d_bm_data, (void*)e->d_bm_Rinv, (void*)e->d_bm_logdet, (void*)e->d_bm_mu})
+    if (p) (void)hipFree(p);
+  for (void* p : e->lg_bufs)
+    if (p) (void)hipFree(p);
+  for (void* p : {(void*)e->d_lg_R, (void*)e->d_lg_alpha, (void*)e->d_lg_theta, (void*)e->d_lg_mu})
     if (p) (void)hipFree(p);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
@@ -1006,6 +1017,164 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
   return PGBP_OK;
 }
 
+// ---- device factor assignment (any linear-Gaussian model, trees and networks) ---------------------------
+
+int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
+  if (!e || !f || f->p <= 0 || f->p > PGBP_MAX_DIM || f->n_families < 0 || f->max_parents < 1 || f->n_rates < 1 ||
+      f->n_rows < 0)
+    return PGBP_ERR_INVALID;
+  if (f->n_families > 0 && (!f->cluster || !f->n_parents || !f->child_pos || !f->data_row || !f->parent_pos || !f->length ||
+                            !f->gamma || !f->color))
+    return PGBP_ERR_INVALID;
+  if (f->n_rows > 0 && !f->data) return e->fail(PGBP_ERR_INVALID, "pgbp_lg_setup: data missing");
+  const Plan& p = e->plan;
+  const int nc = p.n_clusters, K = f->max_parents, pp = f->p;
+  for (size_t i = 0, n = (size_t)p.n_sites * f->n_rows * pp; i < n; ++i)
+    if (!std::isfinite(f->data[i]))
+      return e->fail(PGBP_ERR_INVALID, "pgbp_lg_setup: a tip value is missing or not finite (missing data: the caller's own assignfactors! + pgbp_set_beliefs)");
+  // every family fits its cluster; the blocks of one family do not overlap
+  std::vector<int32_t> count(nc + 1, 0);
+  bool uni_ok = p.max_dim <= 2 && pp == 1;
+  for (int i = 0; i < f->n_families; ++i) {
+    const std::string where = "pgbp_lg_setup: family " + std::to_string(i) + ": ";
+    const int c = f->cluster[i], np = f->n_parents[i];
+    if (c < 0 || c >= nc) return e->fail(PGBP_ERR_INVALID, where + "cluster out of range");
+    if (np < 0 || np > K) return e->fail(PGBP_ERR_INVALID, where + "number of parents out of range");
+    const int m = p.dims[c];
+    std::vector<int> pos;
+    const int cp = f->child_pos[i];
+    if (cp < 0) {
+      if (np == 0) return e->fail(PGBP_ERR_INVALID, where + "a root prior needs the root in scope");
+      if (f->data_row[i] < 0 || f->data_row[i] >= f->n_rows) return e->fail(PGBP_ERR_INVALID, where + "data row out of range");
+    } else {
+      pos.push_back(cp);
+    }
+    if (np == 0 && (f->color[(size_t)i * K] < 0 || f->color[(size_t)i * K] >= f->n_rates))
+      return e->fail(PGBP_ERR_INVALID, where + "rate index out of range");
+    for (int k = 0; k < np; ++k) {
+      const size_t o = (size_t)i * K + k;
+      if (!(f->length[o] > 0.0) || !std::isfinite(f->length[o]))
+        return e->fail(PGBP_ERR_INVALID, where + "parent edge length must be positive (degenerate families are out of scope)");
+      if (!std::isfinite(f->gamma[o])) return e->fail(PGBP_ERR_INVALID, where + "inheritance not finite");
+      if (f->color[o] < 0 || f->color[o] >= f->n_rates) return e->fail(PGBP_ERR_INVALID, where + "rate index out of range");
+      if (f->parent_pos[o] >= 0) pos.push_back(f->parent_pos[o]);
+    }
+    std::sort(pos.begin(), pos.end());
+    for (size_t a = 0; a < pos.size(); ++a)
+      if (pos[a] + pp > m || (a > 0 && pos[a] < pos[a - 1] + pp))
+        return e->fail(PGBP_ERR_INVALID, where + "variable blocks overlap or leave the cluster (dimension " + std::to_string(m) + ")");
+    ++count[c + 1];
+  }
+  for (int c = 0; c < nc; ++c) count[c + 1] += count[c];
+  std::vector<int32_t> fam(std::max(1, f->n_families));
+  {
+    std::vector<int32_t> at(count.begin(), count.end() - 1);
+    for (int i = 0; i < f->n_families; ++i) fam[at[f->cluster[i]]++] = i;  // stable: the reference's loop order
+  }
+  for (void* q : e->lg_bufs)
+    if (q) (void)hipFree(q);
+  e->lg_bufs.clear();
+  for (double** q : {&e->d_lg_R, &e->d_lg_alpha, &e->d_lg_theta, &e->d_lg_mu}) {
+    if (*q) (void)hipFree(*q);
+    *q = nullptr;
+  }
+  e->lg_ready = e->lg_have_params = false;
+  const size_t nf = (size_t)f->n_families, nfk = nf * K;
+  int rc;
+  int32_t *d_off = nullptr, *d_fam = nullptr, *d_np = nullptr, *d_cp = nullptr, *d_row = nullptr, *d_pp = nullptr, *d_col = nullptr;
+  double *d_len = nullptr, *d_gam = nullptr, *d_data = nullptr;
+  auto keep = [&](void* q) { e->lg_bufs.push_back(q); };
+  if ((rc = upload(e, &d_off, count))) return rc; keep(d_off);
+  if ((rc = upload(e, &d_fam, fam))) return rc; keep(d_fam);
+  if ((rc = upload(e, &d_np, std::vector<int32_t>(f->n_parents, f->n_parents + nf)))) return rc; keep(d_np);
+  if ((rc = upload(e, &d_cp, std::vector<int32_t>(f->child_pos, f->child_pos + nf)))) return rc; keep(d_cp);
+  if ((rc = upload(e, &d_row, std::vector<int32_t>(f->data_row, f->data_row + nf)))) return rc; keep(d_row);
+  if ((rc = upload(e, &d_pp, std::vector<int32_t>(f->parent_pos, f->parent_pos + nfk)))) return rc; keep(d_pp);
+  if ((rc = upload(e, &d_col, std::vector<int32_t>(f->color, f->color + nfk)))) return rc; keep(d_col);
+  if ((rc = upload(e, &d_len, std::vector<double>(f->length, f->length + nfk)))) return rc; keep(d_len);
+  if ((rc = upload(e, &d_gam, std::vector<double>(f->gamma, f->gamma + nfk)))) return rc; keep(d_gam);
+  const size_t nd = (size_t)p.n_sites * f->n_rows * pp;
+  if ((rc = dev_alloc(e, &d_data, nd))) return rc; keep(d_data);
+  if (nd) HIPCHK(e, hipMemcpy(d_data, f->data, nd * sizeof(double), hipMemcpyHostToDevice));
+  const size_t ns = (size_t)p.n_sites;
+  if ((rc = dev_alloc(e, &e->d_lg_R, ns * f->n_rates * pp * pp))) return rc;
+  if ((rc = dev_alloc(e, &e->d_lg_alpha, ns))) return rc;
+  if ((rc = dev_alloc(e, &e->d_lg_theta, ns * pp))) return rc;
+  if ((rc = dev_alloc(e, &e->d_lg_mu, ns * pp))) return rc;
+  e->lg = LgStatic{pp, K, f->n_rates, f->n_rows, d_off, d_fam, d_np, d_cp, d_row, d_pp, d_len, d_gam, d_col, d_data};
+  e->lg_ready = true;
+  e->lg_uni_ok = uni_ok;
+  return PGBP_OK;
+}
+
+// also_factors: assignfactors! followed by init_factors_frombeliefs!; without it only the beliefs are written, as in
+// the body of score() (src/calibration.jl:205-209)
+static int lg_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = false) {
+  const Plan& p = e->plan;
+  if (e->layout_sm && e->lg_uni_ok) {
+    launch_lg_fill_uni_sm(e->lg, e->lgp, e->d_pool_sm, also_factors ? e->d_fpool_sm : nullptr, e->d_packed_off, e->d_bdim,
+                          p.n_clusters, p.n_sites, e->st);
+    const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
+    HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
+  } else {
+    if (e->layout_sm) {
+      const int rc0 = ensure_site_minor(e, false);
+      if (rc0) return rc0;
+    }
+    launch_lg_fill(e->lg, e->lgp, e->d_pool, p.pool_stride(), also_factors ? e->d_fpool : nullptr, p.cluster_stride(),
+                   e->d_boff, e->d_bdim, e->layout_bs16 ? 1 : 0, p.fast_p, p.max_dim, p.n_clusters, p.n_sites, e->st);
+    if (!skip_sepsets)
+      launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
+                          p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
+  }
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st,
+                     e->layout_sm ? 1 : 0);
+  if (also_factors) e->have_factors = true;
+  return PGBP_OK;
+}
+
+int pgbp_lg_assignfactors(pgbp_engine* e, const pgbp_lg_params* m) {
+  if (!e || !m || !m->R || !m->mu) return PGBP_ERR_INVALID;
+  if (!e->lg_ready) return e->fail(PGBP_ERR_STATE, "pgbp_lg_assignfactors: call pgbp_lg_setup first");
+  if (m->model != PGBP_LG_BM && m->model != PGBP_LG_OU) return e->fail(PGBP_ERR_INVALID, "pgbp_lg_assignfactors: unknown model");
+  if (m->model == PGBP_LG_OU && (!m->alpha || !m->theta))
+    return e->fail(PGBP_ERR_INVALID, "pgbp_lg_assignfactors: the OU model needs alpha and theta");
+  const size_t n = m->per_site ? (size_t)e->plan.n_sites : 1, pp = (size_t)e->lg.p;
+  HIPCHK(e, hipMemcpyAsync(e->d_lg_R, m->R, n * e->lg.n_rates * pp * pp * sizeof(double), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipMemcpyAsync(e->d_lg_mu, m->mu, n * pp * sizeof(double), hipMemcpyHostToDevice, e->st));
+  if (m->alpha) HIPCHK(e, hipMemcpyAsync(e->d_lg_alpha, m->alpha, n * sizeof(double), hipMemcpyHostToDevice, e->st));
+  if (m->theta) HIPCHK(e, hipMemcpyAsync(e->d_lg_theta, m->theta, n * pp * sizeof(double), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));  // the host buffers may go away
+  e->lgp = LgParams{m->model, m->per_site ? 1 : 0, e->d_lg_R, e->d_lg_alpha, m->theta ? e->d_lg_theta : nullptr, e->d_lg_mu};
+  e->lg_have_params = true;
+  // the fill writes exactly symmetric blocks: the layout the traversals want can be kept
+  e->sym_known = true;
+  e->sym_ok = true;
+  return lg_fill_async(e, true);
+}
+
+int pgbp_enqueue_loglik_lg(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  if (!e->lg_ready || !e->lg_have_params)
+    return e->fail(PGBP_ERR_STATE, "pgbp_enqueue_loglik_lg: call pgbp_lg_setup / pgbp_lg_assignfactors first");
+  if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
+  DevState S = dev_state(e, opts);
+  const Plan& p = e->plan;
+  for (int r = 0; r < reps; ++r) {
+    DevState S1 = S;
+    S1.sep_zero = fresh_sepsets_shortcut(e) ? 1 : 0;
+    if ((rc = lg_fill_async(e, false, S1.sep_zero != 0))) return rc;  // assignfactors!        calibration.jl:205-209
+    enqueue_traversal(e, S1, 0, 0, 0);                                // postorder             :210
+    const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
+    integrate_async(e, root, nullptr);                                // :212
+  }
+  return PGBP_OK;
+}
+
 // ---- benchmarking / zero-copy entry points ---------------------------------------------------
 
 static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_each,
@@ -1082,14 +1251,15 @@ int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
 
 int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each, const pgbp_opts* opts,
                        float* ms_total) {
-  if (!e || !ms_total || kind < 0 || kind > 2) return PGBP_ERR_INVALID;
+  if (!e || !ms_total || kind < 0 || kind > 3) return PGBP_ERR_INVALID;
   hipEvent_t a, b;
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipEventRecord(a, e->st));
   int rc = kind == 0 ? pgbp_enqueue_calibrate(e, reps, reset_each, opts)
-                     : (kind == 2 ? pgbp_enqueue_loglik_bm(e, reps, opts) : pgbp_enqueue_loglik(e, reps, opts));
+                     : (kind == 3 ? pgbp_enqueue_loglik_lg(e, reps, opts)
+                                  : (kind == 2 ? pgbp_enqueue_loglik_bm(e, reps, opts) : pgbp_enqueue_loglik(e, reps, opts)));
   if (rc == PGBP_OK) {
     HIPCHK(e, hipEventRecord(b, e->st));
     HIPCHK(e, hipEventSynchronize(b));

@@ -96,6 +96,27 @@ void launch_bm_tree_fill(double* pool, int64_t pool_stride, double* fpool, int64
                          const double* d_mu, int per_site, int bs16, int fast_p, int n_clusters, int n_sites,
                          hipStream_t st);
 
+// assignfactors! for any linear-Gaussian model (pgbp_lg_families / pgbp_lg_params of include/pgbp.h; pgbp_lgfill.hip)
+struct LgStatic {
+  int32_t p, K, n_rates, n_rows;
+  const int32_t *cl_off, *cl_fam;  // CSR cluster -> its families, in the reference's loop order
+  const int32_t *n_parents, *child_pos, *data_row, *parent_pos;
+  const double *length, *gamma;
+  const int32_t* color;
+  const double* data;
+};
+struct LgParams {
+  int32_t model, per_site;
+  const double *R, *alpha, *theta, *mu;  // device pointers
+};
+// one workgroup per (cluster, site); pool / fpool in the current layout (fpool may be null: beliefs only)
+void launch_lg_fill(const LgStatic& F, const LgParams& M, double* pool, int64_t pool_stride, double* fpool,
+                    int64_t fpool_stride, const int64_t* d_boff, const int32_t* d_dim, int bs16, int fast_p, int max_dim,
+                    int n_clusters, int n_sites, hipStream_t st);
+// univariate batches in the site-minor layout (every dimension <= 2): thread = (cluster, site)
+void launch_lg_fill_uni_sm(const LgStatic& F, const LgParams& M, double* pool_sm, double* fpool_sm, const int64_t* d_poff,
+                           const int32_t* d_dim, int n_clusters, int n_sites, hipStream_t st);
+
 // free_energy (src/score.jl:162-182): per-belief terms + deterministic per-site sum -> out3[site] =
 // (average energy, approximate entropy, free energy); info[site] (preset to INT_MAX) = first non-PD belief + 1
 // lane-blocked version of the same fill (pgbp_fast.hip) for 2 <= p <= 16 when every cluster has dimension 0, p or 2p

@@ -108,3 +108,39 @@ def pack_oracle(cgb, prob):
         out[o + m * m:o + m * m + m] = b.h
         out[o + m * m + m] = b.g[0]
     return out
+
+
+def lg_inputs_from_oracle(P, net, ocgb, model, tbl, taxa):
+    """Inputs of the device factor fill (pgbp_amd.lg_families + assignfactors_lg_ keyword arguments) for the
+    oracle's network / model objects.  Returns (families, data[n_rows, p], kwargs)."""
+    prenodes = net.vec_node
+    p = model.dimension()
+    hetero = isinstance(model, OM.HeterogeneousBrownianMotion)
+    parent_edges, data_row = [], []
+    for ni, nf in enumerate(ocgb.node2family):
+        ch = prenodes[ni]
+        row = []
+        for p1 in nf[1:]:
+            pnode = prenodes[p1 - 1]
+            e = next(e for e in pnode.edges if e.child is ch)   # src/beliefs.jl:813-820
+            row.append((e.length, e.gamma if len(nf) > 2 else 1.0, model._c(e) if hetero else 0))
+        parent_edges.append(row)
+        data_row.append(list(taxa).index(ch.name) if ch.leaf else -1)
+    if hetero:
+        rates = [np.asarray(r, float) for r in model.rates]
+    elif isinstance(model, OM.UnivariateOrnsteinUhlenbeck):
+        rates = [np.array([[model.gamma2]])]
+    else:
+        rates = [np.asarray(model.R, float)]
+    root_color = None
+    v = np.atleast_2d(np.asarray(model.rootpriorvariance(), float))
+    if not model.isrootfixed() and not np.any(np.isinf(np.diag(v))):
+        root_color = len(rates)
+        rates = rates + [v]
+    fam = P.lg_families(ocgb.belief[:ocgb.nclusters], ocgb.node2cluster, ocgb.node2family, ocgb.node2fixed,
+                        parent_edges, data_row, p, n_rates=len(rates), root_prior_color=root_color)
+    data = np.array([[float(tbl[v][r]) for v in range(p)] for r in range(len(taxa))])
+    kw = dict(R=np.stack(rates), mu=model.rootpriormeanvector())
+    if isinstance(model, OM.UnivariateOrnsteinUhlenbeck):
+        kw.update(model="ou", alpha=model.alpha, theta=[model.theta])
+    return fam, data, kw
