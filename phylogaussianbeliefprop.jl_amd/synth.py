@@ -308,6 +308,22 @@ def bm_tree_table(tree: Tree, prob: Problem):
     return kind, length, row
 
 
+
+def lg_tree_table(tree: Tree, prob: Problem, p: int, colors=None):
+    """Node-family table for the general DEVICE factor fill (include/pgbp.h: pgbp_lg_families; the dictionary
+    `factors.lg_families` returns) of a cliquetree_of_tree / bethe_of_tree problem under a fixed-root model: family of
+    node c (preorder, c >= 1) = {c, parent(c)} in factor cluster c - 1; tips carry data row c.
+    colors: per-node 0-based rate index of the edge above it (heterogeneous models), default 0."""
+    N = tree.nnodes
+    c = np.arange(1, N)
+    leaf, pa_root = tree.is_leaf[c], tree.parent[c] == 0
+    col = np.zeros(N - 1, np.int32) if colors is None else np.asarray(colors, np.int32)[c]
+    return dict(p=int(p), max_parents=1, n_rates=int(col.max()) + 1 if col.size else 1,
+                cluster=(c - 1).astype(np.int32), n_parents=np.ones(N - 1, np.int32),
+                child_pos=np.where(leaf, -1, 0).astype(np.int32), data_row=np.where(leaf, c, -1).astype(np.int32),
+                parent_pos=np.where(pa_root, -1, np.where(leaf, 0, p)).astype(np.int32),
+                length=tree.length[c].astype(np.float64), gamma=np.ones(N - 1), color=col)
+
 def bm_loglik_pruning(tree: Tree, R: np.ndarray, mu: np.ndarray, Y: np.ndarray) -> float:
     """Independent O(n p^3) check: Felsenstein-style pruning for BM with a fixed root
     (no shared code with the engine): each subtree is summarised as N(x_hat, v R) x const."""

@@ -145,3 +145,126 @@ def test_lgfill_random_networks(P, graph, which, p):
         assert OC.propagate_1traversal_postorder(ocgb2, *spt)
         oll2 = ocgb2.integratebelief(spt[2][0])[1]
         assert abs(ll2[0] - oll2) <= 1e-8 * max(1.0, abs(oll2)), (ll2, oll2)
+
+
+def _tree_as_network(S, tr):
+    names = [f"n{i}" for i in range(tr.nnodes)]
+    net = ON.read_newick(tr.newick(names))
+    net.set_preorder(names)
+    taxa = [names[i] for i in range(tr.nnodes) if tr.is_leaf[i]]
+    return net, names, taxa
+
+
+def test_lgfill_ou_sites_site_minor(P):
+    """cfg4's likelihood evaluation entirely on the device: univariate OU with one (sigma2, alpha, theta, mu) and one
+    data column per site, 70 sites (site-minor layout, lg_fill_uni_sm) and 5 sites (wavefront kernels): fill +
+    postorder + root integrate against the dense multivariate-normal likelihood of every site, then a calibration
+    from the device-filled factors against the oracle."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(44)
+    tr = S.random_tree(25, rng)
+    net, names, taxa = _tree_as_network(S, tr)
+    prob = S.cliquetree_of_tree(tr, 1)
+    clusters = [(str(i), [int(a), int(b)]) for i, (a, b) in enumerate(prob.cluster_nodes)]
+    edges = [(int(a), int(b), [int(prob.sepset_nodes[k])]) for k, (a, b) in enumerate(prob.sepset_clusters)]
+    cg = OB.ClusterGraph(clusters, edges, "cliquetree")
+    spt = ([str(x) for x in prob.schedule[0][0]], [str(x) for x in prob.schedule[0][1]],
+           prob.schedule[0][0].tolist(), prob.schedule[0][1].tolist())
+    for ns in (70, 5):
+        sig, al = rng.uniform(0.5, 2, ns), rng.uniform(0.1, 1, ns)
+        th, mu = rng.normal(size=ns), rng.normal(size=ns)
+        X = np.zeros((ns, tr.nnodes, 1))
+        X[:, tr.is_leaf, 0] = rng.normal(size=(ns, tr.ntips))
+        eng = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                               np.zeros((ns, int(prob.packed_off[-1]))), n_sites=ns)
+        eng.set_schedule(prob.schedule)
+        eng.lg_setup(S.lg_tree_table(tr, prob, 1), X)
+        assert P.calibrate_(eng, prob.schedule, 1)[0]            # brings the state into the layout of the traversals
+        gam2 = sig / (2 * al)
+        eng.assignfactors_lg_(gam2.reshape(ns, 1, 1, 1), mu[:, None], model="ou", alpha=al, theta=th[:, None])
+        ll, info = eng.loglik_lg(reps=2)
+        assert not info.any()
+        models = [OM.UnivariateOrnsteinUhlenbeck(sig[s], al[s], th[s], mu[s], 0.0) for s in range(ns)]
+        ys = [[float(X[s, i, 0]) for i in range(tr.nnodes) if tr.is_leaf[i]] for s in range(ns)]
+        for s in range(ns):
+            dense = OD.loglik(net, models[s], [ys[s]], taxa)
+            assert abs(ll[s] - dense) <= 1e-8 * max(1.0, abs(dense)), (ns, s, ll[s], dense)
+        eng.assignfactors_lg_(gam2.reshape(ns, 1, 1, 1), mu[:, None], model="ou", alpha=al, theta=th[:, None])
+        assert P.calibrate_(eng, prob.schedule, 2) == (True, True)
+        for s in (0, ns - 1):
+            ocgb = oracle_setup(net, cg, models[s], [ys[s]], taxa)
+            assert OC.calibrate(ocgb, [spt], 2) == (True, True)
+            from helpers import pack_oracle
+            assert np.allclose(eng._packed[s], pack_oracle(ocgb, prob), rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("graph,p,ns", [("cliquetree", 16, 1), ("bethe", 8, 2), ("cliquetree", 5, 3), ("cliquetree", 4, 1)])
+def test_lgfill_hetero_tree_layouts(P, graph, p, ns):
+    """Heterogeneous BM (3 painted rates) on a tree, factors filled on the device while the state is in the layout of
+    the register-resident kernel (symmetric block-packed for even p): likelihood against the oracle's traversal on
+    oracle-filled factors; per-site rates when ns > 1."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(900 + p)
+    tr = S.random_tree(40, rng)
+    net, names, taxa = _tree_as_network(S, tr)
+    prob = S.cliquetree_of_tree(tr, p) if graph == "cliquetree" else S.bethe_of_tree(tr, p)
+    col = rng.integers(0, 3, size=tr.nnodes)
+    X = rng.normal(size=(ns, tr.nnodes, p))
+    eng = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                           np.zeros((ns, int(prob.packed_off[-1]))), n_sites=ns)
+    eng.set_schedule(prob.schedule)
+    fam = S.lg_tree_table(tr, prob, p, colors=col)
+    fam["n_rates"] = 3
+    eng.lg_setup(fam, X)
+    rates = np.zeros((ns, 3, p, p))
+    for s in range(ns):
+        R = S.random_rate_matrix(p, rng)
+        R = (R + R.T) / 2
+        rates[s] = [R * f for f in (0.5, 1.0, 2.0)]
+    mus = rng.normal(size=(ns, p))
+    for rep in range(2):   # rep 1: the state already sits in the traversal layout
+        eng.assignfactors_lg_(rates if ns > 1 else rates[0], mus if ns > 1 else mus[0])
+        ll, info = eng.loglik_lg()
+        assert not info.any()
+        assert P.calibrate_(eng, prob.schedule, 1)[0]
+        ll_cal = eng.integratebelief_(prob.root_cluster, all_sites=True)[1]
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ecol = {e.number: 1 + int(col[int(e.child.name[1:])]) for e in net.edges}
+    for s in range(ns):
+        model = OM.HeterogeneousBrownianMotion(list(rates[s]), ecol, mus[s])
+        tbl = [[float(X[s, int(t[1:]), v]) for t in taxa] for v in range(p)]
+        ocgb = oracle_setup(net, ct, model, tbl, taxa)
+        assert OC.propagate_1traversal_postorder(ocgb, *spt)
+        oll = ocgb.integratebelief(spt[2][0])[1]
+        assert abs(ll[s] - oll) <= 1e-8 * max(1.0, abs(oll)), (s, ll[s], oll)
+        assert abs(ll_cal[s] - oll) <= 1e-8 * max(1.0, abs(oll))
+
+
+def test_lgfill_refusals(P):
+    """Malformed family tables and out-of-order calls are refused with the reference's kind of error, nothing runs."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(3)
+    tr = S.random_tree(8, rng)
+    prob = S.cliquetree_of_tree(tr, 2)
+    eng = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                           np.zeros(int(prob.packed_off[-1])))
+    X = rng.normal(size=(tr.nnodes, 2))
+    with pytest.raises(AttributeError):
+        eng.assignfactors_lg_(np.eye(2)[None], np.zeros(2))          # no lg_setup yet
+    good = S.lg_tree_table(tr, prob, 2)
+    for key, val, msg in (("child_pos", 3, "overlap or leave"), ("cluster", 10 ** 6, "cluster out of range"),
+                          ("length", 0.0, "positive"), ("color", 5, "rate index")):
+        bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in good.items()}
+        i = int(np.nonzero(good["child_pos"] >= 0)[0][-1])
+        bad[key][i] = val
+        with pytest.raises(P.PgbpError, match=msg):
+            eng.lg_setup(bad, X)
+    Xnan = X.copy()
+    Xnan[int(np.nonzero(tr.is_leaf)[0][0]), 1] = np.nan
+    with pytest.raises(P.PgbpError, match="missing"):
+        eng.lg_setup(good, Xnan)
+    eng.lg_setup(good, X)
+    eng.set_schedule(prob.schedule)
+    with pytest.raises(P.PgbpError, match="pgbp_lg_assignfactors first"):
+        eng.loglik_lg()                                               # schedule set? parameters missing
