@@ -114,32 +114,47 @@ def load_pmc_traffic():
 
 
 def run_sites(args, torch, dist, rank, world, local_rank):
-    """cfg4-shaped workload (BASELINE.json configs[3]): many independent univariate sites on one tree, sites
-    sharded contiguously across ranks, no communication during calibration, ONE all-gather (RCCL) of the
-    per-site log-likelihoods at the end.  Univariate BM with a per-site rate stands in for the per-site OU of
-    cfg4 (same message shapes; the OU factor values are parity-tested in tests/test_gpu_parity.py); factors are
-    assigned on the device, so only (sigma2, mu) per site and the tip data cross the bus."""
+    """cfg4 (BASELINE.json configs[3]: "OU model, 8 traits x 1000 independent sites, 20k-tip tree, sites sharded"):
+    the reference's only OU is UnivariateOrnsteinUhlenbeck, so 8 traits x 1000 sites = 8000 independent univariate OU
+    problems (one sigma2, alpha, theta, mu and one data column each) on one tree.  Problems are
+    sharded contiguously across ranks, no communication during calibration, ONE all-gather (RCCL) of the per-problem
+    log-likelihoods at the end.  Factors are assigned on the device (pgbp_lg_assignfactors, OU), so only the four
+    parameters per problem and the tip data cross the bus.  --site-model bm: univariate BM instead."""
     import pgbp_amd
     from pgbp_amd import _lib as L
     from pgbp_amd import synth as S
     from pgbp_amd.sharding import gather_sites, shard_range
     lib = pgbp_amd.load()
-    lo, hi = shard_range(args.sites, rank, world)
+    nprob = args.sites * args.site_traits
+    lo, hi = shard_range(nprob, rank, world)
     ns = hi - lo
     rng = np.random.default_rng(args.seed)               # same tree and parameters on every rank
     tr = S.random_tree(args.ntips, rng)
-    sigma2_all = rng.uniform(0.5, 2.0, size=args.sites)
-    mu_all = rng.normal(size=args.sites)
-    sigma2, mu = sigma2_all[lo:hi], mu_all[lo:hi]
-    X = S.simulate_bm_uni_sites(tr, sigma2, mu, np.random.default_rng(args.seed + 1000 + rank))
-    ll_check = S.bm_loglik_pruning_uni_sites(tr, sigma2, mu, X)
+    sigma2_all = rng.uniform(0.5, 2.0, size=nprob)
+    alpha_all = rng.uniform(0.1, 1.0, size=nprob)
+    theta_all = rng.normal(size=nprob)
+    mu_all = rng.normal(size=nprob)
+    sigma2, alpha, theta, mu = sigma2_all[lo:hi], alpha_all[lo:hi], theta_all[lo:hi], mu_all[lo:hi]
+    rng_x = np.random.default_rng(args.seed + 1000 + rank)
     prob = S.cliquetree_of_tree(tr, 1)
     cgb = pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
-                                                  np.zeros((ns, int(prob.packed_off[-1]))), n_sites=ns,
-                                                  device=local_rank)
+                                                  None, n_sites=ns, device=local_rank)
     cgb.set_schedule(prob.schedule)
-    cgb.bm_tree_setup(*S.bm_tree_table(tr, prob), X[:, :, None])
-    cgb.assignfactors_bm_(sigma2[:, None, None], mu[:, None])
+    ou = args.site_model == "ou"
+    if ou:
+        X = S.simulate_ou_uni_sites(tr, sigma2, alpha, theta, mu, rng_x)
+        ll_check = S.ou_loglik_pruning_uni_sites(tr, sigma2, alpha, theta, mu, X)
+        cgb.lg_setup(S.lg_tree_table(tr, prob, 1), X[:, :, None])
+        cgb.assignfactors_lg_((sigma2 / (2.0 * alpha)).reshape(ns, 1, 1, 1), mu[:, None], model="ou", alpha=alpha,
+                              theta=theta[:, None])
+        enqueue_ll, ll_kind = lib.pgbp_enqueue_loglik_lg, 3
+    else:
+        X = S.simulate_bm_uni_sites(tr, sigma2, mu, rng_x)
+        ll_check = S.bm_loglik_pruning_uni_sites(tr, sigma2, mu, X)
+        cgb.bm_tree_setup(*S.bm_tree_table(tr, prob), X[:, :, None])
+        cgb.assignfactors_bm_(sigma2[:, None, None], mu[:, None])
+        enqueue_ll, ll_kind = lib.pgbp_enqueue_loglik_bm, 2
+    del X
     eng, opts = cgb._eng, cgb._opts()
 
     def check(code):
@@ -147,30 +162,40 @@ def run_sites(args, torch, dist, rank, world, local_rank):
             raise RuntimeError(lib.pgbp_last_error(eng).decode())
     norm = np.zeros(ns)
     info = np.zeros(ns, dtype=np.int32)
-    check(lib.pgbp_enqueue_loglik_bm(eng, 1, C.byref(opts)))
+    check(enqueue_ll(eng, 1, C.byref(opts)))
     check(lib.pgbp_fetch_loglik(eng, L.f64p(norm), L.i32p(info)))
     rel = float(np.max(np.abs(norm - ll_check) / np.maximum(1.0, np.abs(ll_check))))
     if info.any() or rel > 1e-8:
         raise SystemExit(f"parity gate failed (sites): max rel err {rel:.3e}, failures {int(info.astype(bool).sum())}")
-    _, msgs_per_cal = cgb.traffic_model()                 # messages of all local sites per calibrate
+    bytes_per_cal, msgs_per_cal = cgb.traffic_model()     # all local problems, one calibrate
     check(lib.pgbp_enqueue_calibrate(eng, args.warmup, 0, C.byref(opts)))
 
     def k_steps():
         check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
         check(lib.pgbp_sync(eng))
     dt = timed_region(k_steps, dist, torch.cuda.synchronize)
-    # the one collective of this configuration: all ranks get every site's log-likelihood
-    full = gather_sites(norm, args.sites, dist, device=f"cuda:{local_rank}")
-    total_msgs = msgs_per_cal / max(1, ns) * args.sites   # same per-site count on every rank
+    # log-likelihood evaluations (device factor fill + postorder + root integrate) of all local problems per second
+    ms_ll = C.c_float()
+    check(lib.pgbp_time_enqueued(eng, ll_kind, 3, 0, C.byref(opts), C.byref(ms_ll)))
+    # the one collective of this configuration: all ranks get every problem's log-likelihood
+    full = gather_sites(norm, nprob, dist, device=f"cuda:{local_rank}")
+    total_msgs = msgs_per_cal / max(1, ns) * nprob        # same per-problem count on every rank
     if rank == 0:
+        ms_step = dt / args.steps * 1e3
         print(json.dumps({
             "metric": "clique-tree messages/sec (calibrate!), independent univariate sites sharded across GPUs",
             "value": total_msgs * args.steps / dt, "unit": "messages/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg4-shaped: {args.sites} independent univariate BM sites, {args.ntips}-tip tree, "
-                                   f"clique tree, sites sharded over {world} rank(s); one all-gather of per-site log-likelihoods",
-                       "sites_per_rank": ns, "messages_per_site_per_step": int(msgs_per_cal // max(1, ns))},
+            "config": {"workload": f"cfg4: {args.sites} sites x {args.site_traits} traits = {nprob} independent univariate "
+                                   f"{'OU' if ou else 'BM'} problems, {args.ntips}-tip tree, clique tree, sharded over "
+                                   f"{world} rank(s); one all-gather of per-problem log-likelihoods",
+                       "problems_per_rank": ns, "messages_per_problem_per_step": int(msgs_per_cal // max(1, ns))},
+            "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                         "kernel": "bp_level_uni", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate"},
+            "ll_evals_per_s": world * ns * 3 / (ms_ll.value * 1e-3),
+            "ll_eval_note": "problem log-likelihoods per second: device factor fill + postorder + root integrate (score() body)",
             "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": rel}))
 
 
@@ -179,7 +204,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ntips", type=int, default=50000)
+    ap.add_argument("--ntips", type=int, default=None, help="default: 50000 (tree workload), 20000 (sites workload)")
     ap.add_argument("--traits", type=int, default=16)
     ap.add_argument("--graph", default="cliquetree", choices=["cliquetree", "bethe"])
     ap.add_argument("--seed", type=int, default=3)
@@ -187,10 +212,14 @@ def main():
     ap.add_argument("--no-alt-reading", action="store_true",
                     help="skip the 25001-tip (50k-clique) side measurement: profiler runs want one workload per kernel name")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--site-model", default="ou", choices=["ou", "bm"], help="sites workload: per-problem model")
+    ap.add_argument("--site-traits", type=int, default=8, help="sites workload: traits per site (each an independent univariate problem)")
     ap.add_argument("--workload", default="tree", choices=["tree", "sites"],
                     help="tree: the headline one-big-tree workload (default); sites: cfg4-shaped site-sharded batch")
     ap.add_argument("--sites", type=int, default=1000)
     args = ap.parse_args()
+    if args.ntips is None:
+        args.ntips = 20000 if args.workload == "sites" else 50000
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -83,15 +83,17 @@ class ClusterGraphBelief:
     def from_arrays(cls, dims, sepset_clusters, scope_off, scope_idx, packed, n_sites=1, device=0,
                     labels=None):
         """Bulk constructor: description arrays of include/pgbp.h + packed (J,h,g) beliefs
-        [n_sites, packed_size]; the cluster part is snapshot as the factors."""
+        [n_sites, packed_size]; the cluster part is snapshot as the factors.  packed=None: nothing is uploaded and no
+        host mirror is kept (large site batches whose factors are assigned on the device)."""
         self = cls.__new__(cls)
         self._init_common(np.asarray(dims, np.int32), np.asarray(sepset_clusters, np.int32).reshape(-1),
                           np.asarray(scope_off, np.int64), np.asarray(scope_idx, np.int32), n_sites, device)
         self._objs = None
         self._labels = labels
         self.cdict = self.sdict = None
-        self._packed[...] = np.asarray(packed, dtype=np.float64).reshape(self._packed.shape)
-        self._upload(snapshot_factors=True)
+        if packed is not None:   # None: all beliefs start as the constant 1 on the device (a device factor fill follows);
+            self._packed[...] = np.asarray(packed, dtype=np.float64).reshape(self._packed.shape)   # no host mirror until a pull
+            self._upload(snapshot_factors=True)
         return self
 
     # ------------------------------------------------------------------ internals
@@ -117,7 +119,7 @@ class ClusterGraphBelief:
         self._roff = np.concatenate([[0], np.cumsum(s * s + s)])
         assert self._poff[-1] == self._lib.pgbp_packed_size(eng)
         assert self._roff[-1] == self._lib.pgbp_residual_size(eng)
-        self._packed = np.zeros((self.n_sites, int(self._poff[-1])))
+        self._packed_arr = None   # host mirror [n_sites, packed_size], allocated at first use
         self._res = None
         self._flg = None
         self._kl = None
@@ -127,6 +129,12 @@ class ClusterGraphBelief:
         self.belief = _BeliefList(self)
         self.messageresidual = _ResidualDict(self)
         self.last_results = None
+
+    @property
+    def _packed(self):
+        if self._packed_arr is None:
+            self._packed_arr = np.zeros((self.n_sites, int(self._poff[-1])))
+        return self._packed_arr
 
     def __del__(self):
         try:

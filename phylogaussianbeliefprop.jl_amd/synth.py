@@ -410,6 +410,49 @@ def bm_loglik_pruning_uni_sites(tree: Tree, sigma2: np.ndarray, mu: np.ndarray, 
     return lg[:, 0] - 0.5 * (LOG2PI + np.log(v0) + logs2 + d * d / (sigma2 * v0))
 
 
+
+def simulate_ou_uni_sites(tree: Tree, sigma2, alpha, theta, mu, rng: np.random.Generator) -> np.ndarray:
+    """Univariate Ornstein-Uhlenbeck process (src/evomodels/homogeneousornsteinuhlenbeck.jl:59-66) at every node for
+    many independent sites at once, one (sigma2, alpha, theta, mu) per site, root fixed at mu: (n_sites, N)."""
+    ns = len(sigma2)
+    gam2 = sigma2 / (2.0 * alpha)
+    z = rng.standard_normal((ns, tree.nnodes))
+    x = np.empty((ns, tree.nnodes))
+    x[:, 0] = mu
+    for i in range(1, tree.nnodes):
+        a = np.exp(-alpha * tree.length[i])
+        x[:, i] = a * x[:, tree.parent[i]] + (1.0 - a) * theta + np.sqrt(gam2 * (1.0 - a * a)) * z[:, i]
+    return x
+
+
+def ou_loglik_pruning_uni_sites(tree: Tree, sigma2, alpha, theta, mu, X: np.ndarray) -> np.ndarray:
+    """Independent check for the OU site batches: pruning in scalar canonical form, vectorised over sites.
+    Node i holds L_i(x_i) = exp(-A x^2 / 2 + B x + C), the likelihood of the tips below it; an edge
+    x_i | x_pa ~ N(q x_pa + w, V) turns it into a function of x_pa.  (n_sites,) log-likelihoods."""
+    N = tree.nnodes
+    ns = X.shape[0]
+    gam2 = sigma2 / (2.0 * alpha)
+    A = np.zeros((N, ns))
+    B = np.zeros((N, ns))
+    Cc = np.zeros((N, ns))
+    for i in range(N - 1, 0, -1):
+        pa = tree.parent[i]
+        q = np.exp(-alpha * tree.length[i])
+        w = (1.0 - q) * theta
+        V = gam2 * (1.0 - q * q)
+        if tree.is_leaf[i]:
+            r = X[:, i] - w
+            A[pa] += q * q / V
+            B[pa] += q * r / V
+            Cc[pa] += -0.5 * (r * r / V + LOG2PI + np.log(V))
+        else:
+            P = A[i] + 1.0 / V
+            sc = 1.0 / (1.0 + A[i] * V)
+            A[pa] += A[i] * sc * q * q
+            B[pa] += q * sc * (B[i] - A[i] * w)
+            Cc[pa] += sc * (B[i] * w - 0.5 * A[i] * w * w) + 0.5 * B[i] * B[i] / P + Cc[i] - 0.5 * np.log1p(A[i] * V)
+    return -0.5 * A[0] * mu * mu + B[0] * mu + Cc[0]
+
 def bethe_of_tree(tree: Tree, p: int) -> Problem:
     """Bethe cluster graph of a tree (src/clustergraph.jl:473-527): factor cluster {c, parent(c)}
     for every non-root node (ids 0..N-2, as in the clique tree) then one variable cluster {v} for
