@@ -199,14 +199,151 @@ def run_sites(args, torch, dist, rank, world, local_rank):
             "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": rel}))
 
 
+def build_network_workload(args, rank):
+    """cfg5 (BASELINE.json configs[4]): heterogeneous BM (3 painted rates, 4 traits by default) on a random level-3
+    admixture network (20 000 tips, 1 667 level-3 blobs = 5 001 reticulations by default), cluster graph built on the
+    host (Bethe: loopy; joingraph: join-graph structuring with --maxclustersize), scopes allocated on plain arrays."""
+    import pgbp_amd as P
+    rng = np.random.default_rng(args.seed + rank)
+    p = args.traits
+    net = P.random_level3_network(args.ntips, args.blobs, rng, n_colors=3)
+    if args.graph == "joingraph":
+        cn, ed, sn = P.joingraph(net.node2family, args.maxclustersize)
+    else:
+        cn, ed, sn = P.bethe(net.node2family)
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    base = P.synth.random_rate_matrix(p, rng)
+    base = (base + base.T) / 2
+    rates = np.stack([base * f for f in (0.5, 1.0, 2.0)])
+    mu = np.zeros(p)
+    X = P.simulate_bm_network(net, rates, mu, rng)
+    parent_edges = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, parent_edges,
+                        list(range(net.nnodes)), p, n_rates=3)
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    return net, (cn, ed, sn), st, fam, X, rates, mu, sched
+
+
+def run_network(args, torch, dist, rank, world, local_rank):
+    """cfg5: loopy belief propagation on a level-3 network.  A step = one calibrate! iteration (every schedule tree,
+    postorder + preorder) from the regularised start; N > 1: one independent replica (its own network) per GPU."""
+    import pgbp_amd as P
+    from pgbp_amd import _lib as L
+    lib = P.load()
+    t0 = time.time()
+    net, (cn, ed, sn), st, fam, X, rates, mu, sched = build_network_workload(args, rank)
+    t_host = time.time() - t0
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None, device=local_rank)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, mu)                      # assignfactors! on the device (heterogeneous BM, hybrid nodes)
+    eng, opts = cgb._eng, cgb._opts()
+
+    def check(code):
+        if code != 0:
+            raise RuntimeError(lib.pgbp_last_error(eng).decode())
+    loopy = len(ed) > len(cn) - 1
+    if loopy:
+        check(lib.pgbp_regularize_bycluster(eng))         # regularizebeliefs_bycluster! (src/calibration.jl:335-343)
+    cgb.pull()
+    start = cgb._packed[0].copy()                         # the state every run starts from (clusters and sepsets)
+    cgb.set_schedule(sched)
+    # calibrate!(beliefs, sched, 100; auto=true): iterations to convergence, end to end with the host-driven auto stop
+    cgb.init_messagecalibrationflags_reset_()
+    check(lib.pgbp_sync(eng))
+    t = time.perf_counter()
+    res = P.calibrate_(cgb, sched, 100, auto=True, sync=False)
+    t_auto = time.perf_counter() - t
+    r = cgb.last_results[0]
+    if res != (True, True):
+        raise SystemExit(f"network workload: calibrate!(auto) returned {res}")
+    nmsg_tree = [2 * len(s[2]) for s in sched]
+    n_pairs = (r.iter_reached - 1) * len(sched) + r.tree_reached
+    nmsg_auto = sum(nmsg_tree[q % len(sched)] for q in range(n_pairs))
+    cgb.pull()
+    converged = cgb._packed[0].copy()
+    bytes_per_cal, msgs_per_cal = cgb.traffic_model()
+
+    def restart():
+        cgb._packed[0][:] = start
+        cgb.push()
+        cgb.init_messagecalibrationflags_reset_()
+    restart()
+    check(lib.pgbp_enqueue_calibrate(eng, args.warmup, 0, C.byref(opts)))
+    restart()
+    check(lib.pgbp_sync(eng))
+
+    def k_steps():
+        check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
+        check(lib.pgbp_sync(eng))
+    dt = timed_region(k_steps, dist, torch.cuda.synchronize)
+    if rank != 0:
+        return
+    ms_step = dt / args.steps * 1e3
+    out = {
+        "metric": "cluster-graph messages/sec (calibrate!: every schedule tree, postorder+preorder), loopy BP on a level-3 network",
+        "value": whole_job_rate(msgs_per_cal, args.steps, world, dt), "unit": "messages/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg5: heterogeneous BM (3 rates), {args.traits} traits, level-3 network with {args.ntips} tips "
+                               f"and {net.nhybrids} reticulations ({net.nnodes} nodes), "
+                               + (f"join-graph structuring (maxclustersize {args.maxclustersize})" if args.graph == "joingraph" else "Bethe cluster graph")
+                               + (", regularizebeliefs_bycluster!" if loopy else " (a tree here)") + ", spanningtrees_clusterlist schedule",
+                   "clusters": len(cn), "sepsets": len(ed), "schedule_trees": len(sched), "loopy": bool(loopy),
+                   "messages_per_step": int(msgs_per_cal), "max_cluster_dimension": int(st.dims.max()),
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+        "calibrate_auto": {"iterations_to_convergence": [int(r.iter_reached), int(r.tree_reached)], "messages": int(nmsg_auto),
+                           "ms": 1e3 * t_auto, "messages_per_s": nmsg_auto / t_auto,
+                           "note": "calibrate!(beliefs, sched, 100; auto=true) end to end (one host round trip per schedule tree)"},
+        "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "bp_level_generic + bp_level_fast16<4>", "algorithmic_bytes_per_step": bytes_per_cal,
+                     "note": "algorithmic bytes of one calibrate iteration / its wall time; launch-latency-bound (levels per tree >> width)"},
+        "host_setup_s": t_host,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import cengine
+            cengine.use_native_build()
+            ce = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+            t = time.perf_counter()
+            reached = None
+            for it in range(1, 101):
+                for j, spt in enumerate(sched, start=1):
+                    succ, iscal = ce.calibrate(spt[2], spt[3], 1, return_iscal=True)
+                    if iscal:
+                        reached = (it, j)
+                        break
+                if reached:
+                    break
+            t_cpu = time.perf_counter() - t
+            ref = ce.packed()
+            # per belief: max |difference| / max(1, max |reference|) (the tolerance of tests/test_gpu_parity.py)
+            o = cgb._poff[:-1][np.diff(cgb._poff) > 0]
+            err = float(np.max(np.maximum.reduceat(np.abs(converged - ref), o) /
+                               np.maximum(1.0, np.maximum.reduceat(np.abs(ref), o))))
+            out["cpu_baseline"] = {"value": nmsg_auto / t_cpu, "unit": "messages/s", "cores": 1, "kind": "port",
+                                   "sample": f"the same calibrate!(auto) to convergence ({nmsg_auto} messages) on the oracle/c "
+                                             f"sequential engine (gcc -O3 -march=native, 1 thread of {os.cpu_count()} host cpus), {t_cpu:.1f} s",
+                                   "iterations_to_convergence": list(reached) if reached else None,
+                                   "max_rel_belief_diff_gpu_vs_cpu": err}
+            if reached != (r.iter_reached, r.tree_reached) or not err <= 1e-8:
+                raise SystemExit(f"parity gate failed (network): cpu reached {reached}, gpu {(r.iter_reached, r.tree_reached)}, belief diff {err:.3e}")
+        except ImportError as ex:
+            out["cpu_baseline"] = {"value": None, "unit": "messages/s", "cores": 1, "kind": "port", "sample": f"unavailable: {ex}"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ntips", type=int, default=None, help="default: 50000 (tree workload), 20000 (sites workload)")
-    ap.add_argument("--traits", type=int, default=16)
-    ap.add_argument("--graph", default="cliquetree", choices=["cliquetree", "bethe"])
+    ap.add_argument("--traits", type=int, default=None, help="default: 16 (tree workload), 4 (network workload)")
+    ap.add_argument("--graph", default=None, choices=["cliquetree", "bethe", "joingraph"],
+                    help="default: cliquetree (tree workload), bethe (network workload)")
+    ap.add_argument("--blobs", type=int, default=None, help="network workload: level-3 blobs (3 reticulations each); default ntips / 12")
+    ap.add_argument("--maxclustersize", type=int, default=3, help="network workload, --graph joingraph")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-reading", action="store_true",
@@ -214,12 +351,19 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--site-model", default="ou", choices=["ou", "bm"], help="sites workload: per-problem model")
     ap.add_argument("--site-traits", type=int, default=8, help="sites workload: traits per site (each an independent univariate problem)")
-    ap.add_argument("--workload", default="tree", choices=["tree", "sites"],
-                    help="tree: the headline one-big-tree workload (default); sites: cfg4-shaped site-sharded batch")
+    ap.add_argument("--workload", default="tree", choices=["tree", "sites", "network"],
+                    help="tree: the headline one-big-tree workload (default, cfg3 / cfg2); sites: cfg4 site-sharded batch; "
+                         "network: cfg5 loopy BP on a level-3 network")
     ap.add_argument("--sites", type=int, default=1000)
     args = ap.parse_args()
     if args.ntips is None:
-        args.ntips = 20000 if args.workload == "sites" else 50000
+        args.ntips = 50000 if args.workload == "tree" else 20000
+    if args.traits is None:
+        args.traits = 4 if args.workload == "network" else 16
+    if args.graph is None:
+        args.graph = "bethe" if args.workload == "network" else "cliquetree"
+    if args.blobs is None:
+        args.blobs = (args.ntips + 11) // 12
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +380,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "network":
+        run_network(args, torch, dist, rank, world, local_rank)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload == "sites":
         run_sites(args, torch, dist, rank, world, local_rank)
         if dist is not None:

@@ -209,3 +209,151 @@ def spanningtrees_clusterlist(cg: ClusterGraph, net):
         for (_, _, k) in mst:
             used[k] += 1
     return sched
+
+
+# ---------------------------------------------------------------------------
+# join-graph structuring: src/clustergraph.jl:605-757
+# ---------------------------------------------------------------------------
+
+def nodefamilies(net):
+    """src/clustergraph.jl:136-146: [child, parents sorted decreasing], 1-based preorder indices."""
+    pre = net.vec_node
+    pos = {id(n): i + 1 for i, n in enumerate(pre)}
+    return [[i + 1] + sorted((pos[id(p)] for p in net.parents(n)), reverse=True) for i, n in enumerate(pre)]
+
+
+def _assign(bucket, new, maxsize):
+    """src/clustergraph.jl:705-736 assign!: bucket = dict size -> list of minibuckets (sorted lists)."""
+    for sz in sorted(bucket.keys(), reverse=True):
+        mbs = bucket[sz]
+        for i, mb in enumerate(mbs):
+            merged = sorted(set(new) | set(mb))
+            if len(merged) <= maxsize:
+                mbs.pop(i)
+                if not mbs:
+                    del bucket[sz]
+                bucket.setdefault(len(merged), []).append(merged)
+                return merged, mb
+    bucket.setdefault(len(new), []).append(new)
+    return new, []
+
+
+def joingraph(net, maxclustersize, size_order="decreasing") -> ClusterGraph:
+    """src/clustergraph.jl:605-697 (JoinGraphStructuring).  The reference walks the minibuckets of a bucket in the
+    iteration order of a Julia Dict keyed by minibucket size (`values(bd)`, :645), which is an implementation detail
+    of Julia's hashing; here the sizes are walked in `size_order` ("decreasing" / "increasing").  Every order gives a
+    valid join graph (family-preserving, running intersection); they may differ in which minibuckets are chained."""
+    maxfam = max(len(nf) for nf in nodefamilies(net))
+    if maxclustersize < maxfam:
+        raise ValueError(f"maxclustersize {maxclustersize} is smaller than the size of largest node family {maxfam}.")
+    adj = moralize(net)
+    ordering = triangulate_minfill(adj)            # preorder indices in elimination order
+    e2p = list(ordering)                           # elimination position (0-based) -> preorder index
+    p2e = {v: i for i, v in enumerate(e2p)}
+    names = [n.name for n in net.vec_node]
+    buckets = [dict() for _ in ordering]
+    for nf in nodefamilies(net):
+        mb = sorted(p2e[v] for v in nf)
+        _assign(buckets[mb[0]], mb, maxclustersize)
+    labels, nodes_of, edges = [], {}, {}           # cluster labels in creation order; label -> nodes; {l1,l2} -> sepset
+
+    def cluster_of(mb):
+        nodes = sorted((e2p[i] for i in mb), reverse=True)
+        lab = "".join(names[v - 1] for v in nodes)
+        if lab not in nodes_of:
+            nodes_of[lab] = nodes
+            labels.append(lab)
+        return lab, nodes
+
+    def add_edge(l1, l2, sep):
+        if l1 != l2:
+            edges[frozenset((l1, l2))] = list(sep)
+
+    for i in range(len(ordering)):
+        bd = buckets[i]
+        bi = e2p[i]
+        prev = None
+        sizes = sorted(bd.keys(), reverse=(size_order == "decreasing"))
+        for mb in [m for sz in sizes for m in list(bd[sz])]:
+            lab, nodes = cluster_of(mb)
+            if prev is not None:
+                add_edge(prev, lab, [bi])
+            prev = lab
+            mb_new = mb[1:]
+            if not mb_new:
+                continue
+            mb1, mb2 = _assign(buckets[mb_new[0]], mb_new, maxclustersize)
+            lab1, _ = cluster_of(mb1)
+            add_edge(lab, lab1, [v for v in nodes if v != bi])
+            if len(mb1) != len(mb2):
+                nodes2 = sorted((e2p[k] for k in mb2), reverse=True)
+                lab2 = "".join(names[v - 1] for v in nodes2)
+                if mb2 and lab2 in nodes_of:
+                    for key in [k for k in edges if lab2 in k]:
+                        (labn,) = key - {lab2}
+                        add_edge(lab1, labn, edges[key])
+                        del edges[key]
+                    del nodes_of[lab2]
+                    labels.remove(lab2)
+    index = {lab: k for k, lab in enumerate(labels)}
+    out_edges = []
+    for key, sep in edges.items():
+        a, b = sorted(index[l] for l in key)
+        out_edges.append((a, b, sep))
+    out_edges.sort()
+    return ClusterGraph([(lab, nodes_of[lab]) for lab in labels], out_edges, "joingraph")
+
+
+def isfamilypreserving(cg: ClusterGraph, net) -> bool:
+    """src/clustergraph.jl:169-182."""
+    sets = [set(n) for _, n in cg.clusters]
+    return all(any(set(nf) <= s for s in sets) for nf in nodefamilies(net))
+
+
+def check_runningintersection(cg: ClusterGraph, net) -> bool:
+    """src/clustergraph.jl:200-217: for every node, the clusters holding it and the sepsets holding it form a tree."""
+    for v in range(1, len(net.vec_node) + 1):
+        cl = [i for i, (_, n) in enumerate(cg.clusters) if v in n]
+        ed = [(a, b) for (a, b, s) in cg.edges if v in s]
+        if not cl:
+            return False
+        if len(ed) != len(cl) - 1:
+            return False
+        parent = {i: i for i in cl}
+
+        def find(x):
+            while parent[x] != x:
+                x = parent[x]
+            return x
+        for a, b in ed:
+            ra, rb = find(a), find(b)
+            if ra == rb:
+                return False
+            parent[ra] = rb
+    return True
+
+
+def default_rootcluster_nodes(clusters) -> int:
+    """src/clustergraph.jl:1043-1053 (one-argument method): among `clusters` (lists of preorder indices, decreasing),
+    the first one that minimises: 0 if it is only the smallest index, else its second-smallest index; clusters
+    without the smallest index are never chosen.  Returns a position in `clusters`."""
+    i0 = min(n[-1] for n in clusters)
+    best, bestscore = None, None
+    for k, n in enumerate(clusters):
+        if i0 not in n:
+            continue
+        score = 0 if len(n) == 1 else n[-2]
+        if bestscore is None or score < bestscore:
+            best, bestscore = k, score
+    return best
+
+
+def nodesubtree_clusterlist(cg: ClusterGraph, v: int):
+    """src/clustergraph.jl:953-962 with nodesubtree (:219-240): DFS spanning tree (preorder edge list) of the
+    subgraph induced by the clusters holding node v (1-based preorder index) and the sepsets holding v."""
+    cl = [i for i, (_, n) in enumerate(cg.clusters) if v in n]
+    if not cl:
+        raise ValueError(f"no cluster with node {v}")
+    sub = [(a, b, s) for (a, b, s) in cg.edges if a in cl and b in cl and v in s]
+    rootj = cl[default_rootcluster_nodes([cg.clusters[i][1] for i in cl])]
+    return spanningtree_clusterlist(cg, rootj, sub)

@@ -329,3 +329,54 @@ def random_network(ntips: int, nhybrids: int, rng: np.random.Generator, lo=0.1, 
         blocked.add(id(w))
         made += 1
     return Network(root, nodes, edges)
+
+
+def random_level3_network(ntips: int, nblobs: int, rng: np.random.Generator, lo=0.1, hi=1.0) -> Network:
+    """Random rooted level-3 network (BASELINE.json configs[4]): a random bifurcating tree (uniform random joins) in
+    which `nblobs` internal nodes w, with children c1 and c2, are replaced by the level-3 blob of the reference's own
+    test network (test/test_calibration.jl:132: "((#H1,#H2)I1,(((A)#H1,#H3)#H2,(B)#H3)I2)I3"): w -> I1, I2;
+    I1 -> H1, H2 (minor edges); I2 -> H2, H3 (major); H2 -> H1 (major), H3 (minor); H1 -> c1; H3 -> c2.
+    3 reticulations and 5 new nodes per blob; blobs are separated by cut edges, so the level is exactly 3.
+    Minor inheritance gamma ~ U(0.1, 0.5); every edge length > 0."""
+    net = random_network(ntips, 0, rng, lo, hi)
+    nodes, edges = net.nodes, net.edges
+
+    def new_node(hybrid=False):
+        n = Node(name="", hybrid=hybrid)
+        nodes.append(n)
+        return n
+
+    def new_edge(pa, ch, length, gamma=1.0, hybrid=False):
+        e = Edge(number=len(edges) + 1, parent=pa, child=ch, length=float(length), gamma=float(gamma), hybrid=hybrid)
+        edges.append(e)
+        pa.edges.append(e)
+        ch.edges.append(e)
+        return e
+
+    internal = [n for n in nodes if not n.leaf]
+    picks = rng.permutation(len(internal))[:nblobs]
+    for k in picks:
+        w = internal[int(k)]
+        e1, e2 = [e for e in w.edges if e.parent is w]
+        if rng.random() < 0.5:
+            e1, e2 = e2, e1
+        i1, i2 = new_node(), new_node()
+        h1, h2, h3 = new_node(True), new_node(True), new_node(True)
+        # the old child edges become H1 -> c1 and H3 -> c2
+        for e, h in ((e1, h1), (e2, h3)):
+            w.edges.remove(e)
+            e.parent = h
+            h.edges.append(e)
+        new_edge(w, i1, rng.uniform(lo, hi))
+        new_edge(w, i2, rng.uniform(lo, hi))
+        g1, g2, g3 = rng.uniform(0.1, 0.5, size=3)
+        new_edge(i1, h1, rng.uniform(0.05, 0.3), gamma=g1, hybrid=True)
+        new_edge(h2, h1, rng.uniform(0.05, 0.3), gamma=1.0 - g1, hybrid=True)
+        new_edge(i1, h2, rng.uniform(0.05, 0.3), gamma=g2, hybrid=True)
+        new_edge(i2, h2, rng.uniform(0.05, 0.3), gamma=1.0 - g2, hybrid=True)
+        new_edge(h2, h3, rng.uniform(0.05, 0.3), gamma=g3, hybrid=True)
+        new_edge(i2, h3, rng.uniform(0.05, 0.3), gamma=1.0 - g3, hybrid=True)
+    for n in nodes:
+        if not n.leaf and n.name.startswith("I"):
+            n.name = ""
+    return Network(net.root, nodes, edges)

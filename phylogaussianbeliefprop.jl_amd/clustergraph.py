@@ -82,3 +82,228 @@ def spanningtrees_clusterlist(n_clusters: int, edges: Sequence[Tuple[int, int]],
         for k in chosen:
             used[k] += 1
     return schedule
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cluster-graph construction: join-graph structuring (src/clustergraph.jl:605-757), sized for networks with tens of
+# thousands of nodes (the reference's own version is quadratic through Graphs.jl / MetaGraphsNext)
+# ---------------------------------------------------------------------------------------------------------------
+
+def moralize(node2family: Sequence[Sequence[int]]):
+    """moralize(net) (src/clustergraph.jl:43-77) from the node families [child, parents...] (1-based preorder
+    indices): adjacency sets of the moral graph (child - parent edges, parents of one child married)."""
+    adj = {nf[0]: set() for nf in node2family}
+    for nf in node2family:
+        for a in range(len(nf)):
+            for b in range(a + 1, len(nf)):
+                adj[nf[a]].add(nf[b])
+                adj[nf[b]].add(nf[a])
+    return adj
+
+
+def triangulate_minfill(adj):
+    """triangulate_minfill!(graph) (src/clustergraph.jl:87-121): greedy min-fill elimination order, ties broken by
+    the larger preorder index; `adj` gains the fill edges.  Same order as the reference's rescan of all vertices, with
+    a heap and local updates: eliminating v changes the fill count only of v's neighbours and of the common
+    neighbours of a new fill edge's ends."""
+    import heapq
+    g2 = {k: set(v) for k, v in adj.items()}
+
+    def fill(v):
+        nb = list(g2[v])
+        c = 0
+        for i, a in enumerate(nb):
+            ga = g2[a]
+            for b in nb[i + 1:]:
+                if b not in ga:
+                    c += 1
+        return c
+
+    score = {v: fill(v) for v in g2}
+    heap = [(score[v], -v) for v in g2]
+    heapq.heapify(heap)
+    ordering = []
+    while len(g2) > 1:
+        while True:
+            sc, negv = heapq.heappop(heap)
+            v = -negv
+            if v in g2 and score[v] == sc:
+                break
+        nb = sorted(g2[v])
+        touched = set(nb)
+        for i, a in enumerate(nb):
+            for b in nb[i + 1:]:
+                if b not in g2[a]:
+                    touched |= g2[a] & g2[b]          # common neighbours see one missing edge less
+                    g2[a].add(b); g2[b].add(a)
+                    adj[a].add(b); adj[b].add(a)
+        ordering.append(v)
+        for u in nb:
+            g2[u].discard(v)
+        del g2[v]
+        del score[v]
+        touched.discard(v)
+        for u in touched:
+            s = fill(u)
+            if s != score[u]:
+                score[u] = s
+                heapq.heappush(heap, (s, -u))
+    ordering.append(next(iter(g2)))
+    return ordering
+
+
+def _assign(bucket, new, maxsize):
+    """assign!(bucket, new_minibucket, max_minibucket_size) (src/clustergraph.jl:705-736)."""
+    for sz in sorted(bucket, reverse=True):
+        mbs = bucket[sz]
+        for i, mb in enumerate(mbs):
+            merged = sorted(set(new) | set(mb))
+            if len(merged) <= maxsize:
+                mbs.pop(i)
+                if not mbs:
+                    del bucket[sz]
+                bucket.setdefault(len(merged), []).append(merged)
+                return merged, mb
+    bucket.setdefault(len(new), []).append(new)
+    return new, []
+
+
+def joingraph(node2family: Sequence[Sequence[int]], maxclustersize: int):
+    """clustergraph!(net, JoinGraphStructuring(maxclustersize)) (src/clustergraph.jl:405-410, 605-697) from the node
+    families of the network (nodefamilies(net), :136-146: [child, parents by decreasing index], 1-based preorder
+    indices).  Returns (cluster_nodes, edges, sepset_nodes): cluster i holds the nodes cluster_nodes[i] (decreasing
+    preorder index), sepset k = edges[k] = (i, j), i < j, holds sepset_nodes[k].
+    The reference walks a bucket's minibuckets in the iteration order of a Julia Dict keyed by their size (:645);
+    here: by decreasing size, then in order of creation (every order gives a valid join graph)."""
+    maxfam = max(len(nf) for nf in node2family)
+    if maxclustersize < maxfam:
+        raise ValueError(f"maxclustersize {maxclustersize} is smaller than the size of largest node family {maxfam}.")
+    ordering = triangulate_minfill(moralize(node2family))
+    e2p = ordering
+    p2e = {v: i for i, v in enumerate(e2p)}
+    buckets = [dict() for _ in ordering]
+    for nf in node2family:
+        mb = sorted(p2e[v] for v in nf)
+        _assign(buckets[mb[0]], mb, maxclustersize)
+    order: List[Tuple[int, ...]] = []      # cluster keys (node tuples, decreasing) in creation order
+    alive = {}                             # key -> True
+    nbrs = {}                              # key -> {neighbour key: sepset}
+
+    def cluster_of(mb):
+        key = tuple(sorted((e2p[i] for i in mb), reverse=True))
+        if key not in alive:
+            alive[key] = True
+            nbrs[key] = {}
+            order.append(key)
+        return key
+
+    def add_edge(k1, k2, sep):
+        if k1 != k2:
+            nbrs[k1][k2] = list(sep)
+            nbrs[k2][k1] = nbrs[k1][k2]
+
+    for i in range(len(ordering)):
+        bd = buckets[i]
+        bi = e2p[i]
+        prev = None
+        for mb in [m for sz in sorted(bd, reverse=True) for m in list(bd[sz])]:
+            key = cluster_of(mb)
+            if prev is not None:
+                add_edge(prev, key, [bi])          # chain of the bucket's minibuckets: sepset = the bucket's node
+            prev = key
+            mb_new = mb[1:]
+            if not mb_new:
+                continue
+            mb1, mb2 = _assign(buckets[mb_new[0]], mb_new, maxclustersize)
+            key1 = cluster_of(mb1)
+            add_edge(key, key1, [v for v in key if v != bi])
+            if len(mb1) != len(mb2) and mb2:
+                key2 = tuple(sorted((e2p[k] for k in mb2), reverse=True))
+                if key2 in alive:                  # mb2 was absorbed into mb1: contract the two clusters
+                    for kn, sep in list(nbrs[key2].items()):
+                        del nbrs[kn][key2]
+                        add_edge(key1, kn, sep)
+                    del nbrs[key2]
+                    del alive[key2]
+    keys = [k for k in order if k in alive]
+    index = {k: i for i, k in enumerate(keys)}
+    edges, seps = [], []
+    for k in keys:
+        for kn, sep in nbrs[k].items():
+            if index[k] < index[kn]:
+                edges.append((index[k], index[kn]))
+                seps.append(list(sep))
+    o = sorted(range(len(edges)), key=lambda t: edges[t])
+    return [list(k) for k in keys], [edges[t] for t in o], [seps[t] for t in o]
+
+
+def default_rootcluster_nodes(cluster_nodes: Sequence[Sequence[int]]) -> int:
+    """default_rootcluster(clustergraph) (src/clustergraph.jl:1043-1053): among clusters given by their nodes
+    (decreasing preorder index), the first that holds the overall smallest index and minimises: 0 if it holds nothing
+    else, otherwise its second-smallest index."""
+    i0 = min(n[-1] for n in cluster_nodes)
+    best, best_score = None, None
+    for k, n in enumerate(cluster_nodes):
+        if i0 in n:
+            score = 0 if len(n) == 1 else n[-2]
+            if best_score is None or score < best_score:
+                best, best_score = k, score
+    return best
+
+
+def nodesubtree_clusterlist(cluster_nodes: Sequence[Sequence[int]], edges: Sequence[Tuple[int, int]],
+                            sepset_nodes: Sequence[Sequence[int]], node: int, labels: Optional[Sequence] = None):
+    """nodesubtree_clusterlist(clustergraph, nodesymbol) (src/clustergraph.jl:953-962, nodesubtree :219-240): the
+    schedule tree of the subgraph of clusters and sepsets that hold `node` (1-based preorder index), rooted by
+    default_rootcluster(subgraph); cluster indices are those of the whole graph."""
+    cl = [i for i, n in enumerate(cluster_nodes) if node in n]
+    if not cl:
+        raise ValueError(f"no cluster with node {node}")
+    inside = set(cl)
+    sub = [e for e, s in zip(edges, sepset_nodes) if node in s and e[0] in inside and e[1] in inside]
+    rootj = cl[default_rootcluster_nodes([cluster_nodes[i] for i in cl])]
+    return spanningtree_clusterlist(len(cluster_nodes), sub, rootj, labels)
+
+
+def bethe(node2family: Sequence[Sequence[int]]):
+    """clustergraph!(net, Bethe()) (src/clustergraph.jl:473-527) from the node families: one factor cluster per node
+    family, visited by decreasing node index and merged into a child's factor cluster when it is a subset of it (the
+    children are tried by increasing index; the reference tries them in the network's edge order), then one variable
+    cluster {v} for every node in more than one factor cluster, by decreasing index, joined to each of them.
+    Returns (cluster_nodes, edges, sepset_nodes) as `joingraph` does; edges are (variable cluster, factor cluster)."""
+    n = len(node2family)
+    children: List[List[int]] = [[] for _ in range(n + 1)]
+    for nf in node2family:
+        for pa in nf[1:]:
+            children[pa].append(nf[0])
+    cluster_nodes: List[List[int]] = []
+    node2code = {}
+    member: List[List[int]] = [[] for _ in range(n + 1)]
+    for v in range(n, 0, -1):
+        fam = list(node2family[v - 1])
+        if len(fam) == 1:
+            continue
+        merged = False
+        for ch in sorted(children[v]):
+            cc = node2code[ch]
+            cs = cluster_nodes[cc]
+            if all(x in cs for x in fam):
+                node2code[v] = cc
+                merged = True
+                break
+        if merged:
+            continue
+        node2code[v] = len(cluster_nodes)
+        cluster_nodes.append(fam)
+        for x in fam:
+            member[x].append(node2code[v])
+    edges, seps = [], []
+    for v in range(n, 0, -1):
+        if len(member[v]) <= 1:
+            continue
+        vc = len(cluster_nodes)
+        cluster_nodes.append([v])
+        for fc in member[v]:
+            edges.append((vc, fc))
+            seps.append([v])
+    return cluster_nodes, edges, seps

@@ -1,0 +1,188 @@
+"""Synthetic admixture networks and scope allocation on plain arrays, for the loopy-network configuration
+(BASELINE.json configs[4]) at sizes where per-node Python objects and quadratic searches are out of the question.
+
+A network is held as a `NetArrays`: nodes numbered in preorder (1-based labels as in the reference: every node
+after all of its parents, root = 1), each with its node family [child, parents by decreasing label]
+(nodefamilies, src/clustergraph.jl:136-146) and, aligned with the parents, edge length, inheritance and colour."""
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import numpy as np
+
+from .synth import Tree, random_tree
+
+
+@dataclass
+class NetArrays:
+    node2family: List[List[int]]     # [child, parents...] 1-based preorder labels, parents decreasing
+    length: List[List[float]]        # per parent edge, aligned with node2family[i][1:]
+    gamma: List[List[float]]
+    color: List[List[int]]           # 0-based rate index of each parent edge
+    is_leaf: np.ndarray              # (N,) bool, index = label - 1
+
+    @property
+    def nnodes(self):
+        return len(self.node2family)
+
+    @property
+    def nhybrids(self):
+        return sum(1 for nf in self.node2family if len(nf) > 2)
+
+
+def random_level3_network(ntips: int, nblobs: int, rng: np.random.Generator, n_colors: int = 1, lo=0.1, hi=1.0) -> NetArrays:
+    """Random rooted level-3 network: a random bifurcating tree (uniform random joins, lengths U(lo, hi)) in which
+    `nblobs` internal nodes w with children c1, c2 are replaced by the level-3 blob of the reference's own test
+    network (test/test_calibration.jl:132, "((#H1,#H2)I1,(((A)#H1,#H3)#H2,(B)#H3)I2)I3"):
+      w -> I1, I2;  I1 -> H1, H2 (minor);  I2 -> H2, H3 (major);  H2 -> H1 (major), H3 (minor);  H1 -> c1;  H3 -> c2.
+    3 reticulations per blob, blobs separated by cut edges.  Minor inheritance ~ U(0.1, 0.5), hybrid edge lengths
+    U(0.05, 0.3), every length > 0; each edge gets a colour in [0, n_colors)."""
+    tr: Tree = random_tree(ntips, rng, lo, hi)
+    N0 = tr.nnodes
+    internal = np.nonzero(~tr.is_leaf)[0]
+    picks = set(int(x) for x in rng.permutation(internal)[:nblobs])
+    # directed acyclic graph on temporary ids: parents[v] = [(parent id, length, gamma)]
+    parents: List[list] = [[] for _ in range(N0)]
+    children: List[list] = [[] for _ in range(N0)]
+    is_leaf = list(tr.is_leaf)
+    kids = [[] for _ in range(N0)]
+    for v in range(1, N0):
+        kids[tr.parent[v]].append(v)
+
+    def new_node():
+        parents.append([])
+        children.append([])
+        is_leaf.append(False)
+        return len(parents) - 1
+
+    def link(pa, ch, t, g=1.0):
+        parents[ch].append((pa, float(t), float(g)))
+        children[pa].append(ch)
+
+    for w in range(N0):
+        if w in picks and len(kids[w]) == 2:
+            c1, c2 = kids[w]
+            if rng.random() < 0.5:
+                c1, c2 = c2, c1
+            i1, i2, h1, h2, h3 = (new_node() for _ in range(5))
+            g1, g2, g3 = rng.uniform(0.1, 0.5, size=3)
+            t = rng.uniform(0.05, 0.3, size=6)
+            link(w, i1, rng.uniform(lo, hi)); link(w, i2, rng.uniform(lo, hi))
+            link(i1, h1, t[0], g1); link(h2, h1, t[1], 1.0 - g1)
+            link(i1, h2, t[2], g2); link(i2, h2, t[3], 1.0 - g2)
+            link(h2, h3, t[4], g3); link(i2, h3, t[5], 1.0 - g3)
+            link(h1, c1, tr.length[c1]); link(h3, c2, tr.length[c2])
+        else:
+            for c in kids[w]:
+                link(w, c, tr.length[c])
+    # preorder: a node is listed once all of its parents are (depth-first, children in creation order)
+    n = len(parents)
+    indeg = [len(p) for p in parents]
+    order, stack = [], [0]
+    while stack:
+        v = stack.pop()
+        order.append(v)
+        for c in reversed(children[v]):
+            indeg[c] -= 1
+            if indeg[c] == 0:
+                stack.append(c)
+    assert len(order) == n
+    label = np.empty(n, dtype=np.int64)
+    label[np.array(order)] = np.arange(1, n + 1)
+    fam, ln, gm, col = [], [], [], []
+    for v in order:
+        ps = sorted(parents[v], key=lambda q: -label[q[0]])
+        fam.append([int(label[v])] + [int(label[q[0]]) for q in ps])
+        ln.append([q[1] for q in ps])
+        gm.append([q[2] for q in ps])
+        col.append([int(x) for x in rng.integers(0, n_colors, size=len(ps))])
+    return NetArrays(fam, ln, gm, col, np.array([is_leaf[v] for v in order], dtype=bool))
+
+
+def simulate_bm_network(net: NetArrays, rates: Sequence[np.ndarray], mu: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """Trait values at every node (N, p) under a heterogeneous BM on the network (weighted-average merging at hybrid
+    nodes: src/evomodels/evomodels.jl:314-330), root fixed at mu."""
+    p = len(mu)
+    chol = [np.linalg.cholesky(np.asarray(R, float)) for R in rates]
+    x = np.zeros((net.nnodes, p))
+    x[0] = mu
+    for i in range(1, net.nnodes):
+        nf = net.node2family[i]
+        acc = np.zeros(p)
+        for k, pl in enumerate(nf[1:]):
+            g, t, c = net.gamma[i][k], net.length[i][k], net.color[i][k]
+            acc += g * (x[pl - 1] + np.sqrt(t) * (chol[c] @ rng.standard_normal(p)))
+        x[i] = acc
+    return x
+
+
+@dataclass
+class ScopeTables:
+    """What allocatebeliefs (src/beliefs.jl:478-594) establishes for complete data: belief dimensions, scope index
+    maps of both ends of every sepset (the arrays pgbp_desc takes), the cluster of every node family, and light
+    cluster records (nodelabel, inscope) for factors.lg_families."""
+    dims: np.ndarray
+    sepset_clusters: np.ndarray
+    scope_off: np.ndarray
+    scope_idx: np.ndarray
+    node2cluster: List[int]
+    node2fixed: np.ndarray
+    clusters: list
+
+
+class _Scope:
+    __slots__ = ("nodelabel", "inscope")
+
+    def __init__(self, nodelabel, inscope):
+        self.nodelabel, self.inscope = nodelabel, inscope
+
+
+def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, fixedroot: bool = True) -> ScopeTables:
+    """allocatebeliefs (src/beliefs.jl:478-594) for complete tip data on plain arrays: tips (and a fixed root) are out
+    of scope, every other node has all p traits in scope; node2cluster[ni] = the first cluster that contains the
+    family of node ni + 1 (:521-527); scopeindex(sepset, cluster) (:389-405) for both ends of every sepset."""
+    N = net.nnodes
+    fixed = net.is_leaf.copy()
+    if fixedroot:
+        fixed[0] = True
+    holders: List[List[int]] = [[] for _ in range(N + 1)]
+    for ci, nodes in enumerate(cluster_nodes):
+        for v in nodes:
+            holders[v].append(ci)
+    node2cluster = []
+    csets = [None] * len(cluster_nodes)
+    for ni, nf in enumerate(net.node2family):
+        found = None
+        for ci in holders[nf[0]]:                      # increasing cluster index = the reference's findfirst
+            if csets[ci] is None:
+                csets[ci] = set(cluster_nodes[ci])
+            if all(v in csets[ci] for v in nf[1:]):
+                found = ci
+                break
+        if found is None:
+            raise ValueError(f"no cluster containing the node family of node {ni + 1}")
+        node2cluster.append(found)
+    ins = ~fixed
+    cdims = np.array([p * int(sum(ins[v - 1] for v in nodes)) for nodes in cluster_nodes], dtype=np.int32)
+    sdims = np.array([p * int(sum(ins[v - 1] for v in nodes)) for nodes in sepset_nodes], dtype=np.int32)
+    start = []
+    for nodes in cluster_nodes:
+        s, acc = {}, 0
+        for v in nodes:
+            s[v] = acc
+            if ins[v - 1]:
+                acc += p
+        start.append(s)
+    off, idx = [0], []
+    for (a, b), nodes in zip(edges, sepset_nodes):
+        for c in (a, b):
+            cn = cluster_nodes[c]
+            where = [cn.index(v) for v in nodes]         # raises ValueError if not a subset
+            if any(y <= x for x, y in zip(where, where[1:])):
+                raise ValueError("subset labels come in a different order in the belief")
+            for v in nodes:
+                if ins[v - 1]:
+                    idx.extend(range(start[c][v], start[c][v] + p))
+            off.append(len(idx))
+    clusters = [_Scope(list(nodes), np.tile(ins[np.array(nodes) - 1], (p, 1))) for nodes in cluster_nodes]
+    return ScopeTables(np.concatenate([cdims, sdims]).astype(np.int32), np.array(edges, np.int32).reshape(-1, 2),
+                       np.array(off, np.int64), np.array(idx, np.int32), node2cluster, fixed, clusters)

@@ -99,7 +99,28 @@ G["calibration_level3_joingraph"] = {
     "model_fixed": {"kind": "MvFullBM", "R": [[1, 0.5], [0.5, 1]], "mu": [2.128585052670943, 30.00929252633547]},
     "norm_fixed": -3.3498677834866997,
     "posterior_means_fixed": {"I1": [2.121105154896223, 30.005552577448075],
-                              "I2": [2.1360649504455984, 30.013032475222563]}}
+                              "I2": [2.1360649504455984, 30.013032475222563]},
+    # the loopy run itself (:138-149, :161-165): JoinGraphStructuring(3), regularizebeliefs_bynodesubtree!, one
+    # nodesubtree_clusterlist schedule tree per node, calibrate!(cgb, sch, 10; auto=true, info=true)
+    "maxclustersize": 3, "niter": 10,
+    "info_line": "calibration reached: iteration 4, schedule tree 1",
+    "cluster_index_1based": {"I1I2I3": 6, "H1H2I1": 2},
+    "preorder_note": "not literal in the test: a node preordering consistent with the cluster labels the test names "
+                     "(labels list nodes by decreasing preorder index: I1 > I2 > I3, H1 > H2 > I1) and with their "
+                     "indices 6 and 2",
+    "preorder": ["I3", "I2", "I1", "H2", "H3", "B", "H1", "A"]}
+
+G["joingraph_mateescu"] = {
+    "cite": "test/test_clustergraph.jl:4,95-110",
+    "net": "((((g:1)#H4:1)#H2:2.04,(d:1,(#H2:0.01::0.5,#H4:1::0.5)#H3:1)D:1,(#H3:1::0.5)#H1:0.01)B:1,#H1:1.01::0.5)A;",
+    "maxclustersize": 3,
+    "clusters_sorted": [[1], [2, 1], [3, 2, 1], [4, 3, 2], [5, 2], [5, 4, 3], [6, 5, 2], [7, 6, 5], [8, 7], [9, 4]],
+    "sepsets_sorted": [[1], [2], [2, 1], [3, 2], [4], [4, 3], [5], [5, 2], [6, 5], [7]],
+    "is_tree": False,
+    "error_maxclustersize_2": "maxclustersize 2 is smaller than the size of largest node family 3.",
+    "preorder_note": "not literal in the test: the only node numbering under which every node family of the network "
+                     "lies inside one of the listed clusters (the test checks isfamilypreserving)",
+    "preorder": ["A", "B", "H1", "D", "H3", "H2", "H4", "g", "d"]}
 
 G["bpposdef_message"] = {
     "cite": "test/test_calibration.jl:6-12",

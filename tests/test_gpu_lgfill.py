@@ -268,3 +268,72 @@ def test_lgfill_refusals(P):
     eng.set_schedule(prob.schedule)
     with pytest.raises(P.PgbpError, match="pgbp_lg_assignfactors first"):
         eng.loglik_lg()                                               # schedule set? parameters missing
+
+
+@pytest.mark.parametrize("graph,ntips,nblobs,p", [("bethe", 150, 12, 4), ("joingraph", 150, 12, 4), ("bethe", 60, 5, 2),
+                                                  ("joingraph", 40, 3, 16)])
+def test_cfg5_pipeline_on_arrays(P, graph, ntips, nblobs, p):
+    """The cfg5 pipeline of bench.py --workload network at test size, without any oracle object on the product side:
+    level-3 network on plain arrays, Bethe / join-graph cluster graph, scope allocation, device factor fill for a
+    heterogeneous BM with hybrid nodes, regularizebeliefs_bycluster!, calibrate!(auto) -- against the plain-C sequential
+    engine from the same start (iteration / tree of convergence, every belief to 1e-8) and, for the exact (tree-shaped)
+    join graph, the likelihood against the dense multivariate-normal value."""
+    from oracle import cengine
+    rng = np.random.default_rng(77 + ntips + p)
+    net = P.random_level3_network(ntips, nblobs, rng, n_colors=3)
+    assert net.nhybrids == 3 * nblobs
+    cn, ed, sn = P.joingraph(net.node2family, 3) if graph == "joingraph" else P.bethe(net.node2family)
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    base = np.eye(p) + 0.3
+    rates = np.stack([base * f for f in (0.5, 1.0, 2.0)])
+    mu = rng.normal(size=p)
+    X = P.simulate_bm_network(net, rates, mu, rng)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, list(range(net.nnodes)), p, n_rates=3)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, mu)
+    loopy = len(ed) > len(cn) - 1
+    assert loopy == (graph == "bethe")
+    if loopy:
+        assert P.load().pgbp_regularize_bycluster(cgb._eng) == 0
+    cgb.pull()
+    start = cgb._packed[0].copy()
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    assert P.calibrate_(cgb, sched, 100, auto=True) == (True, True)
+    r = cgb.last_results[0]
+    ce = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+    reached = None
+    for it in range(1, 101):
+        for j, spt in enumerate(sched, start=1):
+            succ, iscal = ce.calibrate(spt[2], spt[3], 1, return_iscal=True)
+            assert succ
+            if iscal:
+                reached = (it, j)
+                break
+        if reached:
+            break
+    assert reached == (r.iter_reached, r.tree_reached)
+    ref = ce.packed()
+    assert np.max(np.abs(cgb._packed[0] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
+    if not loopy and p <= 4:
+        # exact graph: the calibrated root cluster integrates to the likelihood
+        nodes = [ON.Node(name=f"n{i + 1}", leaf=bool(net.is_leaf[i]), hybrid=len(net.node2family[i]) > 2) for i in range(net.nnodes)]
+        edges = []
+        for i, nf in enumerate(net.node2family):
+            for k, pl in enumerate(nf[1:]):
+                e = ON.Edge(number=len(edges) + 1, parent=nodes[pl - 1], child=nodes[i], length=net.length[i][k],
+                            gamma=net.gamma[i][k], hybrid=len(nf) > 2)
+                edges.append(e); nodes[pl - 1].edges.append(e); nodes[i].edges.append(e)
+        onet = ON.Network(nodes[0], nodes, edges)
+        onet.set_preorder([n.name for n in nodes])
+        colors = {}
+        for e in edges:
+            ci = int(e.child.name[1:]) - 1
+            colors[e.number] = 1 + net.color[ci][net.node2family[ci][1:].index(int(e.parent.name[1:]))]
+        model = OM.HeterogeneousBrownianMotion(list(rates), colors, mu)
+        taxa = onet.tip_names
+        tbl = [[float(X[int(t[1:]) - 1, v]) for t in taxa] for v in range(p)]
+        dense = OD.loglik(onet, model, tbl, taxa)
+        ll = cgb.integratebelief_(sched[0][2][0])[1]
+        assert abs(ll - dense) <= 1e-8 * max(1.0, abs(dense)), (ll, dense)
