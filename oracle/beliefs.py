@@ -525,7 +525,8 @@ def regularizebeliefs_bynodesubtree(cgb: "ClusterGraphBelief"):
         root = max(cl, key=lambda i: b[i].nodelabel[0])
         eps = bu.EPS
         for i in cl:
-            eps = max(eps, float(np.max(np.abs(b[i].J))))
+            if b[i].J.size:   # maximum(abs, J) of an empty J is 0 in Julia (Base.mapreduce_empty(abs, max, T))
+                eps = max(eps, float(np.max(np.abs(b[i].J))))
         nbr = {i: [] for i in cl}
         for (a, c, j) in ed:
             nbr[a].append((c, j))

@@ -73,7 +73,7 @@ def regularizebeliefs_bynodesubtree_(beliefs, clustergraph=None):
             eps = _EPS
             for i in cl:
                 J = beliefs._views(site, i)[0]
-                if J.size:
+                if J.size:   # maximum(abs, J) of an empty J is 0 in Julia
                     eps = max(eps, float(np.max(np.abs(J))))
             for (c, j) in order:
                 s_ind, c_ind = _scopeindex_node(v, b[j], b[c])

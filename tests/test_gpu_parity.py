@@ -1042,3 +1042,40 @@ def test_differential_fuzz_against_c_oracle(P):
     import fuzz_gpu_vs_c_oracle as F
     n_fail, worst = F.run(150, 2024)
     assert n_fail >= 10 and worst <= 1e-8
+
+
+@pytest.mark.parametrize("variant", ["improper", "fixed"])
+def test_calibration_level3_joingraph_loopy_run_on_device(P, caplog, variant):
+    """test/test_calibration.jl:138-176 on the device, cluster graph and schedule from the product's own host builders
+    (joingraph, nodesubtree_clusterlist on plain arrays): JoinGraphStructuring(3), regularizebeliefs_bynodesubtree!,
+    one schedule tree per node, calibrate!(cgb, sch, 10; auto=true, info=true) -> "calibration reached: iteration 4,
+    schedule tree 1"; normalisation constants at clusters 6 (I1I2I3) and 2 (H1H2I1), posterior means."""
+    g = G["calibration_level3_joingraph"]
+    net = ON.read_newick(g["net"])
+    net.set_preorder(g["preorder"])
+    cn, ed, sn = P.joingraph(OCG.nodefamilies(net), g["maxclustersize"])
+    names = [n.name for n in net.vec_node]
+    cg = OB.ClusterGraph([("".join(names[v - 1] for v in n), n) for n in cn], [(a, b, s) for (a, b), s in zip(ed, sn)], "joingraph")
+    for lab, i1 in g["cluster_index_1based"].items():
+        assert cg.labels[i1 - 1] == lab
+    ocgb, pcgb = build_both(P, net, cg, make_model(g["model_" + variant]), [g["y1"], g["y2"]], g["taxa"])
+    P.regularizebeliefs_bynodesubtree_(pcgb, cg)
+    OB.regularizebeliefs_bynodesubtree(ocgb)
+    assert_beliefs_close(pcgb, ocgb)
+    sch = []
+    for v in range(1, len(names) + 1):
+        st = P.nodesubtree_clusterlist(cn, ed, sn, v, labels=cg.labels)
+        if st[0]:
+            sch.append(st)
+    with caplog.at_level(logging.INFO):
+        assert P.calibrate_(pcgb, sch, g["niter"], auto=True, info=True) == (True, True)
+    if variant == "improper":
+        assert g["info_line"] in caplog.text
+    assert OC.calibrate(ocgb, sch, g["niter"], auto=True) == (True, True)
+    assert_beliefs_close(pcgb, ocgb)
+    for lab, i1 in g["cluster_index_1based"].items():
+        mu, norm = pcgb.integratebelief_(i1 - 1)
+        assert abs(norm - g["norm_" + variant]) <= 1.5e-8 * abs(g["norm_" + variant])
+    mu6 = pcgb.integratebelief_(g["cluster_index_1based"]["I1I2I3"] - 1)[0]
+    want = [x for n in ("I1", "I2", "I3") for x in g["posterior_means_" + variant].get(n, [])]
+    assert np.allclose(mu6[:len(want)], want, rtol=1.5e-8, atol=0)

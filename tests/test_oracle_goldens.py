@@ -370,3 +370,47 @@ def test_residual_kldiv_during_calibration():
     assert OC.calibrate(cgb, [spt], 1, update_residualkldiv=True) == (True, True)
     for mr in cgb.messageresidual.values():
         assert abs(mr.kldiv) < 1e-10 and mr.iscalibrated_kl
+
+
+def test_joingraph_mateescu_golden():
+    """test/test_clustergraph.jl:95-110: JoinGraphStructuring(3) on the Mateescu network: cluster and sepset sets,
+    not a tree, family-preserving, running intersection; maxclustersize below the largest family is an error.
+    Both walk orders of a bucket's minibuckets (the reference's is a Julia Dict's) give the golden sets."""
+    g = G["joingraph_mateescu"]
+    net = ON.read_newick(g["net"])
+    net.set_preorder(g["preorder"])
+    for order in ("decreasing", "increasing"):
+        cg = OCG.joingraph(net, g["maxclustersize"], order)
+        assert sorted(n for _, n in cg.clusters) == g["clusters_sorted"]
+        assert sorted(s for _, _, s in cg.edges) == g["sepsets_sorted"]
+        assert (len(cg.edges) == len(cg.clusters) - 1) == g["is_tree"]
+        assert OCG.isfamilypreserving(cg, net) and OCG.check_runningintersection(cg, net)
+    with pytest.raises(ValueError) as ei:
+        OCG.joingraph(net, 2)
+    assert str(ei.value) == g["error_maxclustersize_2"]
+
+
+@pytest.mark.parametrize("variant", ["improper", "fixed"])
+def test_calibration_level3_joingraph_loopy_run(variant):
+    """test/test_calibration.jl:138-149, 161-176: the loopy run itself -- JoinGraphStructuring(3),
+    regularizebeliefs_bynodesubtree!, one nodesubtree_clusterlist tree per node, calibrate!(cgb, sch, 10; auto=true,
+    info=true) logs "calibration reached: iteration 4, schedule tree 1"; cluster 6 is I1I2I3 and cluster 2 H1H2I1;
+    their normalisation constants and posterior means."""
+    g = G["calibration_level3_joingraph"]
+    net = ON.read_newick(g["net"])
+    net.set_preorder(g["preorder"])
+    cg = OCG.joingraph(net, g["maxclustersize"])
+    for lab, i1 in g["cluster_index_1based"].items():
+        assert cg.labels[i1 - 1] == lab
+    cgb = oracle_setup(net, cg, make_model(g["model_" + variant]), [g["y1"], g["y2"]], g["taxa"])
+    OB.regularizebeliefs_bynodesubtree(cgb)
+    sch = [st for st in (OCG.nodesubtree_clusterlist(cg, v) for v in range(1, len(net.vec_node) + 1)) if st[0]]
+    log = []
+    assert OC.calibrate(cgb, sch, g["niter"], auto=True, info=True, log=log) == (True, True)
+    if variant == "improper":
+        assert log == [("info", g["info_line"])]
+    means = _node_means(cgb, net, cgb.integratebelief)
+    for name, m in g["posterior_means_" + variant].items():
+        assert np.allclose(means[name], m, rtol=1.5e-8, atol=0), (name, means[name], m)   # the reference's isapprox
+    for lab, i1 in g["cluster_index_1based"].items():
+        assert close(cgb.integratebelief(i1 - 1)[1], g["norm_" + variant], rtol=1.5e-8)

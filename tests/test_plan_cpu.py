@@ -320,3 +320,99 @@ def test_schedule_builders_match_the_oracle():
                 assert len(g[2]) == len(nodes) - 1
                 covered |= {frozenset(e) for e in zip(g[2], g[3])}
             assert covered == {frozenset(e) for e in edges}
+
+
+# ----------------------------------------------------------------------------- cluster-graph construction on plain arrays
+
+def _arrays_to_oracle_network(net):
+    from oracle import network as ON
+    nodes = [ON.Node(name=f"n{i + 1}", leaf=bool(net.is_leaf[i]), hybrid=len(net.node2family[i]) > 2)
+             for i in range(net.nnodes)]
+    edges = []
+    for i, nf in enumerate(net.node2family):
+        for k, pl in enumerate(nf[1:]):
+            e = ON.Edge(number=len(edges) + 1, parent=nodes[pl - 1], child=nodes[i], length=net.length[i][k],
+                        gamma=net.gamma[i][k], hybrid=len(nf) > 2)
+            edges.append(e)
+            nodes[pl - 1].edges.append(e)
+            nodes[i].edges.append(e)
+    o = ON.Network(nodes[0], nodes, edges)
+    o.set_preorder([n.name for n in nodes])
+    return o
+
+
+def test_joingraph_minfill_equal_the_oracle_on_random_networks():
+    """The product's heap-based min-fill order and join-graph structuring (clustergraph.py) against the oracle's
+    line-by-line restatement (rescan of every vertex per elimination, src/clustergraph.jl:87-121, 605-697)."""
+    import pgbp_amd as P
+    from oracle import clustergraph as OCG
+    from oracle import network as ON
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        net = (ON.random_network(int(rng.integers(5, 50)), int(rng.integers(0, 12)), rng) if seed % 2 else
+               ON.random_level3_network(int(rng.integers(6, 40)), int(rng.integers(1, 5)), rng))
+        fam = OCG.nodefamilies(net)
+        adj_o, adj_p = OCG.moralize(net), P.moralize(fam)
+        assert OCG.triangulate_minfill(adj_o) == P.triangulate_minfill(adj_p) and adj_o == adj_p
+        for k in (3, 4, 6):
+            cg = OCG.joingraph(net, k)
+            cn, ed, sn = P.joingraph(fam, k)
+            assert [n for _, n in cg.clusters] == cn
+            assert sorted((a, b, tuple(s)) for a, b, s in cg.edges) == sorted((a, b, tuple(s)) for (a, b), s in zip(ed, sn))
+            assert OCG.isfamilypreserving(cg, net) and OCG.check_runningintersection(cg, net)
+            assert max(len(n) for n in cn) <= k
+    with pytest.raises(ValueError, match="smaller than the size of largest node family"):
+        P.joingraph(fam, 2)
+
+
+def test_arrays_pipeline_equals_the_oracle():
+    """networks.py / clustergraph.py on plain arrays == the oracle's objects: node families, Bethe and join-graph
+    cluster graphs, and what allocatebeliefs establishes (dimensions, node2cluster, scopeindex of both sepset ends)."""
+    import pgbp_amd as P
+    from helpers import oracle_setup
+    from oracle import beliefs as OB
+    from oracle import clustergraph as OCG
+    from oracle import models as OM
+    p = 2
+    for seed in range(5):
+        rng = np.random.default_rng(seed)
+        net = P.random_level3_network(int(rng.integers(6, 40)), int(rng.integers(1, 5)), rng, n_colors=3)
+        onet = _arrays_to_oracle_network(net)
+        assert OCG.nodefamilies(onet) == net.node2family
+        for kind in ("bethe", "join"):
+            cn, ed, sn = P.bethe(net.node2family) if kind == "bethe" else P.joingraph(net.node2family, 3)
+            ocg = OCG.bethe(onet) if kind == "bethe" else OCG.joingraph(onet, 3)
+            assert [n for _, n in ocg.clusters] == cn
+            norm = lambda a, b, s: (min(a, b), max(a, b), tuple(s))
+            assert sorted(norm(a, b, s) for a, b, s in ocg.edges) == sorted(norm(a, b, s) for (a, b), s in zip(ed, sn))
+            ocg2 = OB.ClusterGraph([(str(i), n) for i, n in enumerate(cn)], [(a, b, s) for (a, b), s in zip(ed, sn)], kind)
+            st = P.allocate_scopes(cn, ed, sn, net, p)
+            model = OM.MvFullBrownianMotion(np.eye(p), np.zeros(p))
+            taxa = onet.tip_names
+            tbl = [list(rng.normal(size=len(taxa))) for _ in range(p)]
+            ocgb = oracle_setup(onet, ocg2, model, tbl, taxa)
+            assert [b.dimension for b in ocgb.belief] == st.dims.tolist()
+            assert ocgb.node2cluster == st.node2cluster
+            assert list(ocgb.node2fixed) == st.node2fixed.tolist()
+            idx, off = [], [0]
+            for j in range(ocgb.nclusters, len(ocgb.belief)):
+                for c in ocg2.edges[j - ocgb.nclusters][:2]:
+                    idx += OB.scopeindex(ocgb.belief[j], ocgb.belief[c]).tolist()
+                    off.append(len(idx))
+            assert idx == st.scope_idx.tolist() and off == st.scope_off.tolist()
+
+
+def test_nodesubtree_clusterlist_equals_the_oracle():
+    import pgbp_amd as P
+    from oracle import clustergraph as OCG
+    from oracle import network as ON
+    rng = np.random.default_rng(3)
+    net = ON.random_level3_network(30, 4, rng)
+    cg = OCG.bethe(net)
+    cn = [n for _, n in cg.clusters]
+    ed = [(a, b) for a, b, _ in cg.edges]
+    sn = [s for _, _, s in cg.edges]
+    for v in range(1, len(net.vec_node) + 1):
+        o = OCG.nodesubtree_clusterlist(cg, v)
+        q = P.nodesubtree_clusterlist(cn, ed, sn, v)
+        assert (o[2], o[3]) == (q[2], q[3])
