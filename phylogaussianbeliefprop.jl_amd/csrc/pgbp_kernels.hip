@@ -34,6 +34,21 @@ __device__ __forceinline__ int pow2_at_least(int n) {  // n in [1, 64] -> smalle
 
 extern __shared__ double lds[];
 
+#ifdef PGBP_GTRACE
+// experiment-only instrumentation of the generic kernel (tools/trace_generic.py, never in the shipped build):
+// per-phase timestamps of launches with at most 4 tasks
+__device__ unsigned long long g_gtrace[1u << 16][14];
+__device__ unsigned int g_gtrace_n;
+#define GTR(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); gtr[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GTR(i) do { } while (0)
+#endif
+
+// lane -> (lane & (L - 1), lane >> lg) grids with L = 2^lg >= n: index arithmetic without integer division
+__device__ __forceinline__ int log2_ceil(int n) {  // n in [1, 64]
+  return n <= 1 ? 0 : 32 - __clz(n - 1);
+}
+
 // Eliminate the leading `ni` variables of the (mf x (mf+1)) augmented system held row-major in W
 // (leading dimension ld): W[i][j] -= (W[i][k] / W[k][k]) * W[k][j].  Returns 0 or the 1-based index of
 // the first non-positive pivot (LAPACK potrf `info`, src/beliefupdates.jl:68-76). Accumulates
@@ -44,31 +59,28 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
   quad = 0.0;
   double mant = 1.0;
   int expo = 0;
+  // fixed lane grid over the columns 0 .. mf (the last one is h; 65 columns for mf = 64: two passes) and a stripe of rows
+  const int ncol = mf + 1;
+  const int lg = log2_ceil(ncol < kWave ? ncol : kWave);
+  const int L = 1 << lg;
+  const int jj = lane & (L - 1);
+  const int i0 = lane >> lg, R = kWave >> lg;   // R >= 1
   for (int k = 0; k < ni; ++k) {
     const double d = W[k * ld + k];
+    const double hk = W[k * ld + mf];
     if (!(d > 0.0)) return k + 1;
     double rd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + 2 Newton steps: ~1 ulp, half the latency of a division
     rd = fma(fma(-d, rd, 1.0), rd, rd);
     rd = fma(fma(-d, rd, 1.0), rd, rd);
-    const double hk = W[k * ld + mf];
     int ex;
     mant *= frexp(d, &ex);  // log det as mantissa product + exponent sum: one log per message
     expo += ex;
     if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
     quad += hk * hk * rd;
-    const int nc = mf - k;      // columns k+1 .. mf (the last one is h)
-    const int nr = mf - 1 - k;  // rows k+1 .. mf-1
-    const int L = pow2_at_least(nc);
-    const int R = kWave / L;
-    const int jj = lane & (L - 1);
-    const int i0 = lane / L;
-    if (jj < nc) {
-      const int j = k + 1 + jj;
-      const double pkj = W[k * ld + j];
-#pragma unroll 4
-      for (int ii = i0; ii < nr; ii += R) {
-        const int i = k + 1 + ii;
-        W[i * ld + j] -= (W[i * ld + k] * rd) * pkj;
+    for (int j = jj; j < ncol; j += L) {
+      if (j > k) {
+        const double pkj = W[k * ld + j];
+        for (int i = k + 1 + i0; i < mf; i += R) W[i * ld + j] -= (W[i * ld + k] * rd) * pkj;
       }
     }
     __syncthreads();
@@ -83,10 +95,16 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
                                                        unsigned long long stop_below) {
   const int lane = threadIdx.x;
   const int site = blockIdx.y;
+#ifdef PGBP_GTRACE
+  unsigned long long gtr[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  gtr[12] = __builtin_amdgcn_s_memrealtime();
+  gtr[0] = __builtin_amdgcn_s_memtime();
+#endif
   // A message of an EARLIER traversal failed: the reference has stopped (src/calibration.jl:82,129-132).
   // Failures inside the current traversal only stop what is downstream of them (poison), so that the
   // minimum fail key is the first failure of the reference's sequential order.
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  GTR(1);
   const int task = task0 + blockIdx.x;
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
@@ -96,78 +114,112 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
   const int e0 = task_off[task], e1 = task_off[task + 1];
   int mf = 0, ni = 0, ld = 1;
   double gmsg = 0.0;
+  GTR(2);
+  // entry / descriptor of the NEXT message are fetched while the current one is worked on (a task is a chain of
+  // dependent loads otherwise: entry -> descriptor -> operands, about half a microsecond per hop)
+  int en_msg = entries[e0].msg, en_reuse = entries[e0].reuse, en_seq = entries[e0].seq;
+  GTR(3);
+  MsgDesc m = S.msgs[en_msg];
+  GTR(4);
   for (int e = e0; e < e1; ++e) {
-    const Entry en = entries[e];
-    const MsgDesc m = S.msgs[en.msg];
+    const bool more = e + 1 < e1;
+    int nx_msg = en_msg, nx_reuse = 0, nx_seq = 0;
+    if (more) { nx_msg = entries[e + 1].msg; nx_reuse = entries[e + 1].reuse; nx_seq = entries[e + 1].seq; }
     if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
-      if (lane == 0) S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
+      // nothing downstream of a failed message runs: every receiver the rest of this task would have reached
+      // (a fused chain passes through several) is marked
+      if (lane == 0)
+        for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
       return;
     }
+    if (e == e0) GTR(5);
+    const int s = m.s, mt = m.mt;
+    double* __restrict__ sep = pool + m.sep_off;
+    double* __restrict__ to = pool + m.to_off;
+    double* __restrict__ res = rpool + m.res_off;
+    const int32_t* __restrict__ up = S.idx + m.up_map;
+    const bool upc = m.up0 >= 0;                      // update indices contiguous: no index loads
+    // lane grid of the sepset block: a = row, b = b0, b0 + Rs, ...
+    const int lgs = log2_ceil(s > 0 ? s : 1);
+    const int a = lane & ((1 << lgs) - 1), b0 = lane >> lgs, Rs = kWave >> lgs;
+    const int ua = (s > 0 && a < s) ? (upc ? m.up0 + a : up[a]) : 0;
     // sepset and receiver operands of this lane, requested BEFORE the gather / elimination so that their HBM latency
     // runs beside it (small sepsets only: at most 4 (a, b) pairs per lane; larger ones are read after the elimination)
-    const bool pre = m.s > 0 && m.s <= 16;
+    const bool pre = s > 0 && s <= 16;
     double pre_sep[4] = {0, 0, 0, 0}, pre_to[4] = {0, 0, 0, 0}, pre_seph = 0.0, pre_toh = 0.0;
-    if (pre) {
-      const double* __restrict__ sep0 = pool + m.sep_off;
-      const double* __restrict__ to0 = pool + m.to_off;
-      const int32_t* __restrict__ up0 = S.idx + m.up_map;
-      const int s0 = m.s, L0 = pow2_at_least(s0), R0 = kWave / L0, a0 = lane & (L0 - 1);
-      if (a0 < s0) {
-        const int ua = up0[a0];
+    int ubq[4] = {0, 0, 0, 0};
+    if (pre && a < s) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int b = lane / L0 + q * R0;
-          if (b < s0) {
-            pre_sep[q] = sep0[a0 + (int64_t)b * s0];
-            pre_to[q] = to0[ua + (int64_t)up0[b] * m.mt];
-          }
-        }
-        if (lane / L0 == 0) {
-          pre_seph = sep0[(int64_t)s0 * s0 + a0];
-          pre_toh = to0[(int64_t)m.mt * m.mt + ua];
+      for (int q = 0; q < 4; ++q) {
+        const int b = b0 + q * Rs;
+        if (b < s) {
+          ubq[q] = upc ? m.up0 + b : up[b];
+          pre_sep[q] = sep[a + (int64_t)b * s];
+          pre_to[q] = to[ua + (int64_t)ubq[q] * mt];
         }
       }
+      if (b0 == 0) {
+        pre_seph = sep[(int64_t)s * s + a];
+        pre_toh = to[(int64_t)mt * mt + ua];
+      }
     }
-    if (!en.reuse) {
+    double pre_sepg = 0.0, pre_tog = 0.0;             // the two g words (lane 0)
+    if (lane == 0) {
+      pre_sepg = sep[(int64_t)s * s + s];
+      pre_tog = to[(int64_t)mt * mt + mt];
+    }
+    if (!en_reuse) {
       const double* __restrict__ from = pool + m.from_off;
       mf = m.mf;
       ni = m.ni;
       ld = (mf + 1) | 1;  // odd leading dimension: conflict-free column walks
+      const int lgm = log2_ceil(mf > 0 ? mf : 1);
+      const int ci = lane & ((1 << lgm) - 1), r0 = lane >> lgm, Rm = kWave >> lgm;
       __syncthreads();    // W / perm of the previous entry no longer needed
-      for (int i = lane; i < mf; i += kWave)
-        perm[i] = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];
-      __syncthreads();
-      // gather: integrated variables first, kept variables last; h as the extra column
-      {
-        const int L = pow2_at_least(mf > 0 ? mf : 1);
-        const int R = kWave / L;
-        const int i = lane & (L - 1);
-        if (i < mf) {
-          const int pi = perm[i];
-#pragma unroll 4
-          for (int j = lane / L; j < mf; j += R) W[i * ld + j] = from[pi + (int64_t)perm[j] * mf];
-          if (lane / L == 0) W[i * ld + mf] = from[(int64_t)mf * mf + pi];
-        }
+      // integrated variables first, kept variables last.  Kept indices contiguous (keep0 >= 0; every single-node
+      // sepset): the permutation is arithmetic, no index loads
+      const int k0 = m.keep0;
+      for (int i = lane; i < mf; i += kWave) {
+        int pv;
+        if (k0 >= 0) pv = (i < ni) ? (i < k0 ? i : i + s) : k0 + (i - ni);
+        else pv = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];
+        perm[i] = pv;
       }
-      gmsg = from[(int64_t)mf * mf + mf];
       __syncthreads();
+      if (e == e0) GTR(6);
+      // gather; h as the extra column
+      if (ci < mf) {
+        const int pi = perm[ci];
+        for (int j = r0; j < mf; j += Rm) W[ci * ld + j] = from[pi + (int64_t)perm[j] * mf];
+        if (r0 == 0) W[ci * ld + mf] = from[(int64_t)mf * mf + pi];
+      }
+      {
+        // vector load on purpose: in a fused chain the sender was written by THIS wave a moment ago (vector stores);
+        // a wave-uniform address would be fetched through the scalar cache, which those stores do not update
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        gmsg = from[(int64_t)mf * mf + mf + z];
+      }
+      __syncthreads();
+      if (e == e0) GTR(7);
       if (ni > 0) {
         // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
         bool nz = false;
-        for (int idx = lane; idx < mf * ni; idx += kWave) {
-          const int j = idx / mf, i = idx - j * mf;
-          nz |= fabs(W[i * ld + j]) > PGBP_EPS;
+        if (ci < mf) {
+          for (int j = r0; j < ni; j += Rm) nz |= fabs(W[ci * ld + j]) > PGBP_EPS;
+          if (r0 == 0 && ci < ni) nz |= fabs(W[ci * ld + mf]) > PGBP_EPS;
         }
-        for (int i = lane; i < ni; i += kWave) nz |= fabs(W[i * ld + mf]) > PGBP_EPS;
         const bool fake = !__any(nz);
         if (!fake) {
           // Symmetric(J_I): upper triangle only (:68); pivot rows get J_SI' for the kept columns (:77)
-          for (int idx = lane; idx < ni * mf; idx += kWave) {
-            const int i = idx / mf, j = idx - i * mf;
-            if (j > i) {
-              const double v = (j < ni) ? W[i * ld + j] : W[j * ld + i];
-              W[i * ld + j] = v;
-              if (j < ni) W[j * ld + i] = v;
+          if (ci < mf) {
+            const int j = ci;
+            for (int i = r0; i < ni; i += Rm) {
+              if (j > i) {
+                const double v = (j < ni) ? W[i * ld + j] : W[j * ld + i];
+                W[i * ld + j] = v;
+                if (j < ni) W[j * ld + i] = v;
+              }
             }
           }
           __syncthreads();
@@ -175,9 +227,9 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
           const int info = eliminate_leading(W, ld, mf, ni, lane, logdet, quad);
           if (info != 0) {
             if (lane == 0) {
-              S.status[(int64_t)site * S.n_msgs + en.msg] = info;
-              S.poison[(int64_t)site * S.n_clusters + m.to_b] = 1;
-              atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) |
+              S.status[(int64_t)site * S.n_msgs + en_msg] = info;
+              for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
+              atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en_seq) << kInfoBits) |
                                            (unsigned long long)info);
             }
             return;  // nothing of this message is applied; later messages of the task do not run
@@ -186,73 +238,95 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
         }
       }
     }
+    if (e == e0) GTR(8);
+    MsgDesc m_next = m;
+    if (more) m_next = S.msgs[nx_msg];   // its entry was requested at the top of this iteration
     // ---- divide! and mult!
-    double* __restrict__ sep = pool + m.sep_off;
-    double* __restrict__ to = pool + m.to_off;
-    double* __restrict__ res = rpool + m.res_off;
-    const int s = m.s, mt = m.mt;
-    const int32_t* __restrict__ up = S.idx + m.up_map;
     double maxJ = 0.0, maxh = 0.0;
-    if (s > 0) {
-      const int L = pow2_at_least(s);
-      const int R = kWave / L;
-      const int a = lane & (L - 1);
-      if (a < s) {
-        const int ua = up[a];
-        if (pre) {
+    if (s > 0 && a < s) {
+      if (pre) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int b = lane / L + q * R;
-            if (b < s) {
-              const double msg = W[(ni + a) * ld + ni + b];
-              const int64_t o = a + (int64_t)b * s;
-              const double dJ = msg - pre_sep[q];
-              sep[o] = msg;
-              res[o] = dJ;
-              to[ua + (int64_t)up[b] * mt] = pre_to[q] + dJ;
-              maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
-            }
-          }
-        } else {
-#pragma unroll 4
-          for (int b = lane / L; b < s; b += R) {
+        for (int q = 0; q < 4; ++q) {
+          const int b = b0 + q * Rs;
+          if (b < s) {
             const double msg = W[(ni + a) * ld + ni + b];
             const int64_t o = a + (int64_t)b * s;
-            const double dJ = msg - sep[o];
+            const double dJ = msg - pre_sep[q];
             sep[o] = msg;
             res[o] = dJ;
-            to[ua + (int64_t)up[b] * mt] += dJ;
+            to[ua + (int64_t)ubq[q] * mt] = pre_to[q] + dJ;
             maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
           }
         }
-        if (lane / L == 0) {
-          const double msg = W[(ni + a) * ld + mf];
-          const int64_t o = (int64_t)s * s + a;
-          const double dh = msg - (pre ? pre_seph : sep[o]);
+      } else {
+        for (int b = b0; b < s; b += Rs) {
+          const double msg = W[(ni + a) * ld + ni + b];
+          const int64_t o = a + (int64_t)b * s;
+          const double dJ = msg - sep[o];
           sep[o] = msg;
-          res[o] = dh;
-          to[(int64_t)mt * mt + ua] = (pre ? pre_toh : to[(int64_t)mt * mt + ua]) + dh;
-          maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
+          res[o] = dJ;
+          to[ua + (int64_t)(upc ? m.up0 + b : up[b]) * mt] += dJ;
+          maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
         }
+      }
+      if (b0 == 0) {
+        const double msg = W[(ni + a) * ld + mf];
+        const int64_t o = (int64_t)s * s + a;
+        const double dh = msg - (pre ? pre_seph : sep[o]);
+        sep[o] = msg;
+        res[o] = dh;
+        to[(int64_t)mt * mt + ua] = (pre ? pre_toh : to[(int64_t)mt * mt + ua]) + dh;
+        maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
       }
     }
     if (lane == 0) {
-      const int64_t og = (int64_t)s * s + s;
-      const double dg = gmsg - sep[og];
-      sep[og] = gmsg;
-      to[(int64_t)mt * mt + mt] += dg;
-      S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
+      const double dg = gmsg - pre_sepg;
+      sep[(int64_t)s * s + s] = gmsg;
+      to[(int64_t)mt * mt + mt] = pre_tog + dg;
+      S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
     }
     if (S.update_resnorm) {
       // iscalibrated_residnorm!: max|dh|/sqrt(s) <= atol && max|dJ|/s <= atol (src/beliefs.jl:994-1003)
       // x -> fl(x / c) is monotone: every lane tests its own maximum, one ballot instead of two wave reductions
       const bool lane_ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
       const bool ok = __all(lane_ok);
-      if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = ok ? 1 : 0;
+      if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en_msg] = ok ? 1 : 0;
     }
-    if (e + 1 < e1) __threadfence_block();  // next entry of the task may read-modify-write the same receiver
+    if (more) __threadfence_block();  // next entry of the task may read or read-modify-write what this one wrote
+#ifdef PGBP_GTRACE
+    if (e == e0) { gtr[9] = __builtin_amdgcn_s_memtime(); GTR(10); }
+#endif
+    en_msg = nx_msg;
+    en_reuse = nx_reuse;
+    en_seq = nx_seq;
+    m = m_next;
   }
+#ifdef PGBP_GTRACE
+  GTR(11);
+  gtr[13] = __builtin_amdgcn_s_memrealtime();
+  if (gridDim.x <= 4 && lane == 0) {
+    const unsigned int slot = atomicAdd(&g_gtrace_n, 1u);
+    if (slot < (1u << 16)) {
+      for (int q = 0; q < 14; ++q) g_gtrace[slot][q] = gtr[q];
+      g_gtrace[slot][12] = (gtr[13] - gtr[12]) | ((unsigned long long)(e1 - e0) << 32);
+      g_gtrace[slot][13] = (unsigned long long)mf | ((unsigned long long)ni << 8) | ((unsigned long long)gridDim.x << 16);
+    }
+  }
+#endif
 }
+
+#ifdef PGBP_GTRACE
+}  // namespace pgbp
+extern "C" int pgbp_debug_gtrace(unsigned long long* out, unsigned int cap, unsigned int* n, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return 4;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(pgbp::g_gtrace_n), sizeof(unsigned int)) != hipSuccess) return 1;
+  const unsigned int m = *n < cap ? *n : cap;
+  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgbp::g_gtrace), (size_t)m * 14 * sizeof(unsigned long long)) != hipSuccess) return 2;
+  if (reset) { unsigned int z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_gtrace_n), &z, sizeof(z)) != hipSuccess) return 3; }
+  return 0;
+}
+namespace pgbp {
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // Univariate / tiny beliefs (every dimension <= 2): ONE THREAD per (site, task), lanes = sites.

@@ -9,6 +9,7 @@
 //   * postorder = edges in reverse, child -> parent, residual key (pa, ch);
 //     preorder = edges in order, parent -> child, key (ch, pa) (src/calibration.jl:121-151).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -182,6 +183,9 @@ static bool fast_task(const Plan& p, const Traversal& tr, int t, bool postorder,
   for (int e = e0; e < e1; ++e) {
     const MsgDesc& m = p.msgs[tr.entries[e].msg];
     if (!fast_msg(m, p.fast_p)) return false;
+    // a fused chain (build_traversals) passes through several receivers / senders: generic kernel
+    const MsgDesc& m0 = p.msgs[tr.entries[e0].msg];
+    if (postorder ? m.to_b != m0.to_b : m.from_b != m0.from_b) return false;
     if (postorder && m.s > 0) {  // all deltas must land on the same receiver block
       if (up0 >= 0 && (m.up0 != up0 || m.mt != mt)) return false;
       up0 = m.up0;
@@ -289,16 +293,34 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   tr.entries.swap(new_entries);
 }
 
-static void build_traversals(const Plan& p, Tree& t) {
+// Level-synchronous schedules of one spanning tree.
+// fuse: CHAIN FUSION.  A cluster with exactly one child in the schedule tree receives one message and can send at
+// once: the wave that delivered the message goes on with the cluster's own message(s) instead of leaving them to the
+// next level (= the next kernel launch).  Postorder: the single message into a unary cluster X is prepended to the
+// entry X -> parent(X) of the task of parent(X); preorder: the task of a cluster S whose parent has no other child is
+// appended to the parent's task.  Message order into every receiver, sequence numbers and arithmetic are unchanged;
+// only the grouping into waves and levels is: Bethe graphs (factor clusters are unary) lose half of their levels.
+// Fused tasks run on the generic kernel (entries of a task are executed in order by one wavefront).
+static void build_traversals(const Plan& p, Tree& t, bool fuse) {
   const int n = (int)t.pa.size();
   // message id of edge i in each direction: sepset k = (a, b); dir 0 is received by a
   auto msg_to = [&](int i, int receiver) {
     const int k = t.sep[i];
     return 2 * k + (p.sepset_clusters[2 * k] == receiver ? 0 : 1);
   };
-  // ---- postorder: level = height of the child in the schedule tree
+  // child edges and parent edge of every cluster of the tree
+  std::unordered_map<int, int> nchild, only_child_edge, parent_edge;
+  for (int i = 0; i < n; ++i) {
+    if (++nchild[t.pa[i]] == 1) only_child_edge[t.pa[i]] = i;
+    parent_edge[t.ch[i]] = i;
+  }
+  auto unary = [&](int cluster) {
+    auto it = nchild.find(cluster);
+    return fuse && it != nchild.end() && it->second == 1;
+  };
+  // ---- postorder: level = height of the child in the schedule tree (chains collapsed)
   {
-    std::unordered_map<int, int> hnode;
+    std::unordered_map<int, int> hnode;  // cluster -> level at which it can send
     std::vector<int> lvl(n);
     int nlev = 0;
     for (int i = n - 1; i >= 0; --i) {
@@ -307,16 +329,22 @@ static void build_traversals(const Plan& p, Tree& t) {
       if (it != hnode.end()) h = it->second;
       lvl[i] = h;
       int& hp = hnode[t.pa[i]];
-      hp = std::max(hp, h + 1);
+      // a unary parent that has an edge above it sends in the same level, right after this message
+      const bool chained = unary(t.pa[i]) && parent_edge.count(t.pa[i]);
+      hp = std::max(hp, chained ? h : h + 1);
       nlev = std::max(nlev, h + 1);
     }
     // tasks: group by (level, target parent); entries in reference order (decreasing i)
     std::vector<std::vector<int>> bylevel(nlev);
-    for (int i = n - 1; i >= 0; --i) bylevel[lvl[i]].push_back(i);
+    for (int i = n - 1; i >= 0; --i) {
+      const bool chained = unary(t.pa[i]) && parent_edge.count(t.pa[i]);
+      if (!chained) bylevel[lvl[i]].push_back(i);  // chained edges ride in front of the edge above their receiver
+    }
     Traversal& tr = t.post;
     tr = Traversal{};
     tr.level_off.push_back(0);
     tr.task_off.push_back(0);
+    std::vector<int> chain;
     for (int L = 0; L < nlev; ++L) {
       std::unordered_map<int, int> task_of_target;
       std::vector<std::vector<int>> tasks;
@@ -330,24 +358,31 @@ static void build_traversals(const Plan& p, Tree& t) {
         }
       }
       for (auto& tk : tasks) {
-        for (int i : tk) {
-          Entry e{};
-          e.msg = msg_to(i, t.pa[i]);
-          e.edge = i;
-          e.reuse = 0;
-          e.seq = n - 1 - i;
-          tr.entries.push_back(e);
-          tr.max_mf = std::max(tr.max_mf, p.msgs[e.msg].mf);
+        for (int top : tk) {
+          // the chain below `top`: single child edges of unary clusters, deepest first
+          chain.assign(1, top);
+          while (unary(t.ch[chain.back()])) chain.push_back(only_child_edge[t.ch[chain.back()]]);
+          for (int q = (int)chain.size() - 1; q >= 0; --q) {
+            const int i = chain[q];
+            Entry e{};
+            e.msg = msg_to(i, t.pa[i]);
+            e.edge = i;
+            e.reuse = 0;
+            e.seq = n - 1 - i;
+            tr.entries.push_back(e);
+            tr.max_mf = std::max(tr.max_mf, p.msgs[e.msg].mf);
+          }
         }
         tr.task_off.push_back((int)tr.entries.size());
       }
-      tr.level_off.push_back((int)tr.task_off.size() - 1);
+      if (!tasks.empty() || !fuse) tr.level_off.push_back((int)tr.task_off.size() - 1);
     }
     finalize_traversal(p, tr, true);
   }
-  // ---- preorder: level = depth of the parent; tasks group by sender
+  // ---- preorder: level = depth of the parent (chains collapsed); tasks group by sender
   {
-    std::unordered_map<int, int> dnode;
+    std::unordered_map<int, int> dnode;   // cluster -> level at which it sends
+    std::unordered_map<int, int> head;    // cluster -> the cluster whose task carries its messages
     std::vector<int> lvl(n);
     int nlev = 0;
     for (int i = 0; i < n; ++i) {
@@ -355,7 +390,11 @@ static void build_traversals(const Plan& p, Tree& t) {
       auto it = dnode.find(t.pa[i]);
       if (it != dnode.end()) dpt = it->second;
       lvl[i] = dpt;
-      dnode[t.ch[i]] = dpt + 1;
+      const bool chained = unary(t.pa[i]);   // the child's task follows this message in the same wave
+      dnode[t.ch[i]] = chained ? dpt : dpt + 1;
+      auto ih = head.find(t.pa[i]);
+      const int hp = ih == head.end() ? t.pa[i] : ih->second;
+      head[t.ch[i]] = chained ? hp : t.ch[i];
       nlev = std::max(nlev, dpt + 1);
     }
     std::vector<std::vector<int>> bylevel(nlev);
@@ -367,10 +406,12 @@ static void build_traversals(const Plan& p, Tree& t) {
     for (int L = 0; L < nlev; ++L) {
       std::unordered_map<int, int> task_of_sender;
       std::vector<std::vector<int>> tasks;
-      for (int i : bylevel[L]) {
-        auto it = task_of_sender.find(t.pa[i]);
+      for (int i : bylevel[L]) {   // increasing i: a chained child's edges come after the edge into it
+        auto ih = head.find(t.pa[i]);
+        const int key = ih == head.end() ? t.pa[i] : ih->second;
+        auto it = task_of_sender.find(key);
         if (it == task_of_sender.end()) {
-          task_of_sender[t.pa[i]] = (int)tasks.size();
+          task_of_sender[key] = (int)tasks.size();
           tasks.push_back({i});
         } else {
           tasks[it->second].push_back(i);
@@ -402,6 +443,13 @@ static void build_traversals(const Plan& p, Tree& t) {
     }
     finalize_traversal(p, tr, false);
   }
+}
+
+static bool tree_all_fast(const Tree& t) {
+  for (const Traversal* tr : {&t.post, &t.pre})
+    for (size_t L = 0; L + 1 < tr->level_off.size(); ++L)
+      if (tr->level_nfast[L] != tr->level_off[L + 1] - tr->level_off[L]) return false;
+  return true;
 }
 
 int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
@@ -448,7 +496,15 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
       }
       T.sep[i] = it->second;
     }
-    build_traversals(p, T);
+    build_traversals(p, T, false);
+    // Chain fusion is OPT-IN (PGBP_CHAIN_FUSION=1): measured on the cfg5 network (Bethe graph, 20 000 tips) it trades
+    // 398 launches for 152 but a fused level lasts as long as its longest chain (about 5 us per message inside a wave
+    // against about 10 us per launch): 4.8 ms per iteration against 3.9 ms.  It pays on path-like
+    // schedule trees (nodesubtree_clusterlist schedules).  Schedules that the register-resident kernel runs whole and
+    // the thread-per-site kernel of univariate batches always keep the plain levels.
+    static const bool fuse_on = getenv("PGBP_CHAIN_FUSION") != nullptr;
+    const bool uni_batch = p.max_dim <= 2 && p.n_sites >= 8;
+    if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, true);
   }
   p.trees.swap(trees);
   p.all_fast = !p.trees.empty();

@@ -1079,3 +1079,17 @@ def test_calibration_level3_joingraph_loopy_run_on_device(P, caplog, variant):
     mu6 = pcgb.integratebelief_(g["cluster_index_1based"]["I1I2I3"] - 1)[0]
     want = [x for n in ("I1", "I2", "I3") for x in g["posterior_means_" + variant].get(n, [])]
     assert np.allclose(mu6[:len(want)], want, rtol=1.5e-8, atol=0)
+
+
+def test_chain_fusion_opt_in_differential_fuzz(P):
+    """PGBP_CHAIN_FUSION=1 (opt-in, read once per process -> child process): unary clusters of a schedule tree are
+    passed through inside one task of the generic kernel (pgbp_plan.cpp build_traversals).  The differential fuzz
+    against the plain-C sequential engine (beliefs 1e-8, flags, first failure) must hold unchanged."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PGBP_CHAIN_FUSION="1")
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "80", "77"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "80 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])

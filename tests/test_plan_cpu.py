@@ -416,3 +416,121 @@ def test_nodesubtree_clusterlist_equals_the_oracle():
         o = OCG.nodesubtree_clusterlist(cg, v)
         q = P.nodesubtree_clusterlist(cn, ed, sn, v)
         assert (o[2], o[3]) == (q[2], q[3])
+
+
+# ----------------------------------------------------------------------------- fused chains (generic-kernel schedules)
+
+def _check_traversal(lo, to, em, ee, pa, ch, sepcl, d):
+    """Invariants of one traversal (dir d) that make the level-synchronous, chain-fused execution equal to the
+    reference's sequential loop: every edge once; the messages of a task are executed in order by one wave, tasks of a
+    level run concurrently, levels in sequence.  (1) a message is sent only after every message into its sender (of this
+    traversal) has been delivered: in an earlier level or earlier in the same task; (2) two tasks of one level touch
+    disjoint beliefs, except that they may READ a common cluster nobody writes; (3) the messages a task delivers into one
+    receiver are applied in the reference's order (postorder: decreasing edge index; siblings of different heights
+    arrive in different levels, as without fusion: sums then differ from the sequential loop in the last bits only)."""
+    n = len(pa)
+    assert sorted(ee.tolist()) == list(range(n))
+    when = {}
+    for Lv in range(len(lo) - 1):
+        written_by, read_by = {}, {}
+        for t in range(lo[Lv], lo[Lv + 1]):
+            assert to[t + 1] > to[t]
+            for pos, e in enumerate(range(to[t], to[t + 1])):
+                i = int(ee[e])
+                snd, rcv = (int(ch[i]), int(pa[i])) if d == 0 else (int(pa[i]), int(ch[i]))
+                k = int(em[e]) // 2
+                assert {int(sepcl[k][0]), int(sepcl[k][1])} == {snd, rcv} and int(sepcl[k][em[e] % 2]) == rcv
+                when[i] = (Lv, t, pos)
+                written_by.setdefault(rcv, set()).add(t)
+                read_by.setdefault(snd, set()).add(t)
+        for c, ts in written_by.items():
+            assert len(ts) == 1, ("two tasks of a level write cluster", c)
+            assert read_by.get(c, ts) == ts, ("a task reads a cluster another task of the level writes", c)
+    into = {}
+    for i in range(n):
+        rcv = int(pa[i]) if d == 0 else int(ch[i])
+        into.setdefault(rcv, []).append(i)
+    for i in range(n):
+        snd = int(ch[i]) if d == 0 else int(pa[i])
+        for j in into.get(snd, []):
+            (Lj, tj, pj), (Li, ti, pi) = when[j], when[i]
+            assert Lj < Li or (Lj == Li and tj == ti and pj < pi), (d, j, i)
+    if d == 0:
+        for rcv, edges in into.items():
+            for Lv in {when[i][0] for i in edges}:
+                same = [i for i in edges if when[i][0] == Lv]
+                assert sorted(same, key=lambda i: when[i]) == sorted(same, reverse=True), rcv
+
+
+def test_fused_chain_schedule_invariants_subprocess():
+    """Chain fusion is opt-in through PGBP_CHAIN_FUSION, read once per process: the checks run in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PGBP_CHAIN_FUSION="1")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_plan_cpu as T\n"
+            "for g, s in [('bethe_tree', 1), ('bethe_net', 2), ('join_net', 3), ('bethe_net', 4), ('nodesubtrees', 5), ('path', 6)]:\n"
+            "    T._fused_chain_schedule_invariants(g, s, True)\n"
+            "print('fused ok')" % (ROOT, os.path.join(ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fused ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("graph,seed", [("bethe_tree", 1), ("bethe_net", 2), ("join_net", 3), ("nodesubtrees", 5), ("path", 6)])
+def test_generic_schedule_invariants(graph, seed):
+    """The same invariants on the default (unfused) level schedules of generic-kernel graphs."""
+    _fused_chain_schedule_invariants(graph, seed, False)
+
+
+def _fused_chain_schedule_invariants(graph, seed, fused):
+    """Chain fusion (pgbp_plan.cpp build_traversals): unary clusters of the schedule tree are passed through inside one
+    task; Bethe graphs lose about half of their levels."""
+    import pgbp_amd as P
+    rng = np.random.default_rng(seed)
+    if graph == "bethe_tree":
+        tr = S.random_tree(60, rng)
+        prob = S.bethe_of_tree(tr, 1)                    # univariate, one site: generic kernel
+        dims, sepcl, soff, sidx, sched = prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, prob.schedule
+    else:
+        net = P.random_level3_network(80, 6, rng)
+        if graph == "join_net":
+            cn, ed, sn = P.joingraph(net.node2family, 3)
+        else:
+            cn, ed, sn = P.bethe(net.node2family)
+        st = P.allocate_scopes(cn, ed, sn, net, 1)       # univariate, one site: every task on the generic kernel
+        dims, sepcl, soff, sidx = st.dims, st.sepset_clusters, st.scope_off, st.scope_idx
+        if graph == "nodesubtrees":
+            sched = [x for x in (P.nodesubtree_clusterlist(cn, ed, sn, v) for v in range(1, net.nnodes + 1)) if x[0]]
+        elif graph == "path":
+            full = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)[0]
+            # one root-to-leaf path of the spanning tree: every cluster unary -> one level per direction
+            pa_l, ch_l = list(full[2]), list(full[3])
+            node = ch_l[-1]
+            path = []
+            parent = dict(zip(ch_l, pa_l))
+            while node in parent:
+                path.append((parent[node], node))
+                node = parent[node]
+            path.reverse()
+            sched = [(None, None, [a for a, _ in path], [b for _, b in path])]
+        else:
+            sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+        sched = [(np.asarray(t[2], np.int32), np.asarray(t[3], np.int32)) for t in sched]
+    desc, keep = L.make_desc(dims, sepcl, soff, sidx)
+    lib = L.load()
+    pl = C.c_void_p()
+    assert lib.pgbp_plan_create(C.byref(desc), C.byref(pl)) == 0
+    assert _set_sched(lib, pl, sched) == 0, lib.pgbp_plan_last_error(pl)
+    sepcl = np.asarray(sepcl).reshape(-1, 2)
+    for t, (pa, ch) in enumerate(sched):
+        depth = {int(pa[0]): 0} if len(pa) else {}
+        for a, c in zip(pa, ch):
+            depth[int(c)] = depth[int(a)] + 1
+        for d in (0, 1):
+            lo, to, em, ee, er = _traversal(lib, pl, t, d)
+            _check_traversal(lo, to, em, ee, pa, ch, sepcl, d)
+            nlev = len(lo) - 1
+            if fused and graph in ("bethe_tree", "bethe_net") and len(pa) > 20:
+                assert nlev <= 0.65 * max(depth.values())
+            if graph == "path":
+                assert (nlev == 1 and to[1] - to[0] == len(pa)) if fused else nlev == len(pa)
+    lib.pgbp_plan_destroy(pl)
