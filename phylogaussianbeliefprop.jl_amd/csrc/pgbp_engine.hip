@@ -993,6 +993,10 @@ int pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double*
   // R^-1 is symmetric and the fill writes symmetric blocks: the layout the traversals want can be kept
   e->sym_known = true;
   e->sym_ok = true;
+  if (want_site_minor(e) && e->bm_p == 1 && !e->layout_sm) {  // univariate batch: fill straight in the site-minor layout
+    const int rc = ensure_layout(e, false, true);
+    if (rc) return rc;
+  }
   return bm_fill_async(e, true);
 }
 
@@ -1150,6 +1154,12 @@ int pgbp_lg_assignfactors(pgbp_engine* e, const pgbp_lg_params* m) {
   // the fill writes exactly symmetric blocks: the layout the traversals want can be kept
   e->sym_known = true;
   e->sym_ok = true;
+  // a univariate batch is filled straight in the site-minor layout its traversals use (the wavefront-per-cluster
+  // kernel would spend one workgroup per (cluster, site))
+  if (want_site_minor(e) && e->lg_uni_ok && !e->layout_sm) {
+    const int rc = ensure_layout(e, false, true);
+    if (rc) return rc;
+  }
   return lg_fill_async(e, true);
 }
 

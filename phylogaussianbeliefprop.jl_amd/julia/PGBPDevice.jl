@@ -32,6 +32,7 @@ mutable struct DeviceClusterGraphBelief
     packed::Vector{Float64}
     offsets::Vector{Int}
     schedule_set::Any
+    keep::Any                          # arrays the device factor fill's static table points into
 end
 
 check(h, rc) = rc == 0 || error(unsafe_string(@ccall LIB.pgbp_last_error(h::Ptr{Cvoid})::Cstring))
@@ -58,7 +59,7 @@ function DeviceClusterGraphBelief(cgb::PGBP.ClusterGraphBelief; device::Integer=
         rc == 0 || error(unsafe_string(@ccall LIB.pgbp_last_error(C_NULL::Ptr{Cvoid})::Cstring))
     end
     offsets = cumsum(vcat(0, [m*m + m + 1 for m in Int.(dims)]))
-    obj = DeviceClusterGraphBelief(cgb, h[], zeros(offsets[end]), offsets, nothing)
+    obj = DeviceClusterGraphBelief(cgb, h[], zeros(offsets[end]), offsets, nothing, nothing)
     push!(obj); finalizer(o -> @ccall(LIB.pgbp_destroy(o.handle::Ptr{Cvoid})::Cvoid), obj)
     return obj
 end
@@ -132,6 +133,78 @@ function PGBP.integratebelief!(o::DeviceClusterGraphBelief, j::Integer)
     info[] == 0 || throw(PGBP.LA.PosDefException(info[]))
     o.cgb.belief[j].μ[:] = mu[1:m]
     return (mu[1:m], norm[])
+end
+
+# ---- factor assignment on the device (include/pgbp.h: pgbp_lg_families / pgbp_lg_params) --------------------------
+struct LgFamilies      # pgbp_lg_families
+    p::Int32; n_families::Int32; max_parents::Int32; n_rates::Int32; n_rows::Int32
+    cluster::Ptr{Int32}; n_parents::Ptr{Int32}; child_pos::Ptr{Int32}; data_row::Ptr{Int32}
+    parent_pos::Ptr{Int32}; length::Ptr{Float64}; gamma::Ptr{Float64}; color::Ptr{Int32}; data::Ptr{Float64}
+end
+struct LgParams        # pgbp_lg_params
+    model::Int32; per_site::Int32; R::Ptr{Float64}; alpha::Ptr{Float64}; theta::Ptr{Float64}; mu::Ptr{Float64}
+end
+
+"""
+    lg_setup!(o, prenodes, tbl, taxa, colorof = e -> 0; nrates = 1)
+
+Static part of `assignfactors!` (src/beliefs.jl:786-861) for complete tip data: one entry per node family in the order
+of its loop over `node2cluster`; `colorof(edge)` is the 0-based index of the parent edge's variance rate
+(`HeterogeneousBrownianMotion`: its colour; homogeneous models: 0).  Call once per cluster graph.
+"""
+function lg_setup!(o::DeviceClusterGraphBelief, prenodes, tbl, taxa, colorof = e -> 0; nrates::Integer = 1)
+    cgb = o.cgb; b = cgb.belief; p = length(tbl)
+    n2c, n2fam, n2fix = cgb.node2cluster, cgb.node2family, cgb.node2fixed
+    K = max(1, maximum(length(nf) - 1 for nf in n2fam))
+    cl = Int32[]; np = Int32[]; cpos = Int32[]; drow = Int32[]
+    ppos = Int32[]; len = Float64[]; gam = Float64[]; col = Int32[]
+    blockstart(be, lab) = (ind = PGBP.scopeindex([lab], be); isempty(ind) ? Int32(-1) : Int32(ind[1] - 1))
+    for (ni, ci) in enumerate(n2c)
+        nf = n2fam[ni]; length(nf) == 1 && continue      # root prior: append the family with its own colour if proper
+        be = b[ci]; ch = prenodes[ni]
+        push!(cl, ci - 1); push!(np, length(nf) - 1)
+        push!(cpos, n2fix[ni] ? Int32(-1) : blockstart(be, nf[1]))
+        push!(drow, n2fix[ni] ? Int32(findfirst(isequal(ch.name), taxa) - 1) : Int32(-1))
+        for k in 1:K
+            if k < length(nf)
+                pa = prenodes[nf[k+1]]
+                e = first(e for e in pa.edge if PGBP.getchild(e) === ch)            # src/beliefs.jl:813-820
+                push!(ppos, n2fix[nf[k+1]] ? Int32(-1) : blockstart(be, nf[k+1]))
+                push!(len, e.length); push!(gam, length(nf) > 2 ? e.gamma : 1.0); push!(col, colorof(e))
+            else
+                push!(ppos, -1); push!(len, 1.0); push!(gam, 1.0); push!(col, 0)
+            end
+        end
+    end
+    data = Float64[tbl[v][r] for v in 1:p, r in 1:length(taxa)]                   # [row][trait], row-major for C
+    o.keep = (cl, np, cpos, drow, ppos, len, gam, col, data)                       # keep alive
+    f = LgFamilies(p, length(cl), K, nrates, length(taxa), pointer(cl), pointer(np), pointer(cpos), pointer(drow),
+                   pointer(ppos), pointer(len), pointer(gam), pointer(col), pointer(data))
+    GC.@preserve cl np cpos drow ppos len gam col data check(o.handle,
+        @ccall LIB.pgbp_lg_setup(o.handle::Ptr{Cvoid}, Ref(f)::Ref{LgFamilies})::Cint)
+end
+
+"""
+    loglik!(o, rates, mu; alpha = nothing, theta = nothing)
+
+The body of `score(θ)` (src/calibration.jl:195-221) on the device: factors from the model parameters, postorder of
+schedule tree 1, `integratebelief!` at its root cluster.  `rates`: vector of p×p variance matrices
+(OU: the stationary variance).  Only the parameters and the result cross the bus.
+"""
+function loglik!(o::DeviceClusterGraphBelief, rates::Vector{<:AbstractMatrix}, mu::AbstractVector;
+                 alpha = nothing, theta = nothing)
+    R = Float64.(reduce(vcat, vec.(rates))); m = Float64.(mu)
+    ou = alpha !== nothing
+    a = ou ? Float64[alpha] : Float64[0]; th = ou ? Float64.(theta) : zeros(length(m))
+    prm = LgParams(ou ? 1 : 0, 0, pointer(R), ou ? pointer(a) : C_NULL, ou ? pointer(th) : C_NULL, pointer(m))
+    norm = Ref(0.0); info = Ref(Int32(0))
+    GC.@preserve R m a th begin
+        check(o.handle, @ccall LIB.pgbp_lg_assignfactors(o.handle::Ptr{Cvoid}, Ref(prm)::Ref{LgParams})::Cint)
+        check(o.handle, @ccall LIB.pgbp_enqueue_loglik_lg(o.handle::Ptr{Cvoid}, 1::Int32, Ref(Opts(0, 1, 0, 0, 1e-5))::Ref{Opts})::Cint)
+        check(o.handle, @ccall LIB.pgbp_fetch_loglik(o.handle::Ptr{Cvoid}, norm::Ref{Float64}, info::Ref{Int32})::Cint)
+    end
+    info[] == 0 || throw(PGBP.LA.PosDefException(info[]))
+    return norm[]
 end
 
 end # module
