@@ -1093,3 +1093,30 @@ def test_chain_fusion_opt_in_differential_fuzz(P):
     out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "80", "77"], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "80 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+@pytest.mark.parametrize("argv", [
+    ["--ntips", "400", "--traits", "16", "--steps", "2", "--warmup", "1", "--cpu-budget", "0.5"],
+    ["--ntips", "300", "--traits", "8", "--graph", "bethe", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    ["--workload", "sites", "--sites", "40", "--site-traits", "2", "--ntips", "150", "--steps", "2", "--warmup", "1"],
+    ["--workload", "sites", "--site-model", "bm", "--sites", "70", "--site-traits", "1", "--ntips", "120", "--steps", "2", "--warmup", "1"],
+    ["--workload", "network", "--ntips", "240", "--steps", "2", "--warmup", "1"],
+    ["--workload", "network", "--graph", "joingraph", "--ntips", "240", "--steps", "2", "--warmup", "1"],
+], ids=["tree", "tree_bethe", "sites_ou", "sites_bm", "network_bethe", "network_joingraph"])
+def test_bench_workloads_at_test_size(P, argv):
+    """bench.py end to end at test size for every workload: its parity gates (log-likelihood against the independent
+    pruning value; network: beliefs and convergence against the C engine) pass and one JSON line with the contract's
+    keys comes out."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["value"] > 0 and line["dtype"] == "f64" and "workload" in line["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
