@@ -534,3 +534,26 @@ def _fused_chain_schedule_invariants(graph, seed, fused):
             if graph == "path":
                 assert (nlev == 1 and to[1] - to[0] == len(pa)) if fused else nlev == len(pa)
     lib.pgbp_plan_destroy(pl)
+
+
+def test_planner_under_address_and_undefined_sanitizers(tmp_path):
+    """csrc/pgbp_plan.cpp (layout, message table, level schedules, chain fusion: host-only code) built with
+    -fsanitize=address,undefined and driven through the pgbp_plan_* API over trees, Bethe and join graphs of networks,
+    node-subtree schedules and malformed inputs, once with and once without chain fusion.  GPU sanitizers are not
+    available on the pool; this is the host half."""
+    import subprocess
+    import sys
+    so = str(tmp_path / "libpgbp_plan_asan.so")
+    src = os.path.join(ROOT, "phylogaussianbeliefprop.jl_amd", "csrc", "pgbp_plan.cpp")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address,undefined",
+                           "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-shared", "-o", so, src])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    for fuse in (False, True):
+        env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+                   UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+        env.pop("PGBP_CHAIN_FUSION", None)
+        if fuse:
+            env["PGBP_CHAIN_FUSION"] = "1"
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize_plan.py"), so], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "sanitized planner ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
