@@ -211,8 +211,8 @@ int  pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double
                                 int32_t per_site);
 
 /* ---- factor assignment on the device for every linear-Gaussian model of the reference, trees and networks ---- */
-/* assignfactors! (src/beliefs.jl:786-861) with complete tip data (no trait missing at any tip), all parent edges of
- * positive length (no degenerate family): homogeneous / heterogeneous Brownian motion
+/* assignfactors! (src/beliefs.jl:786-861), all parent edges of positive length (no degenerate family); missing tip
+ * values through the optional scope masks below (one missingness pattern for all sites of the engine): homogeneous / heterogeneous Brownian motion
  * (src/evomodels/homogeneousbrownianmotion.jl:222-351, heterogeneousmodels.jl:110-150), Ornstein-Uhlenbeck
  * (homogeneousornsteinuhlenbeck.jl:51-66), tree edges (factor_treeedge), hybrid nodes (factor_hybridnode,
  * evomodels.jl:314-330), root prior (factor_root, evomodels.jl:377-396), leaf data and fixed-root mean absorbed
@@ -238,7 +238,17 @@ typedef struct pgbp_lg_families {
   const int32_t* color;      /* [n_families * K] index into R of the parent edge's variance rate (heterogeneous models:
                                 the edge's colour; homogeneous: 0).  Root prior family: entry [f*K] = index of the
                                 prior variance among R */
-  const double* data;        /* [n_sites][n_rows][p] tip data, host pointer */
+  const double* data;        /* [n_sites][n_rows][p] tip data, host pointer; entries of traits outside a tip's child_mask
+                                are ignored (may be NaN) */
+  /* Missing data (both NULL: complete data, every in-scope node has all p traits).  Bit t of a mask = trait t.
+   * child_mask[f]: an internal child's traits in scope (inscope column of the cluster belief: src/beliefs.jl:551-559) /
+   * a tip's observed traits.  The factor keeps exactly these components of the residual: absorbleaf! marginalises
+   * a tip's missing traits (src/beliefupdates.jl:266-274), assignfactors! an internal node's out-of-scope traits
+   * (src/beliefs.jl:829-857; valid for the reference's models, whose q is a multiple of the identity).
+   * parent_mask[f*K+k]: traits of parent k in scope (its block in the cluster holds popcount of them, in trait order);
+   * must contain child_mask[f].  p <= 64. */
+  const uint64_t* child_mask;  /* [n_families] or NULL */
+  const uint64_t* parent_mask; /* [n_families * K] or NULL */
 } pgbp_lg_families;
 int  pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f);
 

@@ -39,7 +39,8 @@ class LgFamilies(C.Structure):
                 ("n_rows", C.c_int32), ("cluster", C.POINTER(C.c_int32)), ("n_parents", C.POINTER(C.c_int32)),
                 ("child_pos", C.POINTER(C.c_int32)), ("data_row", C.POINTER(C.c_int32)),
                 ("parent_pos", C.POINTER(C.c_int32)), ("length", C.POINTER(C.c_double)),
-                ("gamma", C.POINTER(C.c_double)), ("color", C.POINTER(C.c_int32)), ("data", C.POINTER(C.c_double))]
+                ("gamma", C.POINTER(C.c_double)), ("color", C.POINTER(C.c_int32)), ("data", C.POINTER(C.c_double)),
+                ("child_mask", C.POINTER(C.c_uint64)), ("parent_mask", C.POINTER(C.c_uint64))]
 
 
 class LgParams(C.Structure):

@@ -379,10 +379,14 @@ class ClusterGraphBelief:
         if data.ndim == 2:
             data = data[None]
         assert data.shape[0] == self.n_sites and data.shape[2] == fam["p"]
+        if fam.get("child_mask") is not None:
+            assert fam["parent_mask"].size == len(fam["cluster"]) * max(1, int(fam["max_parents"]))
         k = {n: np.ascontiguousarray(fam[n], np.int32) for n in ("cluster", "n_parents", "child_pos", "data_row",
                                                                  "parent_pos", "color")}
         k.update({n: np.ascontiguousarray(fam[n], np.float64) for n in ("length", "gamma")})
         k["data"] = data
+        for n in ("child_mask", "parent_mask"):
+            k[n] = np.ascontiguousarray(fam[n], np.uint64) if fam.get(n) is not None else None
         self._lg = k  # keep alive
         nf = len(k["cluster"])
         K = max(1, int(fam["max_parents"]))
@@ -390,7 +394,9 @@ class ClusterGraphBelief:
             assert k[n].size == nf * K, n
         t = L.LgFamilies(int(fam["p"]), nf, K, int(fam["n_rates"]), int(data.shape[1]), L.i32p(k["cluster"]),
                          L.i32p(k["n_parents"]), L.i32p(k["child_pos"]), L.i32p(k["data_row"]), L.i32p(k["parent_pos"]),
-                         L.f64p(k["length"]), L.f64p(k["gamma"]), L.i32p(k["color"]), L.f64p(data))
+                         L.f64p(k["length"]), L.f64p(k["gamma"]), L.i32p(k["color"]), L.f64p(data),
+                         k["child_mask"].ctypes.data_as(C.POINTER(C.c_uint64)) if k["child_mask"] is not None else None,
+                         k["parent_mask"].ctypes.data_as(C.POINTER(C.c_uint64)) if k["parent_mask"] is not None else None)
         _check(self._lib.pgbp_lg_setup(self._eng, C.byref(t)), self._eng)
         self._lg_p, self._lg_nrates = int(fam["p"]), int(fam["n_rates"])
 

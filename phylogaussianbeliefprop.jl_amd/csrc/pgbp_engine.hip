@@ -1033,25 +1033,36 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
   if (f->n_rows > 0 && !f->data) return e->fail(PGBP_ERR_INVALID, "pgbp_lg_setup: data missing");
   const Plan& p = e->plan;
   const int nc = p.n_clusters, K = f->max_parents, pp = f->p;
-  for (size_t i = 0, n = (size_t)p.n_sites * f->n_rows * pp; i < n; ++i)
-    if (!std::isfinite(f->data[i]))
-      return e->fail(PGBP_ERR_INVALID, "pgbp_lg_setup: a tip value is missing or not finite (missing data: the caller's own assignfactors! + pgbp_set_beliefs)");
+  if ((f->child_mask || f->parent_mask) && pp > 64) return e->fail(PGBP_ERR_INVALID, "pgbp_lg_setup: scope masks need p <= 64");
+  const unsigned long long full = pp >= 64 ? ~0ull : ((1ull << pp) - 1ull);
+  auto cmask = [&](int i) { return f->child_mask ? (unsigned long long)f->child_mask[i] & full : full; };
+  auto pmask = [&](int i, int k) { return f->parent_mask ? (unsigned long long)f->parent_mask[(size_t)i * f->max_parents + k] & full : full; };
   // every family fits its cluster; the blocks of one family do not overlap
   std::vector<int32_t> count(nc + 1, 0);
   bool uni_ok = p.max_dim <= 2 && pp == 1;
+  if (f->n_rows > 0 && !f->child_mask)
+    for (size_t i = 0, n = (size_t)p.n_sites * f->n_rows * pp; i < n; ++i)
+      if (!std::isfinite(f->data[i]))
+        return e->fail(PGBP_ERR_INVALID, "pgbp_lg_setup: a tip value is missing or not finite (missing values need child_mask / parent_mask)");
   for (int i = 0; i < f->n_families; ++i) {
     const std::string where = "pgbp_lg_setup: family " + std::to_string(i) + ": ";
     const int c = f->cluster[i], np = f->n_parents[i];
     if (c < 0 || c >= nc) return e->fail(PGBP_ERR_INVALID, where + "cluster out of range");
     if (np < 0 || np > K) return e->fail(PGBP_ERR_INVALID, where + "number of parents out of range");
     const int m = p.dims[c];
-    std::vector<int> pos;
+    std::vector<std::pair<int, int>> pos;  // (first variable, number of variables) of every in-scope block
     const int cp = f->child_pos[i];
+    const unsigned long long O = cmask(i);
     if (cp < 0) {
       if (np == 0) return e->fail(PGBP_ERR_INVALID, where + "a root prior needs the root in scope");
       if (f->data_row[i] < 0 || f->data_row[i] >= f->n_rows) return e->fail(PGBP_ERR_INVALID, where + "data row out of range");
+      for (int s2 = 0; s2 < p.n_sites; ++s2)
+        for (int t = 0; t < pp; ++t)
+          if (((O >> t) & 1ull) && !std::isfinite(f->data[((size_t)s2 * f->n_rows + f->data_row[i]) * pp + t]))
+            return e->fail(PGBP_ERR_INVALID, where + "a tip value is missing or not finite where child_mask says observed "
+                                                     "(missing values: clear the trait's bit in child_mask; one pattern for all sites)");
     } else {
-      pos.push_back(cp);
+      pos.push_back({cp, __builtin_popcountll(O)});
     }
     if (np == 0 && (f->color[(size_t)i * K] < 0 || f->color[(size_t)i * K] >= f->n_rates))
       return e->fail(PGBP_ERR_INVALID, where + "rate index out of range");
@@ -1061,11 +1072,15 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
         return e->fail(PGBP_ERR_INVALID, where + "parent edge length must be positive (degenerate families are out of scope)");
       if (!std::isfinite(f->gamma[o])) return e->fail(PGBP_ERR_INVALID, where + "inheritance not finite");
       if (f->color[o] < 0 || f->color[o] >= f->n_rates) return e->fail(PGBP_ERR_INVALID, where + "rate index out of range");
-      if (f->parent_pos[o] >= 0) pos.push_back(f->parent_pos[o]);
+      if (f->parent_pos[o] >= 0) {
+        if ((O & ~pmask(i, k)) != 0)
+          return e->fail(PGBP_ERR_INVALID, where + "a trait kept by the child is out of the parent's scope");
+        pos.push_back({f->parent_pos[o], __builtin_popcountll(pmask(i, k))});
+      }
     }
     std::sort(pos.begin(), pos.end());
     for (size_t a = 0; a < pos.size(); ++a)
-      if (pos[a] + pp > m || (a > 0 && pos[a] < pos[a - 1] + pp))
+      if (pos[a].first + pos[a].second > m || (a > 0 && pos[a].first < pos[a - 1].first + pos[a - 1].second))
         return e->fail(PGBP_ERR_INVALID, where + "variable blocks overlap or leave the cluster (dimension " + std::to_string(m) + ")");
     ++count[c + 1];
   }
@@ -1100,12 +1115,29 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
   const size_t nd = (size_t)p.n_sites * f->n_rows * pp;
   if ((rc = dev_alloc(e, &d_data, nd))) return rc; keep(d_data);
   if (nd) HIPCHK(e, hipMemcpy(d_data, f->data, nd * sizeof(double), hipMemcpyHostToDevice));
+  unsigned long long *d_cm = nullptr, *d_pm = nullptr;
+  if (f->child_mask) {
+    std::vector<unsigned long long> v(nf);
+    for (size_t i = 0; i < nf; ++i) v[i] = cmask((int)i);
+    if ((rc = upload(e, &d_cm, v))) return rc; keep(d_cm);
+  }
+  if (f->parent_mask) {
+    std::vector<unsigned long long> v(nfk);
+    for (size_t i = 0; i < nf; ++i)
+      for (int k = 0; k < K; ++k) v[i * K + k] = pmask((int)i, k);
+    if ((rc = upload(e, &d_pm, v))) return rc; keep(d_pm);
+  }
+  if (d_data && nd) {  // masked-out entries may be NaN on the host: never let them reach arithmetic
+    std::vector<double> clean(f->data, f->data + nd);
+    for (double& x : clean) if (!std::isfinite(x)) x = 0.0;
+    HIPCHK(e, hipMemcpy(d_data, clean.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+  }
   const size_t ns = (size_t)p.n_sites;
   if ((rc = dev_alloc(e, &e->d_lg_R, ns * f->n_rates * pp * pp))) return rc;
   if ((rc = dev_alloc(e, &e->d_lg_alpha, ns))) return rc;
   if ((rc = dev_alloc(e, &e->d_lg_theta, ns * pp))) return rc;
   if ((rc = dev_alloc(e, &e->d_lg_mu, ns * pp))) return rc;
-  e->lg = LgStatic{pp, K, f->n_rates, f->n_rows, d_off, d_fam, d_np, d_cp, d_row, d_pp, d_len, d_gam, d_col, d_data};
+  e->lg = LgStatic{pp, K, f->n_rates, f->n_rows, d_off, d_fam, d_np, d_cp, d_row, d_pp, d_len, d_gam, d_col, d_data, d_cm, d_pm};
   e->lg_ready = true;
   e->lg_uni_ok = uni_ok;
   return PGBP_OK;

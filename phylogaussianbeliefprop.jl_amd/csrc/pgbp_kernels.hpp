@@ -104,6 +104,7 @@ struct LgStatic {
   const double *length, *gamma;
   const int32_t* color;
   const double* data;
+  const unsigned long long *child_mask, *parent_mask;  // null: complete data
 };
 struct LgParams {
   int32_t model, per_site;

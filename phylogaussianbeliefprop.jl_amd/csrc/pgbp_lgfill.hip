@@ -1,5 +1,5 @@
 // assignfactors! (src/beliefs.jl:786-861) on the device for every linear-Gaussian model of the reference, on trees
-// and networks, with complete tip data (include/pgbp.h: pgbp_lg_families / pgbp_lg_params).
+// and networks; missing tip values through scope masks (include/pgbp.h: pgbp_lg_families / pgbp_lg_params).
 //
 // One factor per node family [child, parent_1 .. parent_K]:
 //   X_child | parents ~ N( sum_k q_k X_k + w , V ),   q_k = qc_k * I,  V = sum_k vc_k R[color_k],  w = sum_k wc_k theta
@@ -15,6 +15,8 @@
 // in-scope nodes  J_ab = c_a c_b j,  h_a = c_a j z,  g = -(p log 2pi + log det V + z'jz) / 2.
 // mult!(be, factorind, ...) (src/beliefs.jl:859) adds this at the positions of the family's in-scope nodes in its
 // cluster; families of one cluster are added in the reference's loop order (one workgroup per cluster: no atomics).
+// Missing data: the factor keeps the components O (child_mask) of its residual -- V_OO is inverted instead of V --,
+// what absorbleaf! and the partial-scope marginalisation of assignfactors! (src/beliefs.jl:829-857) leave.
 #include <hip/hip_runtime.h>
 
 #include "pgbp_bs16.hpp"
@@ -68,6 +70,11 @@ __device__ __forceinline__ bool lg_gauss_jordan(double* W, int p, int nc, int ld
   return true;
 }
 
+// rank of trait t inside a node's block = number of in-scope traits before it
+__device__ __forceinline__ int lg_rank(unsigned long long mask, int t) {
+  return __popcll(mask & ((1ull << t) - 1ull));
+}
+
 __global__ __launch_bounds__(64) void lg_fill_kernel(LgStatic F, LgParams M, double* __restrict__ pool, int64_t pool_stride,
                                                      double* __restrict__ fpool, int64_t fpool_stride,
                                                      const int64_t* __restrict__ boff, const int32_t* __restrict__ dim,
@@ -78,22 +85,29 @@ __global__ __launch_bounds__(64) void lg_fill_kernel(LgStatic F, LgParams M, dou
   const int nrec = m * m + m + 1;
   double* rec = lg_lds;               // [m*m | m | 1] plain column-major accumulator of the cluster
   double* W = lg_lds + rec_cap;       // p x ld
-  const int nc = 2 * p + 1, ld = nc | 1;
-  double* cz = W + p * ld;            // c_a (K+1), then pos as doubles is avoided: ints below
-  int* ipos = reinterpret_cast<int*>(cz + (K + 1));
+  const int ldmax = (2 * p + 1) | 1;
+  double* cz = W + p * ldmax;         // c_a (K+1)
+  int* ipos = reinterpret_cast<int*>(cz + (K + 1));   // positions (K+1), then the kept traits o_idx (p)
+  int* oidx = ipos + (K + 1);
   for (int t = lane; t < nrec; t += kWave) rec[t] = 0.0;
   const int64_t ps = M.per_site ? site : 0;
   const double* __restrict__ R = M.R + ps * F.n_rates * p * p;
   const double* __restrict__ mu = M.mu + ps * p;
   const double* __restrict__ theta = M.theta ? M.theta + ps * p : nullptr;
   const double alpha = (M.model == PGBP_LG_OU) ? M.alpha[ps] : 0.0;
+  const unsigned long long full = p >= 64 ? ~0ull : ((1ull << p) - 1ull);
   bool bad = false;
   for (int fi = F.cl_off[c]; fi < F.cl_off[c + 1]; ++fi) {
     const int f = F.cl_fam[fi];
     const int np = F.n_parents[f];
     const int cpos = F.child_pos[f];
+    // O: the components of the residual that the factor keeps (all p without missing data)
+    const unsigned long long O = F.child_mask ? (F.child_mask[f] & full) : full;
+    const int mo = __popcll(O);
+    if (mo == 0) continue;            // nothing observed / in scope below this node: the factor integrates to 1
+    const int nc = 2 * mo + 1, ld = nc | 1;
     __syncthreads();
-    // coefficients c_a and positions (every lane the same values; lane 0 publishes them)
+    // coefficients c_a, positions, kept traits (lane 0 .. publish)
     if (lane <= np) {
       if (lane == 0) {
         cz[0] = 1.0;
@@ -105,63 +119,73 @@ __global__ __launch_bounds__(64) void lg_fill_kernel(LgStatic F, LgParams M, dou
         ipos[lane] = F.parent_pos[(int64_t)f * K + lane - 1];
       }
     }
-    // V, identity, z
-    for (int idx = lane; idx < p * p; idx += kWave) {
-      const int j = idx / p, i = idx - j * p;
+    for (int t = lane; t < p; t += kWave)
+      if ((O >> t) & 1ull) oidx[lg_rank(O, t)] = t;
+    __syncthreads();
+    // V_OO, identity, z_O
+    for (int idx = lane; idx < mo * mo; idx += kWave) {
+      const int j = idx / mo, i = idx - j * mo;
+      const int e = oidx[i] + oidx[j] * p;
       double v = 0.0;
       if (np == 0) {
-        v = R[(int64_t)F.color[(int64_t)f * K] * p * p + idx];
+        v = R[(int64_t)F.color[(int64_t)f * K] * p * p + e];
       } else {
         for (int k = 0; k < np; ++k) {
           double qc, vc, wc;
           lg_coefs(M.model, alpha, F.length[(int64_t)f * K + k], F.gamma[(int64_t)f * K + k], qc, vc, wc);
-          v += vc * R[(int64_t)F.color[(int64_t)f * K + k] * p * p + idx];
+          v += vc * R[(int64_t)F.color[(int64_t)f * K + k] * p * p + e];
         }
       }
       W[i * ld + j] = v;
-      W[i * ld + p + j] = (i == j) ? 1.0 : 0.0;
+      W[i * ld + mo + j] = (i == j) ? 1.0 : 0.0;
     }
-    for (int i = lane; i < p; i += kWave) {
+    for (int i = lane; i < mo; i += kWave) {
+      const int t = oidx[i];
       double z;
       if (np == 0) {
-        z = mu[i];
+        z = mu[t];
       } else {
         z = 0.0;
         for (int k = 0; k < np; ++k) {
           double qc, vc, wc;
           lg_coefs(M.model, alpha, F.length[(int64_t)f * K + k], F.gamma[(int64_t)f * K + k], qc, vc, wc);
-          if (theta) z += wc * theta[i];
-          if (F.parent_pos[(int64_t)f * K + k] < 0) z += qc * mu[i];   // - c_k mu, c_k = -q_k: fixed root
+          if (theta) z += wc * theta[t];
+          if (F.parent_pos[(int64_t)f * K + k] < 0) z += qc * mu[t];   // - c_k mu, c_k = -q_k: fixed root
         }
-        if (cpos < 0) z -= F.data[((int64_t)site * F.n_rows + F.data_row[f]) * p + i];  // - c_0 y: tip
+        if (cpos < 0) z -= F.data[((int64_t)site * F.n_rows + F.data_row[f]) * p + t];  // - c_0 y: tip
       }
-      W[i * ld + 2 * p] = z;
+      W[i * ld + 2 * mo] = z;
     }
     __syncthreads();
     // keep z: the elimination overwrites the last column with j z
-    double zi = (lane < p) ? W[lane * ld + 2 * p] : 0.0;
+    double zi = (lane < mo) ? W[lane * ld + 2 * mo] : 0.0;
     double logdet;
-    if (!lg_gauss_jordan(W, p, nc, ld, lane, logdet)) { bad = true; break; }
+    if (!lg_gauss_jordan(W, mo, nc, ld, lane, logdet)) { bad = true; break; }
     // quadratic term z' j z
-    double q = (lane < p) ? zi * W[lane * ld + 2 * p] : 0.0;
+    double q = (lane < mo) ? zi * W[lane * ld + 2 * mo] : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    // J_ab += c_a c_b j (upper triangle of j mirrored: exactly symmetric), h_a += c_a j z
+    // J_ab += c_a c_b j (upper triangle of j mirrored: exactly symmetric), h_a += c_a j z, at the positions of the kept
+    // traits inside each in-scope node's block
     const int nn = np + 1;
-    for (int idx = lane; idx < nn * nn * p * p; idx += kWave) {
-      const int ab = idx / (p * p), ik = idx - ab * p * p;
+    for (int idx = lane; idx < nn * nn * mo * mo; idx += kWave) {
+      const int ab = idx / (mo * mo), ik = idx - ab * mo * mo;
       const int a = ab / nn, b = ab - a * nn;
-      const int k = ik / p, i = ik - k * p;
+      const int k = ik / mo, i = ik - k * mo;
       const int pa = ipos[a], pb = ipos[b];
       if (pa < 0 || pb < 0) continue;
-      const double jv = (i <= k) ? W[i * ld + p + k] : W[k * ld + p + i];
-      rec[(pa + i) + (int64_t)(pb + k) * m] += cz[a] * cz[b] * jv;
+      const unsigned long long ma = (a == 0 || !F.parent_mask) ? (a == 0 ? O : full) : F.parent_mask[(int64_t)f * K + a - 1];
+      const unsigned long long mb = (b == 0 || !F.parent_mask) ? (b == 0 ? O : full) : F.parent_mask[(int64_t)f * K + b - 1];
+      const double jv = (i <= k) ? W[i * ld + mo + k] : W[k * ld + mo + i];
+      rec[(pa + lg_rank(ma, oidx[i])) + (int64_t)(pb + lg_rank(mb, oidx[k])) * m] += cz[a] * cz[b] * jv;
     }
-    for (int idx = lane; idx < nn * p; idx += kWave) {
-      const int a = idx / p, i = idx - a * p;
-      if (ipos[a] >= 0) rec[m * m + ipos[a] + i] += cz[a] * W[i * ld + 2 * p];
+    for (int idx = lane; idx < nn * mo; idx += kWave) {
+      const int a = idx / mo, i = idx - a * mo;
+      if (ipos[a] < 0) continue;
+      const unsigned long long ma = (a == 0 || !F.parent_mask) ? (a == 0 ? O : full) : F.parent_mask[(int64_t)f * K + a - 1];
+      rec[m * m + ipos[a] + lg_rank(ma, oidx[i])] += cz[a] * W[i * ld + 2 * mo];
     }
-    if (lane == 0) rec[m * m + m] += -0.5 * ((double)p * PGBP_LOG2PI + logdet + q);
+    if (lane == 0) rec[m * m + m] += -0.5 * ((double)mo * PGBP_LOG2PI + logdet + q);
   }
   __syncthreads();
   if (bad && lane == 0) rec[m * m + m] = NAN;  // a variance that is not positive definite: the reference throws here
@@ -214,6 +238,7 @@ __global__ __launch_bounds__(256) void lg_fill_uni_sm_kernel(LgStatic F, LgParam
     for (int fi = F.cl_off[c]; fi < F.cl_off[c + 1]; ++fi) {
       const int f = F.cl_fam[fi];
       const int np = F.n_parents[f], cpos = F.child_pos[f];
+      if (F.child_mask && !(F.child_mask[f] & 1ull)) continue;   // the trait is missing / out of scope below: factor = 1
       double V = 0.0, z = 0.0;
       if (np == 0) {
         V = R[F.color[(int64_t)f * K]];
@@ -279,7 +304,7 @@ void launch_lg_fill(const LgStatic& F, const LgParams& M, double* pool, int64_t 
   const int mm = max_dim < 1 ? 1 : max_dim;
   const int rec_cap = (mm * mm + mm + 1 + 1) & ~1;
   const int ld = (2 * F.p + 1) | 1;
-  const size_t doubles = (size_t)rec_cap + (size_t)F.p * ld + (size_t)(F.K + 1) + (size_t)(F.K + 2) / 2 + 2;
+  const size_t doubles = (size_t)rec_cap + (size_t)F.p * ld + (size_t)(F.K + 1) + (size_t)(F.K + 2 + F.p) / 2 + 2;
   hipLaunchKernelGGL(lg_fill_kernel, dim3(n_clusters, n_sites), dim3(kWave), doubles * sizeof(double), st, F, M, pool,
                      pool_stride, fpool, fpool_stride, d_boff, d_dim, bs16, fast_p, rec_cap);
 }

@@ -137,9 +137,9 @@ def lg_inputs_from_oracle(P, net, ocgb, model, tbl, taxa):
     if not model.isrootfixed() and not np.any(np.isinf(np.diag(v))):
         root_color = len(rates)
         rates = rates + [v]
+    data = np.array([[np.nan if tbl[v][r] is None else float(tbl[v][r]) for v in range(p)] for r in range(len(taxa))])
     fam = P.lg_families(ocgb.belief[:ocgb.nclusters], ocgb.node2cluster, ocgb.node2family, ocgb.node2fixed,
-                        parent_edges, data_row, p, n_rates=len(rates), root_prior_color=root_color)
-    data = np.array([[float(tbl[v][r]) for v in range(p)] for r in range(len(taxa))])
+                        parent_edges, data_row, p, n_rates=len(rates), root_prior_color=root_color, data=data)
     kw = dict(R=np.stack(rates), mu=model.rootpriormeanvector())
     if isinstance(model, OM.UnivariateOrnsteinUhlenbeck):
         kw.update(model="ou", alpha=model.alpha, theta=[model.theta])

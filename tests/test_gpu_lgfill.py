@@ -58,14 +58,10 @@ def _device_fill(P, net, cg, model, tbl, taxa):
     return ocgb, pcgb
 
 
-COMPLETE = [c for c in G["evomodels_postorder"]["cases"]
-            if all(v is not None for t in c["traits"] for v in G["evomodels_postorder"][t])]
-
-
-@pytest.mark.parametrize("case", COMPLETE, ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", G["evomodels_postorder"]["cases"], ids=lambda c: c["name"])
 def test_lgfill_evomodels_goldens(P, case):
-    """test/test_evomodels.jl:74-264 (the cases without missing data): factors filled on the device, postorder,
-    integratebelief! at the root cluster = the golden log-likelihood."""
+    """test/test_evomodels.jl:74-264 (every case, the ones with missing tip values included): factors filled on the
+    device, postorder, integratebelief! at the root cluster = the golden log-likelihood."""
     g = G["evomodels_postorder"]
     net = ON.read_newick(g["net"])
     tbl = [g[t] for t in case["traits"]]
@@ -263,7 +259,14 @@ def test_lgfill_refusals(P):
     Xnan = X.copy()
     Xnan[int(np.nonzero(tr.is_leaf)[0][0]), 1] = np.nan
     with pytest.raises(P.PgbpError, match="missing"):
-        eng.lg_setup(good, Xnan)
+        eng.lg_setup(good, Xnan)                                      # NaN without scope masks
+    masked = dict(good, child_mask=np.full(len(good["cluster"]), 3, np.uint64),
+                  parent_mask=np.full(len(good["cluster"]), 3, np.uint64))
+    with pytest.raises(P.PgbpError, match="missing"):
+        eng.lg_setup(masked, Xnan)                                    # NaN where the mask says observed
+    masked["parent_mask"][int(np.nonzero(good["parent_pos"] >= 0)[0][0])] = 1
+    with pytest.raises(P.PgbpError, match="out of the parent's scope|overlap or leave"):
+        eng.lg_setup(masked, X)
     eng.lg_setup(good, X)
     eng.set_schedule(prob.schedule)
     with pytest.raises(P.PgbpError, match="pgbp_lg_assignfactors first"):
@@ -337,3 +340,50 @@ def test_cfg5_pipeline_on_arrays(P, graph, ntips, nblobs, p):
         dense = OD.loglik(onet, model, tbl, taxa)
         ll = cgb.integratebelief_(sched[0][2][0])[1]
         assert abs(ll - dense) <= 1e-8 * max(1.0, abs(dense)), (ll, dense)
+
+
+@pytest.mark.parametrize("graph", ["cliquetree", "bethe"])
+@pytest.mark.parametrize("which,p", [("bm_fixed", 3), ("bm_random_root", 2), ("hetero", 4), ("bm_improper_root", 3),
+                                     ("hetero", 16)])
+def test_lgfill_missing_data_random_networks(P, graph, which, p):
+    """Missing tip values on random networks (scope masks of pgbp_lg_families): device fill == the oracle's assignfactors!,
+    and on the clique tree the likelihood == the oracle's traversal."""
+    import zlib
+    from test_lg_families_cpu import missing_pattern
+    rng = np.random.default_rng(zlib.crc32(f"gpu-miss-{graph}-{which}-{p}".encode()))
+    net = ON.random_network(14 if p == 16 else 20, 3 if p == 16 else 4, rng)
+    model = _models(p, rng, net, which)
+    tbl, taxa = missing_pattern(net, p, rng, which)
+    cg = OCG.cliquetree(net) if graph == "cliquetree" else OCG.bethe(net)
+    if max(len(nodes) for _, nodes in cg.clusters) * p > 64:
+        pytest.skip("cluster dimension above PGBP_MAX_DIM")
+    ocgb, pcgb = _device_fill(P, net, cg, model, tbl, taxa)
+    _assert_factors_equal(pcgb, ocgb)
+    if graph == "cliquetree":
+        spt = OCG.spanningtree_clusterlist(cg, OCG.default_rootcluster(cg, net))
+        pcgb.set_schedule([spt])
+        ll, info = pcgb.loglik_lg()
+        assert not info.any()
+        assert OC.propagate_1traversal_postorder(ocgb, *spt)
+        oll = ocgb.integratebelief(spt[2][0])[1]
+        assert abs(ll[0] - oll) <= 1e-8 * max(1.0, abs(oll)), (ll, oll)
+
+
+@pytest.mark.parametrize("variant", ["improper", "fixed"])
+def test_lgfill_partial_internal_scopes_level3_golden(P, variant):
+    """test/test_calibration.jl:131-185 with the factors assigned on the device: y2 missing at B leaves hybrid nodes with
+    one of two traits in scope; device fill == oracle fill, and the calibrated clique tree gives the golden
+    normalisation constant at every belief."""
+    g = G["calibration_level3_joingraph"]
+    net = ON.read_newick(g["net"])
+    net.set_preorder(g["preorder"])
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    ocgb, pcgb = _device_fill(P, net, ct, make_model(g["model_" + variant]), [g["y1"], g["y2"]], g["taxa"])
+    assert any(b.dimension % 2 for b in ocgb.belief[:ocgb.nclusters])
+    _assert_factors_equal(pcgb, ocgb)
+    assert P.calibrate_(pcgb, [spt])[0]
+    for i, be in enumerate(ocgb.belief):
+        if be.dimension:
+            norm = pcgb.integratebelief_(i)[1]
+            assert abs(norm - g["norm_" + variant]) <= 1e-9 * abs(g["norm_" + variant])
