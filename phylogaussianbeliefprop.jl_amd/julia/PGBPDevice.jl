@@ -140,6 +140,7 @@ struct LgFamilies      # pgbp_lg_families
     p::Int32; n_families::Int32; max_parents::Int32; n_rates::Int32; n_rows::Int32
     cluster::Ptr{Int32}; n_parents::Ptr{Int32}; child_pos::Ptr{Int32}; data_row::Ptr{Int32}
     parent_pos::Ptr{Int32}; length::Ptr{Float64}; gamma::Ptr{Float64}; color::Ptr{Int32}; data::Ptr{Float64}
+    child_mask::Ptr{UInt64}; parent_mask::Ptr{UInt64}     # C_NULL: complete data
 end
 struct LgParams        # pgbp_lg_params
     model::Int32; per_site::Int32; R::Ptr{Float64}; alpha::Ptr{Float64}; theta::Ptr{Float64}; mu::Ptr{Float64}
@@ -179,7 +180,8 @@ function lg_setup!(o::DeviceClusterGraphBelief, prenodes, tbl, taxa, colorof = e
     data = Float64[tbl[v][r] for v in 1:p, r in 1:length(taxa)]                   # [row][trait], row-major for C
     o.keep = (cl, np, cpos, drow, ppos, len, gam, col, data)                       # keep alive
     f = LgFamilies(p, length(cl), K, nrates, length(taxa), pointer(cl), pointer(np), pointer(cpos), pointer(drow),
-                   pointer(ppos), pointer(len), pointer(gam), pointer(col), pointer(data))
+                   pointer(ppos), pointer(len), pointer(gam), pointer(col), pointer(data), C_NULL, C_NULL)
+    # missing tip values: fill child_mask / parent_mask from `inscope(be)` and the data's `missing`s, as factors.py does
     GC.@preserve cl np cpos drow ppos len gam col data check(o.handle,
         @ccall LIB.pgbp_lg_setup(o.handle::Ptr{Cvoid}, Ref(f)::Ref{LgFamilies})::Cint)
 end
