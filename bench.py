@@ -209,6 +209,8 @@ def build_network_workload(args, rank):
     net = P.random_level3_network(args.ntips, args.blobs, rng, n_colors=3)
     if args.graph == "joingraph":
         cn, ed, sn = P.joingraph(net.node2family, args.maxclustersize)
+    elif args.graph == "cliquetree":
+        cn, ed, sn = P.cliquetree(net.node2family)
     else:
         cn, ed, sn = P.bethe(net.node2family)
     st = P.allocate_scopes(cn, ed, sn, net, p)
@@ -286,7 +288,8 @@ def run_network(args, torch, dist, rank, world, local_rank):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"cfg5: heterogeneous BM (3 rates), {args.traits} traits, level-3 network with {args.ntips} tips "
                                f"and {net.nhybrids} reticulations ({net.nnodes} nodes), "
-                               + (f"join-graph structuring (maxclustersize {args.maxclustersize})" if args.graph == "joingraph" else "Bethe cluster graph")
+                               + (f"join-graph structuring (maxclustersize {args.maxclustersize})" if args.graph == "joingraph"
+                                  else "clique tree" if args.graph == "cliquetree" else "Bethe cluster graph")
                                + (", regularizebeliefs_bycluster!" if loopy else " (a tree here)") + ", spanningtrees_clusterlist schedule",
                    "clusters": len(cn), "sepsets": len(ed), "schedule_trees": len(sched), "loopy": bool(loopy),
                    "messages_per_step": int(msgs_per_cal), "max_cluster_dimension": int(st.dims.max()),

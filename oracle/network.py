@@ -380,3 +380,23 @@ def random_level3_network(ntips: int, nblobs: int, rng: np.random.Generator, lo=
         if not n.leaf and n.name.startswith("I"):
             n.name = ""
     return Network(net.root, nodes, edges)
+
+
+def set_preorder_by_tipsets(net: Network, order, internal_names=None):
+    """Give `net` the node preordering `order`: entries are node names (tips, named hybrids) or, for unnamed internal
+    nodes, the list of tip names below them.  Optionally (re)name those internal nodes."""
+    def tips_below(n):
+        out, stack = set(), [n]
+        while stack:
+            x = stack.pop()
+            if x.leaf:
+                out.add(x.name)
+            stack.extend(net.children(x))
+        return frozenset(out)
+    named = {n.name: n for n in net.nodes if n.leaf or n.hybrid}
+    by_tips = {tips_below(n): n for n in net.nodes if not n.leaf and not n.hybrid}
+    if internal_names:
+        for nm, tips in internal_names.items():
+            by_tips[frozenset(tips)].name = nm
+    seq = [named[x] if isinstance(x, str) else by_tips[frozenset(x)] for x in order]
+    net.set_preorder([n.name for n in seq])

@@ -307,3 +307,42 @@ def bethe(node2family: Sequence[Sequence[int]]):
             edges.append((vc, fc))
             seps.append([v])
     return cluster_nodes, edges, seps
+
+
+def cliquetree(node2family: Sequence[Sequence[int]]):
+    """clustergraph!(net, Cliquetree()) (src/clustergraph.jl:452-466, 757-820) from the node families: moralize, min-fill
+    triangulation, the maximal cliques of the chordal graph, a maximum-weight spanning tree on sepset size.  The
+    reference runs Kruskal over all clique pairs; here each clique C_v = {v} + (its neighbours eliminated later) is joined
+    to the clique of the first-eliminated vertex of C_v - {v}, which is a maximum-weight spanning tree as well (a clique
+    tree: running intersection holds) and costs O(sum of clique sizes).  Returns (cluster_nodes, edges, sepset_nodes)."""
+    adj = moralize(node2family)
+    ordering = triangulate_minfill(adj)
+    posn = {v: i for i, v in enumerate(ordering)}
+    later = {v: sorted((u for u in adj[v] if posn[u] > posn[v]), key=lambda u: posn[u]) for v in ordering}
+    # elimination clique of v; not maximal when it sits inside the clique of an earlier vertex
+    clique = {v: frozenset([v] + later[v]) for v in ordering}
+    rep = {}                      # vertex -> the vertex whose (maximal) clique stands for its elimination clique
+    maximal = []
+    for v in ordering:            # C_v is contained in some C_u with u earlier  <=>  in C_u for u = an earlier neighbour
+        host = None
+        for u in adj[v]:
+            if posn[u] < posn[v] and clique[v] <= clique[rep[u]]:
+                host = rep[u]
+                break
+        if host is None:
+            rep[v] = v
+            maximal.append(v)
+        else:
+            rep[v] = host
+    index = {v: i for i, v in enumerate(maximal)}
+    cluster_nodes = [sorted(clique[v], reverse=True) for v in maximal]
+    edges, seps = [], []
+    for v in maximal:
+        if later[v]:
+            u = rep[later[v][0]]  # the clique that takes over C_v - {v}
+            if u != v:
+                a, b = sorted((index[v], index[u]))
+                edges.append((a, b))
+                seps.append(sorted(clique[v] & clique[u], reverse=True))
+    o = sorted(range(len(edges)), key=lambda t: edges[t])
+    return cluster_nodes, [edges[t] for t in o], [seps[t] for t in o]

@@ -141,6 +141,30 @@ G["doctest_lazaridis"] = {
     "nclusters": 17, "nsepsets": 16,
     "ll": -11.273958980921247, "factored_energy": -11.273958980921261}
 
+G["clustergraph_netstr"] = {
+    "cite": "test/test_clustergraph.jl:2,6-13,36-62,112-125",
+    "net": "(((A:4.0,(B:1.0)#H1:1.1::0.9):0.5,((#H1:1.0::0.1,C:0.6):1.0,C2):1.0):3.0,D:5.0);",
+    # moralize!: nv = numnodes, ne = numedges + 1; triangulate_minfill! order and ne == 13 (:8-13)
+    "moral_nv": 11, "moral_ne": 13 - 1, "minfill_ne": 13,
+    "minfill_order_names": ["A", "B", "H1", "C", "C2", "D", "I5", "I1", "I2", "I3", "I4"],
+    # Bethe (:36-53): nv = (numnodes - 1) + (numnodes - numtaxa), ne = numtaxa + 2 * internal tree edges + 3 * hybrids
+    "bethe_nv": 10 + 6, "bethe_ne": 5 + 2 * 4 + 3 * 1,   # 11 edges: 9 tree edges (5 external, 4 internal), 2 hybrid edges
+    "bethe_variable_clusters": [[1], [3], [4], [6], [8], [9]],
+    "bethe_factor_clusters": [[2, 1], [3, 1], [4, 3], [5, 4], [6, 4], [7, 6], [8, 3], [9, 8, 6], [10, 9], [11, 8]],
+    # clique tree (:112-122)
+    "cliquetree_ne": 8, "cliquetree_sepsets_sorted": [[1], [3], [4], [6], [6, 3], [8], [8, 6], [9]],
+    "preorder_note": "not literal in the test: the node numbering under which the factor clusters listed in its comment "
+                     "(:54-56) are the node families; internal nodes are unnamed in the newick string, so they are given "
+                     "here by the set of tips below them; the names I1..I5 follow from the min-fill order the test expects",
+    "preorder": [["A", "B", "C", "C2", "D"], "D", ["A", "B", "C", "C2"], ["B", "C", "C2"], "C2", ["B", "C"], "C",
+                 ["A", "B"], "H1", "B", "A"],
+    "internal_names": {"I5": ["A", "B", "C", "C2", "D"], "I4": ["A", "B", "C", "C2"], "I3": ["B", "C", "C2"],
+                       "I2": ["B", "C"], "I1": ["A", "B"]}}
+
+G["cliquetree_mateescu"] = {
+    "cite": "test/test_clustergraph.jl:124-127",
+    "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_goldens.json")
 with open(out, "w") as f:
     json.dump(G, f, indent=1)

@@ -414,3 +414,45 @@ def test_calibration_level3_joingraph_loopy_run(variant):
         assert np.allclose(means[name], m, rtol=1.5e-8, atol=0), (name, means[name], m)   # the reference's isapprox
     for lab, i1 in g["cluster_index_1based"].items():
         assert close(cgb.integratebelief(i1 - 1)[1], g["norm_" + variant], rtol=1.5e-8)
+
+
+def _netstr_network():
+    g = G["clustergraph_netstr"]
+    net = ON.read_newick(g["net"])
+    ON.set_preorder_by_tipsets(net, g["preorder"], g["internal_names"])
+    return g, net
+
+
+def test_clustergraph_utilities_bethe_cliquetree_goldens():
+    """test/test_clustergraph.jl:6-13 (moral graph size, min-fill elimination order, one fill edge), :36-57 (Bethe: cluster
+    and edge counts, the listed variable / factor clusters), :112-125 (clique tree: 8 edges, their sepsets, a tree; the
+    largest clique of the Mateescu network) -- oracle restatement and the product's plain-array builders."""
+    import pgbp_amd as P
+    g, net = _netstr_network()
+    names = [n.name for n in net.vec_node]
+    fam = OCG.nodefamilies(net)
+    for moralize, minfill in ((lambda: OCG.moralize(net), OCG.triangulate_minfill), (lambda: P.moralize(fam), P.triangulate_minfill)):
+        adj = moralize()
+        assert len(adj) == g["moral_nv"] and sum(len(v) for v in adj.values()) // 2 == g["moral_ne"]
+        order = minfill(adj)
+        assert [names[v - 1] for v in order] == g["minfill_order_names"]
+        assert sum(len(v) for v in adj.values()) // 2 == g["minfill_ne"]
+    for cn, ed in ((lambda cg: ([n for _, n in cg.clusters], cg.edges))(OCG.bethe(net)),
+                   (lambda t: (t[0], t[1]))(P.bethe(fam))):
+        assert len(cn) == g["bethe_nv"] and len(ed) == g["bethe_ne"]
+        assert sorted(c for c in cn if len(c) == 1) == g["bethe_variable_clusters"]
+        assert sorted(c for c in cn if len(c) > 1) == g["bethe_factor_clusters"]
+    cgb = OCG.bethe(net)
+    assert OCG.isfamilypreserving(cgb, net) and OCG.check_runningintersection(cgb, net)
+    for ct in (OCG.cliquetree(net), (lambda t: OB.ClusterGraph([(str(i), n) for i, n in enumerate(t[0])],
+                                                                [(a, b, s) for (a, b), s in zip(t[1], t[2])], "ct"))(P.cliquetree(fam))):
+        assert len(ct.edges) == g["cliquetree_ne"] == len(ct.clusters) - 1
+        assert sorted(s for _, _, s in ct.edges) == g["cliquetree_sepsets_sorted"]
+        assert OCG.isfamilypreserving(ct, net) and OCG.check_runningintersection(ct, net)
+    gm = G["joingraph_mateescu"]
+    net2 = ON.read_newick(gm["net"])
+    net2.set_preorder(gm["preorder"])
+    for cliques in ([n for _, n in OCG.cliquetree(net2).clusters], P.cliquetree(OCG.nodefamilies(net2))[0]):
+        big = max(cliques, key=len)
+        assert big == G["cliquetree_mateescu"]["largest_clique"]
+        assert "".join(net2.vec_node[v - 1].name for v in big) == G["cliquetree_mateescu"]["largest_clique_label"]

@@ -557,3 +557,26 @@ def test_planner_under_address_and_undefined_sanitizers(tmp_path):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize_plan.py"), so], env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "sanitized planner ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_cliquetree_on_arrays_is_a_clique_tree_with_the_oracles_cliques():
+    """clustergraph.py:cliquetree (elimination-tree construction, linear in the clique sizes) against the oracle's
+    (all clique pairs + Kruskal): same maximal cliques, a tree, family-preserving, running intersection, and the same
+    total sepset weight (both are maximum-weight spanning trees of the clique graph)."""
+    import pgbp_amd as P
+    from oracle import beliefs as OB
+    from oracle import clustergraph as OCG
+    from oracle import network as ON
+    for seed in range(10):
+        rng = np.random.default_rng(100 + seed)
+        net = (ON.random_network(int(rng.integers(5, 60)), int(rng.integers(0, 14)), rng) if seed % 2 else
+               ON.random_level3_network(int(rng.integers(6, 40)), int(rng.integers(1, 5)), rng))
+        cn, ed, sn = P.cliquetree(OCG.nodefamilies(net))
+        oct_ = OCG.cliquetree(net)
+        assert sorted(cn) == sorted(n for _, n in oct_.clusters)
+        assert len(ed) == len(cn) - 1
+        assert sum(len(s) for s in sn) == sum(len(s) for _, _, s in oct_.edges)
+        cg = OB.ClusterGraph([(str(i), n) for i, n in enumerate(cn)], [(a, b, s) for (a, b), s in zip(ed, sn)], "cliquetree")
+        assert OCG.isfamilypreserving(cg, net) and OCG.check_runningintersection(cg, net)
+        for (a, b), s in zip(ed, sn):
+            assert s == sorted(set(cn[a]) & set(cn[b]), reverse=True) and s
