@@ -319,30 +319,40 @@ def cliquetree(node2family: Sequence[Sequence[int]]):
     ordering = triangulate_minfill(adj)
     posn = {v: i for i, v in enumerate(ordering)}
     later = {v: sorted((u for u in adj[v] if posn[u] > posn[v]), key=lambda u: posn[u]) for v in ordering}
-    # elimination clique of v; not maximal when it sits inside the clique of an earlier vertex
+    # Elimination clique of v, and the elimination tree: parent(v) = its first later neighbour.  C_w is not maximal iff it
+    # sits inside the clique that stands for one of w's CHILDREN in that tree (if C_w is inside C_x, x earlier, it is inside
+    # the clique of every vertex on the tree path from x up to w); the cliques a maximal clique absorbs form a path upwards.
     clique = {v: frozenset([v] + later[v]) for v in ordering}
-    rep = {}                      # vertex -> the vertex whose (maximal) clique stands for its elimination clique
+    children = {v: [] for v in ordering}
+    for v in ordering:
+        if later[v]:
+            children[later[v][0]].append(v)
+    rep = {}                      # vertex -> the vertex whose maximal clique stands for its elimination clique
     maximal = []
-    for v in ordering:            # C_v is contained in some C_u with u earlier  <=>  in C_u for u = an earlier neighbour
+    for w in ordering:
         host = None
-        for u in adj[v]:
-            if posn[u] < posn[v] and clique[v] <= clique[rep[u]]:
-                host = rep[u]
+        for c in reversed(children[w]):            # latest-eliminated child first
+            if clique[w] <= clique[rep[c]]:
+                host = rep[c]
                 break
         if host is None:
-            rep[v] = v
-            maximal.append(v)
+            rep[w] = w
+            maximal.append(w)
         else:
-            rep[v] = host
+            rep[w] = host
     index = {v: i for i, v in enumerate(maximal)}
     cluster_nodes = [sorted(clique[v], reverse=True) for v in maximal]
     edges, seps = [], []
     for v in maximal:
-        if later[v]:
-            u = rep[later[v][0]]  # the clique that takes over C_v - {v}
-            if u != v:
-                a, b = sorted((index[v], index[u]))
-                edges.append((a, b))
-                seps.append(sorted(clique[v] & clique[u], reverse=True))
+        # walk up the elimination tree (parent = first later neighbour) past the vertices whose cliques C_v absorbed,
+        # to the clique that takes over what is left of C_v
+        w = later[v][0] if later[v] else None
+        while w is not None and rep[w] == v:
+            w = later[w][0] if later[w] else None
+        if w is not None:
+            u = rep[w]
+            a, b = sorted((index[v], index[u]))
+            edges.append((a, b))
+            seps.append(sorted(clique[v] & clique[u], reverse=True))
     o = sorted(range(len(edges)), key=lambda t: edges[t])
     return cluster_nodes, [edges[t] for t in o], [seps[t] for t in o]
