@@ -211,6 +211,8 @@ def build_network_workload(args, rank):
         cn, ed, sn = P.joingraph(net.node2family, args.maxclustersize)
     elif args.graph == "cliquetree":
         cn, ed, sn = P.cliquetree(net.node2family)
+    elif args.graph == "ltrip":
+        cn, ed, sn = P.ltrip(net.node2family)
     else:
         cn, ed, sn = P.bethe(net.node2family)
     st = P.allocate_scopes(cn, ed, sn, net, p)
@@ -289,7 +291,8 @@ def run_network(args, torch, dist, rank, world, local_rank):
         "config": {"workload": f"cfg5: heterogeneous BM (3 rates), {args.traits} traits, level-3 network with {args.ntips} tips "
                                f"and {net.nhybrids} reticulations ({net.nnodes} nodes), "
                                + (f"join-graph structuring (maxclustersize {args.maxclustersize})" if args.graph == "joingraph"
-                                  else "clique tree" if args.graph == "cliquetree" else "Bethe cluster graph")
+                                  else "clique tree" if args.graph == "cliquetree" else "LTRIP cluster graph (node families)"
+                                  if args.graph == "ltrip" else "Bethe cluster graph")
                                + (", regularizebeliefs_bycluster!" if loopy else " (a tree here)") + ", spanningtrees_clusterlist schedule",
                    "clusters": len(cn), "sepsets": len(ed), "schedule_trees": len(sched), "loopy": bool(loopy),
                    "messages_per_step": int(msgs_per_cal), "max_cluster_dimension": int(st.dims.max()),
@@ -343,7 +346,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ntips", type=int, default=None, help="default: 50000 (tree workload), 20000 (sites workload)")
     ap.add_argument("--traits", type=int, default=None, help="default: 16 (tree workload), 4 (network workload)")
-    ap.add_argument("--graph", default=None, choices=["cliquetree", "bethe", "joingraph"],
+    ap.add_argument("--graph", default=None, choices=["cliquetree", "bethe", "joingraph", "ltrip"],
                     help="default: cliquetree (tree workload), bethe (network workload)")
     ap.add_argument("--blobs", type=int, default=None, help="network workload: level-3 blobs (3 reticulations each); default ntips / 12")
     ap.add_argument("--maxclustersize", type=int, default=3, help="network workload, --graph joingraph")

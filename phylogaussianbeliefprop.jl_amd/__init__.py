@@ -8,7 +8,7 @@ from ._lib import LIB_PATH, PgbpError, load
 from .beliefs import CanonicalBelief, MessageResidual, bclustertype, bsepsettype, scopeindex
 from .beliefupdates import BPPosDefException, integratebelief_, propagate_belief_
 from .calibration import calibrate_, propagate_1traversal_postorder_, propagate_1traversal_preorder_
-from .clustergraph import (bethe, cliquetree, default_rootcluster, default_rootcluster_nodes, joingraph, moralize, nodesubtree_clusterlist,
+from .clustergraph import (bethe, cliquetree, default_rootcluster, ltrip, default_rootcluster_nodes, joingraph, moralize, nodesubtree_clusterlist,
                            spanningtree_clusterlist, spanningtrees_clusterlist, triangulate_minfill)
 from .clustergraphbeliefs import ClusterGraphBelief
 from .factors import lg_families
@@ -21,6 +21,6 @@ __all__ = [
     "bclustertype", "bsepsettype", "calibrate_", "propagate_1traversal_postorder_",
     "propagate_1traversal_preorder_", "propagate_belief_", "regularizebeliefs_bycluster_",
     "regularizebeliefs_bynodesubtree_", "regularizebeliefs_onschedule_", "default_rootcluster",
-    "spanningtree_clusterlist", "spanningtrees_clusterlist", "joingraph", "bethe", "cliquetree", "moralize", "triangulate_minfill",
+    "spanningtree_clusterlist", "spanningtrees_clusterlist", "joingraph", "bethe", "cliquetree", "ltrip", "moralize", "triangulate_minfill",
     "nodesubtree_clusterlist", "default_rootcluster_nodes", "integratebelief_", "lg_families", "NetArrays", "allocate_scopes", "random_level3_network", "simulate_bm_network", "load", "LIB_PATH", "PgbpError",
 ]

@@ -356,3 +356,52 @@ def cliquetree(node2family: Sequence[Sequence[int]]):
             seps.append(sorted(clique[v] & clique[u], reverse=True))
     o = sorted(range(len(edges)), key=lambda t: edges[t])
     return cluster_nodes, [edges[t] for t in o], [seps[t] for t in o]
+
+
+def ltrip(node2family: Sequence[Sequence[int]], clusters: Optional[Sequence[Sequence[int]]] = None):
+    """clustergraph!(net, LTRIP(net)) / LTRIP(clusters, net) (src/clustergraph.jl:330-345, 530-598; Streicher & du Preez
+    2017): the given clusters (default: the node families, one of them the root alone) become the graph's clusters; for
+    every node n, by decreasing index, the clusters holding n are spanned by a maximum-weight tree whose edges get n in
+    their sepset -- weights = size of the clusters' intersection, plus, for both endpoints, the number of maximum-weight
+    edges (within n's subgraph) they touch.  The reference takes Graphs.jl's `kruskal_mst(minimize=false)`; ties among
+    equal weights are broken here by (lower, higher) cluster index.  Returns (cluster_nodes, edges, sepset_nodes)."""
+    if clusters is None:
+        cl = [sorted(nf, reverse=True) for nf in node2family]
+    else:
+        cl = [sorted(c, reverse=True) for c in clusters]
+        sets = [set(c) for c in cl]
+        if not all(any(set(nf) <= s for s in sets) for nf in node2family):
+            raise ValueError("`clusters` is not family preserving with respect to `net`")
+    holders = {}
+    for ci, c in enumerate(cl):
+        for v in c:
+            holders.setdefault(v, []).append(ci)
+    csets = [set(c) for c in cl]
+    sep = {}
+    for v in sorted(holders, reverse=True):
+        hs = holders[v]
+        if len(hs) < 2:
+            continue
+        # every pair of clusters holding v shares at least v: the subgraph is complete
+        w = {(a, b): len(csets[a] & csets[b]) for i, a in enumerate(hs) for b in hs[i + 1:]}
+        maxw = max(w.values())
+        score = {c: 0 for c in hs}
+        for (a, b), x in w.items():
+            if x == maxw:
+                score[a] += 1
+                score[b] += 1
+        adj_w = {e: x + score[e[0]] + score[e[1]] for e, x in w.items()}
+        parent = {c: c for c in hs}
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for (a, b) in sorted(adj_w, key=lambda e: (-adj_w[e], e)):
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[ra] = rb
+                sep.setdefault((a, b), []).append(v)
+    edges = sorted(sep)
+    return [list(c) for c in cl], edges, [sep[e] for e in edges]

@@ -161,6 +161,12 @@ G["clustergraph_netstr"] = {
     "internal_names": {"I5": ["A", "B", "C", "C2", "D"], "I4": ["A", "B", "C", "C2"], "I3": ["B", "C", "C2"],
                        "I2": ["B", "C"], "I1": ["A", "B"]}}
 
+G["ltrip_netstr"] = {
+    "cite": "test/test_clustergraph.jl:72-93 (network: clustergraph_netstr)",
+    "clusters": [[11, 8], [10, 9], [7, 6], [5, 4], [2, 1], [9, 8, 6], [8, 3], [6, 4], [4, 3], [3, 1]],
+    "clusters_not_family_preserving": [[11, 8], [10, 9], [7, 6], [5, 4], [2, 1], [9, 8], [8, 3], [6, 4], [4, 3], [3, 1]],
+    "error": "`clusters` is not family preserving with respect to `net`"}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

@@ -274,7 +274,7 @@ def test_lgfill_refusals(P):
 
 
 @pytest.mark.parametrize("graph,ntips,nblobs,p", [("bethe", 150, 12, 4), ("joingraph", 150, 12, 4), ("bethe", 60, 5, 2),
-                                                  ("joingraph", 40, 3, 16)])
+                                                  ("joingraph", 40, 3, 16), ("cliquetree", 120, 9, 4), ("ltrip", 100, 8, 3)])
 def test_cfg5_pipeline_on_arrays(P, graph, ntips, nblobs, p):
     """The cfg5 pipeline of bench.py --workload network at test size, without any oracle object on the product side:
     level-3 network on plain arrays, Bethe / join-graph cluster graph, scope allocation, device factor fill for a
@@ -285,7 +285,8 @@ def test_cfg5_pipeline_on_arrays(P, graph, ntips, nblobs, p):
     rng = np.random.default_rng(77 + ntips + p)
     net = P.random_level3_network(ntips, nblobs, rng, n_colors=3)
     assert net.nhybrids == 3 * nblobs
-    cn, ed, sn = P.joingraph(net.node2family, 3) if graph == "joingraph" else P.bethe(net.node2family)
+    cn, ed, sn = {"joingraph": lambda f: P.joingraph(f, 3), "bethe": P.bethe, "cliquetree": P.cliquetree,
+                  "ltrip": P.ltrip}[graph](net.node2family)
     st = P.allocate_scopes(cn, ed, sn, net, p)
     base = np.eye(p) + 0.3
     rates = np.stack([base * f for f in (0.5, 1.0, 2.0)])
@@ -297,7 +298,7 @@ def test_cfg5_pipeline_on_arrays(P, graph, ntips, nblobs, p):
     cgb.lg_setup(fam, X)
     cgb.assignfactors_lg_(rates, mu)
     loopy = len(ed) > len(cn) - 1
-    assert loopy == (graph == "bethe")
+    assert loopy == (graph in ("bethe", "ltrip"))
     if loopy:
         assert P.load().pgbp_regularize_bycluster(cgb._eng) == 0
     cgb.pull()

@@ -456,3 +456,44 @@ def test_clustergraph_utilities_bethe_cliquetree_goldens():
         big = max(cliques, key=len)
         assert big == G["cliquetree_mateescu"]["largest_clique"]
         assert "".join(net2.vec_node[v - 1].name for v in big) == G["cliquetree_mateescu"]["largest_clique_label"]
+
+
+def test_ltrip_goldens():
+    """test/test_clustergraph.jl:72-93: LTRIP(clusters, net) keeps the clusters, is connected and has the running
+    intersection property; LTRIP(net) (node families, an extra root cluster) is family-preserving with running
+    intersection; clusters that are not family-preserving are an error."""
+    import pgbp_amd as P
+    g, net = _netstr_network()
+    gl = G["ltrip_netstr"]
+    fam = OCG.nodefamilies(net)
+
+    def as_graph(t):
+        return OB.ClusterGraph([(str(i), n) for i, n in enumerate(t[0])], [(a, b, s) for (a, b), s in zip(t[1], t[2])], "ltrip")
+
+    def connected(cg):
+        seen, stack = {0}, [0]
+        while stack:
+            x = stack.pop()
+            for y in cg.neighbors(x):
+                if y not in seen:
+                    seen.add(y)
+                    stack.append(y)
+        return len(seen) == len(cg.clusters)
+    cg = as_graph(P.ltrip(fam, gl["clusters"]))
+    assert sorted(n for _, n in cg.clusters) == sorted(gl["clusters"])
+    assert connected(cg) and OCG.check_runningintersection(cg, net)
+    cg = as_graph(P.ltrip(fam))
+    assert OCG.check_runningintersection(cg, net) and OCG.isfamilypreserving(cg, net)
+    assert len(cg.clusters) == len(fam)            # the node families, the root's own among them
+    for (a, b, s) in cg.edges:                     # a sepset never exceeds the intersection of its clusters
+        assert set(s) <= set(cg.clusters[a][1]) & set(cg.clusters[b][1]) and s == sorted(s, reverse=True)
+    with pytest.raises(ValueError) as ei:
+        P.ltrip(fam, gl["clusters_not_family_preserving"])
+    assert str(ei.value) == gl["error"]
+    # random networks: the same properties
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        net2 = (ON.random_level3_network(int(rng.integers(6, 40)), int(rng.integers(1, 5)), rng) if seed % 2 else
+                ON.random_network(int(rng.integers(5, 50)), int(rng.integers(0, 12)), rng))
+        cg = as_graph(P.ltrip(OCG.nodefamilies(net2)))
+        assert connected(cg) and OCG.check_runningintersection(cg, net2) and OCG.isfamilypreserving(cg, net2)
