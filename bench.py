@@ -355,6 +355,7 @@ def main():
     ap.add_argument("--no-alt-reading", action="store_true",
                     help="skip the 25001-tip (50k-clique) side measurement: profiler runs want one workload per kernel name")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--ll-batch", type=int, default=8, help="tree workload: parameter sets per pass of the batched log-likelihood figure (1: skip)")
     ap.add_argument("--site-model", default="ou", choices=["ou", "bm"], help="sites workload: per-problem model")
     ap.add_argument("--site-traits", type=int, default=8, help="sites workload: traits per site (each an independent univariate problem)")
     ap.add_argument("--workload", default="tree", choices=["tree", "sites", "network"],
@@ -515,6 +516,29 @@ def main():
                 "ms_per_step": ms.value / args.steps, "messages_per_s": m2 * args.steps / (ms.value * 1e-3),
                 "loglik_rel_err_vs_pruning": float(rel4)}
             del cgb2
+        if world == 1 and args.ll_batch > 1:
+            # several parameter sets per pass: the site dimension of one engine carries B candidate models (R, mu) over
+            # the same data -- what an optimiser's finite-difference gradient or a multi-start issues; the narrow levels
+            # of the schedule are shared by the B evaluations
+            B = args.ll_batch
+            cgbB = pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                                           None, n_sites=B, device=local_rank)
+            cgbB.set_schedule(prob.schedule)
+            cgbB.bm_tree_setup(*S.bm_tree_table(tr, prob), np.broadcast_to(X, (B,) + X.shape).copy())
+            Rs = np.stack([R * (1.0 + 0.05 * b) for b in range(B)])
+            cgbB.assignfactors_bm_(Rs, np.broadcast_to(mu, (B, len(mu))).copy())
+            checkB = lambda code: code == 0 or (_ for _ in ()).throw(RuntimeError(lib.pgbp_last_error(cgbB._eng).decode()))
+            checkB(lib.pgbp_time_enqueued(cgbB._eng, 2, 2, 1, C.byref(opts), C.byref(ms)))
+            checkB(lib.pgbp_time_enqueued(cgbB._eng, 2, nll, 1, C.byref(opts), C.byref(ms)))
+            normB, infoB = np.zeros(B), np.zeros(B, np.int32)
+            checkB(lib.pgbp_fetch_loglik(cgbB._eng, L.f64p(normB), L.i32p(infoB)))
+            refB = S.bm_loglik_pruning(tr, Rs[B - 1], mu, X)
+            relB = abs(normB[B - 1] - refB) / max(1.0, abs(refB))
+            if not (not infoB.any() and relB <= 1e-8 and abs(normB[0] - ll_check) <= 1e-8 * abs(ll_check)) and not skip_parity:
+                raise SystemExit(f"batched loglik parity failed: {normB[B - 1]!r} vs {refB!r}")
+            out["ll_evals_per_s_batched"] = {"parameter_sets_per_pass": B, "value": B * nll / (ms.value * 1e-3),
+                                             "ms_per_pass": ms.value / nll, "loglik_rel_err_vs_pruning": float(relB)}
+            del cgbB
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, packed[0] if packed.ndim > 1 else packed, args.cpu_budget)
             if out["cpu_baseline"].get("value"):
