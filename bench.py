@@ -299,7 +299,7 @@ def run_network(args, torch, dist, rank, world, local_rank):
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
         "calibrate_auto": {"iterations_to_convergence": [int(r.iter_reached), int(r.tree_reached)], "messages": int(nmsg_auto),
                            "ms": 1e3 * t_auto, "messages_per_s": nmsg_auto / t_auto,
-                           "note": "calibrate!(beliefs, sched, 100; auto=true) end to end (one host round trip per schedule tree)"},
+                           "note": "calibrate!(beliefs, sched, 100; auto=true) end to end: the device halts itself at the first calibrated tree, one host round trip per 4 schedule trees"},
         "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "bp_level_generic + bp_level_fast16<4>", "algorithmic_bytes_per_step": bytes_per_cal,

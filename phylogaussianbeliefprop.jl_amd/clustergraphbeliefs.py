@@ -272,12 +272,12 @@ class ClusterGraphBelief:
         ch = np.ascontiguousarray(ch if ch.size else np.zeros(1, np.int32))
         _check(self._lib.pgbp_set_schedule(self._eng, len(trees), L.i32p(off), L.i32p(pa), L.i32p(ch)), self._eng)
         self._schedule = [(t[0].copy(), t[1].copy()) for t in trees]
-        self._schedule_key = [tuple(map(tuple, t)) for t in self._schedule]
 
     def _ensure_schedule(self, schedule):
         trees = [(np.asarray(t[-2], np.int32), np.asarray(t[-1], np.int32)) for t in schedule]
-        key = [tuple(map(tuple, t)) for t in trees]
-        if self._schedule is None or key != self._schedule_key:
+        same = self._schedule is not None and len(trees) == len(self._schedule) and all(
+            np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(trees, self._schedule))
+        if not same:
             self.set_schedule(schedule)
 
     def init_beliefs_reset_fromfactors_(self, sync=True):

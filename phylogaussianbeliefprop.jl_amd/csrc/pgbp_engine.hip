@@ -681,7 +681,7 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   HIPCHK(e, hipGetLastError());
   if (info)
     for (int s = 0; s < p.n_sites; ++s)
-      info[s] = keys[s] == kNoFail ? 0 : (int32_t)(keys[s] & ((1ull << kInfoBits) - 1));
+      info[s] = !is_failure_key(keys[s]) ? 0 : (int32_t)(keys[s] & ((1ull << kInfoBits) - 1));
   return PGBP_OK;
 }
 
@@ -751,7 +751,7 @@ static int collect_results(pgbp_engine* e, pgbp_result* results, const std::vect
     pgbp_result r;
     std::memset(&r, 0, sizeof(r));
     r.fail_edge = -1;
-    if (keys[s] != kNoFail) {
+    if (is_failure_key(keys[s])) {
       r.succ = 0;
       r.iscal = 0;  // (false, false): src/calibration.jl:82
       decode_fail(e, keys[s], r);
@@ -818,6 +818,14 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   bool stop = false;
   std::vector<int32_t> now(ns);
   std::vector<unsigned long long> keys(ns);
+  // `auto` on one site: kAhead schedule trees are enqueued per host round trip.  The device halts itself at the first
+  // tree at which calibration is reached (a key without failure information is min-ed into the fail word right behind
+  // that tree's flag reduction, so every traversal enqueued after it returns at its first instruction) and the host
+  // reads back which tree that was: the beliefs are those of src/calibration.jl:53-56, at a fraction of the round trips.
+  constexpr int kAhead = 4;
+  const bool speculative = auto_stop && ns == 1;
+  const unsigned long long stride = seq_stride(e);
+  int batch_first = 0;
   for (int i = 0; i < niter && !stop; ++i) {
     for (int j = 0; j < nt && !stop; ++j) {
       const unsigned long long pair = (unsigned long long)i * nt + j;
@@ -825,7 +833,22 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
       enqueue_traversal(e, S, j, 1, pair, nullptr, nullptr, kl);
       launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st, e->layout_sm ? 1 : 0);
       ++pairs_done;
-      if (auto_stop) {
+      if (speculative) {
+        launch_halt_if_calibrated(e->d_iscal_hist + pair * ns, e->d_fail, ((pair + 1) * stride - 1) << kInfoBits, ns, e->st);
+        const bool last = (i == niter - 1 && j == nt - 1);
+        if (pairs_done - batch_first < kAhead && !last) continue;
+        std::vector<int32_t> h((size_t)(pairs_done - batch_first));
+        HIPCHK(e, hipMemcpyAsync(h.data(), e->d_iscal_hist + (size_t)batch_first, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, e->st));
+        HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->st));
+        HIPCHK(e, hipStreamSynchronize(e->st));
+        for (size_t q = 0; q < h.size() && !stop; ++q)
+          if (h[q] != 0) {
+            pairs_done = batch_first + (int)q + 1;   // the trees enqueued behind it did nothing
+            stop = true;
+          }
+        if (is_failure_key(keys[0])) stop = true;
+        batch_first = pairs_done;
+      } else if (auto_stop) {
         // `auto`: stop after the first tree at which calibration is reached (src/calibration.jl:53-56);
         // also stop launching once a site has failed
         HIPCHK(e, hipMemcpyAsync(now.data(), e->d_iscal_hist + pair * ns, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
@@ -834,7 +857,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
         bool all_cal = true, any_fail = false;
         for (int s = 0; s < ns; ++s) {
           all_cal &= now[s] != 0;
-          any_fail |= keys[s] != kNoFail;
+          any_fail |= is_failure_key(keys[s]);
         }
         if (all_cal || (any_fail && ns == 1)) stop = true;
       }
@@ -1286,7 +1309,7 @@ int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
     std::vector<unsigned long long> keys(ns);
     HIPCHK(e, hipMemcpy(keys.data(), e->d_fail, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost));
     for (int s = 0; s < ns; ++s)
-      if (keys[s] != kNoFail && info[s] == 0) info[s] = (int32_t)(keys[s] & ((1ull << kInfoBits) - 1));
+      if (is_failure_key(keys[s]) && info[s] == 0) info[s] = (int32_t)(keys[s] & ((1ull << kInfoBits) - 1));
   }
   return PGBP_OK;
 }

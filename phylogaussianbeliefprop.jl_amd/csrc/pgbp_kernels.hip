@@ -1313,6 +1313,19 @@ __global__ __launch_bounds__(256) void reduce_flags_sm_kernel(const int32_t* __r
   if (bad) iscal[site] = 0;
 }
 
+// `auto` without a host round trip per schedule tree: once a site is calibrated, a key without failure information
+// (info = 0) is min-ed into its fail word; every later traversal sees a key below its stop_below and returns at once
+__global__ void halt_if_calibrated_kernel(const int32_t* __restrict__ iscal, unsigned long long* __restrict__ fail,
+                                          unsigned long long key, int n_sites) {
+  const int site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site < n_sites && iscal[site] != 0) atomicMin(&fail[site], key);
+}
+
+void launch_halt_if_calibrated(const int32_t* d_iscal, unsigned long long* d_fail, unsigned long long key, int n_sites,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(halt_if_calibrated_kernel, dim3((n_sites + 63) / 64), dim3(64), 0, st, d_iscal, d_fail, key, n_sites);
+}
+
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st, int sm) {
   (void)hipMemsetAsync(d_iscal, 0x01, sizeof(int32_t) * (size_t)n_sites, st);
   if (n_msgs <= 0) return;

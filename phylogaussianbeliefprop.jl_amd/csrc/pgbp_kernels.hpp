@@ -149,5 +149,10 @@ void launch_regularize_bycluster(double* pool, int64_t pool_stride, const int64_
                                  const int32_t* d_idx, const int32_t* d_sepcl, double* d_eps, int n_clusters,
                                  int n_sepsets, int n_sites, hipStream_t st);
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st, int sm = 0);
+// fail[site] = min(fail[site], key) where iscal[site] != 0 (key carries info = 0: a halt, not a failure)
+void launch_halt_if_calibrated(const int32_t* d_iscal, unsigned long long* d_fail, unsigned long long key, int n_sites,
+                               hipStream_t st);
+// a fail word that reports a failed message (PosDefException.info in its low bits), as opposed to none / a halt key
+inline bool is_failure_key(unsigned long long key) { return key != kNoFail && (key & ((1ull << kInfoBits) - 1)) != 0; }
 
 }  // namespace pgbp
