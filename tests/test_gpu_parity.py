@@ -1120,3 +1120,65 @@ def test_bench_workloads_at_test_size(P, argv):
         assert key in line, key
     assert line["value"] > 0 and line["dtype"] == "f64" and "workload" in line["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+
+
+def test_auto_stop_speculative_batches(P):
+    """calibrate!(...; auto=true) on one site enqueues several schedule trees per host round trip and lets the device halt
+    itself at the first calibrated tree: (1) a loopy Bethe run stops at the tree the C engine stops at for every niter
+    around it, with the same beliefs (nothing runs behind the halt); (2) a failure inside a batch is reported as without
+    `auto`; (3) niter too small to calibrate -> (true, false), no tree reached."""
+    from oracle import cengine
+    rng = np.random.default_rng(123)
+    net = P.random_level3_network(60, 5, rng, n_colors=2)
+    cn, ed, sn = P.bethe(net.node2family)
+    p = 2
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    rates = np.stack([np.eye(p) + 0.2, 2 * np.eye(p) + 0.4])
+    X = P.simulate_bm_network(net, rates, np.zeros(p), rng)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, list(range(net.nnodes)), p, n_rates=2)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, np.zeros(p))
+    assert P.load().pgbp_regularize_bycluster(cgb._eng) == 0
+    cgb.pull()
+    start = cgb._packed[0].copy()
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    ce = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+    reached = None
+    for it in range(1, 60):
+        for j, spt in enumerate(sched, start=1):
+            if ce.calibrate(spt[2], spt[3], 1, return_iscal=True)[1]:
+                reached = (it, j)
+                break
+        if reached:
+            break
+    assert reached and reached[0] >= 3
+    ref = ce.packed()
+    for niter in (reached[0], reached[0] + 1, reached[0] + 7, 50):
+        cgb._packed[0][:] = start
+        cgb.push()
+        cgb.init_messagecalibrationflags_reset_()
+        assert P.calibrate_(cgb, sched, niter, auto=True) == (True, True)
+        r = cgb.last_results[0]
+        assert (r.iter_reached, r.tree_reached) == reached
+        assert np.max(np.abs(cgb._packed[0] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
+    # (3) not enough iterations
+    cgb._packed[0][:] = start
+    cgb.push()
+    cgb.init_messagecalibrationflags_reset_()
+    assert P.calibrate_(cgb, sched, reached[0] - 1, auto=True) == (True, False)
+    assert cgb.last_results[0].iter_reached == 0
+    # (2) a failure in the third tree of a batch: same report with and without auto
+    bad = start.copy()
+    snd = int(next(c for c in sched[0][3] if st.dims[c] >= 2 * p))
+    bad[cgb._poff[snd]] = -1.0e6
+    reports = []
+    for auto in (False, True):
+        cgb._packed[0][:] = bad
+        cgb.push()
+        cgb.init_messagecalibrationflags_reset_()
+        assert P.calibrate_(cgb, sched, 6, auto=auto, verbose=False) == (False, False)
+        r = cgb.last_results[0]
+        reports.append((r.fail_iter, r.fail_tree, r.fail_dir, r.fail_edge, r.fail_info))
+    assert reports[0] == reports[1] and reports[0][4] > 0
