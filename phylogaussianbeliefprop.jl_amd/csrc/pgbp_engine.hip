@@ -1137,7 +1137,6 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
   if ((rc = upload(e, &d_gam, std::vector<double>(f->gamma, f->gamma + nfk)))) return rc; keep(d_gam);
   const size_t nd = (size_t)p.n_sites * f->n_rows * pp;
   if ((rc = dev_alloc(e, &d_data, nd))) return rc; keep(d_data);
-  if (nd) HIPCHK(e, hipMemcpy(d_data, f->data, nd * sizeof(double), hipMemcpyHostToDevice));
   unsigned long long *d_cm = nullptr, *d_pm = nullptr;
   if (f->child_mask) {
     std::vector<unsigned long long> v(nf);
@@ -1150,10 +1149,14 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
       for (int k = 0; k < K; ++k) v[i * K + k] = pmask((int)i, k);
     if ((rc = upload(e, &d_pm, v))) return rc; keep(d_pm);
   }
-  if (d_data && nd) {  // masked-out entries may be NaN on the host: never let them reach arithmetic
-    std::vector<double> clean(f->data, f->data + nd);
-    for (double& x : clean) if (!std::isfinite(x)) x = 0.0;
-    HIPCHK(e, hipMemcpy(d_data, clean.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+  if (d_data && nd) {
+    if (!f->child_mask) {  // complete data: checked finite above
+      HIPCHK(e, hipMemcpy(d_data, f->data, nd * sizeof(double), hipMemcpyHostToDevice));
+    } else {               // masked-out entries may be NaN on the host: never let them reach arithmetic
+      std::vector<double> clean(f->data, f->data + nd);
+      for (double& x : clean) if (!std::isfinite(x)) x = 0.0;
+      HIPCHK(e, hipMemcpy(d_data, clean.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   const size_t ns = (size_t)p.n_sites;
   if ((rc = dev_alloc(e, &e->d_lg_R, ns * f->n_rates * pp * pp))) return rc;
