@@ -76,7 +76,7 @@ def cpu_baseline(prob, packed, budget_s=20.0):
             "loglik": ll}
 
 
-def timed_region(enqueue_and_wait, dist, device_sync, reduce_device="cuda"):
+def timed_region(enqueue_and_wait, dist, device_sync, reduce_device=None):
     """The timing contract: barrier + device sync on both sides of the timed work, MAX over ranks.
     `enqueue_and_wait()` runs exactly the K timed steps of THIS rank.  Returns seconds (same on all ranks).
     Factored out so that the N > 1 path is covered by a 2-rank gloo test on CPU (tests/test_bench_dist.py)."""
@@ -91,6 +91,8 @@ def timed_region(enqueue_and_wait, dist, device_sync, reduce_device="cuda"):
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
+        if reduce_device is None:
+            reduce_device = "cpu" if dist.get_backend() == "gloo" else "cuda"
         t = torch.tensor([dt], device=reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -178,7 +180,7 @@ def run_sites(args, torch, dist, rank, world, local_rank):
     ms_ll = C.c_float()
     check(lib.pgbp_time_enqueued(eng, ll_kind, 3, 0, C.byref(opts), C.byref(ms_ll)))
     # the one collective of this configuration: all ranks get every problem's log-likelihood
-    full = gather_sites(norm, nprob, dist, device=f"cuda:{local_rank}")
+    full = gather_sites(norm, nprob, dist, device="cpu" if os.environ.get("PGBP_BENCH_REHEARSAL") == "1" else f"cuda:{local_rank}")
     total_msgs = msgs_per_cal / max(1, ns) * nprob        # same per-problem count on every rank
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -376,6 +378,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 code on a one-GPU box: every rank on device 0, gloo instead of RCCL (two RCCL ranks cannot
+    # share a device); never set by the driver
+    rehearsal = os.environ.get("PGBP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -385,7 +392,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if args.workload == "network":
         run_network(args, torch, dist, rank, world, local_rank)

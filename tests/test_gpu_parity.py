@@ -1182,3 +1182,34 @@ def test_auto_stop_speculative_batches(P):
         r = cgb.last_results[0]
         reports.append((r.fail_iter, r.fail_tree, r.fail_dir, r.fail_edge, r.fail_info))
     assert reports[0] == reports[1] and reports[0][4] > 0
+
+
+@pytest.mark.parametrize("argv", [
+    ["--ntips", "300", "--traits", "16", "--steps", "2", "--warmup", "1"],
+    ["--workload", "sites", "--sites", "37", "--site-traits", "3", "--ntips", "120", "--steps", "2", "--warmup", "1"],
+    ["--workload", "network", "--ntips", "200", "--steps", "2", "--warmup", "1"],
+], ids=["tree_replicas", "sites_sharded", "network_replicas"])
+def test_bench_two_ranks_rehearsal(P, argv):
+    """bench.py's N > 1 path end to end on the one GPU of this box: 2 ranks launched as the driver launches them
+    (torch.distributed.run), both on device 0, gloo in place of RCCL (PGBP_BENCH_REHEARSAL=1): per-rank engines, the
+    barrier / MAX timing contract, the site shards and their one all-gather, rank 0's single JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGBP_BENCH_REHEARSAL="1")
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + argv
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    if argv[:2] == ["--workload", "sites"]:
+        assert line["scaling"] == "strong" and line["config"]["problems_per_rank"] in (55, 56)   # 111 problems over 2 ranks
+        assert line["loglik_max_rel_err_vs_pruning"] <= 1e-8
+    else:
+        assert line["scaling"] == "weak"
