@@ -194,7 +194,8 @@ def test_lgfill_ou_sites_site_minor(P):
             assert np.allclose(eng._packed[s], pack_oracle(ocgb, prob), rtol=1e-8, atol=1e-8)
 
 
-@pytest.mark.parametrize("graph,p,ns", [("cliquetree", 16, 1), ("bethe", 8, 2), ("cliquetree", 5, 3), ("cliquetree", 4, 1)])
+@pytest.mark.parametrize("graph,p,ns", [("cliquetree", 16, 1), ("bethe", 8, 2), ("cliquetree", 5, 3), ("cliquetree", 4, 1),
+                                        ("cliquetree", 32, 1), ("bethe", 21, 2)])
 def test_lgfill_hetero_tree_layouts(P, graph, p, ns):
     """Heterogeneous BM (3 painted rates) on a tree, factors filled on the device while the state is in the layout of
     the register-resident kernel (symmetric block-packed for even p): likelihood against the oracle's traversal on
