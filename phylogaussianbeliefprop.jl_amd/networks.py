@@ -186,3 +186,114 @@ def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, 
     clusters = [_Scope(list(nodes), np.tile(ins[np.array(nodes) - 1], (p, 1))) for nodes in cluster_nodes]
     return ScopeTables(np.concatenate([cdims, sdims]).astype(np.int32), np.array(edges, np.int32).reshape(-1, 2),
                        np.array(off, np.int64), np.array(idx, np.int32), node2cluster, fixed, clusters)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data formats on the caller's side of the path: extended Newick (the reference reads networks with
+# PhyloNetworks.readnewick: test/example_networks/*.phy, docs/src/man/getting_started.md:30-60)
+# ---------------------------------------------------------------------------------------------------------------
+
+def read_newick(text: str, prefix: str = "I"):
+    """Rooted network from an extended Newick string: `#Hk` marks the two (or more) appearances of hybrid node k,
+    `:length:support:gamma` follows a node.  A missing inheritance gamma is the complement of the given one (0.5 each if
+    none is given).  A root of degree one is suppressed (as PhyloNetworks does); unnamed internal nodes are named
+    `prefix`1, `prefix`2, ... (preprocessnet!, src/clustergraph.jl:18-37).  Returns (NetArrays, names): nodes in a
+    preorder (every node after all of its parents, root first; depth first, children in file order), `names[i]` the
+    name of the node labelled i + 1; every edge gets colour 0."""
+    s = "".join(text.split())
+    pos = 0
+    parents: List[list] = []     # per temporary id: [(parent id, length, gamma or None)]
+    kids: List[list] = []
+    names: List[str] = []
+    hybrid_id = {}
+
+    def new(name):
+        parents.append([]); kids.append([]); names.append(name)
+        return len(names) - 1
+
+    def number():
+        nonlocal pos
+        a = pos
+        while pos < len(s) and s[pos] not in ":,();":
+            pos += 1
+        return float(s[a:pos]) if pos > a else None
+
+    def subtree():
+        """-> (node id, length, gamma) of the branch above the subtree that starts at `pos`"""
+        nonlocal pos
+        below = []
+        if s[pos] == "(":
+            pos += 1
+            while True:
+                below.append(subtree())
+                if s[pos] == ",":
+                    pos += 1
+                    continue
+                if s[pos] == ")":
+                    pos += 1
+                    break
+                raise ValueError(f"unexpected {s[pos]!r} at position {pos}")
+        a = pos
+        while pos < len(s) and s[pos] not in ":,();":
+            pos += 1
+        name = s[a:pos]
+        vals = []
+        while pos < len(s) and s[pos] == ":":
+            pos += 1
+            vals.append(number())
+        if name.startswith("#"):
+            key = name[1:]
+            if key not in hybrid_id:
+                hybrid_id[key] = new(key)
+            v = hybrid_id[key]
+        else:
+            v = new(name)
+        for (c, t, g) in below:
+            parents[c].append([v, float("nan") if t is None else t, g])   # no length given: NaN (the factor fill refuses it)
+            kids[v].append(c)
+        return v, (vals[0] if vals else None), (vals[2] if len(vals) > 2 else None)
+
+    root, _, _ = subtree()
+    # inheritance of hybrid edges
+    for v, ps in enumerate(parents):
+        if len(ps) >= 2:
+            given = [q[2] for q in ps if q[2] is not None]
+            rest = [q for q in ps if q[2] is None]
+            for q in rest:
+                q[2] = (1.0 - sum(given)) / len(rest) if given else 1.0 / len(ps)
+        elif ps:
+            ps[0][2] = 1.0
+    while len(kids[root]) == 1 and len(parents[kids[root][0]]) == 1 and kids[kids[root][0]]:
+        nxt = kids[root][0]          # degree-one root above a tree node: suppressed
+        parents[nxt] = []
+        kids[root] = []
+        root = nxt
+    indeg = [len(p) for p in parents]
+    order, stack = [], [root]
+    while stack:
+        v = stack.pop()
+        order.append(v)
+        for c in reversed(kids[v]):
+            indeg[c] -= 1
+            if indeg[c] == 0:
+                stack.append(c)
+    label = {v: i + 1 for i, v in enumerate(order)}
+    used = {names[v] for v in order if names[v]}
+    k = 1
+    out_names = []
+    for v in order:
+        nm = names[v]
+        if not nm:
+            while f"{prefix}{k}" in used:
+                k += 1
+            nm = f"{prefix}{k}"
+            used.add(nm)
+        out_names.append(nm)
+    fam, ln, gm, col = [], [], [], []
+    for v in order:
+        ps = sorted(parents[v], key=lambda q: -label[q[0]])
+        fam.append([label[v]] + [label[q[0]] for q in ps])
+        ln.append([float(q[1]) for q in ps])
+        gm.append([float(q[2]) for q in ps])
+        col.append([0] * len(ps))
+    return NetArrays(fam, ln, gm, col, np.array([not kids[v] for v in order], dtype=bool)), out_names

@@ -389,3 +389,30 @@ def test_lgfill_partial_internal_scopes_level3_golden(P, variant):
         if be.dimension:
             norm = pcgb.integratebelief_(i)[1]
             assert abs(norm - g["norm_" + variant]) <= 1e-9 * abs(g["norm_" + variant])
+
+
+def test_getting_started_pipeline_product_only(P):
+    """docs/src/man/getting_started.md:30-292 with the product's own host side from the Newick string to the likelihood --
+    no oracle object anywhere: read_newick, clique tree (17 clusters, 16 sepsets as the doctest prints), scope allocation,
+    spanning-tree schedule, factors assigned on the device (UnivariateBrownianMotion(1, 0)), calibrate!, and
+    integratebelief! at every belief = the doctest's log-likelihood; factored_energy = the same value."""
+    g = G["doctest_lazaridis"]
+    net, names = P.read_newick(g["net"])
+    assert sorted(n for n, leaf in zip(names, net.is_leaf) if leaf) == sorted(g["taxa"])
+    cn, ed, sn = P.cliquetree(net.node2family)
+    assert (len(cn), len(ed)) == (g["nclusters"], g["nsepsets"])
+    st = P.allocate_scopes(cn, ed, sn, net, 1)
+    row = {t: r for r, t in enumerate(g["taxa"])}
+    data_row = [row.get(names[i], -1) for i in range(net.nnodes)]
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, data_row, 1)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, np.array(g["x"], float)[:, None])
+    cgb.assignfactors_lg_(np.array([[[g["model"]["sigma2"]]]], float), [g["model"]["mu"]])
+    sched = [P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))]
+    assert P.calibrate_(cgb, sched) == (True, False)      # one iteration: exact, not yet flagged as calibrated
+    assert P.calibrate_(cgb, sched, 5, auto=True) == (True, True)
+    for i in range(len(st.dims)):
+        if st.dims[i]:
+            assert abs(cgb.integratebelief_(i, all_sites=True)[1][0] - g["ll"]) <= 1e-9 * abs(g["ll"])
+    assert abs(cgb.factored_energy()[2] - g["factored_energy"]) <= 1e-9 * abs(g["factored_energy"])

@@ -580,3 +580,39 @@ def test_cliquetree_on_arrays_is_a_clique_tree_with_the_oracles_cliques():
         assert OCG.isfamilypreserving(cg, net) and OCG.check_runningintersection(cg, net)
         for (a, b), s in zip(ed, sn):
             assert s == sorted(set(cn[a]) & set(cn[b]), reverse=True) and s
+
+
+def test_read_newick_equals_the_oracles_reader_on_the_golden_networks():
+    """networks.read_newick (product, plain arrays) against the oracle's independent reader on every network string of
+    the goldens: same tips, same number of nodes and hybrids, and the same parent sets / edge lengths / inheritances once
+    nodes are identified by the tips below them."""
+    import pgbp_amd as P
+    from helpers import goldens
+    from oracle import network as ON
+    Gd = goldens()
+    for key in ("doctest_lazaridis", "calibration_level3_joingraph", "joingraph_mateescu", "clustergraph_netstr",
+                "exactBM_tree_calibrate", "canonicalform_six_messages"):
+        s = Gd[key]["net"]
+        net, names = P.read_newick(s)
+        o = ON.read_newick(s)
+        kids = [[] for _ in range(net.nnodes)]
+        for nf in net.node2family:
+            for pa in nf[1:]:
+                kids[pa - 1].append(nf[0] - 1)
+        below = [None] * net.nnodes
+        for i in range(net.nnodes - 1, -1, -1):
+            below[i] = frozenset([names[i]]) if net.is_leaf[i] else frozenset().union(*[below[c] for c in kids[i]])
+        # a hybrid and the tree node right above / below it can share their tip set: add the node's own name if it has one
+        tag = lambda nm, b: (tuple(sorted(b)), nm if not (nm[:1] == "I" and nm[1:].isdigit()) else "")
+        a = sorted((tag(names[nf[0] - 1], below[nf[0] - 1]), sorted(tuple(sorted(below[x - 1])) for x in nf[1:]),
+                    sorted(np.nan_to_num(net.length[i], nan=-1.0).tolist()), sorted(net.gamma[i]))
+                   for i, nf in enumerate(net.node2family))
+        ob = {}
+        for n in reversed(o.vec_node):
+            ob[id(n)] = frozenset([n.name]) if n.leaf else frozenset().union(*[ob[id(c)] for c in o.children(n)])
+        b = sorted((tag(n.name, ob[id(n)]), sorted(tuple(sorted(ob[id(e.parent)])) for e in o.parent_edges(n)),
+                    sorted(e.length for e in o.parent_edges(n)),
+                    sorted((e.gamma if len(o.parent_edges(n)) > 1 else 1.0) for e in o.parent_edges(n))) for n in o.vec_node)
+        assert len(a) == len(b) and net.nhybrids == sum(n.hybrid for n in o.nodes), key
+        for x, y in zip(a, b):
+            assert x[0] == y[0] and x[1] == y[1] and np.allclose(x[2], y[2]) and np.allclose(x[3], y[3]), (key, x, y)
