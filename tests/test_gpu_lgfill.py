@@ -416,3 +416,12 @@ def test_getting_started_pipeline_product_only(P):
         if st.dims[i]:
             assert abs(cgb.integratebelief_(i, all_sites=True)[1][0] - g["ll"]) <= 1e-9 * abs(g["ll"])
     assert abs(cgb.factored_energy()[2] - g["factored_energy"]) <= 1e-9 * abs(g["factored_energy"])
+
+
+def test_lgfill_differential_fuzz(P):
+    """A slice of tests/fuzz_lgfill_vs_oracle.py in the suite: 120 random (network, cluster graph, model, trait count,
+    missing-value pattern) cases, device factor fill against the oracle's assignfactors! (1e-10) and, on exact graphs,
+    the likelihood against the oracle's traversal (1e-8)."""
+    import fuzz_lgfill_vs_oracle as F
+    n_missing, worst = F.run(120, 2025)
+    assert n_missing >= 20 and worst <= 1e-10
