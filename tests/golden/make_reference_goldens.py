@@ -167,6 +167,12 @@ G["ltrip_netstr"] = {
     "clusters_not_family_preserving": [[11, 8], [10, 9], [7, 6], [5, 4], [2, 1], [9, 8], [8, 3], [6, 4], [4, 3], [3, 1]],
     "error": "`clusters` is not family preserving with respect to `net`"}
 
+G["optimization_mateescu"] = {
+    "cite": "test/test_optimization.jl:5-49 (network: joingraph_mateescu; file test/example_networks/mateescu_2010.phy)",
+    "taxa": ["d", "g"], "y": [1.0, -1.0], "start": {"sigma2": 1.0, "mu": 0.0},
+    "ref_mu": -0.07534357691418593, "ref_sigma2": 0.5932930079336234, "ref_ll": -3.2763180687070053,
+    "bethe_rtol": {"mu": 2e-5, "sigma2": 2e-6, "fenergy": 3e-2}}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

@@ -425,3 +425,42 @@ def test_lgfill_differential_fuzz(P):
     import fuzz_lgfill_vs_oracle as F
     n_missing, worst = F.run(120, 2025)
     assert n_missing >= 20 and worst <= 1e-10
+
+
+def _mateescu_on_device(P, graph):
+    g = G["optimization_mateescu"]
+    net, names = P.read_newick(G["joingraph_mateescu"]["net"])
+    cn, ed, sn = P.cliquetree(net.node2family) if graph == "cliquetree" else P.bethe(net.node2family)
+    st = P.allocate_scopes(cn, ed, sn, net, 1)
+    row = {t: r for r, t in enumerate(g["taxa"])}
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed,
+                        [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)],
+                        [row.get(names[i], -1) for i in range(net.nnodes)], 1)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, np.array(g["y"], float)[:, None])
+    return g, net, (cn, ed, sn), cgb
+
+
+def test_calibrate_optimize_cliquetree_golden(P):
+    """test/test_optimization.jl:5-26: maximum-likelihood (sigma2, mu) of a univariate BM on the Mateescu network (level 4,
+    hybrid ladder, a hybrid with a hybrid parent), every likelihood evaluation on the device: the reference's estimates
+    and maximised log-likelihood."""
+    g, net, (cn, ed, sn), cgb = _mateescu_on_device(P, "cliquetree")
+    spt = P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))
+    R, mu, ll, opt = P.calibrate_optimize_cliquetree_(cgb, spt, [[g["start"]["sigma2"]]], [g["start"]["mu"]])
+    assert abs(ll - g["ref_ll"]) <= 1e-12 * abs(g["ref_ll"])                  # measured 3e-16
+    assert abs(R[0, 0] - g["ref_sigma2"]) <= 1e-7 * g["ref_sigma2"]           # measured 2e-10 (the reference's autodiff
+    assert abs(mu[0] - g["ref_mu"]) <= 1e-7 * abs(g["ref_mu"])                # cross-check allows 3e-11 / 4e-10)
+
+
+def test_calibrate_optimize_clustergraph_golden(P):
+    """test/test_optimization.jl:39-48: the same estimation through the Bethe cluster graph (factored energy maximised,
+    regularizebeliefs_bycluster! + calibrate!(auto) per evaluation, all on the device), within the reference's tolerances
+    of the clique-tree estimates."""
+    g, net, (cn, ed, sn), cgb = _mateescu_on_device(P, "bethe")
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    R, mu, fe, opt = P.calibrate_optimize_clustergraph_(cgb, sched, [[g["start"]["sigma2"]]], [g["start"]["mu"]])
+    tol = g["bethe_rtol"]
+    assert abs(mu[0] - g["ref_mu"]) <= tol["mu"] * abs(g["ref_mu"])           # the reference's own tolerances (:46-48)
+    assert abs(R[0, 0] - g["ref_sigma2"]) <= tol["sigma2"] * g["ref_sigma2"]
+    assert abs(fe - g["ref_ll"]) <= tol["fenergy"] * abs(g["ref_ll"])
