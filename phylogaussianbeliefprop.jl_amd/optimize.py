@@ -17,11 +17,14 @@ class _BMTransform:
     """params_optimize / params_original of UnivariateBrownianMotion (log sigma2, mu:
     src/evomodels/homogeneousbrownianmotion.jl:48-49) and MvFullBrownianMotion (log-Cholesky of R, then mu: :130-157)."""
 
-    def __init__(self, p):
+    def __init__(self, p, diagonal=False):
         self.p = p
+        self.diagonal = diagonal   # MvDiagBrownianMotion: log of the rates, then mu (:89-90)
 
     def forward(self, R, mu):
         R = np.atleast_2d(np.asarray(R, float))
+        if self.diagonal:
+            return np.array(list(np.log(np.diag(R))) + list(np.asarray(mu, float).reshape(self.p)))
         U = np.linalg.cholesky(R).T
         p = self.p
         above = [U[i, j] for j in range(1, p) for i in range(j)]
@@ -29,6 +32,8 @@ class _BMTransform:
 
     def back(self, theta):
         p = self.p
+        if self.diagonal:
+            return np.diag(np.exp(np.asarray(theta[:p], float))), np.asarray(theta[p:2 * p], float)
         U = np.zeros((p, p))
         k = 0
         for i in range(p):
@@ -52,14 +57,15 @@ def _minimise(score, x0, maxiter):
     return minimize(score, x0, jac=grad, method="L-BFGS-B", options={"maxiter": maxiter, "ftol": 1e-15, "gtol": 1e-9})
 
 
-def calibrate_optimize_cliquetree_(beliefs, schedule_tree, R0, mu0, extra_rates=(), maxiter=200):
+def calibrate_optimize_cliquetree_(beliefs, schedule_tree, R0, mu0, extra_rates=(), maxiter=200, diagonal=False):
     """calibrate_optimize_cliquetree! (src/calibration.jl:183-221) for a homogeneous Brownian motion (univariate or full
     rate matrix): maximise the log-likelihood over (R, mu); the root prior variance, if the root is random, stays fixed
     (`extra_rates`: the matrices that follow R in the rate table of lg_setup, e.g. the root prior variance).
     Each evaluation = assignfactors! + postorder of `schedule_tree` + integratebelief! at its root, on the device.
+    diagonal: MvDiagBrownianMotion (independent traits: only the diagonal of R is estimated).
     Returns (R, mu, loglik, scipy result)."""
     p = beliefs._lg_p
-    tf = _BMTransform(p)
+    tf = _BMTransform(p, diagonal)
     beliefs._ensure_schedule([schedule_tree])
 
     def score(theta):
@@ -77,14 +83,15 @@ def calibrate_optimize_cliquetree_(beliefs, schedule_tree, R0, mu0, extra_rates=
     return R, mu, -float(opt.fun), opt
 
 
-def calibrate_optimize_clustergraph_(beliefs, schedule, R0, mu0, extra_rates=(), maxiter_calibration=100, maxiter=200):
+def calibrate_optimize_clustergraph_(beliefs, schedule, R0, mu0, extra_rates=(), maxiter_calibration=100, maxiter=200,
+                                     diagonal=False):
     """calibrate_optimize_clustergraph! (src/calibration.jl:309-359): maximise the factored energy (= minus the Bethe free
     energy; the log-likelihood on a clique tree) over (R, mu).  Each evaluation = assignfactors! + factors from beliefs +
     regularizebeliefs_bycluster! + calibrate!(schedule, maxiter_calibration; auto=true) + free_energy, on the device.
     Returns (R, mu, factored energy, scipy result)."""
     from .calibration import calibrate_
     p = beliefs._lg_p
-    tf = _BMTransform(p)
+    tf = _BMTransform(p, diagonal)
     lib = beliefs._lib
 
     def score(theta):

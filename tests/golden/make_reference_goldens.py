@@ -173,6 +173,22 @@ G["optimization_mateescu"] = {
     "ref_mu": -0.07534357691418593, "ref_sigma2": 0.5932930079336234, "ref_ll": -3.2763180687070053,
     "bethe_rtol": {"mu": 2e-5, "sigma2": 2e-6, "fenergy": 3e-2}}
 
+G["optimization_level1"] = {
+    "cite": "test/test_calibration.jl:187-320",
+    # Bethe + Optim (:188-205), compared there with RxInfer + Optim
+    "bethe": {"net": "(A:2.5,((B:1,#H1:0.5::0.1):1,(C:1,(D:0.5)#H1:0.5::0.9):1):0.5);", "taxa": ["A", "B", "C", "D"],
+              "y": [11.275034507978296, 10.032494469945764, 11.49586603350308, 11.004447427824012],
+              "start": {"sigma2": 1, "mu": 0}, "fenergy": -3.4312133894974126, "mu": 10.931640613828181,
+              "sigma2": 0.15239159696122745, "rtol": 1e-4},
+    # clique tree (:206-305): analytic ML values (:262-280)
+    "cliquetree": {"net": "(((A:4.0,((B1:1.0,B2:1.0)i6:0.6)#H5:1.1::0.9)i4:0.5,(#H5:2.0::0.1,C:0.1)i2:1.0)i1:3.0);",
+                   "taxa": ["A", "B1", "B2", "C"], "x": [10, 10, None, 0], "y": [1.0, 0.9, 1, -1],
+                   "start_y": {"sigma2": 1, "mu": -2}, "ll_y": -5.174720533524127, "mu_y": -0.26000871507162693,
+                   "sigma2_y": 0.35360518758586457,
+                   "start_xy": {"R": [2, 1], "mu": [1, -1]}, "ll_xy": -14.39029465611705,
+                   "mu_xy": [3.500266520382341, -0.26000871507162693],
+                   "sigma2_xy": [11.257682945973125, 0.35360518758586457]}}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

@@ -464,3 +464,52 @@ def test_calibrate_optimize_clustergraph_golden(P):
     assert abs(mu[0] - g["ref_mu"]) <= tol["mu"] * abs(g["ref_mu"])           # the reference's own tolerances (:46-48)
     assert abs(R[0, 0] - g["ref_sigma2"]) <= tol["sigma2"] * g["ref_sigma2"]
     assert abs(fe - g["ref_ll"]) <= tol["fenergy"] * abs(g["ref_ll"])
+
+
+def _on_device_from_newick(P, netstr, taxa, columns, graph):
+    """columns: list of per-trait value lists (None = missing), rows ordered as `taxa`."""
+    net, names = P.read_newick(netstr)
+    p = len(columns)
+    data = np.array([[np.nan if columns[v][r] is None else float(columns[v][r]) for v in range(p)] for r in range(len(taxa))])
+    build = {"cliquetree": P.cliquetree, "bethe": P.bethe}[graph]
+    cn, ed, sn = build(net.node2family)
+    # scopes with missing data: a node keeps a trait iff some tip below it has it (src/beliefs.jl:509-520, 551-559)
+    row = {t: r for r, t in enumerate(taxa)}
+    has = np.zeros((net.nnodes, p), bool)
+    for i in range(net.nnodes - 1, -1, -1):
+        if net.is_leaf[i]:
+            has[i] = np.isfinite(data[row[names[i]]])
+        for pa in net.node2family[i][1:]:
+            has[pa - 1] |= has[i]
+    assert has[~net.is_leaf].all()          # these cases keep every internal scope full
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed,
+                        [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)],
+                        [row.get(names[i], -1) for i in range(net.nnodes)], p, data=data)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, data)
+    return net, (cn, ed, sn), cgb
+
+
+def test_calibrate_optimize_level1_goldens(P):
+    """test/test_calibration.jl:187-305: (1) univariate BM through the Bethe graph of a level-1 network, factored energy
+    maximised: the values the reference checks against RxInfer (rtol 1e-4); (2) clique tree, one trait: the analytic ML
+    values; (3) two independent traits (MvDiagBrownianMotion), one value missing: log-likelihood, means and rates."""
+    g = G["optimization_level1"]
+    b = g["bethe"]
+    net, (cn, ed, sn), cgb = _on_device_from_newick(P, b["net"], b["taxa"], [b["y"]], "bethe")
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    R, mu, fe, _ = P.calibrate_optimize_clustergraph_(cgb, sched, [[b["start"]["sigma2"]]], [b["start"]["mu"]])
+    assert abs(fe - b["fenergy"]) <= b["rtol"] * abs(b["fenergy"])
+    assert abs(mu[0] - b["mu"]) <= b["rtol"] * abs(b["mu"]) and abs(R[0, 0] - b["sigma2"]) <= b["rtol"] * b["sigma2"]
+    c = g["cliquetree"]
+    net, (cn, ed, sn), cgb = _on_device_from_newick(P, c["net"], c["taxa"], [c["y"]], "cliquetree")
+    spt = P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))
+    R, mu, ll, _ = P.calibrate_optimize_cliquetree_(cgb, spt, [[c["start_y"]["sigma2"]]], [c["start_y"]["mu"]])
+    assert abs(ll - c["ll_y"]) <= 1e-10 * abs(c["ll_y"])
+    assert abs(mu[0] - c["mu_y"]) <= 1e-6 * abs(c["mu_y"]) and abs(R[0, 0] - c["sigma2_y"]) <= 1e-6 * c["sigma2_y"]
+    net, (cn, ed, sn), cgb = _on_device_from_newick(P, c["net"], c["taxa"], [c["x"], c["y"]], "cliquetree")
+    spt = P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))
+    R, mu, ll, _ = P.calibrate_optimize_cliquetree_(cgb, spt, np.diag(c["start_xy"]["R"]), c["start_xy"]["mu"], diagonal=True)
+    assert abs(ll - c["ll_xy"]) <= 1e-9 * abs(c["ll_xy"])
+    assert np.allclose(mu, c["mu_xy"], rtol=1e-5, atol=0) and np.allclose(np.diag(R), c["sigma2_xy"], rtol=1e-5, atol=0)
