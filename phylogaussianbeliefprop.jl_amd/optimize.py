@@ -54,7 +54,27 @@ def _minimise(score, x0, maxiter):
             e = np.zeros_like(x); e[i] = h
             g[i] = (score(x + e) - score(x - e)) / (2 * h)
         return g
-    return minimize(score, x0, jac=grad, method="L-BFGS-B", options={"maxiter": maxiter, "ftol": 1e-15, "gtol": 1e-9})
+    # L-BFGS-B, restarted from its own end point while it still improves (its line search gives up early on badly scaled
+    # starts, e.g. rates two orders of magnitude off), then a Nelder-Mead polish when a restart stalls above the tolerance
+    best = minimize(score, x0, jac=grad, method="L-BFGS-B", options={"maxiter": maxiter, "ftol": 1e-15, "gtol": 1e-9})
+    for _ in range(20):
+        nxt = minimize(score, best.x, jac=grad, method="L-BFGS-B", options={"maxiter": maxiter, "ftol": 1e-15, "gtol": 1e-9})
+        improved = nxt.fun < best.fun - 1e-13 * max(1.0, abs(best.fun))
+        nxt.nfev += best.nfev
+        if nxt.fun <= best.fun:
+            best = nxt
+        if not improved:
+            break
+    if np.linalg.norm(grad(best.x)) > 1e-5 * max(1.0, abs(best.fun)):
+        pol = minimize(score, best.x, method="Nelder-Mead", options={"xatol": 1e-10, "fatol": 1e-13, "maxiter": 400 * len(x0)})
+        pol.nfev += best.nfev
+        if pol.fun <= best.fun:
+            best = pol
+            nxt = minimize(score, best.x, jac=grad, method="L-BFGS-B", options={"maxiter": maxiter, "ftol": 1e-15, "gtol": 1e-9})
+            if nxt.fun <= best.fun:
+                nxt.nfev += best.nfev
+                best = nxt
+    return best
 
 
 def calibrate_optimize_cliquetree_(beliefs, schedule_tree, R0, mu0, extra_rates=(), maxiter=200, diagonal=False):

@@ -189,6 +189,21 @@ G["optimization_level1"] = {
                    "mu_xy": [3.500266520382341, -0.26000871507162693],
                    "sigma2_xy": [11.257682945973125, 0.35360518758586457]}}
 
+G["optimization_sun2023"] = {
+    "cite": "test/test_optimization.jl:52-100 (data file test/example_networks/sun_2023.phy: 42 nodes, 10 tips, 6 hybrids, "
+            "level 6, hybrid ladder; clique tree with clusters of 2 to 5 nodes)",
+    "net": "(PUN:259.0,(PLE:742.0,(((((#H2:1.0::0.26)I1:3.0,TIG:8.0)#H1:1.0::0.79)I2:48.0,((SUM:56.0,(((JAX:15.0)#H3:1.0::0.7)I3:7.0,((COR:9.0)#H4:1.0::0.68)I4:4.0)I5:5.0)I6:2.0,((((VIR:51.0)#H2:1.0::0.74)I7:28.0,(ALT:36.0,(((((#H1:1.0::0.21)I8:3.0,(#H3:1.0::0.3)I9:1.0)I10:13.0,(#H4:1.0::0.32)I11:1.0)I12:19.0,(#H5:1.0::0.34)I13:3.0)I14:10.0,((RUSA21:23.0)#H6:1.0::0.54)I15:7.0)I16:16.0)I17:2.0)I18:9.0,((AMO:28.0)#H5:1.0::0.66)I19:12.0)I20:8.0)I21:3.0)I22:4.0,(#H6:1.0::0.46)I23:5.0)I24:411)I25:259)I26;",
+    "taxa_in_file_order": ["PUN", "PLE", "TIG", "SUM", "JAX", "COR", "VIR", "ALT", "RUSA21", "AMO"],
+    "y1": [-1.001, 0.608, -3.606, -7.866, -5.977, -6.013, -7.774, -5.511, -6.392, -6.471],
+    "y2": [0.262, 5.124, -5.076, -6.223, -7.033, -6.062, -6.42, -6.34, -6.516, -6.501],
+    "start_R": [[2.0, 1.0], [1.0, 2.0]], "root_variance": "improper (Inf on the diagonal)",
+    # the run recorded in the test's comment (:78-98): L-BFGS stopped at 1000 iterations with |g| = 1e-7
+    "ll_max": -32.22404541422671,
+    "R_recorded": [[3.717085841556895, 1.7464551312269698], [1.7464551312269698, 2.0994767855707854]],
+    "R_scale_note": "the recorded rate matrix is 100 x the maximiser for the edge lengths of the file as it is now (R t, "
+                    "hence the likelihood, is invariant): the comment predates a rescaling of the file's lengths",
+    "R_scale": 100.0, "reference_seconds_run": 248, "reference_f_calls": 3180}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

@@ -513,3 +513,28 @@ def test_calibrate_optimize_level1_goldens(P):
     R, mu, ll, _ = P.calibrate_optimize_cliquetree_(cgb, spt, np.diag(c["start_xy"]["R"]), c["start_xy"]["mu"], diagonal=True)
     assert abs(ll - c["ll_xy"]) <= 1e-9 * abs(c["ll_xy"])
     assert np.allclose(mu, c["mu_xy"], rtol=1e-5, atol=0) and np.allclose(np.diag(R), c["sigma2_xy"], rtol=1e-5, atol=0)
+
+
+def test_calibrate_optimize_sun2023_bivariate_improper_root(P):
+    """test/test_optimization.jl:52-100: full 2 x 2 rate matrix of a bivariate BM with an improper root prior on the
+    level-6 network of Sun et al. (clique tree, clusters of up to 5 nodes = 10 variables): the maximised log-likelihood the
+    reference records (its L-BFGS ran 1000 iterations, 3180 evaluations, 248 s), and its rate matrix up to the rescaling of
+    the file's edge lengths noted in the golden."""
+    g = G["optimization_sun2023"]
+    net, names = P.read_newick(g["net"])
+    assert (net.nnodes, int(net.is_leaf.sum()), net.nhybrids) == (42, 10, 6)
+    assert [n for n, leaf in sorted(zip(names, net.is_leaf), key=lambda t: g["taxa_in_file_order"].index(t[0]) if t[1] else -1)
+            if leaf] == g["taxa_in_file_order"]
+    cn, ed, sn = P.cliquetree(net.node2family)
+    assert (min(len(c) for c in cn), max(len(c) for c in cn)) == (2, 5)
+    st = P.allocate_scopes(cn, ed, sn, net, 2, fixedroot=False)
+    row = {t: r for r, t in enumerate(g["taxa_in_file_order"])}
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed,
+                        [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)],
+                        [row.get(names[i], -1) for i in range(net.nnodes)], 2)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, np.stack([g["y1"], g["y2"]], axis=1))
+    spt = P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))
+    R, mu, ll, opt = P.calibrate_optimize_cliquetree_(cgb, spt, g["start_R"], [0.0, 0.0], maxiter=500)
+    assert abs(ll - g["ll_max"]) <= 1e-9 * abs(g["ll_max"]), (ll, opt.nfev)
+    assert np.allclose(R * g["R_scale"], g["R_recorded"], rtol=1e-4, atol=0), R
