@@ -204,6 +204,17 @@ G["optimization_sun2023"] = {
                     "hence the likelihood, is invariant): the comment predates a rescaling of the file's lengths",
     "R_scale": 100.0, "reference_seconds_run": 248, "reference_f_calls": 3180}
 
+G["exact_reml_level1"] = {
+    "cite": "test/test_exactBM.jl:170-226 (calibrate_exact_cliquetree!: REML estimates, improper root prior)",
+    "net": "(((A:4.0,((B1:1.0,B2:1.0)i6:0.6)#H5:1.1::0.9)i4:0.5,(#H5:2.0::0.1,C:0.1)i2:1.0)i1:3.0);",
+    "taxa": ["A", "B1", "B2", "C"], "x": [10, 10, 2, 0], "y": [1.0, 0.9, 1, -1],
+    "uni": {"ll": -5.250084678427689, "mu": -0.260008715071627, "sigma2": 0.4714735834478194},
+    "bi": {"mu": [2.791001688545128, -0.260008715071627],
+           "R": [[17.93326111121198, 1.6089749098736517], [1.6089749098736517, 0.4714735834478195]]},
+    "note": "the REML estimate of the rate maximises the likelihood integrated over the root under the improper prior (its "
+            "maximum is the restricted likelihood of calibration_cliquetree_level1), the estimate of the mean is the root's "
+            "posterior mean there; uni.ll is the likelihood of the model the function returns: root fixed at that mean, REML rate"}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

@@ -538,3 +538,50 @@ def test_calibrate_optimize_sun2023_bivariate_improper_root(P):
     R, mu, ll, opt = P.calibrate_optimize_cliquetree_(cgb, spt, g["start_R"], [0.0, 0.0], maxiter=500)
     assert abs(ll - g["ll_max"]) <= 1e-9 * abs(g["ll_max"]), (ll, opt.nfev)
     assert np.allclose(R * g["R_scale"], g["R_recorded"], rtol=1e-4, atol=0), R
+
+
+@pytest.mark.parametrize("traits", ["uni", "bi"])
+def test_exact_reml_estimates_through_the_device_objective(P, traits):
+    """test/test_exactBM.jl:185-226: the REML estimates calibrate_exact_cliquetree! gets in closed form -- the rate (matrix)
+    that maximises the likelihood under the improper root prior, the root's posterior mean there, and (one trait) the
+    maximised value -- obtained here by maximising the device-computed likelihood."""
+    g = G["exact_reml_level1"]
+    cols = [g["y"]] if traits == "uni" else [g["x"], g["y"]]
+    p = len(cols)
+    net, names = P.read_newick(g["net"])
+    cn, ed, sn = P.cliquetree(net.node2family)
+    st = P.allocate_scopes(cn, ed, sn, net, p, fixedroot=False)
+    row = {t: r for r, t in enumerate(g["taxa"])}
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed,
+                        [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)],
+                        [row.get(names[i], -1) for i in range(net.nnodes)], p)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, np.array(cols, float).T.copy())
+    spt = P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))
+    R, _, ll, _ = P.calibrate_optimize_cliquetree_(cgb, spt, np.eye(p), np.zeros(p))
+    want = g[traits]
+    if traits == "uni":
+        restricted = G["calibration_cliquetree_level1"]["ll_every_belief"]      # phylolm's restricted likelihood (:41-46)
+        assert abs(ll - restricted) <= 1e-10 * abs(restricted)
+        assert abs(R[0, 0] - want["sigma2"]) <= 1e-6 * want["sigma2"]
+    else:
+        assert np.allclose(R, want["R"], rtol=1e-5, atol=0)
+    # the root's posterior mean at the estimate: calibrate, integrate a cluster that holds the root (label 1: listed last)
+    cgb.assignfactors_lg_(np.stack([R]), np.zeros(p))
+    assert P.calibrate_(cgb, [spt])[0]
+    ci = next(i for i, c in enumerate(cn) if 1 in c)
+    mu_root = cgb.integratebelief_(ci)[0][-p:]
+    assert np.allclose(mu_root, want["mu"], rtol=1e-8, atol=0)
+    if traits == "uni":
+        # the score calibrate_exact_cliquetree! returns: the likelihood of the model it returns, root FIXED at the estimated
+        # mean with the REML rate
+        st2 = P.allocate_scopes(cn, ed, sn, net, p, fixedroot=True)
+        fam2 = P.lg_families(st2.clusters, st2.node2cluster, net.node2family, st2.node2fixed,
+                             [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)],
+                             [row.get(names[i], -1) for i in range(net.nnodes)], p)
+        cgb2 = P.ClusterGraphBelief.from_arrays(st2.dims, st2.sepset_clusters, st2.scope_off, st2.scope_idx, None)
+        cgb2.lg_setup(fam2, np.array(cols, float).T.copy())
+        cgb2.set_schedule([spt])
+        cgb2.assignfactors_lg_(np.array([[[want["sigma2"]]]]), [want["mu"]])
+        ll2, info = cgb2.loglik_lg()
+        assert not info.any() and abs(ll2[0] - want["ll"]) <= 1e-10 * abs(want["ll"])
