@@ -1076,7 +1076,9 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
     std::vector<std::pair<int, int>> pos;  // (first variable, number of variables) of every in-scope block
     const int cp = f->child_pos[i];
     const unsigned long long O = cmask(i);
-    if (cp < 0) {
+    if (cp < 0 && O == 0 && f->child_mask) {
+      // a node with nothing in scope (no data below it) or a tip with every trait missing: the factor integrates to 1
+    } else if (cp < 0) {
       if (np == 0) return e->fail(PGBP_ERR_INVALID, where + "a root prior needs the root in scope");
       if (f->data_row[i] < 0 || f->data_row[i] >= f->n_rows) return e->fail(PGBP_ERR_INVALID, where + "data row out of range");
       for (int s2 = 0; s2 < p.n_sites; ++s2)

@@ -136,14 +136,27 @@ class _Scope:
         self.nodelabel, self.inscope = nodelabel, inscope
 
 
-def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, fixedroot: bool = True) -> ScopeTables:
-    """allocatebeliefs (src/beliefs.jl:478-594) for complete tip data on plain arrays: tips (and a fixed root) are out
-    of scope, every other node has all p traits in scope; node2cluster[ni] = the first cluster that contains the
-    family of node ni + 1 (:521-527); scopeindex(sepset, cluster) (:389-405) for both ends of every sepset."""
+def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, fixedroot: bool = True, data=None,
+                    data_row=None) -> ScopeTables:
+    """allocatebeliefs (src/beliefs.jl:478-594) on plain arrays: tips (and a fixed root) are out of scope; an internal node
+    has trait t in scope iff some tip below it has a value for t (:509-520, 551-559) -- every trait without `data`;
+    node2cluster[ni] = the first cluster that contains the family of node ni + 1 (:521-527); scopeindex(sepset, cluster)
+    (:389-405) for both ends of every sepset.  data: [n_rows, p] tip values, NaN where missing; data_row[ni]: the row of
+    tip ni (as for factors.lg_families)."""
     N = net.nnodes
     fixed = net.is_leaf.copy()
     if fixedroot:
         fixed[0] = True
+    has = np.ones((N, p), dtype=bool)
+    if data is not None:
+        data = np.asarray(data, float)
+        has[:] = False
+        for i in range(N - 1, -1, -1):          # children before parents
+            if net.is_leaf[i]:
+                has[i] = np.isfinite(data[int(data_row[i])])
+            for pa in net.node2family[i][1:]:
+                has[pa - 1] |= has[i]
+    ins = has & ~fixed[:, None]                  # (N, p)
     holders: List[List[int]] = [[] for _ in range(N + 1)]
     for ci, nodes in enumerate(cluster_nodes):
         for v in nodes:
@@ -161,16 +174,15 @@ def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, 
         if found is None:
             raise ValueError(f"no cluster containing the node family of node {ni + 1}")
         node2cluster.append(found)
-    ins = ~fixed
-    cdims = np.array([p * int(sum(ins[v - 1] for v in nodes)) for nodes in cluster_nodes], dtype=np.int32)
-    sdims = np.array([p * int(sum(ins[v - 1] for v in nodes)) for nodes in sepset_nodes], dtype=np.int32)
+    ndim = ins.sum(axis=1)
+    cdims = np.array([int(sum(ndim[v - 1] for v in nodes)) for nodes in cluster_nodes], dtype=np.int32)
+    sdims = np.array([int(sum(ndim[v - 1] for v in nodes)) for nodes in sepset_nodes], dtype=np.int32)
     start = []
     for nodes in cluster_nodes:
         s, acc = {}, 0
         for v in nodes:
             s[v] = acc
-            if ins[v - 1]:
-                acc += p
+            acc += int(ndim[v - 1])
         start.append(s)
     off, idx = [0], []
     for (a, b), nodes in zip(edges, sepset_nodes):
@@ -180,10 +192,9 @@ def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, 
             if any(y <= x for x, y in zip(where, where[1:])):
                 raise ValueError("subset labels come in a different order in the belief")
             for v in nodes:
-                if ins[v - 1]:
-                    idx.extend(range(start[c][v], start[c][v] + p))
+                idx.extend(range(start[c][v], start[c][v] + int(ndim[v - 1])))
             off.append(len(idx))
-    clusters = [_Scope(list(nodes), np.tile(ins[np.array(nodes) - 1], (p, 1))) for nodes in cluster_nodes]
+    clusters = [_Scope(list(nodes), ins[np.array(nodes) - 1].T.copy()) for nodes in cluster_nodes]
     return ScopeTables(np.concatenate([cdims, sdims]).astype(np.int32), np.array(edges, np.int32).reshape(-1, 2),
                        np.array(off, np.int64), np.array(idx, np.int32), node2cluster, fixed, clusters)
 

@@ -215,6 +215,12 @@ G["exact_reml_level1"] = {
             "maximum is the restricted likelihood of calibration_cliquetree_level1), the estimate of the mean is the root's "
             "posterior mean there; uni.ll is the likelihood of the model the function returns: root fixed at that mean, REML rate"}
 
+G["exact_reml_missing"] = {
+    "cite": "test/test_exactBM.jl:228-251 (x missing at the two sister tips B1, B2: their parent i6 has nothing in scope)",
+    "net": "((((B1:1.0,B2:1.0)i6:4.0,(A:0.6)#H5:1.1::0.9)i4:0.5,(#H5:2.0::0.1,C:0.1)i2:1.0)i1:3.0);",
+    "taxa": ["A", "B1", "B2", "C"], "x": [10, None, None, 0],
+    "mu": 3.538570417551306, "sigma2": 35.385704175513084, "ll": -6.2771970782154565}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

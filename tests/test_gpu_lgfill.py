@@ -585,3 +585,37 @@ def test_exact_reml_estimates_through_the_device_objective(P, traits):
         cgb2.assignfactors_lg_(np.array([[[want["sigma2"]]]]), [want["mu"]])
         ll2, info = cgb2.loglik_lg()
         assert not info.any() and abs(ll2[0] - want["ll"]) <= 1e-10 * abs(want["ll"])
+
+
+def test_exact_reml_with_fully_missing_sisters(P):
+    """test/test_exactBM.jl:228-251: the trait is missing at two sister tips, so their parent has nothing in scope (a
+    zero-dimensional block, families that integrate to 1): scopes from allocate_scopes(data=...), factors from the masked
+    device fill; REML rate, root posterior mean, and the score of the returned fixed-root model."""
+    g = G["exact_reml_missing"]
+    net, names = P.read_newick(g["net"])
+    row = {t: r for r, t in enumerate(g["taxa"])}
+    data_row = [row.get(names[i], -1) for i in range(net.nnodes)]
+    data = np.array([[np.nan if v is None else float(v)] for v in g["x"]])
+    cn, ed, sn = P.cliquetree(net.node2family)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    engines = {}
+    for fixedroot in (False, True):
+        st = P.allocate_scopes(cn, ed, sn, net, 1, fixedroot=fixedroot, data=data, data_row=data_row)
+        fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, data_row, 1, data=data)
+        cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+        cgb.lg_setup(fam, data)
+        engines[fixedroot] = (st, cgb)
+    st, cgb = engines[False]
+    assert 0 in st.dims[:len(cn)].tolist() or any(d == 1 for d in st.dims[:len(cn)])      # reduced scopes are there
+    spt = P.spanningtree_clusterlist(len(cn), ed, P.default_rootcluster(cn, net.is_leaf))
+    R, _, ll, _ = P.calibrate_optimize_cliquetree_(cgb, spt, [[1.0]], [0.0])
+    assert abs(R[0, 0] - g["sigma2"]) <= 1e-6 * g["sigma2"]
+    cgb.assignfactors_lg_(np.stack([R]), [0.0])
+    assert P.calibrate_(cgb, [spt])[0]
+    ci = next(i for i, c in enumerate(cn) if 1 in c and st.dims[i] > 0)
+    assert abs(cgb.integratebelief_(ci)[0][-1] - g["mu"]) <= 1e-8 * abs(g["mu"])
+    st2, cgb2 = engines[True]
+    cgb2.set_schedule([spt])
+    cgb2.assignfactors_lg_(np.array([[[g["sigma2"]]]]), [g["mu"]])
+    ll2, info = cgb2.loglik_lg()
+    assert not info.any() and abs(ll2[0] - g["ll"]) <= 1e-10 * abs(g["ll"])

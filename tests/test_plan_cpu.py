@@ -616,3 +616,39 @@ def test_read_newick_equals_the_oracles_reader_on_the_golden_networks():
         assert len(a) == len(b) and net.nhybrids == sum(n.hybrid for n in o.nodes), key
         for x, y in zip(a, b):
             assert x[0] == y[0] and x[1] == y[1] and np.allclose(x[2], y[2]) and np.allclose(x[3], y[3]), (key, x, y)
+
+
+def test_allocate_scopes_with_missing_data_equals_the_oracle():
+    """networks.allocate_scopes with missing tip values (scattered, whole tips, a trait missing below whole subtrees so that
+    internal nodes lose it) == the oracle's allocatebeliefs: dimensions, scopes of every cluster, both scopeindex maps."""
+    import pgbp_amd as P
+    from oracle import beliefs as OB
+    from oracle import clustergraph as OCG
+    from oracle import models as OM
+    p = 3
+    for seed in range(6):
+        rng = np.random.default_rng(40 + seed)
+        net = P.random_level3_network(int(rng.integers(8, 30)), int(rng.integers(1, 4)), rng)
+        onet = _arrays_to_oracle_network(net)
+        taxa = onet.tip_names
+        row = {t: r for r, t in enumerate(taxa)}
+        data = rng.normal(size=(len(taxa), p))
+        data[rng.random(data.shape) < 0.35] = np.nan
+        data[0] = 0.5                                   # at least one complete tip
+        tbl = [[None if np.isnan(data[r, v]) else float(data[r, v]) for r in range(len(taxa))] for v in range(p)]
+        data_row = [row.get(f"n{i + 1}", -1) for i in range(net.nnodes)]
+        for kind in ("bethe", "cliquetree"):
+            cn, ed, sn = P.bethe(net.node2family) if kind == "bethe" else P.cliquetree(net.node2family)
+            ocg = OB.ClusterGraph([(str(i), n) for i, n in enumerate(cn)], [(a, b, s) for (a, b), s in zip(ed, sn)], kind)
+            st = P.allocate_scopes(cn, ed, sn, net, p, data=data, data_row=data_row)
+            ob, (n2c, n2f, n2fix, _, _) = OB.allocatebeliefs(tbl, taxa, onet, ocg, OM.MvDiagBrownianMotion(np.ones(p), np.zeros(p)))
+            assert [b.dimension for b in ob] == st.dims.tolist()
+            assert n2c == st.node2cluster
+            for i in range(len(cn)):
+                assert np.array_equal(ob[i].inscope, st.clusters[i].inscope)
+            idx, off = [], [0]
+            for j in range(len(cn), len(ob)):
+                for c in ocg.edges[j - len(cn)][:2]:
+                    idx += OB.scopeindex(ob[j], ob[c]).tolist()
+                    off.append(len(idx))
+            assert idx == st.scope_idx.tolist() and off == st.scope_off.tolist()
