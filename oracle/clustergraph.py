@@ -238,11 +238,26 @@ def _assign(bucket, new, maxsize):
     return new, []
 
 
-def joingraph(net, maxclustersize, size_order="decreasing") -> ClusterGraph:
+def _julia_slot(k: int) -> int:
+    """(Base.hash(::Int64) & 15) of Julia 1.x: the slot of key k in a fresh 16-slot Dict."""
+    M = (1 << 64) - 1
+    a = k & M
+    a = (~a + (a << 21)) & M
+    a ^= a >> 24
+    a = (a + (a << 3) + (a << 8)) & M
+    a ^= a >> 14
+    a = (a + (a << 2) + (a << 4)) & M
+    a ^= a >> 28
+    a = (a + (a << 31)) & M
+    return a & 15
+
+
+def joingraph(net, maxclustersize, size_order="julia") -> ClusterGraph:
     """src/clustergraph.jl:605-697 (JoinGraphStructuring).  The reference walks the minibuckets of a bucket in the
-    iteration order of a Julia Dict keyed by minibucket size (`values(bd)`, :645), which is an implementation detail
-    of Julia's hashing; here the sizes are walked in `size_order` ("decreasing" / "increasing").  Every order gives a
-    valid join graph (family-preserving, running intersection); they may differ in which minibuckets are chained."""
+    iteration order of a Julia Dict keyed by minibucket size (`values(bd)`, :645): size_order="julia" walks the sizes by
+    their hash slot (the keys 1..10 fall into distinct slots of the initial 16-slot table), which reproduces the join
+    graphs of the reference's doctests cluster for cluster; "decreasing" / "increasing" are other valid orders.  Vertex
+    numbers follow MetaGraphsNext: deleting a vertex gives its number to the last one."""
     maxfam = max(len(nf) for nf in nodefamilies(net))
     if maxclustersize < maxfam:
         raise ValueError(f"maxclustersize {maxclustersize} is smaller than the size of largest node family {maxfam}.")
@@ -273,7 +288,8 @@ def joingraph(net, maxclustersize, size_order="decreasing") -> ClusterGraph:
         bd = buckets[i]
         bi = e2p[i]
         prev = None
-        sizes = sorted(bd.keys(), reverse=(size_order == "decreasing"))
+        sizes = (sorted(bd.keys(), key=lambda k: (_julia_slot(k), k)) if size_order == "julia" else
+                 sorted(bd.keys(), reverse=(size_order == "decreasing")))
         for mb in [m for sz in sizes for m in list(bd[sz])]:
             lab, nodes = cluster_of(mb)
             if prev is not None:
@@ -294,7 +310,9 @@ def joingraph(net, maxclustersize, size_order="decreasing") -> ClusterGraph:
                         add_edge(lab1, labn, edges[key])
                         del edges[key]
                     del nodes_of[lab2]
-                    labels.remove(lab2)
+                    i2 = labels.index(lab2)       # Graphs.rem_vertex!: the last vertex takes the deleted one's number
+                    labels[i2] = labels[-1]
+                    labels.pop()
     index = {lab: k for k, lab in enumerate(labels)}
     out_edges = []
     for key, sep in edges.items():

@@ -152,6 +152,28 @@ def triangulate_minfill(adj):
     return ordering
 
 
+def _julia_hash_int(n: int) -> int:
+    """Base.hash(::Int64) of Julia 1.x (hash_64_64 bit mixing), for `_julia_dict_order`."""
+    M = (1 << 64) - 1
+    a = n & M
+    a = (~a + (a << 21)) & M
+    a ^= a >> 24
+    a = (a + (a << 3) + (a << 8)) & M
+    a ^= a >> 14
+    a = (a + (a << 2) + (a << 4)) & M
+    a ^= a >> 28
+    a = (a + (a << 31)) & M
+    return a
+
+
+def _julia_dict_order(keys):
+    """Iteration order of a Julia `Dict{<:Integer}` holding these small keys: slot = hash & 15 in the initial 16-slot
+    table (the keys 1..10 have distinct slots, so deletions and re-insertions do not move them).  The reference walks a
+    bucket's minibucket sizes in this order (`values(bd)`, src/clustergraph.jl:645); with it the join graphs of the
+    reference's doctests come out cluster for cluster (docs/src/man/clustergraphs.md)."""
+    return sorted(keys, key=lambda k: (_julia_hash_int(int(k)) & 15, int(k)))
+
+
 def _assign(bucket, new, maxsize):
     """assign!(bucket, new_minibucket, max_minibucket_size) (src/clustergraph.jl:705-736)."""
     for sz in sorted(bucket, reverse=True):
@@ -173,8 +195,9 @@ def joingraph(node2family: Sequence[Sequence[int]], maxclustersize: int):
     families of the network (nodefamilies(net), :136-146: [child, parents by decreasing index], 1-based preorder
     indices).  Returns (cluster_nodes, edges, sepset_nodes): cluster i holds the nodes cluster_nodes[i] (decreasing
     preorder index), sepset k = edges[k] = (i, j), i < j, holds sepset_nodes[k].
-    The reference walks a bucket's minibuckets in the iteration order of a Julia Dict keyed by their size (:645);
-    here: by decreasing size, then in order of creation (every order gives a valid join graph)."""
+    The reference walks a bucket's minibuckets in the iteration order of a Julia Dict keyed by their size (:645):
+    `_julia_dict_order`; clusters are numbered as the vertices of its MetaGraph end up (a deleted vertex's number goes
+    to the last vertex: Graphs.rem_vertex!), which is the order LTRIP(clusters, net) and the beliefs see."""
     maxfam = max(len(nf) for nf in node2family)
     if maxclustersize < maxfam:
         raise ValueError(f"maxclustersize {maxclustersize} is smaller than the size of largest node family {maxfam}.")
@@ -206,7 +229,7 @@ def joingraph(node2family: Sequence[Sequence[int]], maxclustersize: int):
         bd = buckets[i]
         bi = e2p[i]
         prev = None
-        for mb in [m for sz in sorted(bd, reverse=True) for m in list(bd[sz])]:
+        for mb in [m for sz in _julia_dict_order(bd) for m in list(bd[sz])]:
             key = cluster_of(mb)
             if prev is not None:
                 add_edge(prev, key, [bi])          # chain of the bucket's minibuckets: sepset = the bucket's node
@@ -225,7 +248,10 @@ def joingraph(node2family: Sequence[Sequence[int]], maxclustersize: int):
                         add_edge(key1, kn, sep)
                     del nbrs[key2]
                     del alive[key2]
-    keys = [k for k in order if k in alive]
+                    i2 = order.index(key2)         # rem_vertex!: the last vertex takes the deleted one's number
+                    order[i2] = order[-1]
+                    order.pop()
+    keys = order
     index = {k: i for i, k in enumerate(keys)}
     edges, seps = [], []
     for k in keys:

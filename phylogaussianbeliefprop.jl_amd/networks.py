@@ -204,13 +204,18 @@ def allocate_scopes(cluster_nodes, edges, sepset_nodes, net: NetArrays, p: int, 
 # PhyloNetworks.readnewick: test/example_networks/*.phy, docs/src/man/getting_started.md:30-60)
 # ---------------------------------------------------------------------------------------------------------------
 
-def read_newick(text: str, prefix: str = "I"):
+def read_newick(text: str, prefix: str = "I", order: str = "phylonetworks"):
     """Rooted network from an extended Newick string: `#Hk` marks the two (or more) appearances of hybrid node k,
     `:length:support:gamma` follows a node.  A missing inheritance gamma is the complement of the given one (0.5 each if
     none is given).  A root of degree one is suppressed (as PhyloNetworks does); unnamed internal nodes are named
-    `prefix`1, `prefix`2, ... (preprocessnet!, src/clustergraph.jl:18-37).  Returns (NetArrays, names): nodes in a
-    preorder (every node after all of its parents, root first; depth first, children in file order), `names[i]` the
-    name of the node labelled i + 1; every edge gets colour 0."""
+    `prefix`1, `prefix`2, ... in the order in which their subtrees close in the string (preprocessnet!,
+    src/clustergraph.jl:18-37).  Returns (NetArrays, names): nodes in a preorder (every node after all of its parents,
+    root first), `names[i]` the name of the node labelled i + 1; every edge gets colour 0.
+    order = "phylonetworks": the node ordering of PhyloNetworks.preorder!, which the reference's cluster-graph builders
+    break their ties with (src/clustergraph.jl:87-121): a stack; a node's children are pushed in file order, so the LAST
+    child is visited first; a hybrid node is pushed by the parent that is visited last.  (It reproduces the node
+    numberings that the reference's tests and doctests imply: tests/golden/reference_goldens.json.)
+    order = "file": depth first with the first child first."""
     s = "".join(text.split())
     pos = 0
     parents: List[list] = []     # per temporary id: [(parent id, length, gamma or None)]
@@ -280,26 +285,26 @@ def read_newick(text: str, prefix: str = "I"):
         kids[root] = []
         root = nxt
     indeg = [len(p) for p in parents]
+    walk = order
     order, stack = [], [root]
     while stack:
         v = stack.pop()
         order.append(v)
-        for c in reversed(kids[v]):
+        for c in (kids[v] if walk == "phylonetworks" else reversed(kids[v])):
             indeg[c] -= 1
             if indeg[c] == 0:
                 stack.append(c)
     label = {v: i + 1 for i, v in enumerate(order)}
-    used = {names[v] for v in order if names[v]}
+    # unnamed internal nodes: numbered in the order of their temporary ids = the order in which their subtrees close
+    used = {nm for nm in names if nm}
     k = 1
-    out_names = []
-    for v in order:
-        nm = names[v]
-        if not nm:
+    for v in sorted(label):
+        if not names[v]:
             while f"{prefix}{k}" in used:
                 k += 1
-            nm = f"{prefix}{k}"
-            used.add(nm)
-        out_names.append(nm)
+            names[v] = f"{prefix}{k}"
+            used.add(names[v])
+    out_names = [names[v] for v in order]
     fam, ln, gm, col = [], [], [], []
     for v in order:
         ps = sorted(parents[v], key=lambda q: -label[q[0]])

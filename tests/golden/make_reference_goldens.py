@@ -221,6 +221,22 @@ G["exact_reml_missing"] = {
     "taxa": ["A", "B1", "B2", "C"], "x": [10, None, None, 0],
     "mu": 3.538570417551306, "sigma2": 35.385704175513084, "ll": -6.2771970782154565}
 
+G["clustergraphs_muller2022"] = {
+    "cite": "docs/src/man/clustergraphs.md:30-215 (doctests on test/example_networks/muller_2022.phy, kept beside this file as "
+            "tests/golden/muller_2022.phy: a data file of the reference's tests)",
+    "nodes": 801, "edges": 1161, "tips": 40, "hybrids": 361,
+    "cliquetree": {"clusters": 664, "edges": 663, "mean": 6.728916, "std": 6.120608, "min": 2, "q1": 4, "median": 5, "q3": 7,
+                   "max": 54, "first_cluster_labels": ["I300", "I301", "I302", "I189"],
+                   "first_cluster_preorder": [722, 719, 717, 487]},
+    "bethe": {"clusters": 1557, "edges": 1914, "mean": 1.743738, "std": 0.809151, "min": 1, "q1": 1, "median": 2, "q3": 2, "max": 3},
+    "joingraph10": {"clusters": 1001, "edges": 1200, "mean": 6.036963, "std": 2.177070, "min": 1, "q1": 4, "median": 6, "q3": 8,
+                    "max": 10},
+    "joingraph2_error": "maxclustersize 2 is smaller than the size of largest node family 3.",
+    "joingraph54": {"clusters": 801, "edges": 800, "mean": 9.539326, "std": 9.953078, "min": 1, "q1": 4, "median": 5, "q3": 10,
+                    "max": 54},
+    "ltrip_of_joingraph10_clusters": {"clusters": 1001, "edges": 1249},
+    "ltrip": {"clusters": 801, "edges": 1158}}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

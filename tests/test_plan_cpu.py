@@ -652,3 +652,60 @@ def test_allocate_scopes_with_missing_data_equals_the_oracle():
                     idx += OB.scopeindex(ob[j], ob[c]).tolist()
                     off.append(len(idx))
             assert idx == st.scope_idx.tolist() and off == st.scope_off.tolist()
+
+
+def test_clustergraphs_md_doctests_on_the_muller_network():
+    """docs/src/man/clustergraphs.md:30-215 on the Müller et al. virus recombination network (801 nodes, 361 hybrids), with
+    the product's host side only: reader + PhyloNetworks' preorder, then the four cluster-graph methods.  Every number the
+    doctests print: cluster and edge counts, the summary statistics of the cluster sizes, the clique tree's first cluster
+    by labels and preorder indices, the join graphs for k* = 10 and 54 (the latter a clique tree), the error for k* = 2,
+    LTRIP from the join graph's clusters and from the node families."""
+    import pgbp_amd as P
+    from helpers import goldens
+    g = goldens()["clustergraphs_muller2022"]
+    with open(os.path.join(ROOT, "tests", "golden", "muller_2022.phy")) as f:
+        net, names = P.read_newick(f.read())
+    assert (net.nnodes, sum(len(nf) - 1 for nf in net.node2family), int(net.is_leaf.sum()), net.nhybrids) == \
+        (g["nodes"], g["edges"], g["tips"], g["hybrids"])
+
+    def check(cn, ed, want):
+        a = np.array([len(c) for c in cn])
+        assert (len(cn), len(ed)) == (want["clusters"], want["edges"])
+        if "mean" in want:
+            assert abs(a.mean() - want["mean"]) < 5e-7 and abs(a.std(ddof=1) - want["std"]) < 5e-7
+            assert (a.min(), np.percentile(a, 25), np.median(a), np.percentile(a, 75), a.max()) == \
+                (want["min"], want["q1"], want["median"], want["q3"], want["max"])
+    fam = net.node2family
+    cn, ed, sn = P.cliquetree(fam)
+    check(cn, ed, g["cliquetree"])
+    first = g["cliquetree"]["first_cluster_preorder"]
+    assert first in cn and [names[v - 1] for v in first] == g["cliquetree"]["first_cluster_labels"]
+    check(*P.bethe(fam)[:2], g["bethe"])
+    jcn, jed, jsn = P.joingraph(fam, 10)
+    check(jcn, jed, g["joingraph10"])
+    with pytest.raises(ValueError) as ei:
+        P.joingraph(fam, 2)
+    assert str(ei.value) == g["joingraph2_error"]
+    cn54, ed54, _ = P.joingraph(fam, 54)
+    check(cn54, ed54, g["joingraph54"])
+    lcn, led, _ = P.ltrip(fam, jcn)
+    check(lcn, led, g["ltrip_of_joingraph10_clusters"])
+    lcn, led, _ = P.ltrip(fam)
+    check(lcn, led, g["ltrip"])
+
+
+def test_read_newick_gives_the_preorders_the_reference_tests_imply():
+    """PhyloNetworks.preorder! as restated in networks.read_newick reproduces the node numberings (and the names of unnamed
+    internal nodes) that four of the reference's tests imply through cluster labels, cluster indices and the expected
+    min-fill order (derived independently in tests/golden/make_reference_goldens.py)."""
+    import pgbp_amd as P
+    from helpers import goldens
+    Gd = goldens()
+    for key in ("calibration_level3_joingraph", "joingraph_mateescu"):
+        assert P.read_newick(Gd[key]["net"])[1] == Gd[key]["preorder"]
+    g = Gd["clustergraph_netstr"]
+    net, names = P.read_newick(g["net"])
+    inv = {tuple(sorted(v)): k for k, v in g["internal_names"].items()}
+    want = [x if isinstance(x, str) else inv[tuple(sorted(x))] for x in g["preorder"]]
+    assert names == want
+    assert [names[v - 1] for v in P.triangulate_minfill(P.moralize(net.node2family))] == g["minfill_order_names"]
