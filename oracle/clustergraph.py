@@ -165,48 +165,127 @@ def default_rootcluster(cg: ClusterGraph, net) -> int:
     return best
 
 
-def spanningtree_clusterlist(cg: ClusterGraph, rootj: int, edge_subset=None):
-    """src/clustergraph.jl:885-894: DFS spanning tree, clusters in preorder.
-    Returns (pa_lab, ch_lab, pa_j, ch_j) with 0-based cluster indices."""
-    nb = {i: [] for i in range(len(cg.clusters))}
-    edges = cg.edges if edge_subset is None else edge_subset
-    for (a, b, _) in edges:
-        nb[a].append(b)
-        nb[b].append(a)
-    for k in nb:
-        nb[k].sort()
-    seen = {rootj}
-    pa_j, ch_j = [], []
-    stack = [(rootj, iter(nb[rootj]))]
+
+def _graphs_jl_tree_order(n, nbrs, root):
+    """The vertex order `spanningtree_clusterlist` gets from Graphs.jl (src/clustergraph.jl:885-894):
+    `par = dfs_parents(g, root)` -- an iterative depth-first search that always follows the first unseen neighbour in
+    increasing vertex code -- then `topological_sort(tree(par))` = `topological_sort_by_dfs`: depth-first searches started
+    from every vertex in increasing code, vertices listed by REVERSE finishing time (so of two children the one with the
+    larger code comes first, and whatever hangs below vertex 0 ... comes last when vertex 0 is not the root).
+    nbrs[v]: neighbours of v in increasing code.  Returns (parents, vertices after the root in that order)."""
+    par = [-1] * n
+    seen = [False] * n
+    stack = [root]
+    seen[root] = True
+    par[root] = root
+    nxt = [0] * n
     while stack:
-        v, it = stack[-1]
-        advanced = False
-        for u in it:
-            if u not in seen:
-                seen.add(u)
-                pa_j.append(v)
-                ch_j.append(u)
-                stack.append((u, iter(nb[u])))
-                advanced = True
-                break
-        if not advanced:
+        v = stack[-1]
+        while nxt[v] < len(nbrs[v]) and seen[nbrs[v][nxt[v]]]:
+            nxt[v] += 1
+        if nxt[v] == len(nbrs[v]):
             stack.pop()
+            continue
+        u = nbrs[v][nxt[v]]
+        seen[u] = True
+        par[u] = v
+        stack.append(u)
+    kids = [[] for _ in range(n)]
+    for v in range(n):
+        if par[v] >= 0 and par[v] != v:
+            kids[par[v]].append(v)          # increasing code
+    color = [0] * n
+    finished = []
+    pos = [0] * n
+    for s in range(n):
+        if color[s] or par[s] < 0:
+            continue
+        color[s] = 1
+        stack = [s]
+        while stack:
+            u = stack[-1]
+            while pos[u] < len(kids[u]) and color[kids[u][pos[u]]]:
+                pos[u] += 1
+            if pos[u] == len(kids[u]):
+                color[u] = 2
+                finished.append(u)
+                stack.pop()
+            else:
+                w = kids[u][pos[u]]
+                color[w] = 1
+                stack.append(w)
+    order = finished[::-1]
+    assert order and order[0] == root
+    return par, order[1:]
+
+
+def spanningtree_clusterlist(cg: ClusterGraph, rootj: int, edge_subset=None, vertices=None):
+    """src/clustergraph.jl:885-894: depth-first spanning tree from cluster `rootj`, clusters listed as Graphs.jl lists
+    them (see _graphs_jl_tree_order).  `vertices`: the vertex numbering of the (sub)graph the reference works on, as a
+    list of cluster indices (induced_subgraph renumbers); default: all clusters in index order.
+    Returns (pa_lab, ch_lab, pa_j, ch_j) with 0-based cluster indices of `cg`."""
+    edges = cg.edges if edge_subset is None else edge_subset
+    if vertices is None:
+        vertices = list(range(len(cg.clusters)))
+    code = {c: i for i, c in enumerate(vertices)}
+    nbrs = [[] for _ in vertices]
+    for (a, b, _) in edges:
+        if a in code and b in code:
+            nbrs[code[a]].append(code[b])
+            nbrs[code[b]].append(code[a])
+    for lst in nbrs:
+        lst.sort()
+    par, order = _graphs_jl_tree_order(len(vertices), nbrs, code[rootj])
+    ch_j = [vertices[v] for v in order]
+    pa_j = [vertices[par[v]] for v in order]
     labs = cg.labels
     return ([labs[i] for i in pa_j], [labs[i] for i in ch_j], pa_j, ch_j)
 
 
 def spanningtrees_clusterlist(cg: ClusterGraph, net):
-    """src/clustergraph.jl:908-937: spanning trees that together cover all edges
-    (Kruskal min spanning tree on "times used so far" weights)."""
+    """src/clustergraph.jl:908-937: spanning trees that together cover all edges.  Each is Graphs.jl's kruskal_mst on
+    "number of earlier trees using the edge" (edges in lexicographic (smaller, larger) vertex order, stable sort by
+    weight, stop at n - 1 edges); `induced_subgraph(cg, mst_edges)` renumbers the clusters in the order in which they first
+    appear in that edge list, and the tree is rooted and listed in THAT numbering (default_rootcluster takes the first
+    minimum; the depth-first search follows increasing new numbers)."""
+    pre = net.vec_node
+    nclu = len(cg.clusters)
+    und = sorted(range(len(cg.edges)), key=lambda k: (min(cg.edges[k][:2]), max(cg.edges[k][:2])))
     used = [0] * len(cg.edges)
     sched = []
     while any(u == 0 for u in used):
-        wedges = [(used[k], a, b, k) for k, (a, b, _) in enumerate(cg.edges)]
-        mst = _kruskal(len(cg.clusters), wedges, maximize=False)
-        sub = [cg.edges[k] for (_, _, k) in mst]
-        rootj = default_rootcluster(cg, net)
-        sched.append(spanningtree_clusterlist(cg, rootj, sub))
-        for (_, _, k) in mst:
+        parent = list(range(nclu))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        mst = []
+        for k in sorted(und, key=lambda k: used[k]):      # stable: ties keep the lexicographic edge order
+            a, b = sorted(cg.edges[k][:2])
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[ra] = rb
+                mst.append(k)
+                if len(mst) >= nclu - 1:
+                    break
+        vmap = []
+        for k in mst:
+            for v in sorted(cg.edges[k][:2]):
+                if v not in vmap:
+                    vmap.append(v)
+        best, bestscore = None, None
+        for v in vmap:                                     # default_rootcluster(sg, prenodes): first minimum in sg order
+            nodes = cg.clusters[v][1]
+            if 1 in nodes:
+                score = sum(1 for i in nodes if pre[i - 1].leaf)
+                if bestscore is None or score < bestscore:
+                    best, bestscore = v, score
+        if best is None:
+            raise ValueError("no cluster contains the root")
+        sched.append(spanningtree_clusterlist(cg, best, [cg.edges[k] for k in mst], vertices=vmap))
+        for k in mst:
             used[k] += 1
     return sched
 
@@ -374,4 +453,4 @@ def nodesubtree_clusterlist(cg: ClusterGraph, v: int):
         raise ValueError(f"no cluster with node {v}")
     sub = [(a, b, s) for (a, b, s) in cg.edges if a in cl and b in cl and v in s]
     rootj = cl[default_rootcluster_nodes([cg.clusters[i][1] for i in cl])]
-    return spanningtree_clusterlist(cg, rootj, sub)
+    return spanningtree_clusterlist(cg, rootj, sub, vertices=cl)      # induced_subgraph(cgraph, clusters_i): that order

@@ -22,35 +22,80 @@ def default_rootcluster(cluster_nodes: Sequence[Sequence[int]], is_leaf: Sequenc
     return best
 
 
-def spanningtree_clusterlist(n_clusters: int, edges: Sequence[Tuple[int, int]], rootj: int,
-                             labels: Optional[Sequence] = None):
-    """spanningtree_clusterlist(clustergraph, root_index) (src/clustergraph.jl:885-894): depth-first spanning tree
-    from `rootj`, neighbours in increasing cluster index; clusters other than the root in preorder, each with its
-    parent."""
-    nb: List[List[int]] = [[] for _ in range(n_clusters)]
-    for (a, b) in edges:
-        nb[a].append(b)
-        nb[b].append(a)
-    for lst in nb:
-        lst.sort()
-    seen = [False] * n_clusters
-    seen[rootj] = True
-    pa_j: List[int] = []
-    ch_j: List[int] = []
-    stack = [(rootj, 0)]
+
+def _graphs_jl_tree_order(n: int, nbrs: List[List[int]], root: int):
+    """The vertex order `spanningtree_clusterlist` gets from Graphs.jl (src/clustergraph.jl:885-894):
+    `par = dfs_parents(g, root)` -- an iterative depth-first search that always follows the first unseen neighbour in
+    increasing vertex code -- then `topological_sort(tree(par))` = `topological_sort_by_dfs`: depth-first searches started
+    from every vertex in increasing code, vertices listed by REVERSE finishing time (so of two children the one with the
+    larger code comes first, and whatever hangs below vertex 0 ... comes last when vertex 0 is not the root).
+    nbrs[v]: neighbours of v in increasing code.  Returns (parents, vertices after the root in that order)."""
+    par = [-1] * n
+    seen = [False] * n
+    stack = [root]
+    seen[root] = True
+    par[root] = root
+    nxt = [0] * n
     while stack:
-        v, pos = stack[-1]
-        while pos < len(nb[v]) and seen[nb[v][pos]]:
-            pos += 1
-        if pos == len(nb[v]):
+        v = stack[-1]
+        while nxt[v] < len(nbrs[v]) and seen[nbrs[v][nxt[v]]]:
+            nxt[v] += 1
+        if nxt[v] == len(nbrs[v]):
             stack.pop()
             continue
-        u = nb[v][pos]
-        stack[-1] = (v, pos + 1)
+        u = nbrs[v][nxt[v]]
         seen[u] = True
-        pa_j.append(v)
-        ch_j.append(u)
-        stack.append((u, 0))
+        par[u] = v
+        stack.append(u)
+    kids = [[] for _ in range(n)]
+    for v in range(n):
+        if par[v] >= 0 and par[v] != v:
+            kids[par[v]].append(v)          # increasing code
+    color = [0] * n
+    finished = []
+    pos = [0] * n
+    for s in range(n):
+        if color[s] or par[s] < 0:
+            continue
+        color[s] = 1
+        stack = [s]
+        while stack:
+            u = stack[-1]
+            while pos[u] < len(kids[u]) and color[kids[u][pos[u]]]:
+                pos[u] += 1
+            if pos[u] == len(kids[u]):
+                color[u] = 2
+                finished.append(u)
+                stack.pop()
+            else:
+                w = kids[u][pos[u]]
+                color[w] = 1
+                stack.append(w)
+    order = finished[::-1]
+    assert order and order[0] == root
+    return par, order[1:]
+
+
+def spanningtree_clusterlist(n_clusters: int, edges: Sequence[Tuple[int, int]], rootj: int,
+                             labels: Optional[Sequence] = None, vertices: Optional[Sequence[int]] = None):
+    """spanningtree_clusterlist(clustergraph, root_index) (src/clustergraph.jl:885-894): depth-first spanning tree from
+    `rootj`; the clusters other than the root, each with its parent, in the order Graphs.jl's dfs_parents +
+    topological_sort produce (`_graphs_jl_tree_order`).  `vertices`: the numbering of the subgraph the reference works on
+    (Graphs.induced_subgraph renumbers its vertices), as a list of cluster indices; default 0 .. n_clusters - 1."""
+    if vertices is None:
+        vertices = range(n_clusters)
+    vertices = list(vertices)
+    code = {c: i for i, c in enumerate(vertices)}
+    nb: List[List[int]] = [[] for _ in vertices]
+    for (a, b) in edges:
+        if a in code and b in code:
+            nb[code[a]].append(code[b])
+            nb[code[b]].append(code[a])
+    for lst in nb:
+        lst.sort()
+    par, order = _graphs_jl_tree_order(len(vertices), nb, code[rootj])
+    ch_j = [vertices[v] for v in order]
+    pa_j = [vertices[par[v]] for v in order]
     lab = (lambda i: i) if labels is None else (lambda i: labels[i])
     return [lab(i) for i in pa_j], [lab(i) for i in ch_j], pa_j, ch_j
 
@@ -59,10 +104,13 @@ def spanningtrees_clusterlist(n_clusters: int, edges: Sequence[Tuple[int, int]],
                               cluster_nodes: Sequence[Sequence[int]], is_leaf: Sequence[bool],
                               labels: Optional[Sequence] = None):
     """spanningtrees_clusterlist(clustergraph, nodevector_preordered) (src/clustergraph.jl:908-937): spanning trees
-    that together cover every edge: Kruskal minimum spanning trees with weight = number of earlier trees that used
-    the edge, each rooted at `default_rootcluster` and listed as by `spanningtree_clusterlist`."""
+    that together cover every edge.  Each is Graphs.jl's kruskal_mst with weight = number of earlier trees that used the
+    edge (edges in lexicographic (smaller, larger) cluster order, stable sort by weight, stop at n - 1 edges); the reference
+    then works on `induced_subgraph(cg, mst_edges)`, whose vertices are numbered in the order of their first appearance in
+    that edge list: the root is the first cluster of that numbering among those that hold the network's root with the
+    fewest tips (default_rootcluster), and the depth-first search follows that numbering."""
+    und = sorted(range(len(edges)), key=lambda k: (min(edges[k]), max(edges[k])))
     used = [0] * len(edges)
-    rootj = default_rootcluster(cluster_nodes, is_leaf)
     schedule = []
     while any(u == 0 for u in used):
         parent = list(range(n_clusters))
@@ -73,12 +121,29 @@ def spanningtrees_clusterlist(n_clusters: int, edges: Sequence[Tuple[int, int]],
                 x = parent[x]
             return x
         chosen = []
-        for k in sorted(range(len(edges)), key=lambda k: (used[k], edges[k][0], edges[k][1])):
-            ra, rb = find(edges[k][0]), find(edges[k][1])
+        for k in sorted(und, key=lambda k: used[k]):       # stable: ties keep the lexicographic edge order
+            ra, rb = find(min(edges[k])), find(max(edges[k]))
             if ra != rb:
                 parent[ra] = rb
                 chosen.append(k)
-        schedule.append(spanningtree_clusterlist(n_clusters, [edges[k] for k in chosen], rootj, labels))
+                if len(chosen) >= n_clusters - 1:
+                    break
+        vmap, seen = [], set()
+        for k in chosen:
+            for v in sorted(edges[k]):
+                if v not in seen:
+                    seen.add(v)
+                    vmap.append(v)
+        best, best_score = None, None
+        for v in vmap:
+            nodes = cluster_nodes[v]
+            if 1 in nodes:
+                score = sum(1 for i in nodes if is_leaf[i - 1])
+                if best_score is None or score < best_score:
+                    best, best_score = v, score
+        if best is None:
+            raise ValueError("no cluster contains the root")
+        schedule.append(spanningtree_clusterlist(n_clusters, [edges[k] for k in chosen], best, labels, vertices=vmap))
         for k in chosen:
             used[k] += 1
     return schedule
@@ -288,7 +353,7 @@ def nodesubtree_clusterlist(cluster_nodes: Sequence[Sequence[int]], edges: Seque
     inside = set(cl)
     sub = [e for e, s in zip(edges, sepset_nodes) if node in s and e[0] in inside and e[1] in inside]
     rootj = cl[default_rootcluster_nodes([cluster_nodes[i] for i in cl])]
-    return spanningtree_clusterlist(len(cluster_nodes), sub, rootj, labels)
+    return spanningtree_clusterlist(len(cluster_nodes), sub, rootj, labels, vertices=cl)   # induced_subgraph: that numbering
 
 
 def bethe(node2family: Sequence[Sequence[int]]):

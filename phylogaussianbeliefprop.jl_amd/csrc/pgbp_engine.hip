@@ -275,7 +275,9 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
   const Traversal& tr = dir == 0 ? T.post : T.pre;
   const DevTraversal& d = dir == 0 ? e->dpost[tree] : e->dpre[tree];
   const unsigned long long seq_base = pair_index * seq_stride(e);
-  // preorder does not run at all once the postorder of the same tree failed (src/calibration.jl:80-82)
+  // Once the postorder of a tree failed, its preorder does not run here.  (The reference still walks it, on beliefs the
+  // sequential postorder left half-updated, may log a second failure, and returns (false, false): src/calibration.jl:80-82.
+  // The first failure of the reference's order is what the engine reports; the state after a failure is unspecified.)
   const unsigned long long stop_below = seq_base + (dir == 0 ? 0ull : (unsigned long long)T.pa.size());
   const int nlev = (int)tr.level_off.size() - 1;
   // timing mode: ONE event pair brackets all level launches of the traversal (they run back to back on

@@ -237,6 +237,19 @@ G["clustergraphs_muller2022"] = {
     "ltrip_of_joingraph10_clusters": {"clusters": 1001, "edges": 1249},
     "ltrip": {"clusters": 801, "edges": 1158}}
 
+G["doctests_lipson2020b"] = {
+    "cite": "docs/src/man/regularization.md:133-200, docs/src/man/message_schedules.md:55-75 (doctests on "
+            "test/example_networks/lipson_2020b.phy, kept beside this file as tests/golden/lipson_2020b.phy)",
+    "nodes": 44, "edges": 54, "tips": 12, "hybrids": 11,
+    "x_in_tiplabels_order": [0.431, 1.606, 0.72, 0.944, 0.647, 1.263, 0.46, 1.079, 0.877, 0.748, 1.529, -0.469],
+    "model": {"kind": "UnivariateBM", "sigma2": 1, "mu": 0},
+    # regularization.md:179-183: one iteration over the Bethe graph's spanning trees without regularisation
+    "errors_without_regularization": ["belief H5I5I16, integrating [2, 3]", "belief H10I8I15, integrating [2, 3]"],
+    # :188-199: no ill-defined message after regularizebeliefs_bynodesubtree! / regularizebeliefs_onschedule!
+    # message_schedules.md:60-67: beliefs WITHOUT factors (the doctest's setup never calls assignfactors!),
+    # regularizebeliefs_bynodesubtree!, calibrate!(cgb, sched, 100; auto=true, info=true)
+    "info_line_without_factors": "calibration reached: iteration 1, schedule tree 2"}
+
 G["cliquetree_mateescu"] = {
     "cite": "test/test_clustergraph.jl:124-127",
     "largest_clique_label": "H3DH1B", "largest_clique": [5, 4, 3, 2]}

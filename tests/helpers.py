@@ -144,3 +144,26 @@ def lg_inputs_from_oracle(P, net, ocgb, model, tbl, taxa):
     if isinstance(model, OM.UnivariateOrnsteinUhlenbeck):
         kw.update(model="ou", alpha=model.alpha, theta=[model.theta])
     return fam, data, kw
+
+
+def network_from_newick_file(P, path):
+    """(product NetArrays, names, oracle Network with the same preorder and names, tip names in file order =
+    PhyloNetworks.tiplabels) for a network file of tests/golden/."""
+    import re
+    with open(path) as f:
+        s = f.read()
+    net, names = P.read_newick(s)
+    nodes = [ON.Node(name=names[i], leaf=bool(net.is_leaf[i]), hybrid=len(net.node2family[i]) > 2) for i in range(net.nnodes)]
+    edges = []
+    for i, nf in enumerate(net.node2family):
+        for k, pl in enumerate(nf[1:]):
+            e = ON.Edge(number=len(edges) + 1, parent=nodes[pl - 1], child=nodes[i], length=net.length[i][k],
+                        gamma=net.gamma[i][k], hybrid=len(nf) > 2)
+            edges.append(e)
+            nodes[pl - 1].edges.append(e)
+            nodes[i].edges.append(e)
+    onet = ON.Network(nodes[0], nodes, edges)
+    onet.set_preorder(names)
+    tipset = {n for n, leaf in zip(names, net.is_leaf) if leaf}
+    tips = [t for t in re.findall(r"[(,]([A-Za-z_][A-Za-z0-9_.|]*)", s) if t in tipset]
+    return net, names, onet, tips

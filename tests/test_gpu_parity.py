@@ -1213,3 +1213,47 @@ def test_bench_two_ranks_rehearsal(P, argv):
         assert line["loglik_max_rel_err_vs_pruning"] <= 1e-8
     else:
         assert line["scaling"] == "weak"
+
+
+def test_regularization_and_schedule_doctests_on_the_lipson_network_device(P, caplog):
+    """docs/src/man/regularization.md:133-200 and message_schedules.md:55-75 on the device (Lipson et al. network, 44
+    nodes, 11 hybrids, Bethe graph; cluster graph and schedule from the product's own host builders): the two error
+    lines of the unregularised iteration, none after either regulariser, and "calibration reached: iteration 1, schedule
+    tree 2" for beliefs without factors."""
+    import os
+    from helpers import network_from_newick_file
+    g = G["doctests_lipson2020b"]
+    net, names, onet, tips = network_from_newick_file(P, os.path.join(os.path.dirname(__file__), "golden", "lipson_2020b.phy"))
+    cn, ed, sn = P.bethe(net.node2family)
+    labels = ["".join(names[v - 1] for v in c) for c in cn]
+    cg = OB.ClusterGraph(list(zip(labels, cn)), [(a, b, s) for (a, b), s in zip(ed, sn)], "Bethe")
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf, labels)
+    model = make_model(g["model"])
+    ocgb, pcgb = build_both(P, onet, cg, model, [g["x_in_tiplabels_order"]], tips)
+    with caplog.at_level(logging.ERROR):
+        assert P.calibrate_(pcgb, sched) == (False, False)
+    errors = [r.getMessage() for r in caplog.records if r.levelno >= logging.ERROR]
+    # The reference logs two lines: the postorder of schedule tree 1 stops at its first ill-defined message, then the
+    # preorder of the same tree still runs on the partially updated beliefs and stops at another one
+    # (src/calibration.jl:80-82).  The engine reports the FIRST failure of the reference's order and stops (the state
+    # after a failure is unspecified: a level-synchronous pass cannot stop "mid-level"): the first line, exactly.
+    assert errors == g["errors_without_regularization"][:1]
+    r = pcgb.last_results[0]
+    assert (r.fail_iter, r.fail_tree, r.fail_dir) == (1, 1, 0)
+    for regul in (P.regularizebeliefs_bynodesubtree_, P.regularizebeliefs_onschedule_):
+        pcgb.init_beliefs_reset_fromfactors_()
+        pcgb.init_messagecalibrationflags_reset_()
+        caplog.clear()
+        regul(pcgb, cg)
+        with caplog.at_level(logging.ERROR):
+            assert P.calibrate_(pcgb, sched)[0]
+        assert not [r for r in caplog.records if r.levelno >= logging.ERROR]
+    # beliefs without factors (the setup of the message_schedules.md doctest)
+    b, (n2c, n2f, n2fix, n2d, c2n) = OB.allocatebeliefs([g["x_in_tiplabels_order"]], tips, onet, cg, model)
+    from helpers import product_beliefs_from_oracle
+    p0 = P.ClusterGraphBelief(product_beliefs_from_oracle(b), n2c, n2f, n2fix, c2n)
+    P.regularizebeliefs_bynodesubtree_(p0, cg)
+    caplog.clear()
+    with caplog.at_level(logging.INFO):
+        assert P.calibrate_(p0, sched, 100, auto=True, info=True) == (True, True)
+    assert g["info_line_without_factors"] in caplog.text

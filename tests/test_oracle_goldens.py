@@ -4,6 +4,7 @@ reference's tests hold for the hot path (tests/golden/reference_goldens.json)
 and against the independent dense-MVN log-likelihood.
 Julia's `≈` is rtol = sqrt(eps) ~ 1.5e-8; we hold the oracle to RTOL below.
 """
+import os
 import numpy as np
 import pytest
 
@@ -497,3 +498,46 @@ def test_ltrip_goldens():
                 ON.random_network(int(rng.integers(5, 50)), int(rng.integers(0, 12)), rng))
         cg = as_graph(P.ltrip(OCG.nodefamilies(net2)))
         assert connected(cg) and OCG.check_runningintersection(cg, net2) and OCG.isfamilypreserving(cg, net2)
+
+
+def _lipson_bethe():
+    import pgbp_amd as P
+    from helpers import network_from_newick_file
+    g = G["doctests_lipson2020b"]
+    net, names, onet, tips = network_from_newick_file(P, os.path.join(os.path.dirname(__file__), "golden", "lipson_2020b.phy"))
+    assert (net.nnodes, sum(len(nf) - 1 for nf in net.node2family), len(tips), net.nhybrids) == \
+        (g["nodes"], g["edges"], g["tips"], g["hybrids"])
+    cn, ed, sn = P.bethe(net.node2family)
+    labels = ["".join(names[v - 1] for v in c) for c in cn]
+    cg = OB.ClusterGraph(list(zip(labels, cn)), [(a, b, s) for (a, b), s in zip(ed, sn)], "Bethe")
+    return g, net, onet, tips, cg
+
+
+def test_regularization_and_schedule_doctests_on_the_lipson_network():
+    """docs/src/man/regularization.md:133-200 and message_schedules.md:55-75 (Lipson et al. network, Bethe graph, schedule
+    from spanningtrees_clusterlist): without regularisation one iteration reports exactly the two ill-defined messages
+    the doctest prints (one per schedule tree: cluster names, integrated indices); after regularizebeliefs_bynodesubtree!
+    or regularizebeliefs_onschedule! none; with beliefs that carry no factors (the second doctest's setup) calibration is
+    reached at iteration 1, schedule tree 2.  This pins the whole host chain cluster graph -> spanning trees -> message
+    order (Graphs.jl's kruskal_mst / induced_subgraph / dfs_parents / topological_sort as restated)."""
+    g, net, onet, tips, cg = _lipson_bethe()
+    sched = OCG.spanningtrees_clusterlist(cg, onet)
+    assert len(sched) == 2
+    model = make_model(g["model"])
+    cgb = oracle_setup(onet, cg, model, [g["x_in_tiplabels_order"]], tips)
+    log = []
+    OC.calibrate(cgb, sched, 1, log=log)
+    assert [t for lvl, t in log if lvl == "error"] == g["errors_without_regularization"]
+    for regul in ("bynodesubtree", "onschedule"):
+        cgb.init_beliefs_reset_fromfactors()
+        cgb.init_messagecalibrationflags_reset()
+        getattr(OB, "regularizebeliefs_" + regul)(cgb)
+        log = []
+        assert OC.calibrate(cgb, sched, 1, log=log)[0] and not log
+    b, (n2c, n2f, n2fix, n2d, c2n) = OB.allocatebeliefs([g["x_in_tiplabels_order"]], tips, onet, cg, model)
+    cgb0 = OB.ClusterGraphBelief(b, n2c, n2f, n2fix, c2n)          # no assignfactors!
+    cgb0.init_beliefs_reset_fromfactors()
+    OB.regularizebeliefs_bynodesubtree(cgb0)
+    log = []
+    assert OC.calibrate(cgb0, sched, 100, auto=True, info=True, log=log) == (True, True)
+    assert log == [("info", g["info_line_without_factors"])]
