@@ -112,6 +112,12 @@ int  pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t*
 /* level_nfast[n_levels]: how many tasks of each level (they come first) run on the register-resident
  * kernel; the rest run on the generic in-LDS kernel. */
 int  pgbp_plan_level_nfast(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_nfast);
+/* Dataflow form of a traversal that the register-resident kernel runs whole (one launch; a task waits for the arrival
+ * counters of its operands instead of for a level boundary).  n_tasks = 0: the traversal has no such form.
+ * records[n_tasks * k * 7]: per record {valid, message id, sender, receiver, arrivals at the sender to wait for,
+ * arrivals at the receiver to wait for, arrivals it signals}. */
+int  pgbp_plan_dataflow_sizes(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_tasks, int32_t* k);
+int  pgbp_plan_dataflow(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* records);
 const char* pgbp_plan_last_error(const pgbp_plan* p);
 
 /* ---- engine lifetime ------------------------------------------------------------------ */

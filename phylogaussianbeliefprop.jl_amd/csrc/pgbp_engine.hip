@@ -24,6 +24,7 @@ struct DevTraversal {
   int32_t* d_task_off = nullptr;
   Entry* d_entries = nullptr;
   FEntry* d_fentries = nullptr;
+  FEntry* d_dfentries = nullptr;  // the traversal's dataflow form (Traversal::dfentries), if it has one
 };
 
 }  // namespace
@@ -47,6 +48,7 @@ struct pgbp_engine {
   double* d_eps = nullptr;          // [n_sites][n_clusters] regularisation scratch
   unsigned long long* d_fail = nullptr;
   int32_t* d_poison = nullptr;      // [n_sites][n_clusters]
+  int32_t* d_dcnt = nullptr;        // [n_sites][n_clusters] arrival counters of a dataflow launch
   int32_t* d_iscal = nullptr;       // [n_sites]
   int32_t* d_iscal_hist = nullptr;  // [hist_cap][n_sites]
   int64_t hist_cap = 0;
@@ -251,6 +253,7 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_task_off) (void)hipFree(d.d_task_off);
       if (d.d_entries) (void)hipFree(d.d_entries);
       if (d.d_fentries) (void)hipFree(d.d_fentries);
+      if (d.d_dfentries) (void)hipFree(d.d_dfentries);
     }
     v->clear();
   }
@@ -289,7 +292,22 @@ void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, uns
     (void)hipEventRecord(a, e->st);
   }
   int launches = 0;
-  for (int L = 0; L < nlev; ++L) {
+  // OPT-IN (PGBP_DATAFLOW=1): a traversal that the register-resident kernel runs whole goes out as ONE dataflow launch
+  // (build_dataflow in pgbp_plan.cpp): tasks wait for the arrival counters of their operands instead of for a kernel
+  // boundary per level.  Bit-identical results, but measured slower on the 50 000-tip tree (1.16 ms per calibrate
+  // against 1.02 ms): on an idle chip a hand-off inside the launch costs what a kernel boundary costs (5.6 against
+  // 5.9 us per level on a path of 32-dim clusters), and under the load of the streaming tasks that now run beside the
+  // chain its poll, acquire, drain and counter add each queue behind thousands of loads.
+  // residual_kldiv! reads receivers between levels, so it always keeps the level launches.
+  static const bool dataflow_on = [] { const char* v = getenv("PGBP_DATAFLOW"); return v && v[0] == '1'; }();
+  const bool dataflow = dataflow_on && d.d_dfentries && !kl && !e->layout_sm && tr.df_tasks > 0;
+  if (dataflow) {
+    (void)hipMemsetAsync(e->d_dcnt, 0, sizeof(int32_t) * (((size_t)e->plan.n_sites * e->plan.n_clusters + 3) / 4 * 4),
+                         e->st);
+    launch_level_fast16(S, d.d_dfentries, tr.df_k, tr.df_tasks, e->plan.n_sites, seq_base, stop_below, e->st, e->d_dcnt);
+    launches = 1;
+  }
+  for (int L = 0; L < nlev && !dataflow; ++L) {
     const int t0 = tr.level_off[L], nt = tr.level_off[L + 1] - t0;
     const int nf = tr.level_nfast[L];
     launch_level_fast16(S, d.d_fentries + tr.level_fbase[L], tr.level_fk[L], nf, e->plan.n_sites, seq_base,
@@ -376,7 +394,7 @@ void pgbp_destroy(pgbp_engine* e) {
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
                   (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_flags_alt, (void*)e->d_status_alt,
                   (void*)e->d_klflags_alt, (void*)e->d_poison_alt, (void*)e->d_kldiv_alt, (void*)e->d_fail, (void*)e->d_poison,
-                  (void*)e->d_iscal,
+                  (void*)e->d_dcnt, (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
                   (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_bdim, (void*)e->d_rdim,
@@ -451,6 +469,7 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   }
   if ((rc = dev_alloc(e, &e->d_fail, ns))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_poison, ns * (size_t)p.n_clusters))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_dcnt, (ns * (size_t)p.n_clusters + 3) / 4 * 4))) return bail(rc);  // zeroed 16 bytes at a time
   if ((rc = dev_alloc(e, &e->d_iscal, ns))) return bail(rc);
   if ((rc = upload(e, &e->d_boff, p.boff))) return bail(rc);
   if ((rc = upload(e, &e->d_packed_off, p.packed_off))) return bail(rc);
@@ -642,7 +661,8 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       DevTraversal& d = dir == 0 ? e->dpost[t] : e->dpre[t];
       if ((rc = upload(e, &d.d_task_off, tr.task_off))) break;
       if ((rc = upload(e, &d.d_entries, tr.entries))) break;
-      rc = upload(e, &d.d_fentries, tr.fentries);
+      if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
+      if (!tr.dfentries.empty()) rc = upload(e, &d.d_dfentries, tr.dfentries);
     }
   }
   if (rc) {  // out of device memory half way: leave the engine without a schedule rather than with half of one

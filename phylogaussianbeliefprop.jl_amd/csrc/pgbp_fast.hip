@@ -213,6 +213,77 @@ __device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double
   }
 }
 
+// ---- dataflow launch (DF): hand-offs between workgroups inside one launch ---------------------------------------------
+// Producer: every store of a receiver block is write-through (sc1), the storing wave drains them (s_waitcnt vmcnt(0)),
+// then ONE lane adds to the receiver's arrival counter (agent-scope atomic).  Consumer: one wave polls that ONE word
+// (relaxed, agent scope, s_sleep between polls, bounded), then one agent-scope acquire, then plain loads.  Receiver
+// records are whole 128-byte lines of their own (kRecAlign), so no line is shared with another producer.
+typedef unsigned int df_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kDfMaxSpins = 1 << 18;  // about a second: a dependency that never arrives ends as a reported failure
+// 16 / 32 bytes, write-through.  Inline asm on the address registers the plain store would use (a buffer descriptor
+// costs the instance its fourth wave per SIMD); the compiler does not count these stores in vmcnt, which is safe
+// where they stand: behind the last load of the kernel, in front of an explicit s_waitcnt vmcnt(0).
+// sbase: wave-uniform record base (SGPR pair), idx: this lane's element index inside the record
+__device__ __forceinline__ void df_store16(double* sbase, int idx, double x, double y) {
+  df_u32x4 v;
+  const double xy[2] = {x, y};
+  __builtin_memcpy(&v, xy, 16);
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(idx * 8), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void df_store32(double* sbase, int idx, double x, double y, double z, double w) {
+  df_u32x4 lo, hi;
+  const double xy[2] = {x, y}, zw[2] = {z, w};
+  __builtin_memcpy(&lo, xy, 16);
+  __builtin_memcpy(&hi, zw, 16);
+  asm volatile("global_store_dwordx4 %0, %1, %3 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc1\n\ts_nop 1" ::"v"(idx * 8),
+               "v"(lo), "v"(hi), "s"(sbase)
+               : "memory");
+}
+__device__ __forceinline__ void df_store8(double* p, double x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool df_wait(const int32_t* cnt, int need) {
+  // the whole poll loop is one asm statement: as a C++ loop it costs the kernel 6 VGPRs (and its fourth wave per SIMD)
+  int seen, spins, tmp;
+  asm volatile(
+      "s_mov_b32 %1, 0\n"
+      ".Ldf_poll_%=:\n\t"
+      "global_load_dword %2, %3, %4 sc1\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "v_readfirstlane_b32 %0, %2\n\t"
+      "s_cmp_ge_i32 %0, %5\n\t"
+      "s_cbranch_scc1 .Ldf_done_%=\n\t"
+      "s_add_u32 %1, %1, 1\n\t"
+      "s_cmp_lt_u32 %1, %6\n\t"
+      "s_cbranch_scc0 .Ldf_done_%=\n\t"
+      "s_sleep 1\n\t"
+      "s_branch .Ldf_poll_%=\n"
+      ".Ldf_done_%=:"
+      : "=&s"(seen), "=&s"(spins), "=&v"(tmp)
+      : "v"(0), "s"(cnt), "s"(need), "s"(kDfMaxSpins)
+      : "scc", "memory");
+  return seen >= need;
+}
+// the receiver block, write-through: same element placement as store_blk
+template <bool BS, bool ODD>
+__device__ __forceinline__ void df_store_blk(double* __restrict__ base, int ld, int a, int b, bool up, bool act, int kidx,
+                                             const Blk& v, int n) {
+  if constexpr (BS) {
+    if (up) df_store32(base, kidx, v.x, v.y, v.z, v.w);
+  } else if constexpr (ODD) {
+    if (act) {
+      const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
+      if (r0 < n && c0 < n) df_store8(base + r0 + (int64_t)ld * c0, v.x);
+      if (r1 < n && c0 < n) df_store8(base + r1 + (int64_t)ld * c0, v.y);
+      if (r0 < n && c1 < n) df_store8(base + r0 + (int64_t)ld * c1, v.z);
+      if (r1 < n && c1 < n) df_store8(base + r1 + (int64_t)ld * c1, v.w);
+    }
+  } else if (act) {
+    df_store16(base, 2 * a + ld * (2 * b), v.x, v.y);
+    df_store16(base, 2 * a + ld * (2 * b + 1), v.z, v.w);
+  }
+}
+
 // One workgroup = one task; wave w of the workgroup = message w of the task (records padded to K per task).
 //   * accumulate tasks (postorder, several children into one receiver block): every wave computes its
 //     message and divides; waves > 0 hand their delta to wave 0 through LDS; wave 0 adds the deltas in the
@@ -222,13 +293,15 @@ __device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double
 // BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
 // ODD: the sepsets really have PR = P - 1 variables (an odd trait count): same lane grid, one phantom variable per
 // block, unit precision where it is integrated so that its pivot is 1 (log det and quadratic term unchanged).
-template <int P, bool BS, bool ODD>
+// DF: the dataflow launch (build_dataflow in pgbp_plan.cpp): the records carry arrival counts to wait for, dcnt is the
+// [n_sites][n_clusters] arrival counter array (zeroed before the launch); see the hand-off helpers above.
+template <int P, bool BS, bool ODD, bool DF = false>
 #ifdef PGBP_TRACE_LIGHT
 __attribute__((amdgpu_waves_per_eu(4, 4)))  // keep the production kernel's occupancy despite the extra live values
 #endif
 __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEntry* __restrict__ recs_arg, int K_arg,
                                                        unsigned long long seq_base_arg,
-                                                       unsigned long long stop_below_arg) {
+                                                       unsigned long long stop_below_arg, int32_t* __restrict__ dcnt) {
   // The 0x90-byte kernarg segment spans three cache lines and the compiler fetches arguments one group at a
   // time, each a dependent round trip on the critical path of a narrow level.  Pinning the plain scalars of
   // all three lines in SGPRs here makes ONE batch of scalar loads touch every line; the pointer arguments are
@@ -319,6 +392,19 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
   double2 sh = make_double2(0.0, 0.0);
   double sg = 0.0;
   int info = 0;
+  if constexpr (DF) {
+    if (state == 1) {
+      const int wf = provider ? en.wait_from : 0, wt = own ? (en.wait_sig & 0xFFFFFF) : 0;
+      bool arrived = true;
+      if (wf > 0) arrived = df_wait(dcnt + (int64_t)site * S.n_clusters + en.from_b, wf);
+      if (wt > 0 && arrived) arrived = df_wait(dcnt + (int64_t)site * S.n_clusters + en.to_b, wt);
+      if (wf > 0 || wt > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!arrived) {  // never in a correct schedule: reported like a failed message, with an impossible pivot index
+        state = 2;
+        info = kDfTimeoutInfo;
+      }
+    }
+  }
   if (state == 1) {
     const int poisoned = S.poison[(int64_t)site * S.n_clusters + en.from_b];
     // ---- every load of this message is issued before any arithmetic; the sender (the largest operand and
@@ -453,7 +539,16 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
             double mant = 1.0, quad = 0.0;
             int expo = 0;
             PGBP_TR(2);
+            if constexpr (DF) {
+              // the prefetched sepset block waits in this wave's (idle) hand-over slot: with the poll in front the
+              // instance would otherwise need 134 VGPRs and lose its fourth wave per SIMD
+              *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(sJ.x, sJ.y, sJ.z, sJ.w);
+            }
             info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
+            if constexpr (DF) {
+              const double4 v = *reinterpret_cast<const double4*>(slot + kSlotJ + 4 * lane);
+              sJ = Blk{v.x, v.y, v.z, v.w};
+            }
             PGBP_TR_NOWAIT(3);
             if (info == 0) {
               const double logdet = log(mant) + (double)expo * PGBP_LN2;
@@ -533,13 +628,15 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
     }
   } else if (state >= 2 && lane == 0) {
     // not positive definite, or downstream of a failure: nothing of this message is applied
-    S.poison[(int64_t)site * S.n_clusters + en.to_b] = 1;
+    if constexpr (DF) __hip_atomic_store(&S.poison[(int64_t)site * S.n_clusters + en.to_b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else S.poison[(int64_t)site * S.n_clusters + en.to_b] = 1;
     if (state == 2) {
       S.status[(int64_t)site * S.n_msgs + en.msg] = info;
       atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
     }
   }
   // ---- mult! (src/beliefupdates.jl:483-488)
+  [[maybe_unused]] bool df_poison_to = false;  // DF: a wave of this accumulate task failed; wave 0 publishes the poison mark
   if (accum) {
     // waves > 0 publish their delta; wave 0 adds them in the reference's order
     if (wave > 0) {
@@ -559,7 +656,10 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
       tg += dg;
       for (int w = 1; w < K; ++w) {
         const double* src = fast_lds + w * kSlotDoubles;
-        if ((int)src[kSlotStatus] != 1) break;  // the reference stops at the first failing message
+        if ((int)src[kSlotStatus] != 1) {  // the reference stops at the first failing message
+          if constexpr (DF) df_poison_to = (int)src[kSlotStatus] >= 2;
+          break;
+        }
         const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
         tJ = Blk{tJ.x + v.x, tJ.y + v.y, tJ.z + v.z, tJ.w + v.w};
         if (b == 0) {
@@ -574,7 +674,31 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
     th[0] += dh0; th[1] += dh1;
     tg += dg;
   }
-  if (own && state == 1) {
+  if constexpr (DF) {
+    if (own && state == 1) {
+      if (accum || has_block) {
+        df_store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
+        if (act && b == 0) {
+          if constexpr (ODD) {
+            if (2 * a < PR) df_store8(to + tH0 + 2 * a, th[0]);
+            if (2 * a + 1 < PR) df_store8(to + tH0 + 2 * a + 1, th[1]);
+          } else {
+            df_store16(to + tH0, 2 * a, th[0], th[1]);
+          }
+        }
+      }
+      if (lane == 0) df_store8(to + tG0, tg);
+    }
+    if (own && en.valid) {
+      // the arrival signal: this wave's write-through stores (block, poison mark) have left the CU, then one add
+      if (df_poison_to && lane == 0)
+        __hip_atomic_store(&S.poison[(int64_t)site * S.n_clusters + en.to_b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_fetch_add(dcnt + (int64_t)site * S.n_clusters + en.to_b, (int)((unsigned int)en.wait_sig >> 24),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (own && state == 1) {
     if (accum || has_block) {
       store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
       if (act && b == 0) store_pair<ODD>(to + tH0, a, th[0], th[1], PR);
@@ -617,17 +741,26 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
 
 template <int P, bool ODD>
 static void launch_fast_p(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
-                          unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
+                          unsigned long long seq_base, unsigned long long stop_below, int32_t* dcnt, hipStream_t st) {
   const size_t lds = sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K;
+  int32_t* none = nullptr;
   if constexpr (!ODD) {
     if (S.bs16) {
-      hipLaunchKernelGGL((bp_level_fast16<P, true, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
-                         seq_base, stop_below);
+      if (dcnt)
+        hipLaunchKernelGGL((bp_level_fast16<P, true, false, true>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S,
+                           d_recs, K, seq_base, stop_below, dcnt);
+      else
+        hipLaunchKernelGGL((bp_level_fast16<P, true, false, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S,
+                           d_recs, K, seq_base, stop_below, none);
       return;
     }
   }
-  hipLaunchKernelGGL((bp_level_fast16<P, false, ODD>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs, K,
-                     seq_base, stop_below);
+  if (dcnt)
+    hipLaunchKernelGGL((bp_level_fast16<P, false, ODD, true>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs,
+                       K, seq_base, stop_below, dcnt);
+  else
+    hipLaunchKernelGGL((bp_level_fast16<P, false, ODD, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs,
+                       K, seq_base, stop_below, none);
 }
 
 // ---- assignfactors! for MvFullBrownianMotion on a tree (pgbp_bm_tree of include/pgbp.h), lane-blocked ---------------
@@ -782,24 +915,24 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
 // 1 for P = 2), and each instance once more for the odd dimension P - 1 (plain layout, a phantom variable per block);
 // the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
-                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
+                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st, int32_t* dcnt) {
   if (ntasks <= 0) return;
   switch (S.fast_p) {  // the real sepset dimension; odd ones run on the next even instance with a phantom variable
-    case 16: launch_fast_p<16, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 15: launch_fast_p<16, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 14: launch_fast_p<14, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 13: launch_fast_p<14, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 12: launch_fast_p<12, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 11: launch_fast_p<12, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 10: launch_fast_p<10, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 9: launch_fast_p<10, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 8: launch_fast_p<8, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 7: launch_fast_p<8, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 6: launch_fast_p<6, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 5: launch_fast_p<6, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 4: launch_fast_p<4, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 3: launch_fast_p<4, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
-    case 2: launch_fast_p<2, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, st); break;
+    case 16: launch_fast_p<16, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 15: launch_fast_p<16, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 14: launch_fast_p<14, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 13: launch_fast_p<14, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 12: launch_fast_p<12, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 11: launch_fast_p<12, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 10: launch_fast_p<10, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 9: launch_fast_p<10, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 8: launch_fast_p<8, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 7: launch_fast_p<8, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 6: launch_fast_p<6, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 5: launch_fast_p<6, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 4: launch_fast_p<4, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 3: launch_fast_p<4, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 2: launch_fast_p<2, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
     default: break;  // the planner never marks a task fast for another P
   }
 #ifdef PGBP_TRACE

@@ -49,7 +49,10 @@ struct FEntry {
   uint8_t src_wave;      // wave of the workgroup that computes this record's marginal (== own index unless reused)
   uint8_t mode;          // bit 0: this wave loads+stores the receiver block itself; bit 1: accumulate task
                          // (wave 0 owns the receiver block, the other waves hand their delta over through LDS)
-  int32_t pad[2];
+  // dataflow launch only (Traversal::dfentries; zero in the level records):
+  int32_t wait_from;     // poll the sender's arrival counter up to this many messages before loading it (0: no wait)
+  int32_t wait_sig;      // low 24 bits: the same for the receiver block this wave owns; high 8 bits: what the wave adds
+                         // to the receiver's arrival counter once its stores have drained
 };
 static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
 constexpr int kFOwn = 1, kFAccum = 2;
@@ -65,6 +68,11 @@ struct Traversal {
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;
+  // DATAFLOW form of a traversal that the register-resident kernel runs whole (pgbp_plan.cpp, build_dataflow):
+  // every task of the traversal in ONE launch, ordered so that a task only ever waits for workgroups with a smaller
+  // index (postorder: receivers far from the root first; preorder: senders near the root first), df_k records per task
+  std::vector<FEntry> dfentries;
+  int32_t df_k = 0, df_tasks = 0;
 };
 
 struct Tree {

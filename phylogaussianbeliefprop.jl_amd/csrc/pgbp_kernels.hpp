@@ -49,8 +49,12 @@ void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry*
                       int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
 
 // register-resident kernel for sepsets of dimension 16 (pgbp_fast.hip)
+// dcnt != nullptr: the DATAFLOW launch -- d_recs are a traversal's dfentries (all its tasks), dcnt the zeroed
+// [n_sites][n_clusters] arrival counters (pgbp_plan.cpp, build_dataflow)
 void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
-                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
+                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st,
+                         int32_t* dcnt = nullptr);
+constexpr int kDfTimeoutInfo = (1 << 20) - 1;  // "pivot index" reported when a dataflow wait gave up (never expected)
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
                       double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);

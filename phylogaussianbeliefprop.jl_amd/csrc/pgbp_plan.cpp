@@ -445,6 +445,80 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
   }
 }
 
+// DATAFLOW form of one traversal (Traversal::dfentries): all its tasks in one launch of the register-resident kernel.
+// A task may start as soon as the messages its operands depend on have arrived, which the kernel learns from one
+// arrival counter per cluster (messages received so far in this traversal); the level barrier -- a kernel boundary
+// plus the slowest wave of every level, 76 times per calibrate on a 50 000-tip tree -- is gone.  The order of the
+// grid makes waiting safe: a workgroup only ever waits for workgroups with a smaller index, and the hardware
+// dispatches in index order (per XCD), so the resident workgroup with the smallest index can always finish.
+//   postorder: tasks sorted by the depth of their receiver, deepest first (a task's senders are one deeper);
+//   preorder:  tasks sorted by the depth of their sender, root first (the sender's own receipt is one shallower);
+// ties keep the level order, so the order of the deltas added into one receiver is the one of the level schedule.
+// Returns false (and leaves the form empty) if the traversal is not all register-resident or a count does not fit.
+static bool build_dataflow(const Plan& p, const Tree& T, Traversal& tr, bool postorder) {
+  tr.dfentries.clear();
+  tr.df_k = tr.df_tasks = 0;
+  const int nlev = (int)tr.level_off.size() - 1;
+  if (nlev <= 0 || T.pa.empty()) return false;
+  std::vector<int32_t> depth(p.n_clusters, -1);
+  depth[T.pa[0]] = 0;
+  for (size_t i = 0; i < T.pa.size(); ++i) depth[T.ch[i]] = depth[T.pa[i]] + 1;
+  struct TaskRef { int64_t rec0; int32_t k, key; };
+  std::vector<TaskRef> tasks;
+  std::vector<int32_t> inbound(p.n_clusters, 0), delivered(p.n_clusters, 0);
+  int K = 1;
+  for (int L = 0; L < nlev; ++L) {
+    const int nt = tr.level_off[L + 1] - tr.level_off[L];
+    if (tr.level_nfast[L] != nt) return false;
+    const int k = tr.level_fk[L];
+    K = std::max(K, k);
+    for (int q = 0; q < nt; ++q) {
+      const int64_t r0 = tr.level_fbase[L] + (int64_t)q * k;
+      const FEntry& f0 = tr.fentries[r0];  // record 0 of a task is always valid
+      const int c = postorder ? f0.to_b : f0.from_b;
+      if (!f0.valid || depth[c] < 0) return false;
+      tasks.push_back({r0, k, postorder ? -depth[c] : depth[c]});
+      for (int w = 0; w < k; ++w)
+        if (tr.fentries[r0 + w].valid) ++inbound[tr.fentries[r0 + w].to_b];
+    }
+  }
+  std::stable_sort(tasks.begin(), tasks.end(), [](const TaskRef& x, const TaskRef& y) { return x.key < y.key; });
+  std::vector<FEntry> out;
+  out.reserve(tasks.size() * (size_t)K);
+  for (const TaskRef& t : tasks) {
+    int nvalid = 0;
+    bool accum = false;
+    for (int w = 0; w < t.k; ++w) {
+      nvalid += tr.fentries[t.rec0 + w].valid;
+      accum |= (tr.fentries[t.rec0 + w].mode & kFAccum) != 0;
+    }
+    for (int w = 0; w < K; ++w) {
+      FEntry f{};
+      if (w < t.k) f = tr.fentries[t.rec0 + w];
+      else if (accum) f.mode = kFAccum;  // padding wave of an accumulate task: joins the barriers, ends the list
+      f.wait_from = f.wait_sig = 0;
+      if (f.valid) {
+        if (f.src_wave == w) {  // this wave reads the sender: every message into the sender must have arrived
+          if (delivered[f.from_b] != inbound[f.from_b]) return false;  // (not a topological order: cannot happen)
+          f.wait_from = inbound[f.from_b];
+        }
+        if (f.mode & kFOwn) {
+          const int nsig = accum ? nvalid : 1;
+          if (delivered[f.to_b] >= (1 << 24) || nsig > 255) return false;
+          f.wait_sig = delivered[f.to_b] | (nsig << 24);
+        }
+      }
+      out.push_back(f);
+    }
+    for (int w = 0; w < t.k; ++w)
+      if (tr.fentries[t.rec0 + w].valid) ++delivered[tr.fentries[t.rec0 + w].to_b];
+  }
+  tr.dfentries.swap(out);
+  tr.df_k = K;
+  tr.df_tasks = (int32_t)tasks.size();
+  return true;
+}
+
 static bool tree_all_fast(const Tree& t) {
   for (const Traversal* tr : {&t.post, &t.pre})
     for (size_t L = 0; L + 1 < tr->level_off.size(); ++L)
@@ -505,6 +579,13 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
     static const bool fuse_on = getenv("PGBP_CHAIN_FUSION") != nullptr;
     const bool uni_batch = p.max_dim <= 2 && p.n_sites >= 8;
     if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, true);
+    if (tree_all_fast(T)) {
+      if (!build_dataflow(p, T, T.post, true) || !build_dataflow(p, T, T.pre, false)) {
+        T.post.dfentries.clear();
+        T.pre.dfentries.clear();
+        T.post.df_tasks = T.pre.df_tasks = 0;
+      }
+    }
   }
   p.trees.swap(trees);
   p.all_fast = !p.trees.empty();
@@ -592,6 +673,26 @@ int pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* 
     if (entry_msg) entry_msg[i] = tr->entries[i].msg;
     if (entry_edge) entry_edge[i] = tr->entries[i].edge;
     if (entry_reuse) entry_reuse[i] = tr->entries[i].reuse;
+  }
+  return PGBP_OK;
+}
+
+int pgbp_plan_dataflow_sizes(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_tasks, int32_t* k) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr || !n_tasks || !k) return PGBP_ERR_INVALID;
+  *n_tasks = tr->df_tasks;
+  *k = tr->df_k;
+  return PGBP_OK;
+}
+
+int pgbp_plan_dataflow(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* records) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr || !records) return PGBP_ERR_INVALID;
+  for (size_t i = 0; i < tr->dfentries.size(); ++i) {
+    const pgbp::FEntry& f = tr->dfentries[i];
+    int32_t* r = records + 7 * i;
+    r[0] = f.valid; r[1] = f.msg; r[2] = f.from_b; r[3] = f.to_b;
+    r[4] = f.wait_from; r[5] = f.wait_sig & 0xFFFFFF; r[6] = (int32_t)((uint32_t)f.wait_sig >> 24);
   }
   return PGBP_OK;
 }

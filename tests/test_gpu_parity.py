@@ -1095,6 +1095,21 @@ def test_chain_fusion_opt_in_differential_fuzz(P):
     assert out.returncode == 0 and "80 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
+def test_dataflow_launch_opt_in_differential_fuzz(P):
+    """PGBP_DATAFLOW=1 (opt-in, read once per process -> child process): a traversal that the register-resident kernel
+    runs whole goes out as one launch whose tasks wait for arrival counters (pgbp_plan.cpp build_dataflow; write-through
+    stores, agent-scope counter adds, poll + acquire in pgbp_fast.hip).  The differential fuzz against the plain-C
+    sequential engine (beliefs 1e-8, flags, first failure of the reference's order, several sites) must hold unchanged."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PGBP_DATAFLOW="1")
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "120", "91"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 @pytest.mark.parametrize("argv", [
     ["--ntips", "400", "--traits", "16", "--steps", "2", "--warmup", "1", "--cpu-budget", "0.5"],
     ["--ntips", "300", "--traits", "8", "--graph", "bethe", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],

@@ -709,3 +709,71 @@ def test_read_newick_gives_the_preorders_the_reference_tests_imply():
     want = [x if isinstance(x, str) else inv[tuple(sorted(x))] for x in g["preorder"]]
     assert names == want
     assert [names[v - 1] for v in P.triangulate_minfill(P.moralize(net.node2family))] == g["minfill_order_names"]
+
+
+@pytest.mark.parametrize("ntips,p,kind", [(3, 2, "random"), (40, 4, "random"), (500, 16, "random"), (300, 8, "random"),
+                                          (30, 16, "caterpillar"), (70, 16, "poly4"), (120, 5, "random")])
+def test_dataflow_form_invariants(ntips, p, kind):
+    """The one-launch form of a traversal (build_dataflow in pgbp_plan.cpp): replaying the grid in index order, every
+    arrival count a record waits for has been signalled completely by workgroups with a SMALLER index (so a workgroup
+    never waits for one dispatched after it), the counts are the ones the data dependencies ask for, every message of
+    the level schedule appears once, and the messages into one receiver keep the order of the level schedule."""
+    rng = np.random.default_rng(ntips + p)
+    if kind == "random":
+        tr = S.random_tree(ntips, rng)
+    elif kind == "caterpillar":
+        tr = S.caterpillar_tree(ntips, rng)
+    else:
+        tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0, lib.pgbp_plan_last_error(pl)
+    assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
+    nclusters = prob.nclusters
+    for d in (0, 1):
+        lo, to, em, ee, er = _traversal(lib, pl, 0, d)
+        nf = np.zeros(len(lo) - 1, np.int32)
+        assert lib.pgbp_plan_level_nfast(pl, 0, d, L.i32p(nf)) == 0
+        all_fast = all(nf[i] == lo[i + 1] - lo[i] for i in range(len(lo) - 1))
+        nt, k = C.c_int32(), C.c_int32()
+        assert lib.pgbp_plan_dataflow_sizes(pl, 0, d, C.byref(nt), C.byref(k)) == 0
+        if not all_fast:
+            assert nt.value == 0
+            continue
+        assert nt.value == len(to) - 1 and 1 <= k.value <= 4
+        rec = np.zeros((nt.value, k.value, 7), np.int32)
+        assert lib.pgbp_plan_dataflow(pl, 0, d, L.i32p(rec)) == 0
+        # what each cluster receives in this traversal, in level-schedule order
+        level_order = {}
+        for e in range(len(em)):
+            k_sep, side = divmod(int(em[e]), 2)
+            rcv = int(prob.sepset_clusters[k_sep][side])
+            level_order.setdefault(rcv, []).append(int(em[e]))
+        inbound = {c: len(v) for c, v in level_order.items()}
+        arrived = np.zeros(nclusters, int)
+        seen_order = {}
+        msgs = []
+        for t in range(nt.value):
+            pending = []
+            for w in range(k.value):
+                valid, msg, snd, rcv, wait_from, wait_to, nsig = (int(x) for x in rec[t, w])
+                if not valid:
+                    assert wait_from == 0 and wait_to == 0 and nsig == 0
+                    continue
+                msgs.append(msg)
+                seen_order.setdefault(rcv, []).append(msg)
+                # the sender is complete: everything it receives in this traversal has arrived already
+                assert arrived[snd] == inbound.get(snd, 0), (d, t, w)
+                assert wait_from in (0, inbound.get(snd, 0))            # 0: a wave that reuses another wave's marginal
+                if wait_from == 0 and inbound.get(snd, 0) > 0:
+                    assert any(int(rec[t, v, 2]) == snd and int(rec[t, v, 4]) > 0 for v in range(k.value))
+                if nsig:
+                    assert wait_to == arrived[rcv]                      # earlier tasks into the same receiver
+                    pending.append((rcv, nsig))
+            for rcv, nsig in pending:
+                arrived[rcv] += nsig
+        assert sorted(msgs) == sorted(int(m) for m in em)
+        for c, n_in in inbound.items():
+            assert arrived[c] == n_in
+            assert seen_order[c] == level_order[c]
+    lib.pgbp_plan_destroy(pl)
