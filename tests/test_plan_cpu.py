@@ -777,3 +777,106 @@ def test_dataflow_form_invariants(ntips, p, kind):
             assert arrived[c] == n_in
             assert seen_order[c] == level_order[c]
     lib.pgbp_plan_destroy(pl)
+
+
+def _header_structs_and_functions():
+    """(struct name -> [(C type, field)], function name -> (return type, [C argument types])) of include/pgbp.h."""
+    hdr = open(os.path.join(ROOT, "include", "pgbp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    structs = {}
+    for name, body in re.findall(r"typedef struct (pgbp_\w+) \{(.*?)\} \1;", hdr, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if decl:
+                m = re.fullmatch(r"(.*?)\s*(\w+)", decl)
+                fields.append((m.group(1).replace(" *", "*"), m.group(2)))
+        structs[name] = fields
+    funcs = {}
+    for ret, name, args in re.findall(r"^\s*((?:const )?\w+\s*\*?)\s*(pgbp_\w+)\s*\((.*?)\)\s*;", hdr, flags=re.S | re.M):
+        argt = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if a and a != "void":
+                m = re.fullmatch(r"(.*?)\s*(\w+)", a)     # every prototype names its parameters
+                argt.append(m.group(1).replace(" *", "*"))
+        funcs[name] = (" ".join(ret.split()).replace(" *", "*"), argt)
+    return structs, funcs
+
+
+def _c_kind(ctype):
+    """Layout class of a C type as a foreign-function binding sees it."""
+    t = ctype.replace("const ", "").strip()
+    if t.endswith("*"):
+        return "ptr"
+    return {"int32_t": "i32", "int": "i32", "int64_t": "i64", "uint64_t": "u64", "double": "f64", "void": "void"}[t]
+
+
+def test_julia_shim_and_ctypes_mirror_agree_with_the_header():
+    """The Julia @ccall shim (julia/PGBPDevice.jl) cannot run here (no Julia), so its declarations are
+    checked against include/pgbp.h textually: every struct it mirrors has the header's fields in the header's order
+    with the same machine types, and every @ccall names an exported function with the header's argument count, argument
+    classes and return class.  The same for the ctypes structures and prototypes of the Python host mirror."""
+    structs, funcs = _header_structs_and_functions()
+    assert {"pgbp_desc", "pgbp_opts", "pgbp_result", "pgbp_lg_families", "pgbp_lg_params"} <= set(structs)
+    jl = open(os.path.join(ROOT, "phylogaussianbeliefprop.jl_amd", "julia", "PGBPDevice.jl")).read()
+    jkind = {"Int32": "i32", "Cint": "i32", "Int64": "i64", "UInt64": "u64", "Float64": "f64", "Cdouble": "f64",
+             "Cvoid": "void", "Cstring": "ptr"}
+
+    def jl_kind(t):
+        t = t.strip()
+        return "ptr" if t.startswith(("Ptr{", "Ref{")) else jkind[t]
+
+    n_structs = 0
+    for jname, cname, body in re.findall(r"^struct (\w+)\s*# (pgbp_\w+)\n(.*?)^end", jl, flags=re.S | re.M):
+        body = re.sub(r"#.*", "", body)
+        jfields = re.findall(r"(\w+)::([\w{}]+)", body)
+        cfields = structs[cname]
+        assert [f for f, _ in jfields] == [f for _, f in cfields], (jname, cname)
+        assert [jl_kind(t) for _, t in jfields] == [_c_kind(t) for t, _ in cfields], (jname, cname)
+        n_structs += 1
+    assert n_structs >= 5
+    calls = []
+    for m in re.finditer(r"@ccall\(?\s*LIB\.(pgbp_\w+)\(", jl):
+        i, depth = m.end(), 1
+        while depth:                      # the matching parenthesis of the argument list
+            depth += jl[i] in "([{"
+            depth -= jl[i] in ")]}"
+            i += 1
+        ret = re.match(r"::(\w+)", jl[i:])
+        calls.append((m.group(1), jl[m.end():i - 1], ret.group(1)))
+    assert len(calls) >= 15
+    for name, args, ret in calls:
+        assert name in funcs, f"PGBPDevice.jl calls {name}, which include/pgbp.h does not declare"
+        cret, cargs = funcs[name]
+        # split the arguments at top-level commas; each ends in ::Type
+        parts, depth, cur = [], 0, ""
+        for ch in args:
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur)
+        jtypes = [p.rsplit("::", 1)[1] for p in parts]
+        assert len(jtypes) == len(cargs), (name, jtypes, cargs)
+        assert [jl_kind(t) for t in jtypes] == [_c_kind(t) for t in cargs], (name, jtypes, cargs)
+        assert jl_kind(ret) == _c_kind(cret), (name, ret, cret)
+    # the ctypes mirror: structures field by field, prototypes argument by argument
+    ckind = {C.c_int32: "i32", C.c_int: "i32", C.c_int64: "i64", C.c_uint64: "u64", C.c_double: "f64", None: "void"}
+
+    def ct_kind(t):
+        return ckind[t] if t in ckind else "ptr"
+
+    for cname, cls in (("pgbp_desc", L.Desc), ("pgbp_opts", L.Opts), ("pgbp_result", L.Result),
+                       ("pgbp_lg_families", L.LgFamilies), ("pgbp_lg_params", L.LgParams), ("pgbp_bm_tree", L.BmTree)):
+        assert [f for f, _ in cls._fields_] == [f for _, f in structs[cname]], cname
+        assert [ct_kind(t) for _, t in cls._fields_] == [_c_kind(t) for t, _ in structs[cname]], cname
+    for name, (restype, argtypes) in L.SYMBOLS.items():
+        cret, cargs = funcs[name]
+        assert len(argtypes) == len(cargs), name
+        assert [ct_kind(t) for t in argtypes] == [_c_kind(t) for t in cargs], (name, cargs)
+        assert ct_kind(restype) == _c_kind(cret), name
