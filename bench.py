@@ -104,10 +104,11 @@ def whole_job_rate(units_per_rank_step, steps, world, dt):
     return world * units_per_rank_step * steps / dt
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(name="pmc_traffic_latest.json"):
     """HBM bytes per launch of the message kernel from the committed rocprofv3 PMC passes
-    (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json); None if absent."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json; the sites workload: pmc_traffic_sites_latest.json);
+    None if absent."""
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             return json.load(f)
@@ -179,6 +180,13 @@ def run_sites(args, torch, dist, rank, world, local_rank):
     # log-likelihood evaluations (device factor fill + postorder + root integrate) of all local problems per second
     ms_ll = C.c_float()
     check(lib.pgbp_time_enqueued(eng, ll_kind, 3, 0, C.byref(opts), C.byref(ms_ll)))
+    # launches per calibrate (one per level and direction) for the per-launch roofline figures
+    ms_k, nl_k = C.c_float(), C.c_int32()
+    check(lib.pgbp_time_message_kernels(eng, 1, C.byref(opts), C.byref(ms_k), C.byref(nl_k)))
+    n_launches_per_cal = int(nl_k.value)
+    sites_traffic = load_pmc_traffic("pmc_traffic_sites_latest.json")
+    default_size = (world == 1 and args.sites == 1000 and args.site_traits == 8 and args.ntips == 20000 and ou
+                    and args.seed == 3)
     # the one collective of this configuration: all ranks get every problem's log-likelihood
     full = gather_sites(norm, nprob, dist, device="cpu" if os.environ.get("PGBP_BENCH_REHEARSAL") == "1" else f"cuda:{local_rank}")
     total_msgs = msgs_per_cal / max(1, ns) * nprob        # same per-problem count on every rank
@@ -194,7 +202,12 @@ def run_sites(args, torch, dist, rank, world, local_rank):
                                    f"{world} rank(s); one all-gather of per-problem log-likelihoods",
                        "problems_per_rank": ns, "messages_per_problem_per_step": int(msgs_per_cal // max(1, ns))},
             "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                         "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / 8000.0,
+                         # PMC passes of the default-size run (8000 problems, 20 000 tips); not valid for other sizes
+                         "traffic": (sites_traffic or {}).get("hbm_bytes_per_launch") if default_size else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                                         "profiles/pmc_traffic_sites_latest.json)",
+                         "algorithmic_bytes_per_launch": bytes_per_cal / max(1, n_launches_per_cal),
                          "kernel": "bp_level_uni", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate"},
             "ll_evals_per_s": world * ns * 3 / (ms_ll.value * 1e-3),
             "ll_eval_note": "problem log-likelihoods per second: device factor fill + postorder + root integrate (score() body)",

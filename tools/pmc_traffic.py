@@ -10,7 +10,10 @@ re-validated inside the same run on the reset-from-factors copy kernel, whose by
 (the cluster records, read once and written once: `copy_strided_kernel` in the plain layout,
 `copy_records_kernel` -- only the part of each slot in use -- in the packed layout).
 
-usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel]
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel [kernel]]
+  copy_kernel: calibration kernel with a known byte count each way (default copy_strided_kernel; a name without "pgbp::" is
+               looked up as given, e.g. __amd_rocclr_copyBuffer for the site-minor reset of the sites workload)
+  kernel:      the message kernel to reduce (default bp_level_fast16; bp_level_uni for the sites workload)
 """
 import csv
 import json
@@ -29,23 +32,29 @@ def per_kernel(path, counter):
 
 def main():
     f_csv, w_csv, copy_bytes, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
-    ck = "pgbp::" + (sys.argv[5] if len(sys.argv) > 5 else "copy_strided_kernel")
+    ck = sys.argv[5] if len(sys.argv) > 5 else "copy_strided_kernel"
+    if not ck.startswith("__"):
+        ck = "pgbp::" + ck
+    kname = sys.argv[6] if len(sys.argv) > 6 else "bp_level_fast16"
     F = per_kernel(f_csv, "FETCH_SIZE")
     W = per_kernel(w_csv, "WRITE_SIZE")
-    cal_f = 2.0 * 1024 * sum(F[ck]) / len(F[ck])
-    cal_w = 1024 * sum(W[ck]) / len(W[ck])
-    k = "pgbp::bp_level_fast16"
+    have_cal = copy_bytes > 0 and ck in F and ck in W   # copy_bytes 0: calibrated elsewhere (tools/copy8_microbench.hip)
+    cal_f = 2.0 * 1024 * sum(F[ck]) / len(F[ck]) if have_cal else 0.0
+    cal_w = 1024 * sum(W[ck]) / len(W[ck]) if have_cal else 0.0
+    k = "pgbp::" + kname
     n = len(F[k])
     fetch = 2.0 * 1024 * sum(F[k])
     write = 1024 * sum(W[k])
     res = {
-        "kernel": "bp_level_fast16", "launches": n,
+        "kernel": kname, "launches": n,
         "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / len(W[k]),
         "hbm_bytes_per_launch": fetch / n + write / len(W[k]),
         "corrections": "KiB units; FETCH_SIZE x2 (16-B/lane reads on gfx950); WRITE_SIZE exact",
-        "calibration_copy_kernel": {"kernel": ck, "known_bytes_each_way": copy_bytes, "fetch_corrected": cal_f, "write": cal_w,
-                                    "fetch_ratio": cal_f / copy_bytes, "write_ratio": cal_w / copy_bytes},
-        "note": "average over every bp_level_fast16 launch of one bench.py run (postorder and preorder levels)",
+        "calibration_copy_kernel": ({"kernel": ck, "known_bytes_each_way": copy_bytes, "fetch_corrected": cal_f, "write": cal_w,
+                                     "fetch_ratio": cal_f / copy_bytes, "write_ratio": cal_w / copy_bytes} if have_cal else
+                                    "tools/copy8_microbench.hip under the same two passes: FETCH_SIZE x 2 = bytes read and "
+                                    "WRITE_SIZE = bytes written, to three digits, for 8-B-per-lane and 16-B-per-lane accesses"),
+        "note": "average over every %s launch of one bench.py run (postorder and preorder levels)" % kname,
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
