@@ -104,6 +104,28 @@ def whole_job_rate(units_per_rank_step, steps, world, dt):
     return world * units_per_rank_step * steps / dt
 
 
+def measured_copy_bandwidth(torch, local_rank):
+    """GB/s (read + write) of a 1 GiB device-to-device copy, best of 5, timed with events on torch's current stream."""
+    try:
+        dev = f"cuda:{local_rank}"
+        x = torch.empty(1 << 27, dtype=torch.float64, device=dev)
+        y = torch.empty_like(x)
+        x.zero_()
+        best = None
+        for _ in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            y.copy_(x)
+            b.record()
+            b.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None else min(best, ms)
+        del x, y
+        return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
+    except Exception:
+        return None
+
+
 def load_pmc_traffic(name="pmc_traffic_latest.json"):
     """HBM bytes per launch of the message kernel from the committed rocprofv3 PMC passes
     (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json; the sites workload: pmc_traffic_sites_latest.json);
@@ -494,6 +516,7 @@ def main():
         kern_ms = ms.value
         pmc = load_pmc_traffic()
         achieved = bytes_per_cal * reps / (kern_ms * 1e-3) / 1e9
+        copy_bw = measured_copy_bandwidth(torch, local_rank) if rank == 0 else None
         out = {
             "metric": "clique-tree messages/sec (calibrate!: postorder+preorder), 16-trait BM",
             "value": value, "unit": "messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -514,7 +537,10 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_cal / max(1, nl.value // reps),
                          "kernel": "bp_level_fast16", "launches_per_step": nl.value // reps,
                          "algorithmic_bytes_per_step": bytes_per_cal,
-                         "kernel_ms_per_step": kern_ms / reps},
+                         "kernel_ms_per_step": kern_ms / reps,
+                         # context for `frac`: what a plain device-to-device copy of 1 GiB reaches on this box
+                         # (bytes read + bytes written per second; SURVEY.md section 8(d) asks for it beside the peak)
+                         "measured_copy_GBps": copy_bw},
         }
         if world == 1 and not args.no_alt_reading and (args.traits, args.ntips, args.graph) == (16, 50000, "cliquetree"):
             # BASELINE.json says "50k-clique" in `metric` and "50k-tip tree" in `configs[2]`: the
