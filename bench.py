@@ -24,6 +24,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before torch initialises HIP (see pgbp_amd/_lib.py)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
