@@ -112,12 +112,15 @@ int  pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t*
 /* level_nfast[n_levels]: how many tasks of each level (they come first) run on the register-resident
  * kernel; the rest run on the generic in-LDS kernel. */
 int  pgbp_plan_level_nfast(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_nfast);
-/* Dataflow form of a traversal that the register-resident kernel runs whole (one launch; a task waits for the arrival
- * counters of its operands instead of for a level boundary).  n_tasks = 0: the traversal has no such form.
- * records[n_tasks * k * 7]: per record {valid, message id, sender, receiver, arrivals at the sender to wait for,
- * arrivals at the receiver to wait for, arrivals it signals}. */
-int  pgbp_plan_dataflow_sizes(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_tasks, int32_t* k);
-int  pgbp_plan_dataflow(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* records);
+/* Launch form of the fast-class tasks of one traversal (caller-allocated arrays, any may be NULL):
+ * level_ngroups[n_levels]: workgroup passes ("groups" of 4 wavefront records) of each level;
+ * *tail_levels: how many levels at the root end of the schedule tree (the last ones of a postorder, the first of a
+ *   preorder) are walked by the single-workgroup tail launch (8 records per level);
+ * records[6 * 4 * sum(level_ngroups)], tail_records[6 * 8 * tail_levels]: per record {valid, message id, first record of
+ *   its task inside the group, messages of the task, record that computes its marginal, mode bits (1 own receiver
+ *   block, 2 accumulate task)}. */
+int  pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_ngroups, int32_t* tail_levels,
+                      int32_t* records, int32_t* tail_records);
 const char* pgbp_plan_last_error(const pgbp_plan* p);
 
 /* ---- engine lifetime ------------------------------------------------------------------ */
@@ -299,6 +302,12 @@ int  pgbp_sync(pgbp_engine* e);
  * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik, 2 = loglik_bm, 3 = loglik_lg (2, 3: with the device factor fill). */
 int  pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each,
                         const pgbp_opts* opts, float* ms_total);
+/* pgbp_enqueue_calibrate with one HIP event pair on the engine's stream around the message launches of every schedule
+ * tree (they run back to back), so that a caller who times the whole region on the host gets the message kernels' share
+ * of exactly those repetitions: pgbp_fetch_kernel_time waits for the stream and returns the sum of the event intervals
+ * (*ms_kernels) and the number of message launches inside them. */
+int  pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts);
+int  pgbp_fetch_kernel_time(pgbp_engine* e, float* ms_kernels, int32_t* n_launches);
 /* Time only the message-kernel launches of `reps` calibrate iterations (reset from factors before each):
  * one HIP event pair on the engine's stream brackets the back-to-back level launches of every traversal;
  * *ms_kernels = sum over traversals, *n_launches = number of level launches inside them. */

@@ -81,8 +81,7 @@ SYMBOLS = {
     "pgbp_plan_traversal_sizes": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P]),
     "pgbp_plan_traversal": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P, _I32P]),
     "pgbp_plan_level_nfast": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P]),
-    "pgbp_plan_dataflow_sizes": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P]),
-    "pgbp_plan_dataflow": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P]),
+    "pgbp_plan_groups": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P]),
     "pgbp_plan_last_error": (C.c_char_p, [_P]),
     "pgbp_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_P)]),
     "pgbp_destroy": (None, [_P]),
@@ -113,6 +112,8 @@ SYMBOLS = {
     "pgbp_lg_assignfactors": (C.c_int, [_P, C.POINTER(LgParams)]),
     "pgbp_enqueue_loglik_lg": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_enqueue_calibrate": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_enqueue_calibrate_timed": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_fetch_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), _I32P]),
     "pgbp_enqueue_loglik": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),
     "pgbp_sync": (C.c_int, [_P]),

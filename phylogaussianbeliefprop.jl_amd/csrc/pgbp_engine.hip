@@ -20,11 +20,18 @@ namespace {
 
 std::string g_create_error;
 
+// Kernel arguments in device memory: without it every launch of a narrow level pays a host-memory read for its
+// 0x90-byte argument segment (measured: cfg3 +7 %, cfg5 +20 % per calibrate).  The HIP runtime reads the variable
+// when it initialises, i.e. at the process's first HIP call; this constructor runs when the library is loaded
+// (priority 101: ahead of the code object registration of this library), so a host that has not touched HIP yet --
+// a Julia session that `dlopen`s libpgbp.so -- gets the setting without reading INTEGRATION.md.  A value the user
+// exported is left alone; a host that initialised HIP earlier keeps whatever it had.
+__attribute__((constructor(101))) void pgbp_default_environment() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
 struct DevTraversal {
   int32_t* d_task_off = nullptr;
   Entry* d_entries = nullptr;
   FEntry* d_fentries = nullptr;
-  FEntry* d_dfentries = nullptr;  // the traversal's dataflow form (Traversal::dfentries), if it has one
 };
 
 }  // namespace
@@ -48,7 +55,6 @@ struct pgbp_engine {
   double* d_eps = nullptr;          // [n_sites][n_clusters] regularisation scratch
   unsigned long long* d_fail = nullptr;
   int32_t* d_poison = nullptr;      // [n_sites][n_clusters]
-  int32_t* d_dcnt = nullptr;        // [n_sites][n_clusters] arrival counters of a dataflow launch
   int32_t* d_iscal = nullptr;       // [n_sites]
   int32_t* d_iscal_hist = nullptr;  // [hist_cap][n_sites]
   int64_t hist_cap = 0;
@@ -74,6 +80,10 @@ struct pgbp_engine {
   int32_t* d_one_task_off = nullptr;  // single-message task for pgbp_propagate
   Entry* d_one_entry = nullptr;
   std::vector<DevTraversal> dpost, dpre;
+  std::vector<FEntry*> d_tail;   // per tree: the tail groups of its postorder followed by those of its preorder
+  // HIP events of the last pgbp_enqueue_calibrate_timed call (resolved by pgbp_fetch_kernel_time)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
+  int32_t kernel_launches = 0;
   bool have_factors = false;
   // pgbp_bm_tree: static description + last parameters of the device factor fill
   int32_t bm_p = 0, bm_rows = 0, bm_per_site = 0;
@@ -253,10 +263,12 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_task_off) (void)hipFree(d.d_task_off);
       if (d.d_entries) (void)hipFree(d.d_entries);
       if (d.d_fentries) (void)hipFree(d.d_fentries);
-      if (d.d_dfentries) (void)hipFree(d.d_dfentries);
     }
     v->clear();
   }
+  for (FEntry* t : e->d_tail)
+    if (t) (void)hipFree(t);
+  e->d_tail.clear();
 }
 
 int check_opts(pgbp_engine* e, const pgbp_opts* o) {
@@ -270,65 +282,79 @@ unsigned long long seq_stride(const pgbp_engine* e) {
   return 2ull * (mx + 1);
 }
 
-// enqueue one traversal: one launch per level
-void enqueue_traversal(pgbp_engine* e, const DevState& S, int tree, int dir, unsigned long long pair_index,
-                       std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev = nullptr, int* n_launches = nullptr,
-                       bool kl = false) {
-  const Tree& T = e->plan.trees[tree];
-  const Traversal& tr = dir == 0 ? T.post : T.pre;
-  const DevTraversal& d = dir == 0 ? e->dpost[tree] : e->dpre[tree];
-  const unsigned long long seq_base = pair_index * seq_stride(e);
-  // Once the postorder of a tree failed, its preorder does not run here.  (The reference still walks it, on beliefs the
-  // sequential postorder left half-updated, may log a second failure, and returns (false, false): src/calibration.jl:80-82.
-  // The first failure of the reference's order is what the engine reports; the state after a failure is unspecified.)
-  const unsigned long long stop_below = seq_base + (dir == 0 ? 0ull : (unsigned long long)T.pa.size());
-  const int nlev = (int)tr.level_off.size() - 1;
-  // timing mode: ONE event pair brackets all level launches of the traversal (they run back to back on
-  // the stream), so that sum / launches is the average launch duration without per-launch event overhead
-  hipEvent_t a = nullptr, b = nullptr;
-  if (ev) {
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, e->st);
+// Launch tuning read once from the environment (A/B runs and debugging; the defaults are what was measured best):
+//   PGBP_NO_TAIL=1     no single-workgroup tail launch: every level gets its own launch
+//   PGBP_STREAM=1      persistent streaming launch for wide levels (measured slower than one workgroup per group on the
+//                      50 000-tip tree: 1.00 against 0.94 ms per calibrate)
+//   PGBP_STREAM_MIN=n  a level streams when it has at least n groups of 4 messages (default 1536)
+//   PGBP_STREAM_GRID=n at most n workgroups per streaming launch (tests: many passes per workgroup on small inputs)
+struct LaunchTuning {
+  bool tail = true, stream = false;
+  int stream_min = 1536, stream_grid = 0;
+  LaunchTuning() {
+    if (getenv("PGBP_NO_TAIL")) tail = false;
+    if (getenv("PGBP_STREAM")) stream = true;
+    if (const char* v = getenv("PGBP_STREAM_MIN")) stream_min = std::max(1, atoi(v));
+    if (const char* v = getenv("PGBP_STREAM_GRID")) stream_grid = std::max(1, atoi(v));
   }
-  int launches = 0;
-  // OPT-IN (PGBP_DATAFLOW=1): a traversal that the register-resident kernel runs whole goes out as ONE dataflow launch
-  // (build_dataflow in pgbp_plan.cpp): tasks wait for the arrival counters of their operands instead of for a kernel
-  // boundary per level.  Bit-identical results, but measured slower on the 50 000-tip tree (1.16 ms per calibrate
-  // against 1.02 ms): on an idle chip a hand-off inside the launch costs what a kernel boundary costs (5.6 against
-  // 5.9 us per level on a path of 32-dim clusters), and under the load of the streaming tasks that now run beside the
-  // chain its poll, acquire, drain and counter add each queue behind thousands of loads.
-  // residual_kldiv! reads receivers between levels, so it always keeps the level launches.
-  static const bool dataflow_on = [] { const char* v = getenv("PGBP_DATAFLOW"); return v && v[0] == '1'; }();
-  const bool dataflow = dataflow_on && d.d_dfentries && !kl && !e->layout_sm && tr.df_tasks > 0;
-  if (dataflow) {
-    (void)hipMemsetAsync(e->d_dcnt, 0, sizeof(int32_t) * (((size_t)e->plan.n_sites * e->plan.n_clusters + 3) / 4 * 4),
-                         e->st);
-    launch_level_fast16(S, d.d_dfentries, tr.df_k, tr.df_tasks, e->plan.n_sites, seq_base, stop_below, e->st, e->d_dcnt);
-    launches = 1;
-  }
-  for (int L = 0; L < nlev && !dataflow; ++L) {
+};
+const LaunchTuning& tuning() {
+  static const LaunchTuning t;
+  return t;
+}
+
+// how many levels at the root end of a traversal the tail launch takes over (0: none)
+int tail_levels(const pgbp_engine* e, const Traversal& tr, bool kl) {
+  // residual_kldiv! runs between levels; the site-minor layout belongs to the thread-per-site kernel
+  if (kl || e->layout_sm || !tuning().tail) return 0;
+  return tr.tail_levels;
+}
+
+// levels [L0, L1) of one traversal: one launch per level (two where a level mixes fast-class and generic tasks)
+void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, const DevTraversal& d, int L0, int L1,
+                    unsigned long long seq_base, unsigned long long stop_below, bool kl, int* launches) {
+  for (int L = L0; L < L1; ++L) {
     const int t0 = tr.level_off[L], nt = tr.level_off[L + 1] - t0;
-    const int nf = tr.level_nfast[L];
-    launch_level_fast16(S, d.d_fentries + tr.level_fbase[L], tr.level_fk[L], nf, e->plan.n_sites, seq_base,
-                        stop_below, e->st);
+    const int nf = tr.level_nfast[L], ng = tr.level_ngroups[L];
+    const int mode = (tuning().stream && !kl && ng >= tuning().stream_min) ? kFastStream : kFastLevel;
+    launch_fast16(S, d.d_fentries + tr.level_fbase[L], mode, ng, ng, e->plan.n_sites, seq_base, stop_below, stop_below,
+                  e->st, tuning().stream_grid);
     if (e->plan.max_dim <= 2 && e->plan.n_sites >= 8)  // many tiny problems: lanes = sites
       launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->st);
     else
       launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, e->st);
-    launches += (nf > 0) + (nt - nf > 0);
+    if (launches) *launches += (nf > 0) + (nt - nf > 0);
     if (kl) {  // residual_kldiv! right after the messages of the level (src/calibration.jl:128,154)
       const int e0 = tr.task_off[t0], e1 = tr.task_off[t0 + nt];
       launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, e->max_s, e->d_kldiv, e->d_klflags, e->plan.n_sites,
                             stop_below, e->st);
     }
   }
-  if (ev) {
-    (void)hipEventRecord(b, e->st);
-    ev->push_back({a, b});
-    if (n_launches) *n_launches += launches;
+}
+
+// Traversals of one schedule tree.  dirs: 1 = postorder only, 2 = preorder only, 3 = postorder then preorder (one
+// iteration of calibrate! on this tree: src/calibration.jl:72-84).  The narrow levels at the root end of the tree go out
+// as ONE single-workgroup launch (Traversal::tail_levels); in a postorder + preorder pair the postorder's last levels and
+// the preorder's first ones share it.
+// Once the postorder of a tree failed, its preorder does not run here.  (The reference still walks it, on beliefs the
+// sequential postorder left half-updated, may log a second failure, and returns (false, false): src/calibration.jl:80-82.
+// The first failure of the reference's order is what the engine reports; the state after a failure is unspecified.)
+void enqueue_tree(pgbp_engine* e, const DevState& S, int tree, int dirs, unsigned long long pair_index, bool kl = false,
+                  int* n_launches = nullptr) {
+  const Tree& T = e->plan.trees[tree];
+  const unsigned long long seq_base = pair_index * seq_stride(e);
+  const unsigned long long stop_post = seq_base, stop_pre = seq_base + (unsigned long long)T.pa.size();
+  const int np = (dirs & 1) ? tail_levels(e, T.post, kl) : 0, nq = (dirs & 2) ? tail_levels(e, T.pre, kl) : 0;
+  const int nlev_post = (int)T.post.level_off.size() - 1, nlev_pre = (int)T.pre.level_off.size() - 1;
+  if (dirs & 1) enqueue_levels(e, S, T.post, e->dpost[tree], 0, nlev_post - np, seq_base, stop_post, kl, n_launches);
+  if (np + nq > 0) {
+    // d_tail = the postorder's tail groups followed by the preorder's
+    const FEntry* recs = e->d_tail[tree] + (size_t)(np > 0 ? 0 : T.post.tail_levels) * kTailWaves;
+    launch_fast16(S, recs, kFastTail, np + nq, np, e->plan.n_sites, seq_base, stop_post, stop_pre, e->st);
+    if (n_launches) *n_launches += 1;
   }
+  if (dirs & 2) enqueue_levels(e, S, T.pre, e->dpre[tree], nq, nlev_pre, seq_base, stop_pre, kl, n_launches);
 }
 
 // integratebelief! of one belief in whatever layout the state is in
@@ -391,10 +417,14 @@ void pgbp_destroy(pgbp_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->plan.device);
   free_traversals(e);
+  for (auto& pr : e->kernel_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
                   (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_flags_alt, (void*)e->d_status_alt,
                   (void*)e->d_klflags_alt, (void*)e->d_poison_alt, (void*)e->d_kldiv_alt, (void*)e->d_fail, (void*)e->d_poison,
-                  (void*)e->d_dcnt, (void*)e->d_iscal,
+                  (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
                   (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_bdim, (void*)e->d_rdim,
@@ -469,7 +499,6 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   }
   if ((rc = dev_alloc(e, &e->d_fail, ns))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_poison, ns * (size_t)p.n_clusters))) return bail(rc);
-  if ((rc = dev_alloc(e, &e->d_dcnt, (ns * (size_t)p.n_clusters + 3) / 4 * 4))) return bail(rc);  // zeroed 16 bytes at a time
   if ((rc = dev_alloc(e, &e->d_iscal, ns))) return bail(rc);
   if ((rc = upload(e, &e->d_boff, p.boff))) return bail(rc);
   if ((rc = upload(e, &e->d_packed_off, p.packed_off))) return bail(rc);
@@ -515,6 +544,7 @@ int32_t pgbp_n_messages(const pgbp_engine* e) { return e ? e->plan.n_msgs() : -1
 int pgbp_sync(pgbp_engine* e) {
   if (!e) return PGBP_ERR_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());  // a launch that failed since the last check (bad grid, LDS size) surfaces here
   return PGBP_OK;
 }
 
@@ -662,7 +692,12 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_task_off, tr.task_off))) break;
       if ((rc = upload(e, &d.d_entries, tr.entries))) break;
       if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
-      if (!tr.dfentries.empty()) rc = upload(e, &d.d_dfentries, tr.dfentries);
+    }
+    if (rc == PGBP_OK) {
+      std::vector<FEntry> tail(e->plan.trees[t].post.tentries);
+      tail.insert(tail.end(), e->plan.trees[t].pre.tentries.begin(), e->plan.trees[t].pre.tentries.end());
+      FEntry* dt = nullptr;
+      if ((rc = upload(e, &dt, tail)) == PGBP_OK) e->d_tail.push_back(dt);
     }
   }
   if (rc) {  // out of device memory half way: leave the engine without a schedule rather than with half of one
@@ -803,7 +838,7 @@ int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* op
   if ((rc = reset_fail(e))) return rc;
   if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e) && !(opts && opts->update_residualkldiv)))) return rc;
   DevState S = dev_state(e, opts);
-  enqueue_traversal(e, S, tree, dir, (unsigned long long)tree, nullptr, nullptr, opts && opts->update_residualkldiv);
+  enqueue_tree(e, S, tree, dir == 0 ? 1 : 2, (unsigned long long)tree, opts && opts->update_residualkldiv);
   launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st, e->layout_sm ? 1 : 0);
   return collect_results(e, results, nullptr, 0);
 }
@@ -851,8 +886,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   for (int i = 0; i < niter && !stop; ++i) {
     for (int j = 0; j < nt && !stop; ++j) {
       const unsigned long long pair = (unsigned long long)i * nt + j;
-      enqueue_traversal(e, S, j, 0, pair, nullptr, nullptr, kl);
-      enqueue_traversal(e, S, j, 1, pair, nullptr, nullptr, kl);
+      enqueue_tree(e, S, j, 3, pair, kl);
       launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st, e->layout_sm ? 1 : 0);
       ++pairs_done;
       if (speculative) {
@@ -1059,7 +1093,7 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
     DevState S1 = S;
     S1.sep_zero = fresh_sepsets_shortcut(e) ? 1 : 0;
     if ((rc = bm_fill_async(e, false, S1.sep_zero != 0))) return rc;   // assignfactors!        calibration.jl:205-209
-    enqueue_traversal(e, S1, 0, 0, 0);                           // postorder             :210
+    enqueue_tree(e, S1, 0, 1, 0);                                // postorder             :210
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
     integrate_async(e, root, nullptr);  // :212
   }
@@ -1260,7 +1294,7 @@ int pgbp_enqueue_loglik_lg(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
     DevState S1 = S;
     S1.sep_zero = fresh_sepsets_shortcut(e) ? 1 : 0;
     if ((rc = lg_fill_async(e, false, S1.sep_zero != 0))) return rc;  // assignfactors!        calibration.jl:205-209
-    enqueue_traversal(e, S1, 0, 0, 0);                                // postorder             :210
+    enqueue_tree(e, S1, 0, 1, 0);                                     // postorder             :210
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
     integrate_async(e, root, nullptr);                                // :212
   }
@@ -1269,6 +1303,8 @@ int pgbp_enqueue_loglik_lg(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
 
 // ---- benchmarking / zero-copy entry points ---------------------------------------------------
 
+// one iteration of calibrate! over every schedule tree.  ev != null: one HIP event pair around the message launches of
+// each tree (they run back to back on the stream), *n_launches += their number
 static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_each,
                                   std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev, int* n_launches = nullptr) {
   const Plan& p = e->plan;
@@ -1278,8 +1314,17 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
     launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);
   }
   for (int j = 0; j < (int)p.trees.size(); ++j) {
-    enqueue_traversal(e, S, j, 0, (unsigned long long)j, ev, n_launches);
-    enqueue_traversal(e, S, j, 1, (unsigned long long)j, ev, n_launches);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (ev) {
+      HIPCHK(e, hipEventCreate(&a));
+      HIPCHK(e, hipEventCreate(&b));
+      HIPCHK(e, hipEventRecord(a, e->st));
+    }
+    enqueue_tree(e, S, j, 3, (unsigned long long)j, false, n_launches);
+    if (ev) {
+      HIPCHK(e, hipEventRecord(b, e->st));
+      ev->push_back({a, b});
+    }
     launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st, e->layout_sm ? 1 : 0);
   }
   return PGBP_OK;
@@ -1298,6 +1343,47 @@ int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, con
   return PGBP_OK;
 }
 
+static void drop_kernel_events(pgbp_engine* e) {
+  for (auto& pr : e->kernel_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  e->kernel_events.clear();
+  e->kernel_launches = 0;
+}
+
+int pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts) {
+  if (!e) return PGBP_ERR_INVALID;
+  int rc = check_opts(e, opts);
+  if (rc) return rc;
+  if ((rc = need_schedule(e, 0))) return rc;
+  if ((rc = reset_fail(e))) return rc;
+  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
+  drop_kernel_events(e);
+  DevState S = dev_state(e, opts);
+  int launches = 0;
+  for (int r = 0; r < reps; ++r)
+    if ((rc = enqueue_calibrate_once(e, S, reset_each, &e->kernel_events, &launches))) return rc;
+  e->kernel_launches = launches;
+  return PGBP_OK;
+}
+
+int pgbp_fetch_kernel_time(pgbp_engine* e, float* ms_kernels, int32_t* n_launches) {
+  if (!e || !ms_kernels) return PGBP_ERR_INVALID;
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  HIPCHK(e, hipGetLastError());
+  double total = 0;
+  for (auto& pr : e->kernel_events) {
+    float ms = 0;
+    HIPCHK(e, hipEventElapsedTime(&ms, pr.first, pr.second));
+    total += ms;
+  }
+  *ms_kernels = (float)total;
+  if (n_launches) *n_launches = e->kernel_launches;
+  drop_kernel_events(e);
+  return PGBP_OK;
+}
+
 static int enqueue_loglik_once(pgbp_engine* e, const DevState& S0) {
   const Plan& p = e->plan;
   DevState S = S0;
@@ -1305,7 +1391,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S0) {
   int rc = reset_from_factors_async(e, S.sep_zero != 0);
   if (rc) return rc;
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);  // calibration.jl:209
-  enqueue_traversal(e, S, 0, 0, 0);                                                         // :210
+  enqueue_tree(e, S, 0, 1, 0);                                                              // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
   integrate_async(e, root, nullptr);         // :212
   return PGBP_OK;
@@ -1365,27 +1451,9 @@ int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset
 int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opts, float* ms_kernels,
                               int32_t* n_launches) {
   if (!e || !ms_kernels) return PGBP_ERR_INVALID;
-  int rc = check_opts(e, opts);
+  int rc = pgbp_enqueue_calibrate_timed(e, reps, 1, opts);
   if (rc) return rc;
-  if ((rc = need_schedule(e, 0))) return rc;
-  if ((rc = reset_fail(e))) return rc;
-  if ((rc = ensure_layout(e, want_bs16(e), want_site_minor(e)))) return rc;
-  DevState S = dev_state(e, opts);
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-  int launches = 0;
-  for (int r = 0; r < reps; ++r)
-    if ((rc = enqueue_calibrate_once(e, S, 1, &ev, &launches))) break;
-  HIPCHK(e, hipStreamSynchronize(e->st));
-  double total = 0;
-  for (auto& pr : ev) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) total += ms;
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
-  }
-  *ms_kernels = (float)total;
-  if (n_launches) *n_launches = (int32_t)launches;
-  return rc;
+  return pgbp_fetch_kernel_time(e, ms_kernels, n_launches);
 }
 
 int pgbp_traffic_model(const pgbp_engine* e, double* bytes_per_calibrate, int64_t* messages_per_calibrate) {

@@ -1,7 +1,7 @@
-// Register-resident message kernel for gfx950 (wave64), sepsets of dimension P = 16.
+// Register-resident message kernel for gfx950 (wave64), sepsets of dimension P (2 .. 16; described for P = 16).
 //
-// One wavefront = one task (ordered list of messages sharing a receiver or a sender), no LDS
-// allocation, every HBM access a 16-byte-per-lane coalesced vector access issued up front.
+// One wavefront = one message; the waves of a workgroup = the messages of a few tasks (ordered lists of messages
+// sharing a receiver or a sender); every HBM access a 16- or 32-byte-per-lane coalesced vector access issued up front.
 //
 // Lane geometry: lane = 8*b + a, a = row group, b = column group (0..7 each).
 // A 32 x 32 sender precision, re-indexed so that the 16 integrated variables come first
@@ -12,11 +12,11 @@
 // the kept block i, j >= 2, which is exactly the sepset's 16 x 16 layout (2 x 2 block per lane) and the
 // receiver's sub-block layout: divide!/mult! need no data movement at all.
 //
-// marginalize (src/beliefupdates.jl:55-83) = 16 symmetric rank-1 eliminations
-//     W <- W - x x' / d,   x = column k of W (rows > k), d = W[k][k]
+// marginalize (src/beliefupdates.jl:55-83) = 8 rounds of 2 x 2-blocked symmetric elimination
+//     W <- W - X D^-1 X',   X = columns 2R, 2R+1 of W, D = their 2 x 2 pivot block
 // which reads exactly what the reference reads: upper(J_I) (the integrated block is symmetrised from its
 // upper triangle at load, like PDMat(Symmetric(J_I)) at :68), J_SI (Jki at :59) and J_S.  J_IS is never
-// loaded.  Column k is broadcast with ds_bpermute (no LDS allocation), pivots with v_readlane.
+// loaded.  The pivot columns go through a wave-private LDS strip.
 // log det J_I is accumulated as mantissa product + exponent sum (one log per message).
 #include <hip/hip_runtime.h>
 
@@ -26,34 +26,6 @@
 #include "pgbp_kernels.hpp"
 
 namespace pgbp {
-
-#ifdef PGBP_TRACE
-// experiment-only instrumentation (tools/, never in the shipped build): per-phase timestamps of wave 0 of
-// single-task launches
-constexpr unsigned int kTraceCap = 1u << 19;
-__device__ unsigned long long g_trace[kTraceCap][10];
-__device__ unsigned int g_trace_n;
-__device__ unsigned int g_trace_all;  // 0: wave 0 of single-task launches only; 1: every wave of every launch
-__device__ unsigned int g_trace_base;  // first slot of the running launch (advanced by trace_advance between launches)
-__global__ void trace_advance(unsigned int n) {
-  if (g_trace_all) { g_trace_base += n; g_trace_n = g_trace_base; }
-}
-__device__ __forceinline__ unsigned long long trace_vgpr(unsigned long long t) {
-  unsigned int lo = (unsigned int)t, hi = (unsigned int)(t >> 32);
-  asm("" : "+v"(lo), "+v"(hi));
-  return ((unsigned long long)hi << 32) | lo;
-}
-#ifdef PGBP_TRACE_LIGHT  // start / end / hardware id only: must not change the kernel's register budget
-#define PGBP_TR(i) do { } while (0)
-#define PGBP_TR_NOWAIT(i) do { } while (0)
-#else
-#define PGBP_TR(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); tr[i] = trace_vgpr(__builtin_amdgcn_s_memtime()); } while (0)
-#define PGBP_TR_NOWAIT(i) do { tr[i] = trace_vgpr(__builtin_amdgcn_s_memtime()); } while (0)
-#endif
-#else
-#define PGBP_TR(i) do { } while (0)
-#define PGBP_TR_NOWAIT(i) do { } while (0)
-#endif
 
 #define PGBP_LOG2PI 1.8378770664093454835606594728112
 #define PGBP_LN2 0.69314718055994530941723212145818
@@ -66,12 +38,6 @@ struct Frag {
   double w[4][4];  // w[i][j] = W[R(i)][C(j)]; w[0..1][2..3] (integrated rows x kept cols) is never used
   double h[4];     // h[i] = h[R(i)], replicated over b
 };
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 
 // Wave-synchronous exchange through LDS: the hardware executes a wave's DS instructions in order, but the
 // compiler reasons per thread; this fence pair + wave barrier stops it from forwarding a lane's own stale
@@ -213,359 +179,387 @@ __device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double
   }
 }
 
-// ---- dataflow launch (DF): hand-offs between workgroups inside one launch ---------------------------------------------
-// Producer: every store of a receiver block is write-through (sc1), the storing wave drains them (s_waitcnt vmcnt(0)),
-// then ONE lane adds to the receiver's arrival counter (agent-scope atomic).  Consumer: one wave polls that ONE word
-// (relaxed, agent scope, s_sleep between polls, bounded), then one agent-scope acquire, then plain loads.  Receiver
-// records are whole 128-byte lines of their own (kRecAlign), so no line is shared with another producer.
-typedef unsigned int df_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kDfMaxSpins = 1 << 18;  // about a second: a dependency that never arrives ends as a reported failure
-// 16 / 32 bytes, write-through.  Inline asm on the address registers the plain store would use (a buffer descriptor
-// costs the instance its fourth wave per SIMD); the compiler does not count these stores in vmcnt, which is safe
-// where they stand: behind the last load of the kernel, in front of an explicit s_waitcnt vmcnt(0).
-// sbase: wave-uniform record base (SGPR pair), idx: this lane's element index inside the record
-__device__ __forceinline__ void df_store16(double* sbase, int idx, double x, double y) {
-  df_u32x4 v;
-  const double xy[2] = {x, y};
-  __builtin_memcpy(&v, xy, 16);
-  asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(idx * 8), "v"(v), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void df_store32(double* sbase, int idx, double x, double y, double z, double w) {
-  df_u32x4 lo, hi;
-  const double xy[2] = {x, y}, zw[2] = {z, w};
-  __builtin_memcpy(&lo, xy, 16);
-  __builtin_memcpy(&hi, zw, 16);
-  asm volatile("global_store_dwordx4 %0, %1, %3 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc1\n\ts_nop 1" ::"v"(idx * 8),
-               "v"(lo), "v"(hi), "s"(sbase)
-               : "memory");
-}
-__device__ __forceinline__ void df_store8(double* p, double x) {
-  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool df_wait(const int32_t* cnt, int need) {
-  // the whole poll loop is one asm statement: as a C++ loop it costs the kernel 6 VGPRs (and its fourth wave per SIMD)
-  int seen, spins, tmp;
-  asm volatile(
-      "s_mov_b32 %1, 0\n"
-      ".Ldf_poll_%=:\n\t"
-      "global_load_dword %2, %3, %4 sc1\n\t"
-      "s_waitcnt vmcnt(0)\n\t"
-      "v_readfirstlane_b32 %0, %2\n\t"
-      "s_cmp_ge_i32 %0, %5\n\t"
-      "s_cbranch_scc1 .Ldf_done_%=\n\t"
-      "s_add_u32 %1, %1, 1\n\t"
-      "s_cmp_lt_u32 %1, %6\n\t"
-      "s_cbranch_scc0 .Ldf_done_%=\n\t"
-      "s_sleep 1\n\t"
-      "s_branch .Ldf_poll_%=\n"
-      ".Ldf_done_%=:"
-      : "=&s"(seen), "=&s"(spins), "=&v"(tmp)
-      : "v"(0), "s"(cnt), "s"(need), "s"(kDfMaxSpins)
-      : "scc", "memory");
-  return seen >= need;
-}
-// the receiver block, write-through: same element placement as store_blk
-template <bool BS, bool ODD>
-__device__ __forceinline__ void df_store_blk(double* __restrict__ base, int ld, int a, int b, bool up, bool act, int kidx,
-                                             const Blk& v, int n) {
-  if constexpr (BS) {
-    if (up) df_store32(base, kidx, v.x, v.y, v.z, v.w);
-  } else if constexpr (ODD) {
-    if (act) {
-      const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
-      if (r0 < n && c0 < n) df_store8(base + r0 + (int64_t)ld * c0, v.x);
-      if (r1 < n && c0 < n) df_store8(base + r1 + (int64_t)ld * c0, v.y);
-      if (r0 < n && c1 < n) df_store8(base + r0 + (int64_t)ld * c1, v.z);
-      if (r1 < n && c1 < n) df_store8(base + r1 + (int64_t)ld * c1, v.w);
-    }
-  } else if (act) {
-    df_store16(base, 2 * a + ld * (2 * b), v.x, v.y);
-    df_store16(base, 2 * a + ld * (2 * b + 1), v.z, v.w);
-  }
-}
-
-// One workgroup = one task; wave w of the workgroup = message w of the task (records padded to K per task).
-//   * accumulate tasks (postorder, several children into one receiver block): every wave computes its
-//     message and divides; waves > 0 hand their delta to wave 0 through LDS; wave 0 adds the deltas in the
+// ---------------------------------------------------------------------------------------------------------------------
+// The message kernel.  A launch walks GROUPS of W records (FEntry, pgbp_internal.hpp): wave w of the workgroup runs
+// record w of the group; the records of one task (messages sharing a receiver in a postorder, a sender in a preorder)
+// are consecutive inside their group:
+//   * accumulate tasks (postorder, several children into one receiver block): every wave computes its message and
+//     divides; the task's later waves hand their delta to its first wave through LDS, which adds them in the
 //     reference's order and stores the receiver block once;
-//   * reuse (preorder, one sender, several children): the providing wave computes the marginal once and
-//     hands it to the others through LDS; every wave divides by its own sepset and updates its own receiver.
+//   * reuse (preorder, one sender, several children): the providing wave computes the marginal once and hands it to the
+//     others through LDS; every wave divides by its own sepset and updates its own receiver.
+// Every wave of the workgroup executes the same two workgroup barriers per group whatever its record holds (an invalid
+// record = a wave with nothing to do: it skips the work, not the barriers).
+//
+// Three launch modes of the same body:
+//   kLevel  one group per workgroup, W = 4: one launch per level of the schedule (pgbp_plan.cpp);
+//   kStream wide levels: a PERSISTENT grid (as many workgroups as the chip holds) strides over the level's groups, and
+//           while a wave eliminates message i the packed record of the sender of its message i + 1 is already on its way
+//           into the wave's LDS image by LDS-DMA (global_load_lds_dwordx4: no registers, 1 KiB per instruction), so the
+//           HBM stream no longer stops while the waves compute; BS16 layout only (a packed 2P record is 4.6 KB);
+//   kTail   the narrow levels at the root end of the schedule tree: ONE workgroup of 8 waves walks them, one group per
+//           level, a workgroup barrier between levels instead of a kernel boundary (what a level hands to the next one
+//           never leaves this CU's L2 slice); a postorder's tail and the following preorder's head go out as one launch.
 // BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
 // ODD: the sepsets really have PR = P - 1 variables (an odd trait count): same lane grid, one phantom variable per
 // block, unit precision where it is integrated so that its pivot is 1 (log det and quadratic term unchanged).
-// DF: the dataflow launch (build_dataflow in pgbp_plan.cpp): the records carry arrival counts to wait for, dcnt is the
-// [n_sites][n_clusters] arrival counter array (zeroed before the launch); see the hand-off helpers above.
-template <int P, bool BS, bool ODD, bool DF = false>
-#ifdef PGBP_TRACE_LIGHT
-__attribute__((amdgpu_waves_per_eu(4, 4)))  // keep the production kernel's occupancy despite the extra live values
+constexpr int kLevel = 0, kStream = 1, kTail = 2;
+// kStream, per wave: LDS image of a packed sender record (5 LDS-DMA pieces of 128 doubles; lanes past the record's end
+// stay idle, so 584 doubles hold the 577 of a 2P record) + the sepset tile + the receiver tile (144 doubles each)
+constexpr int kImgSender = 584, kImgTile = 144, kImgDoubles = kImgSender + 2 * kImgTile;
+
+// LDS exchange between the waves of a workgroup: release / acquire fences restricted to the LDS address space around the
+// barrier, i.e. s_waitcnt lgkmcnt(0) + s_barrier.  Unlike __syncthreads() this does NOT wait for outstanding global
+// loads / stores / LDS-DMA (vmcnt): the prefetch of the next sender stays in flight across it.  (The barrier has to be
+// the builtin, which the compiler knows as a convergent operation: an inline-asm s_barrier may be duplicated into the
+// two arms of a lane-divergent branch, and a wave that runs both arms then arrives twice.)
+__device__ __forceinline__ void wg_barrier_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// level boundary inside the tail launch: this wave's global stores are complete (vmcnt) before the other waves of the
+// workgroup -- same CU, same vector L1 -- load them after the barrier: the workgroup-scope release / acquire of
+// __syncthreads()
+__device__ __forceinline__ void wg_barrier_global() { __syncthreads(); }
+
+// One 64-byte record by scalar loads, pinned in SGPRs: left to itself the compiler sinks the field loads into the
+// branches that use them, and the wave then pays a dependent memory round trip per field group.
+__device__ __forceinline__ FEntry load_record(const FEntry* __restrict__ r) {
+  const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(r);
+  uint4 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
+  asm("; record resident"
+      : "+s"(q0.x), "+s"(q0.y), "+s"(q0.z), "+s"(q0.w), "+s"(q1.x), "+s"(q1.y), "+s"(q1.z), "+s"(q1.w), "+s"(q2.x),
+        "+s"(q2.y), "+s"(q2.z), "+s"(q2.w), "+s"(q3.x), "+s"(q3.y), "+s"(q3.z), "+s"(q3.w));
+  const uint4 q[4] = {q0, q1, q2, q3};
+  FEntry en;
+  __builtin_memcpy(&en, q, sizeof(FEntry));
+  return en;
+}
+
+// What a wave must know of a record to prefetch its sender: the first 8 bytes (from_off) and bytes 48..55 (the byte-sized
+// fields), two scalar loads instead of the whole 64-byte record.
+struct FHead {
+  int64_t from_off;
+  uint8_t valid, mf, mt, s, keep0, up0, src_wave, mode;
+};
+__device__ __forceinline__ FHead load_head(const FEntry* __restrict__ r) {
+  const uint2* __restrict__ rq = reinterpret_cast<const uint2*>(r);
+  uint2 q0 = rq[0], q6 = rq[6];
+  asm("; record head resident" : "+s"(q0.x), "+s"(q0.y), "+s"(q6.x), "+s"(q6.y));
+  const uint2 q[2] = {q0, q6};
+  FHead h;
+  __builtin_memcpy(&h, q, sizeof(FHead));
+  return h;
+}
+static_assert(sizeof(FHead) == 16 && offsetof(FEntry, valid) == 48, "FHead mirrors FEntry");
+
+// kStream: start the LDS-DMA of the packed sender record of `en` (if this wave computes a marginal from one) into `img`
+template <int P>
+__device__ __forceinline__ void prefetch_sender(const FHead& en, int wave, const double* __restrict__ pool, double* img,
+                                                int lane) {
+  if (!en.valid || en.src_wave != wave || en.mf == 0) return;
+  const int len = en.mf == P ? bs16::len1(P) : bs16::len2(P);  // doubles in use of the packed record
+  const double* __restrict__ g = pool + en.from_off;
+#pragma unroll
+  for (int piece = 0; piece * 128 < bs16::len2(P); ++piece) {
+    const int d = piece * 128 + lane * 2;  // this lane's 16 bytes
+    if (piece * 128 < len && d < len)      // (wave-uniform && lane mask: lanes past the record's end stay idle)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + d),
+                                       (__attribute__((address_space(3))) void*)(img + piece * 128), 16, 0, 0);
+  }
+}
+
+// kStream: one packed symmetric tile (sepset precision, receiver block) by LDS-DMA instead of into registers: the
+// 2 x 2 blocks wait in LDS while the elimination needs every register the instance has at four waves per SIMD
+template <int P>
+__device__ __forceinline__ void dma_tile(const double* __restrict__ g, double* timg, int lane) {
+  constexpr int len = bs16::sym_len(P);
+#pragma unroll
+  for (int piece = 0; piece * 128 < len; ++piece) {
+    const int d = piece * 128 + lane * 2;
+    if (d < len)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + d),
+                                       (__attribute__((address_space(3))) void*)(timg + piece * 128), 16, 0, 0);
+  }
+}
+
+template <int P, bool BS, bool ODD, int MODE>
+#ifdef PGBP_FORCE4
+__attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-__global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEntry* __restrict__ recs_arg, int K_arg,
-                                                       unsigned long long seq_base_arg,
-                                                       unsigned long long stop_below_arg, int32_t* __restrict__ dcnt) {
-  // The 0x90-byte kernarg segment spans three cache lines and the compiler fetches arguments one group at a
-  // time, each a dependent round trip on the critical path of a narrow level.  Pinning the plain scalars of
-  // all three lines in SGPRs here makes ONE batch of scalar loads touch every line; the pointer arguments are
-  // left alone (an asm operand would cost them their global-address-space provenance) and hit the scalar cache.
-#if defined(PGBP_TRACE) && !defined(PGBP_TRACE_LIGHT)
-  unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const bool trace_on = g_trace_all != 0 || (gridDim.x == 1 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0);
-  tr[8] = trace_vgpr(__builtin_amdgcn_s_memrealtime());
-  PGBP_TR_NOWAIT(0);
-#endif
+__global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 64) void bp_fast16(
+    DevState S_arg, const FEntry* __restrict__ recs_arg, int ngroups_arg, int split_arg, unsigned long long seq_base_arg,
+    unsigned long long stop_a_arg, unsigned long long stop_b_arg) {
+  constexpr int W = MODE == kTail ? kTailWaves : kFastMaxWaves;
+  static_assert(!(ODD && BS), "odd dimensions run in the plain layout");
+  static_assert(MODE != kStream || BS, "the streaming launch prefetches packed records");
+  // The kernarg segment spans three cache lines and the compiler fetches arguments one group at a time, each a
+  // dependent round trip on the critical path of a narrow level.  Pinning the plain scalars of all three lines in SGPRs
+  // here makes ONE batch of scalar loads touch every line; the pointer arguments are left alone (an asm operand would
+  // cost them their global-address-space provenance) and hit the scalar cache.
   DevState S = S_arg;
   const FEntry* __restrict__ recs = recs_arg;
-  int K = K_arg;
-  unsigned long long seq_base = seq_base_arg, stop_below = stop_below_arg;
+  int ngroups = ngroups_arg, split = split_arg;
+  unsigned long long seq_base = seq_base_arg, stop_a = stop_a_arg, stop_b = stop_b_arg;
   {
     unsigned long long atol_bits = __double_as_longlong(S.atol);
     asm("; kernel arguments resident"
         : "+s"(S.pool_stride), "+s"(S.rpool_stride), "+s"(S.n_clusters), "+s"(S.n_msgs), "+s"(S.update_resnorm),
-          "+s"(atol_bits), "+s"(K), "+s"(seq_base), "+s"(stop_below));
+          "+s"(atol_bits), "+s"(ngroups), "+s"(split), "+s"(seq_base), "+s"(stop_a), "+s"(stop_b));
     S.atol = __longlong_as_double(atol_bits);
   }
-  const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
-  static_assert(!(ODD && BS), "odd dimensions run in the plain layout");
-  constexpr int PR = P - (ODD ? 1 : 0);            // the real sepset dimension
-  constexpr int G = P / 2;                         // lane grid G x G (all 64 lanes for P = 16)
-  const bool act = lane < G * G;                   // lanes beyond the grid shadow lane (0, 0) and never store
-  const int a = act ? lane % G : 0, b = act ? lane / G : 0;
-  const bool up = act && a <= b;                   // this lane's block is stored in the packed layout
-  const int kidx = (b * (b + 1) / 2 + a) * 4;      // its offset inside a packed symmetric tile
-  // The whole 64-byte record and the site's fail key are fetched by ONE batch of scalar loads and pinned in
-  // SGPRs here: left to itself the compiler sinks them into the branches that use them, and the wave then
-  // pays a dependent memory round trip per field group (valid -> fail key -> offsets -> ...).
-  FEntry en;
-  unsigned long long failkey;
-#if defined(PGBP_TRACE) && !defined(PGBP_TRACE_LIGHT)
-  en = recs[(int64_t)blockIdx.x * K + wave];  // (the timestamp reads defeat the scalar-load pinning below)
-  failkey = S.fail[site];
-#else
-  {
-    const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs + ((int64_t)blockIdx.x * K + wave));
-    uint4 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
-    failkey = S.fail[site];
-    unsigned int fl = (unsigned int)failkey, fh = (unsigned int)(failkey >> 32);
-    asm("; record + fail key resident"
-                 : "+s"(q0.x), "+s"(q0.y), "+s"(q0.z), "+s"(q0.w), "+s"(q1.x), "+s"(q1.y), "+s"(q1.z), "+s"(q1.w),
-                   "+s"(q2.x), "+s"(q2.y), "+s"(q2.z), "+s"(q2.w), "+s"(q3.x), "+s"(q3.y), "+s"(q3.z), "+s"(q3.w),
-                   "+s"(fl), "+s"(fh));
-    const uint4 q[4] = {q0, q1, q2, q3};
-    __builtin_memcpy(&en, q, sizeof(FEntry));
-    failkey = ((unsigned long long)fh << 32) | fl;
-  }
-#endif
-#ifdef PGBP_TRACE_LIGHT
-  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();  // after the pinned scalar loads (see above)
-#endif
-  PGBP_TR(1);
+  constexpr int PR = P - (ODD ? 1 : 0);  // the real sepset dimension
+  constexpr int G = P / 2;               // lane grid G x G (all 64 lanes for P = 16)
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
-  double* slot = fast_lds + wave * kSlotDoubles;
-  double* col = fast_lds + K * kSlotDoubles + wave * kColDoubles;  // private strip of this wave
+  double* const slot = fast_lds + wave * kSlotDoubles;
+  double* const col = fast_lds + W * kSlotDoubles + wave * kColDoubles;  // private strip of this wave
+  // kStream only: this wave's images of the sender record, the sepset tile and the receiver tile
+  double* const img = fast_lds + W * (kSlotDoubles + kColDoubles) + wave * kImgDoubles;
+  double* const simg = img + kImgSender;
+  double* const timg = simg + kImgTile;
 
-  // A padding record (tasks are padded to the K of their launch) outside an accumulate task has nothing to hand
-  // over: its wave ends here and gives its slot and registers back.  The workgroup's barriers wait only for the
-  // surviving waves (S_BARRIER semantics of the ISA).
-  if (!en.valid && !(en.mode & kFAccum)) return;
-  // state 0: nothing to do / stopped; 1: message available; 2: failed (not PD); 3: sender poisoned
-  int state = (en.valid && !((failkey >> kInfoBits) < stop_below)) ? 1 : 0;
-  const bool has_block = en.s > 0;                // the message has a J/h part
-  const bool own = (en.mode & kFOwn) != 0;        // this wave loads/stores the receiver block
-  const bool accum = (en.mode & kFAccum) != 0;
-  const bool provider = en.src_wave == wave;      // computes the marginal itself
+  int g = MODE == kTail ? 0 : blockIdx.x;
+  const int gstride = MODE == kStream ? gridDim.x : 1;
+  FEntry en = load_record(recs + ((int64_t)g * W + wave));
+  unsigned long long failkey = S.fail[site];
+  if constexpr (MODE == kStream) prefetch_sender<P>(load_head(recs + ((int64_t)g * W + wave)), wave, pool, img, threadIdx.x & 63);
 
-  double* __restrict__ sep = pool + en.sep_off;
-  double* __restrict__ to = pool + en.to_off;
-  double* __restrict__ res = rpool + en.res_off;
-  const int mt = en.mt, up0 = en.up0;
-  // offsets inside the sepset / receiver / residual records
-  const bool tpk = BS && (mt == P || mt == 2 * P);                                // receiver record is packed
-  const int sepH = BS ? bs16::h1(P) : PR * PR, sepG = has_block ? (BS ? bs16::g1(P) : PR * PR + PR) : 0;
-  const int64_t tJ0 = tpk ? ((mt == 2 * P && up0 == P) ? bs16::t11(P) : 0) : (up0 + (int64_t)mt * up0);
-  const int64_t tH0 = (tpk ? (mt == P ? bs16::h1(P) : bs16::h2(P)) : (int64_t)mt * mt) + up0;
-  const int64_t tG0 = tpk ? (mt == P ? bs16::g1(P) : bs16::g2(P)) : (int64_t)mt * mt + mt;
+  for (;;) {
+    // lane geometry, re-derived per pass from an opaque copy of the lane id so that nothing of it is carried in
+    // registers across the loop (the loop-free kLevel mode compiles to what it was)
+    int lane = threadIdx.x & 63;
+    if constexpr (MODE != kLevel) asm volatile("" : "+v"(lane));
+    const bool act = lane < G * G;  // lanes beyond the grid shadow lane (0, 0) and never store
+    const int a = act ? lane % G : 0, b = act ? lane / G : 0;
+    const bool up = act && a <= b;               // this lane's block is stored in the packed layout
+    const int kidx = (b * (b + 1) / 2 + a) * 4;  // its offset inside a packed symmetric tile
 
-  Blk mJ{0, 0, 0, 0}, tJ{0, 0, 0, 0}, sJ{0, 0, 0, 0};
-  double mh[2] = {0, 0}, gmsg = 0.0, th[2] = {0, 0}, tg = 0.0;
-  double2 sh = make_double2(0.0, 0.0);
-  double sg = 0.0;
-  int info = 0;
-  if constexpr (DF) {
+    // the next pass's record: its head now (kStream: what the prefetch of its sender needs), the rest at the end of
+    // this pass
+    const bool has_next = MODE != kLevel && g + gstride < ngroups;
+    FHead nh{};
+    if (MODE == kStream && has_next) nh = load_head(recs + ((int64_t)(g + gstride) * W + wave));
+    if constexpr (MODE == kTail) {
+      // a failure in the postorder part of this launch must stop its preorder part: at the first preorder level the fail
+      // word is read again, coherently (every other level keeps the value read at the start: a dependent memory round
+      // trip less on the critical path of a level)
+      if (g == split && split > 0) {
+        failkey = __hip_atomic_load(&S.fail[site], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the builtin returns int: without the unsigned casts a low word with bit 31 set would sign-extend over the high one)
+        failkey = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(failkey >> 32)) << 32) |
+                  (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)failkey);
+      }
+    }
+    const unsigned long long stop_below = (MODE == kTail && g >= split) ? stop_b : stop_a;
+
+    // state 0: nothing to do / stopped; 1: message available; 2: failed (not PD); 3: sender poisoned
+    int state = (en.valid && !((failkey >> kInfoBits) < stop_below)) ? 1 : 0;
+    const bool has_block = en.s > 0;                // the message has a J/h part
+    const bool own = (en.mode & kFOwn) != 0;        // this wave loads/stores the receiver block
+    const bool accum = (en.mode & kFAccum) != 0;
+    const bool provider = en.src_wave == wave;      // computes the marginal itself
+    const int first_wave = en.grp_base;             // first wave of this record's task
+
+    double* __restrict__ sep = pool + en.sep_off;
+    double* __restrict__ to = pool + en.to_off;
+    double* __restrict__ res = rpool + en.res_off;
+    const int mt = en.mt, up0 = en.up0;
+    // offsets inside the sepset / receiver / residual records
+    const bool tpk = BS && (mt == P || mt == 2 * P);                                // receiver record is packed
+    const int sepH = BS ? bs16::h1(P) : PR * PR, sepG = has_block ? (BS ? bs16::g1(P) : PR * PR + PR) : 0;
+    const int64_t tJ0 = tpk ? ((mt == 2 * P && up0 == P) ? bs16::t11(P) : 0) : (up0 + (int64_t)mt * up0);
+    const int64_t tH0 = (tpk ? (mt == P ? bs16::h1(P) : bs16::h2(P)) : (int64_t)mt * mt) + up0;
+    const int64_t tG0 = tpk ? (mt == P ? bs16::g1(P) : bs16::g2(P)) : (int64_t)mt * mt + mt;
+
+    Blk mJ{0, 0, 0, 0}, tJ{0, 0, 0, 0}, sJ{0, 0, 0, 0};
+    double mh[2] = {0, 0}, gmsg = 0.0, th[2] = {0, 0}, tg = 0.0;
+    double2 sh = make_double2(0.0, 0.0);
+    double sg = 0.0;
+    int info = 0;
+    if constexpr (MODE == kStream) {
+      // the image of this pass's sender has landed (this also drains the previous pass's stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (state == 1) {
-      const int wf = provider ? en.wait_from : 0, wt = own ? (en.wait_sig & 0xFFFFFF) : 0;
-      bool arrived = true;
-      if (wf > 0) arrived = df_wait(dcnt + (int64_t)site * S.n_clusters + en.from_b, wf);
-      if (wt > 0 && arrived) arrived = df_wait(dcnt + (int64_t)site * S.n_clusters + en.to_b, wt);
-      if (wf > 0 || wt > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (!arrived) {  // never in a correct schedule: reported like a failed message, with an impossible pivot index
-        state = 2;
-        info = kDfTimeoutInfo;
-      }
-    }
-  }
-  if (state == 1) {
-    const int poisoned = S.poison[(int64_t)site * S.n_clusters + en.from_b];
-    // ---- every load of this message is issued before any arithmetic; the sender (the largest operand and
-    // the one the elimination waits for) goes first, the sepset and the receiver block right behind it
-    auto load_sep_to = [&]() {
-      if (!S.sep_zero) {
-        if (has_block) {
-          sJ = load_blk<BS, ODD>(sep, PR, a, b, up, kidx, PR);
-          if (b == 0) sh = load_pair<ODD>(sep + sepH, a, PR);
-        }
-        sg = sep[sepG];
-      }
-      if (own) {
-        if (accum || has_block) {
-          tJ = load_blk<BS, ODD>(to + tJ0, mt, a, b, up, kidx, PR);
-          if (b == 0) {
-            const double2 t2 = load_pair<ODD>(to + tH0, a, PR);
-            th[0] = t2.x; th[1] = t2.y;
+      // (kTail: the mark may have been set by an earlier level of this very launch -- by a wave of this workgroup, i.e.
+      // through this CU's own vector L1, behind the level's barrier: a plain load sees it)
+      // In the loop modes the load goes through a per-lane (opaque zero) offset: as a wave-uniform value the compiler
+      // fetches it and waits for it on the spot -- a dependent memory round trip in front of the operand loads of every
+      // level of the tail; like this it is waited for where it is used, behind the elimination.
+      int zero_v = 0;
+      if constexpr (MODE != kLevel) asm volatile("" : "+v"(zero_v));
+      const int poison_v = S.poison[(int64_t)site * S.n_clusters + en.from_b + zero_v];
+      // ---- every load of this message is issued before any arithmetic; the sender (the largest operand and
+      // the one the elimination waits for) goes first, the sepset and the receiver block right behind it
+      auto load_sep_to = [&]() {
+        if (!S.sep_zero) {
+          if (has_block) {
+            if constexpr (MODE == kStream) dma_tile<P>(sep, simg, lane);  // read back before divide!
+            else sJ = load_blk<BS, ODD>(sep, PR, a, b, up, kidx, PR);
+            if (b == 0) sh = load_pair<ODD>(sep + sepH, a, PR);
           }
+          sg = sep[sepG];
         }
-        tg = to[tG0];
-      }
-    };
-    if (!provider) load_sep_to();
-    if (provider) {
-      const double* __restrict__ from = pool + en.from_off;
-      if (en.mf == 0) {
-        gmsg = from[0];  // a constant factor
-        load_sep_to();
-      } else if (en.mf == PR && has_block) {
-        // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
-        mJ = load_blk<BS, ODD>(from, PR, a, b, up, kidx, PR);
-        const double2 ch = load_pair<ODD>(from + (BS ? bs16::h1(P) : PR * PR), a, PR);
-        mh[0] = ch.x; mh[1] = ch.y;
-        gmsg = from[BS ? bs16::g1(P) : PR * PR + PR];
-        load_sep_to();
-      } else {
-        Frag f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) f.w[i][j] = 0.0;
-        if (en.mf == PR) {
-          // everything is integrated (dimension-0 sepset): the 16 x 16 precision is the integrated block
-          const Blk v = load_blk<BS, ODD>(from, PR, a, b, up, kidx, PR);
-          const double2 vh = load_pair<ODD>(from + (BS ? bs16::h1(P) : PR * PR), a, PR);
-          f.w[0][0] = v.x; f.w[1][0] = v.y; f.w[0][1] = v.z; f.w[1][1] = v.w;
-          if (ODD && a == G - 1 && b == G - 1) f.w[1][1] = 1.0;  // the phantom variable: decoupled, unit precision
-          f.h[0] = vh.x; f.h[1] = vh.y; f.h[2] = 0.0; f.h[3] = 0.0;
+        if (own) {
+          if (accum || has_block) {
+            if constexpr (MODE == kStream) dma_tile<P>(to + tJ0, timg, lane);  // read back before mult!
+            else tJ = load_blk<BS, ODD>(to + tJ0, mt, a, b, up, kidx, PR);
+            if (b == 0) {
+              const double2 t2 = load_pair<ODD>(to + tH0, a, PR);
+              th[0] = t2.x; th[1] = t2.y;
+            }
+          }
+          tg = to[tG0];
+        }
+      };
+      if (!provider) load_sep_to();
+      if (provider) {
+        const double* __restrict__ gfrom = pool + en.from_off;
+        // kStream: the packed record was brought into this wave's LDS image one pass ahead
+        const double* __restrict__ from = MODE == kStream ? img : gfrom;
+        if (en.mf == 0) {
+          gmsg = gfrom[0];  // a constant factor
+          load_sep_to();
+        } else if (en.mf == PR && has_block) {
+          // nothing to integrate: the message is the sender's belief (src/beliefupdates.jl:56)
+          mJ = load_blk<BS, ODD>(from, PR, a, b, up, kidx, PR);
+          const double2 ch = load_pair<ODD>(from + (BS ? bs16::h1(P) : PR * PR), a, PR);
+          mh[0] = ch.x; mh[1] = ch.y;
           gmsg = from[BS ? bs16::g1(P) : PR * PR + PR];
-        } else if constexpr (ODD) {
-          // 2 PR-dim sender, odd PR: logical index l in [0, 2P) (integrated block first) -> physical index, -1: phantom
-          const int rot = (en.keep0 == 0) ? PR : 0;
-          auto phys = [&](int l) -> int {
-            const int Kb = l >= P ? 1 : 0, i = l - Kb * P;
-            if (i >= PR) return -1;
-            const int q = Kb * PR + i + rot;
-            return q >= 2 * PR ? q - 2 * PR : q;
-          };
-          int pr[4], pc[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            pr[i] = phys((i & 1) + 2 * a + (i >> 1) * P);
-            pc[i] = phys((i & 1) + 2 * b + (i >> 1) * P);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (!(i < 2 && j >= 2) && pr[i] >= 0 && pc[j] >= 0) f.w[i][j] = from[pr[i] + (int64_t)pc[j] * (2 * PR)];
-          if (a == G - 1 && b == G - 1) f.w[1][1] = 1.0;  // the phantom integrated variable: decoupled, unit precision
-#pragma unroll
-          for (int i = 0; i < 4; ++i) f.h[i] = pr[i] >= 0 ? from[4 * PR * PR + pr[i]] : 0.0;
-          gmsg = from[4 * PR * PR + 2 * PR];
-        } else if constexpr (BS) {
-          // 32-dim sender, packed: tiles T00 | T10 | T11.  integrated block = tile 0 (postorder, keep0 = 16)
-          // or tile 1 (preorder, keep0 = 0)
-          const bool itrail = en.keep0 == 0;
-          const Blk ii = load_blk<true>(from + (itrail ? bs16::t11(P) : 0), P, a, b, up, kidx);
-          const Blk ss = load_blk<true>(from + (itrail ? 0 : bs16::t11(P)), P, a, b, up, kidx);
-          // J_SI block (rows of S = my a, cols of I = my b): block (a, b) of T10, or block (b, a) transposed
-          const double4 t = *reinterpret_cast<const double4*>(from + bs16::t10(P) + (itrail ? (b + G * a) : (a + G * b)) * 4);
-          f.w[0][0] = ii.x; f.w[1][0] = ii.y; f.w[0][1] = ii.z; f.w[1][1] = ii.w;
-          f.w[2][2] = ss.x; f.w[3][2] = ss.y; f.w[2][3] = ss.z; f.w[3][3] = ss.w;
-          f.w[2][0] = t.x; f.w[3][0] = itrail ? t.z : t.y; f.w[2][1] = itrail ? t.y : t.z; f.w[3][1] = t.w;
-          const double2 hi = *reinterpret_cast<const double2*>(from + bs16::h2(P) + (itrail ? P : 0) + 2 * a);
-          const double2 hs = *reinterpret_cast<const double2*>(from + bs16::h2(P) + (itrail ? 0 : P) + 2 * a);
-          f.h[0] = hi.x; f.h[1] = hi.y; f.h[2] = hs.x; f.h[3] = hs.y;
-          gmsg = from[bs16::g2(P)];
+          load_sep_to();
         } else {
-          // logical index = original index rotated so that the integrated block comes first
-          const int rot = (en.keep0 == 0) ? P : 0;
-          const int r0 = (2 * a + rot) % (2 * P), r1 = (2 * a + P + rot) % (2 * P);
+          Frag f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int cl = 2 * b + (j & 1) + (j >> 1) * P;  // logical column C_b(j)
-            const int64_t co = (int64_t)((cl + rot) % (2 * P)) * (2 * P);
-            if (j < 2) {
-              const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
-              f.w[0][j] = v.x; f.w[1][j] = v.y;
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f.w[i][j] = 0.0;
+          if (en.mf == PR) {
+            // everything is integrated (dimension-0 sepset): the 16 x 16 precision is the integrated block
+            const Blk v = load_blk<BS, ODD>(from, PR, a, b, up, kidx, PR);
+            const double2 vh = load_pair<ODD>(from + (BS ? bs16::h1(P) : PR * PR), a, PR);
+            f.w[0][0] = v.x; f.w[1][0] = v.y; f.w[0][1] = v.z; f.w[1][1] = v.w;
+            if (ODD && a == G - 1 && b == G - 1) f.w[1][1] = 1.0;  // the phantom variable: decoupled, unit precision
+            f.h[0] = vh.x; f.h[1] = vh.y; f.h[2] = 0.0; f.h[3] = 0.0;
+            gmsg = from[BS ? bs16::g1(P) : PR * PR + PR];
+          } else if constexpr (ODD) {
+            // 2 PR-dim sender, odd PR: logical index l in [0, 2P) (integrated block first) -> physical index, -1: phantom
+            const int rot = (en.keep0 == 0) ? PR : 0;
+            auto phys = [&](int l) -> int {
+              const int Kb = l >= P ? 1 : 0, i = l - Kb * P;
+              if (i >= PR) return -1;
+              const int q = Kb * PR + i + rot;
+              return q >= 2 * PR ? q - 2 * PR : q;
+            };
+            int pr[4], pc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              pr[i] = phys((i & 1) + 2 * a + (i >> 1) * P);
+              pc[i] = phys((i & 1) + 2 * b + (i >> 1) * P);
             }
-            const double2 u = *reinterpret_cast<const double2*>(from + r1 + co);
-            f.w[2][j] = u.x; f.w[3][j] = u.y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (!(i < 2 && j >= 2) && pr[i] >= 0 && pc[j] >= 0) f.w[i][j] = from[pr[i] + (int64_t)pc[j] * (2 * PR)];
+            if (a == G - 1 && b == G - 1) f.w[1][1] = 1.0;  // the phantom integrated variable: decoupled, unit precision
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f.h[i] = pr[i] >= 0 ? from[4 * PR * PR + pr[i]] : 0.0;
+            gmsg = from[4 * PR * PR + 2 * PR];
+          } else if constexpr (BS) {
+            // 32-dim sender, packed: tiles T00 | T10 | T11.  integrated block = tile 0 (postorder, keep0 = 16)
+            // or tile 1 (preorder, keep0 = 0)
+            const bool itrail = en.keep0 == 0;
+            const Blk ii = load_blk<true>(from + (itrail ? bs16::t11(P) : 0), P, a, b, up, kidx);
+            const Blk ss = load_blk<true>(from + (itrail ? 0 : bs16::t11(P)), P, a, b, up, kidx);
+            // J_SI block (rows of S = my a, cols of I = my b): block (a, b) of T10, or block (b, a) transposed
+            const double4 t = *reinterpret_cast<const double4*>(from + bs16::t10(P) + (itrail ? (b + G * a) : (a + G * b)) * 4);
+            f.w[0][0] = ii.x; f.w[1][0] = ii.y; f.w[0][1] = ii.z; f.w[1][1] = ii.w;
+            f.w[2][2] = ss.x; f.w[3][2] = ss.y; f.w[2][3] = ss.z; f.w[3][3] = ss.w;
+            f.w[2][0] = t.x; f.w[3][0] = itrail ? t.z : t.y; f.w[2][1] = itrail ? t.y : t.z; f.w[3][1] = t.w;
+            const double2 hi = *reinterpret_cast<const double2*>(from + bs16::h2(P) + (itrail ? P : 0) + 2 * a);
+            const double2 hs = *reinterpret_cast<const double2*>(from + bs16::h2(P) + (itrail ? 0 : P) + 2 * a);
+            f.h[0] = hi.x; f.h[1] = hi.y; f.h[2] = hs.x; f.h[3] = hs.y;
+            gmsg = from[bs16::g2(P)];
+          } else {
+            // logical index = original index rotated so that the integrated block comes first
+            const int rot = (en.keep0 == 0) ? P : 0;
+            const int r0 = (2 * a + rot) % (2 * P), r1 = (2 * a + P + rot) % (2 * P);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int cl = 2 * b + (j & 1) + (j >> 1) * P;  // logical column C_b(j)
+              const int64_t co = (int64_t)((cl + rot) % (2 * P)) * (2 * P);
+              if (j < 2) {
+                const double2 v = *reinterpret_cast<const double2*>(from + r0 + co);
+                f.w[0][j] = v.x; f.w[1][j] = v.y;
+              }
+              const double2 u = *reinterpret_cast<const double2*>(from + r1 + co);
+              f.w[2][j] = u.x; f.w[3][j] = u.y;
+            }
+            const double2 v = *reinterpret_cast<const double2*>(from + 4 * P * P + r0);
+            const double2 u = *reinterpret_cast<const double2*>(from + 4 * P * P + r1);
+            f.h[0] = v.x; f.h[1] = v.y; f.h[2] = u.x; f.h[3] = u.y;
+            gmsg = from[4 * P * P + 2 * P];
           }
-          const double2 v = *reinterpret_cast<const double2*>(from + 4 * P * P + r0);
-          const double2 u = *reinterpret_cast<const double2*>(from + 4 * P * P + r1);
-          f.h[0] = v.x; f.h[1] = v.y; f.h[2] = u.x; f.h[3] = u.y;
-          gmsg = from[4 * P * P + 2 * P];
+          load_sep_to();
+          if constexpr (MODE == kStream) {
+            // the image has been read into registers (lgkmcnt): the next pass's sender may now overwrite it.  Issued
+            // here, behind this message's own loads (the memory pipe returns in order), in flight during the elimination.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (has_next) prefetch_sender<P>(nh, wave, pool, img, lane);
+          }
+          // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
+          // (in BS16 the lanes a > b hold nothing yet: all four of their entries come from lane (b, a))
+          {
+            const int tl = a * G + b;  // lane holding the transposed 2 x 2 block
+            const double t00 = __shfl(f.w[0][0], tl), t01 = __shfl(f.w[1][0], tl);
+            const double t10 = __shfl(f.w[0][1], tl), t11 = __shfl(f.w[1][1], tl);
+            // the "fake"-message test below must see the RAW lower triangle in the plain layout
+            bool nzraw = false;
+            if constexpr (!BS) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) nzraw |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
+            }
+            if (2 * a + 0 > 2 * b + 0) f.w[0][0] = t00;
+            if (2 * a + 0 > 2 * b + 1) f.w[0][1] = t01;
+            if (2 * a + 1 > 2 * b + 0) f.w[1][0] = t10;
+            if (2 * a + 1 > 2 * b + 1) f.w[1][1] = t11;
+            // "fake" message: J_I, J_SI, h_I all ~ 0 (src/beliefupdates.jl:62-66)
+            bool nz = nzraw || fabs(f.h[0]) > PGBP_EPS || fabs(f.h[1]) > PGBP_EPS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nz |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
+            if (__any(nz)) {
+              double mant = 1.0, quad = 0.0;
+              int expo = 0;
+              info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
+              if (info == 0) {
+                const double logdet = log(mant) + (double)expo * PGBP_LN2;
+                gmsg += 0.5 * ((double)PR * PGBP_LOG2PI - logdet + quad);  // :81
+              }
+            }
+          }
+          mJ = Blk{f.w[2][2], f.w[3][2], f.w[2][3], f.w[3][3]};
+          mh[0] = f.h[2]; mh[1] = f.h[3];
         }
-        load_sep_to();
-        // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
-        // (in BS16 the lanes a > b hold nothing yet: all four of their entries come from lane (b, a))
-        {
-          const int tl = a * G + b;  // lane holding the transposed 2 x 2 block
-          const double t00 = __shfl(f.w[0][0], tl), t01 = __shfl(f.w[1][0], tl);
-          const double t10 = __shfl(f.w[0][1], tl), t11 = __shfl(f.w[1][1], tl);
-          // the "fake"-message test below must see the RAW lower triangle in the plain layout
-          bool nzraw = false;
-          if constexpr (!BS) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) nzraw |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
-          }
-          if (2 * a + 0 > 2 * b + 0) f.w[0][0] = t00;
-          if (2 * a + 0 > 2 * b + 1) f.w[0][1] = t01;
-          if (2 * a + 1 > 2 * b + 0) f.w[1][0] = t10;
-          if (2 * a + 1 > 2 * b + 1) f.w[1][1] = t11;
-          // "fake" message: J_I, J_SI, h_I all ~ 0 (src/beliefupdates.jl:62-66)
-          bool nz = nzraw || fabs(f.h[0]) > PGBP_EPS || fabs(f.h[1]) > PGBP_EPS;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) nz |= fabs(f.w[i][0]) > PGBP_EPS || fabs(f.w[i][1]) > PGBP_EPS;
-          if (__any(nz)) {
-            double mant = 1.0, quad = 0.0;
-            int expo = 0;
-            PGBP_TR(2);
-            if constexpr (DF) {
-              // the prefetched sepset block waits in this wave's (idle) hand-over slot: with the poll in front the
-              // instance would otherwise need 134 VGPRs and lose its fourth wave per SIMD
-              *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(sJ.x, sJ.y, sJ.z, sJ.w);
-            }
-            info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
-            if constexpr (DF) {
-              const double4 v = *reinterpret_cast<const double4*>(slot + kSlotJ + 4 * lane);
-              sJ = Blk{v.x, v.y, v.z, v.w};
-            }
-            PGBP_TR_NOWAIT(3);
-            if (info == 0) {
-              const double logdet = log(mant) + (double)expo * PGBP_LN2;
-              gmsg += 0.5 * ((double)PR * PGBP_LOG2PI - logdet + quad);  // :81
-            }
-          }
-        }
-        mJ = Blk{f.w[2][2], f.w[3][2], f.w[2][3], f.w[3][3]};
-        mh[0] = f.h[2]; mh[1] = f.h[3];
+      }
+      if (__builtin_amdgcn_readfirstlane(poison_v)) state = 3;
+      else if (info != 0) state = 2;
+    }
+    if constexpr (MODE == kStream) {
+      // waves that did not come through the elimination path above (no sender of their own this pass, a light message,
+      // a stopped or invalid record) start the next pass's prefetch here; the image is theirs alone, its last reader was
+      // this wave, and those reads have returned
+      const bool through_elim = state >= 1 && provider && en.mf != 0 && !(en.mf == PR && has_block);
+      if (!through_elim) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (has_next) prefetch_sender<P>(nh, wave, pool, img, lane);
       }
     }
-    if (poisoned) state = 3;
-    else if (info != 0) state = 2;
-  }
-  if (K > 1) {
-    // hand the marginal over to the waves that reuse it
-    if (provider && en.valid && !accum) {
+    // ---- hand the marginal over to the waves that reuse it
+    if (provider && en.valid && !accum && en.grp_len > 1) {
       if (state == 1) {
         *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(mJ.x, mJ.y, mJ.z, mJ.w);
         if (act && b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(mh[0], mh[1]);
@@ -575,7 +569,7 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
         slot[kSlotStatus] = (double)state;
       }
     }
-    __syncthreads();
+    wg_barrier_lds();
     if (!provider && state == 1) {
       const double* src = fast_lds + en.src_wave * kSlotDoubles;
       const int pst = (int)src[kSlotStatus];
@@ -591,177 +585,155 @@ __global__ __launch_bounds__(256) void bp_level_fast16(DevState S_arg, const FEn
         state = 3;  // the marginal it depends on failed or was skipped: as good as a poisoned sender
       }
     }
-  }
-  PGBP_TR_NOWAIT(4);
-  // ---- divide! (src/beliefupdates.jl:579-587): every wave for its own sepset
-  Blk dJ{0, 0, 0, 0};
-  double dh0 = 0.0, dh1 = 0.0, dg = 0.0;
-  if (state == 1) {
-    double maxJ = 0.0, maxh = 0.0;
-    if (has_block) {
-      dJ = Blk{mJ.x - sJ.x, mJ.y - sJ.y, mJ.z - sJ.z, mJ.w - sJ.w};
-      store_blk<BS, ODD>(sep, PR, a, b, up, act, kidx, mJ, PR);
-      store_blk<BS, ODD>(res, PR, a, b, up, act, kidx, dJ, PR);
-      if (BS ? up : act) {
-        maxJ = fmax(fmax(fabs(dJ.x), fabs(dJ.y)), fmax(fabs(dJ.z), fabs(dJ.w)));
-        if (dJ.x != dJ.x || dJ.y != dJ.y || dJ.z != dJ.z || dJ.w != dJ.w) maxJ = INFINITY;
+    // ---- divide! (src/beliefupdates.jl:579-587): every wave for its own sepset
+    Blk dJ{0, 0, 0, 0};
+    double dh0 = 0.0, dh1 = 0.0, dg = 0.0;
+    if constexpr (MODE == kStream) {
+      // the tiles brought in by LDS-DMA (and, as it happens, the next sender) have landed; take them into registers
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (state == 1 && has_block && !S.sep_zero) sJ = load_blk<true>(simg, P, a, b, up, kidx);
+      if (state == 1 && own && (accum || has_block)) tJ = load_blk<true>(timg, P, a, b, up, kidx);
+    }
+    if (state == 1) {
+      double maxJ = 0.0, maxh = 0.0;
+      if (has_block) {
+        dJ = Blk{mJ.x - sJ.x, mJ.y - sJ.y, mJ.z - sJ.z, mJ.w - sJ.w};
+        store_blk<BS, ODD>(sep, PR, a, b, up, act, kidx, mJ, PR);
+        store_blk<BS, ODD>(res, PR, a, b, up, act, kidx, dJ, PR);
+        if (BS ? up : act) {
+          maxJ = fmax(fmax(fabs(dJ.x), fabs(dJ.y)), fmax(fabs(dJ.z), fabs(dJ.w)));
+          if (dJ.x != dJ.x || dJ.y != dJ.y || dJ.z != dJ.z || dJ.w != dJ.w) maxJ = INFINITY;
+        }
+        if (act && b == 0) {
+          dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
+          store_pair<ODD>(sep + sepH, a, mh[0], mh[1], PR);
+          store_pair<ODD>(res + (BS ? bs16::h1(P) : PR * PR), a, dh0, dh1, PR);
+          maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
+        }
       }
-      if (act && b == 0) {
-        dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
-        store_pair<ODD>(sep + sepH, a, mh[0], mh[1], PR);
-        store_pair<ODD>(res + (BS ? bs16::h1(P) : PR * PR), a, dh0, dh1, PR);
-        maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
+      dg = gmsg - sg;
+      if (lane == 0) {
+        sep[sepG] = gmsg;
+        S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
+      }
+      if (S.update_resnorm) {
+        // iscalibrated_residnorm! (src/beliefs.jl:994-1003); an empty message is calibrated
+        // x -> fl(x / c) is monotone, so "max over the wave, divide, compare" equals "every lane divides and
+        // compares its own maximum": one ballot instead of two 6-step wave reductions on the critical path
+        const bool lane_ok = maxh / sqrt((double)PR) <= S.atol && maxJ / sqrt((double)PR * (double)PR) <= S.atol;
+        const bool all_ok = __all(lane_ok);
+        if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = (!has_block || all_ok) ? 1 : 0;
+      }
+    } else if (state >= 2 && lane == 0) {
+      // not positive definite, or downstream of a failure: nothing of this message is applied
+      S.poison[(int64_t)site * S.n_clusters + en.to_b] = 1;
+      if (state == 2) {
+        S.status[(int64_t)site * S.n_msgs + en.msg] = info;
+        atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
       }
     }
-    dg = gmsg - sg;
-    if (lane == 0) {
-      sep[sepG] = gmsg;
-      S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
-    }
-    if (S.update_resnorm) {
-      // iscalibrated_residnorm! (src/beliefs.jl:994-1003); an empty message is calibrated
-      // x -> fl(x / c) is monotone, so "max over the wave, divide, compare" equals "every lane divides and
-      // compares its own maximum": one ballot instead of two 6-step wave reductions on the critical path
-      const bool lane_ok = maxh / sqrt((double)PR) <= S.atol && maxJ / sqrt((double)PR * (double)PR) <= S.atol;
-      const bool all_ok = __all(lane_ok);
-      if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = (!has_block || all_ok) ? 1 : 0;
-    }
-  } else if (state >= 2 && lane == 0) {
-    // not positive definite, or downstream of a failure: nothing of this message is applied
-    if constexpr (DF) __hip_atomic_store(&S.poison[(int64_t)site * S.n_clusters + en.to_b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else S.poison[(int64_t)site * S.n_clusters + en.to_b] = 1;
-    if (state == 2) {
-      S.status[(int64_t)site * S.n_msgs + en.msg] = info;
-      atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
-    }
-  }
-  // ---- mult! (src/beliefupdates.jl:483-488)
-  [[maybe_unused]] bool df_poison_to = false;  // DF: a wave of this accumulate task failed; wave 0 publishes the poison mark
-  if (accum) {
-    // waves > 0 publish their delta; wave 0 adds them in the reference's order
-    if (wave > 0) {
+    // ---- mult! (src/beliefupdates.jl:483-488)
+    if (accum && wave > first_wave) {
+      // the task's later waves publish their delta; its first wave adds them in the reference's order
       if (state == 1) {
         *reinterpret_cast<double4*>(slot + kSlotJ + 4 * lane) = make_double4(dJ.x, dJ.y, dJ.z, dJ.w);
         if (act && b == 0) *reinterpret_cast<double2*>(slot + kSlotH + 2 * a) = make_double2(dh0, dh1);
       }
       if (lane == 0) {
         slot[kSlotG] = dg;
-        slot[kSlotStatus] = en.valid ? (double)state : 0.0;  // padding waves end the list
+        slot[kSlotStatus] = (double)state;
       }
     }
-    __syncthreads();
-    if (wave == 0 && state == 1) {
+    wg_barrier_lds();
+    FEntry nx{};
+    if (MODE != kLevel && has_next) nx = load_record(recs + ((int64_t)(g + gstride) * W + wave));
+    if (state == 1) {
       tJ = Blk{tJ.x + dJ.x, tJ.y + dJ.y, tJ.z + dJ.z, tJ.w + dJ.w};
       th[0] += dh0; th[1] += dh1;
       tg += dg;
-      for (int w = 1; w < K; ++w) {
-        const double* src = fast_lds + w * kSlotDoubles;
-        if ((int)src[kSlotStatus] != 1) {  // the reference stops at the first failing message
-          if constexpr (DF) df_poison_to = (int)src[kSlotStatus] >= 2;
-          break;
-        }
-        const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
-        tJ = Blk{tJ.x + v.x, tJ.y + v.y, tJ.z + v.z, tJ.w + v.w};
-        if (b == 0) {
-          const double2 u = *reinterpret_cast<const double2*>(src + kSlotH + 2 * a);
-          th[0] += u.x; th[1] += u.y;
-        }
-        tg += src[kSlotG];
-      }
-    }
-  } else if (state == 1) {
-    tJ = Blk{tJ.x + dJ.x, tJ.y + dJ.y, tJ.z + dJ.z, tJ.w + dJ.w};
-    th[0] += dh0; th[1] += dh1;
-    tg += dg;
-  }
-  if constexpr (DF) {
-    if (own && state == 1) {
-      if (accum || has_block) {
-        df_store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
-        if (act && b == 0) {
-          if constexpr (ODD) {
-            if (2 * a < PR) df_store8(to + tH0 + 2 * a, th[0]);
-            if (2 * a + 1 < PR) df_store8(to + tH0 + 2 * a + 1, th[1]);
-          } else {
-            df_store16(to + tH0, 2 * a, th[0], th[1]);
+      if (accum && wave == first_wave) {
+        for (int w = 1; w < en.grp_len; ++w) {
+          const double* src = fast_lds + (first_wave + w) * kSlotDoubles;
+          if ((int)src[kSlotStatus] != 1) break;  // the reference stops at the first failing message
+          const double4 v = *reinterpret_cast<const double4*>(src + kSlotJ + 4 * lane);
+          tJ = Blk{tJ.x + v.x, tJ.y + v.y, tJ.z + v.z, tJ.w + v.w};
+          if (b == 0) {
+            const double2 u = *reinterpret_cast<const double2*>(src + kSlotH + 2 * a);
+            th[0] += u.x; th[1] += u.y;
           }
+          tg += src[kSlotG];
         }
       }
-      if (lane == 0) df_store8(to + tG0, tg);
+      if (own) {
+        if (accum || has_block) {
+          store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
+          if (act && b == 0) store_pair<ODD>(to + tH0, a, th[0], th[1], PR);
+        }
+        if (lane == 0) to[tG0] = tg;
+      }
     }
-    if (own && en.valid) {
-      // the arrival signal: this wave's write-through stores (block, poison mark) have left the CU, then one add
-      if (df_poison_to && lane == 0)
-        __hip_atomic_store(&S.poison[(int64_t)site * S.n_clusters + en.to_b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_fetch_add(dcnt + (int64_t)site * S.n_clusters + en.to_b, (int)((unsigned int)en.wait_sig >> 24),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else if (own && state == 1) {
-    if (accum || has_block) {
-      store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
-      if (act && b == 0) store_pair<ODD>(to + tH0, a, th[0], th[1], PR);
-    }
-    if (lane == 0) to[tG0] = tg;
+    if constexpr (MODE == kLevel) break;
+    g += gstride;
+    if (g >= ngroups) break;
+    // the hand-over slots are reused by the next pass: every wave has finished reading them (kTail: and every global
+    // store of this level is complete before the next level's loads)
+    if constexpr (MODE == kTail) wg_barrier_global();
+    else wg_barrier_lds();
+    en = nx;
   }
-#ifdef PGBP_TRACE_LIGHT
-  {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
-    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-    const unsigned int slot = g_trace_base + blockIdx.x * K + (threadIdx.x >> 6);
-    if (g_trace_all && lane == 0 && slot < kTraceCap) {
-      const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-      g_trace[slot][0] = ((unsigned long long)xcc << 32) | hw;
-      g_trace[slot][7] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
-      g_trace[slot][8] = t_start;
-      g_trace[slot][9] = t_end;
-    }
-  }
-#elif defined(PGBP_TRACE)
-  PGBP_TR_NOWAIT(5);
-  PGBP_TR(6);  // all stores acknowledged
-  tr[9] = trace_vgpr(__builtin_amdgcn_s_memrealtime());
-  if (trace_on && lane == 0) {
-    const unsigned int slot = g_trace_all ? g_trace_base + blockIdx.x * K + (threadIdx.x >> 6) : atomicAdd(&g_trace_n, 1u);
-    if (slot < kTraceCap) {
-      // marks 0 and 7 carry identification in full-trace mode: grid size / workgroup, hardware ids
-      tr[7] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
-      const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-      const unsigned long long t0 = tr[0];
-      for (int i = 1; i < 7; ++i) g_trace[slot][i] = tr[i] - t0;
-      g_trace[slot][0] = ((unsigned long long)xcc << 32) | hw;
-      g_trace[slot][7] = tr[7];
-      g_trace[slot][8] = tr[8];
-      g_trace[slot][9] = tr[9];
-    }
-  }
-#endif
 }
 
+namespace {
+
+size_t fast_lds_bytes(int mode) {
+  const int W = mode == kTail ? kTailWaves : kFastMaxWaves;
+  return sizeof(double) * (size_t)W * (size_t)(kSlotDoubles + kColDoubles + (mode == kStream ? kImgDoubles : 0));
+}
+
+int g_stream_grid = 0;  // workgroups of a persistent streaming launch: what the device holds at once
+
 template <int P, bool ODD>
-static void launch_fast_p(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
-                          unsigned long long seq_base, unsigned long long stop_below, int32_t* dcnt, hipStream_t st) {
-  const size_t lds = sizeof(double) * (size_t)(kSlotDoubles + kColDoubles) * K;
-  int32_t* none = nullptr;
+void launch_fast_p(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
+                   unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
+                   int max_grid) {
+  const size_t lds = fast_lds_bytes(mode);
   if constexpr (!ODD) {
     if (S.bs16) {
-      if (dcnt)
-        hipLaunchKernelGGL((bp_level_fast16<P, true, false, true>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S,
-                           d_recs, K, seq_base, stop_below, dcnt);
-      else
-        hipLaunchKernelGGL((bp_level_fast16<P, true, false, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S,
-                           d_recs, K, seq_base, stop_below, none);
+      if (mode == kStream) {
+        if (g_stream_grid == 0) {
+          int dev = 0, cus = 256, per_cu = 0;
+          (void)hipGetDevice(&dev);
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp_fast16<P, true, false, kStream>, kFastMaxWaves * 64,
+                                                           lds) != hipSuccess || per_cu <= 0)
+            per_cu = 4;
+          g_stream_grid = cus * per_cu;
+        }
+        // as many workgroups as stay resident, shrunk so that every one walks the same number of groups
+        const int cap = max_grid > 0 ? std::min(max_grid, g_stream_grid) : g_stream_grid;
+        const int passes = (ngroups + cap - 1) / cap;
+        const int grid = (ngroups + passes - 1) / passes;
+        hipLaunchKernelGGL((bp_fast16<P, true, false, kStream>), dim3(grid, n_sites), dim3(kFastMaxWaves * 64), lds, st, S,
+                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b);
+      } else if (mode == kTail) {
+        hipLaunchKernelGGL((bp_fast16<P, true, false, kTail>), dim3(1, n_sites), dim3(kTailWaves * 64), lds, st, S, d_recs,
+                           ngroups, split, seq_base, stop_a, stop_b);
+      } else {
+        hipLaunchKernelGGL((bp_fast16<P, true, false, kLevel>), dim3(ngroups, n_sites), dim3(kFastMaxWaves * 64), lds, st, S,
+                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b);
+      }
       return;
     }
   }
-  if (dcnt)
-    hipLaunchKernelGGL((bp_level_fast16<P, false, ODD, true>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs,
-                       K, seq_base, stop_below, dcnt);
-  else
-    hipLaunchKernelGGL((bp_level_fast16<P, false, ODD, false>), dim3(ntasks, n_sites), dim3(kWave * K), lds, st, S, d_recs,
-                       K, seq_base, stop_below, none);
+  if (mode == kTail)
+    hipLaunchKernelGGL((bp_fast16<P, false, ODD, kTail>), dim3(1, n_sites), dim3(kTailWaves * 64), lds, st, S, d_recs, ngroups,
+                       split, seq_base, stop_a, stop_b);
+  else  // plain layout: no streaming instance (a plain 2P record is 8.5 KB)
+    hipLaunchKernelGGL((bp_fast16<P, false, ODD, kLevel>), dim3(ngroups, n_sites), dim3(kFastMaxWaves * 64),
+                       fast_lds_bytes(kLevel), st, S, d_recs, ngroups, ngroups, seq_base, stop_a, stop_b);
 }
+
+}  // namespace
 
 // ---- assignfactors! for MvFullBrownianMotion on a tree (pgbp_bm_tree of include/pgbp.h), lane-blocked ---------------
 // One wavefront per cluster, same lane geometry as the message kernel: lane (a, b) holds the 2 x 2 block
@@ -914,48 +886,39 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
 // The kernel is instantiated for every even sepset dimension P <= 16 ((P/2)^2 lanes: all 64 for P = 16, 16 for P = 8,
 // 1 for P = 2), and each instance once more for the odd dimension P - 1 (plain layout, a phantom variable per block);
 // the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
-void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
-                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st, int32_t* dcnt) {
-  if (ntasks <= 0) return;
+// mode: kLevel (0) one group of kFastMaxWaves records per workgroup; kStream (1) persistent grid with LDS-DMA prefetch
+// (packed layout only: falls back to kLevel otherwise); kTail (2) one workgroup walks `ngroups` groups of kTailWaves
+// records, groups >= split stop below stop_b instead of stop_a (a postorder's tail followed by a preorder's head).
+void launch_fast16(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
+                   unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
+                   int max_grid) {
+  if (ngroups <= 0) return;
+  if (mode == kStream && !(S.bs16 && S.fast_p % 2 == 0)) mode = kLevel;
+#ifdef PGBP_ONLY_P16  // experiment builds: one instance, seconds to compile
+  if (S.fast_p == 16) launch_fast_p<16, false>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid);
+#else
+#define PGBP_FAST(PP, OD) launch_fast_p<PP, OD>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid); break
   switch (S.fast_p) {  // the real sepset dimension; odd ones run on the next even instance with a phantom variable
-    case 16: launch_fast_p<16, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 15: launch_fast_p<16, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 14: launch_fast_p<14, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 13: launch_fast_p<14, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 12: launch_fast_p<12, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 11: launch_fast_p<12, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 10: launch_fast_p<10, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 9: launch_fast_p<10, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 8: launch_fast_p<8, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 7: launch_fast_p<8, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 6: launch_fast_p<6, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 5: launch_fast_p<6, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 4: launch_fast_p<4, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 3: launch_fast_p<4, true>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
-    case 2: launch_fast_p<2, false>(S, d_recs, K, ntasks, n_sites, seq_base, stop_below, dcnt, st); break;
+    case 16: PGBP_FAST(16, false);
+    case 15: PGBP_FAST(16, true);
+    case 14: PGBP_FAST(14, false);
+    case 13: PGBP_FAST(14, true);
+    case 12: PGBP_FAST(12, false);
+    case 11: PGBP_FAST(12, true);
+    case 10: PGBP_FAST(10, false);
+    case 9: PGBP_FAST(10, true);
+    case 8: PGBP_FAST(8, false);
+    case 7: PGBP_FAST(8, true);
+    case 6: PGBP_FAST(6, false);
+    case 5: PGBP_FAST(6, true);
+    case 4: PGBP_FAST(4, false);
+    case 3: PGBP_FAST(4, true);
+    case 2: PGBP_FAST(2, false);
     default: break;  // the planner never marks a task fast for another P
   }
-#ifdef PGBP_TRACE
-  hipLaunchKernelGGL(trace_advance, dim3(1), dim3(1), 0, st, (unsigned int)(ntasks * K));
+#undef PGBP_FAST
 #endif
 }
 
 }  // namespace pgbp
 
-#ifdef PGBP_TRACE
-extern "C" int pgbp_debug_trace_mode(unsigned int all) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_trace_all), &all, sizeof(all)) == hipSuccess ? 0 : 1;
-}
-extern "C" int pgbp_debug_trace(unsigned long long* out, unsigned int cap, unsigned int* n, int reset) {
-  if (hipDeviceSynchronize() != hipSuccess) return 4;
-  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(pgbp::g_trace_n), sizeof(unsigned int)) != hipSuccess) return 1;
-  const unsigned int k = *n < cap ? *n : cap;
-  if (k && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgbp::g_trace), sizeof(unsigned long long) * (size_t)k * 10) != hipSuccess) return 2;
-  if (reset) {
-    unsigned int z = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_trace_n), &z, sizeof(z)) != hipSuccess) return 3;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_trace_base), &z, sizeof(z)) != hipSuccess) return 3;
-  }
-  return 0;
-}
-#endif

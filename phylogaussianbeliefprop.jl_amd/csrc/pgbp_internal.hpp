@@ -36,9 +36,11 @@ struct Entry {
 constexpr int kTLoad = 1, kTStore = 2;
 
 // Self-contained message record of the register-resident kernel (pgbp_fast.hip): everything a wavefront
-// needs is in ONE 64-byte line, so the dependent-load chain is  record -> data.  A fast task owns K
-// consecutive records (K = waves per workgroup of its level); records beyond the task's length have
-// valid = 0.
+// needs is in ONE 64-byte line, so the dependent-load chain is  record -> data.  The fast-class tasks of a level
+// (at most kFastMaxWaves messages each) are packed into GROUPS of W records: one group = one workgroup pass, one
+// wavefront per record; a task's records are consecutive inside its group (grp_base .. grp_base + grp_len - 1).
+// W = kFastMaxWaves for the level and streaming launches, kTailWaves for the single-workgroup tail launch; records
+// beyond a group's last task have valid = 0 (their waves only join the barriers).
 struct FEntry {
   int64_t from_off, to_off, sep_off, res_off;  // doubles, inside one site's pools
   int32_t msg, seq, from_b, to_b;
@@ -48,31 +50,32 @@ struct FEntry {
   uint8_t up0;           // first index of the receiver's block
   uint8_t src_wave;      // wave of the workgroup that computes this record's marginal (== own index unless reused)
   uint8_t mode;          // bit 0: this wave loads+stores the receiver block itself; bit 1: accumulate task
-                         // (wave 0 owns the receiver block, the other waves hand their delta over through LDS)
-  // dataflow launch only (Traversal::dfentries; zero in the level records):
-  int32_t wait_from;     // poll the sender's arrival counter up to this many messages before loading it (0: no wait)
-  int32_t wait_sig;      // low 24 bits: the same for the receiver block this wave owns; high 8 bits: what the wave adds
-                         // to the receiver's arrival counter once its stores have drained
+                         // (its first wave owns the receiver block, the other waves hand their delta over through LDS)
+  uint8_t grp_base;      // wave (record index inside the group) of the first message of this record's task
+  uint8_t grp_len;       // number of messages of the task
+  uint8_t pad[6];
 };
 static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
 constexpr int kFOwn = 1, kFAccum = 2;
-constexpr int kFastMaxWaves = 4;
+constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = records per group of a level launch
+constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
 
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first
-  std::vector<int32_t> level_nfast;  // [n_levels] how many of the level's tasks run on the fast kernel
-  std::vector<FEntry> fentries;      // padded records of the fast tasks, level after level
+  std::vector<int32_t> level_nfast;  // [n_levels] how many of the level's tasks run on the register-resident kernel
+  std::vector<FEntry> fentries;      // packed groups of the fast tasks (kFastMaxWaves records each), level after level
   std::vector<int64_t> level_fbase;  // [n_levels] first record of the level in fentries
-  std::vector<int32_t> level_fk;     // [n_levels] records (= waves) per fast task of the level
+  std::vector<int32_t> level_ngroups;  // [n_levels] groups of the level
+  std::vector<int32_t> level_nrecs;    // [n_levels] messages (valid records) of the level's fast tasks
+  // TAIL: the run of narrow levels at the root end of the schedule tree (the last tail_levels levels of a postorder, the
+  // first of a preorder), every one all fast-class with at most kTailWaves messages: ONE single-workgroup launch walks
+  // them with a workgroup barrier per level instead of a kernel boundary.  tentries = tail_levels groups of kTailWaves.
+  int32_t tail_levels = 0;
+  std::vector<FEntry> tentries;
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;
-  // DATAFLOW form of a traversal that the register-resident kernel runs whole (pgbp_plan.cpp, build_dataflow):
-  // every task of the traversal in ONE launch, ordered so that a task only ever waits for workgroups with a smaller
-  // index (postorder: receivers far from the root first; preorder: senders near the root first), df_k records per task
-  std::vector<FEntry> dfentries;
-  int32_t df_k = 0, df_tasks = 0;
 };
 
 struct Tree {

@@ -48,13 +48,15 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
 void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
                       int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
 
-// register-resident kernel for sepsets of dimension 16 (pgbp_fast.hip)
-// dcnt != nullptr: the DATAFLOW launch -- d_recs are a traversal's dfentries (all its tasks), dcnt the zeroed
-// [n_sites][n_clusters] arrival counters (pgbp_plan.cpp, build_dataflow)
-void launch_level_fast16(const DevState& S, const FEntry* d_recs, int K, int ntasks, int n_sites,
-                         unsigned long long seq_base, unsigned long long stop_below, hipStream_t st,
-                         int32_t* dcnt = nullptr);
-constexpr int kDfTimeoutInfo = (1 << 20) - 1;  // "pivot index" reported when a dataflow wait gave up (never expected)
+// register-resident message kernel (pgbp_fast.hip): `ngroups` groups of records (FEntry) of a traversal.
+// mode 0 (level): one group of kFastMaxWaves records per workgroup; 1 (stream): persistent grid over the groups with the
+// next sender prefetched by LDS-DMA (packed layout; other layouts run as mode 0); 2 (tail): ONE workgroup walks the groups
+// (kTailWaves records each) with a workgroup barrier between them; groups >= split stop below stop_b instead of stop_a.
+constexpr int kFastLevel = 0, kFastStream = 1, kFastTail = 2;
+// max_grid > 0: cap on the workgroups of a streaming launch (tests).
+void launch_fast16(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
+                   unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
+                   int max_grid = 0);
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
                       double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);

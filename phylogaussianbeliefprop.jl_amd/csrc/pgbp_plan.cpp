@@ -198,8 +198,51 @@ static bool fast_task(const Plan& p, const Traversal& tr, int t, bool postorder,
   return true;
 }
 
-// Reorder the tasks of every level so that fast-class tasks come first, build their padded records, set the
-// receiver load/store flags of the generic tasks.
+// The W-record group of fast-class tasks `members` (sum of their lengths <= W): one record per message, a task's
+// records consecutive, invalid records behind the last task.
+static void append_group(const Plan& p, const Traversal& tr, const std::vector<int>& members,
+                         const std::vector<std::pair<int, int>>& blk_of_task, int t_first, bool postorder, int W,
+                         std::vector<FEntry>& out) {
+  int fill = 0;
+  for (int t : members) {
+    const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1], len = e1 - e0;
+    const bool accum = postorder && len > 1;
+    const std::pair<int, int>& blk = blk_of_task[t - t_first];
+    int provider = fill;
+    for (int w = 0; w < len; ++w) {
+      const Entry& en = tr.entries[e0 + w];
+      const MsgDesc& m = p.msgs[en.msg];
+      FEntry f{};
+      f.from_off = m.from_off; f.to_off = m.to_off; f.sep_off = m.sep_off; f.res_off = m.res_off;
+      f.msg = en.msg; f.seq = en.seq; f.from_b = m.from_b; f.to_b = m.to_b;
+      f.valid = 1;
+      f.mf = (uint8_t)m.mf; f.mt = (uint8_t)m.mt; f.s = (uint8_t)m.s;
+      f.keep0 = (uint8_t)(m.keep0 < 0 ? 0 : m.keep0);
+      f.up0 = (uint8_t)(m.s > 0 ? m.up0 : 0);
+      if (!en.reuse) provider = fill + w;
+      f.src_wave = (uint8_t)provider;
+      f.grp_base = (uint8_t)fill;
+      f.grp_len = (uint8_t)len;
+      if (accum) {
+        // the task's first wave owns the shared receiver block (even if its own message is g-only)
+        f.mode = (uint8_t)(kFAccum | (w == 0 ? kFOwn : 0));
+        if (w == 0 && m.s == 0) {
+          f.up0 = (uint8_t)blk.first;
+          f.mt = (uint8_t)(blk.second >= 0 ? blk.second : m.mt);
+        }
+      } else {
+        f.mode = kFOwn;
+      }
+      out.push_back(f);
+    }
+    fill += len;
+  }
+  for (; fill < W; ++fill) out.push_back(FEntry{});
+}
+
+// Reorder the tasks of every level so that fast-class tasks come first, pack them into groups of kFastMaxWaves records
+// (first fit, largest task first: no wave of a workgroup idles beside a shorter task), set the receiver load/store
+// flags of the generic tasks, and cut the tail (Traversal::tail_levels).
 static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   const int nlev = (int)tr.level_off.size() - 1;
   std::vector<int32_t> new_task_off{0};
@@ -207,19 +250,24 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   new_entries.reserve(tr.entries.size());
   tr.level_nfast.assign(nlev, 0);
   tr.level_fbase.assign(nlev, 0);
-  tr.level_fk.assign(nlev, 1);
+  tr.level_ngroups.assign(nlev, 0);
+  tr.level_nrecs.assign(nlev, 0);
   tr.fentries.clear();
+  tr.tentries.clear();
+  tr.tail_levels = 0;
   tr.max_mf = 0;
+  std::vector<std::vector<int>> level_fast(nlev);               // fast tasks of each level (old task ids)
+  std::vector<std::vector<std::pair<int, int>>> level_blk(nlev);  // (up0, mt) of the receiver block, per task of the level
   for (int L = 0; L < nlev; ++L) {
     std::vector<int> fast, slow;
-    std::vector<std::pair<int, int>> blk;  // (up0, mt) of the receiver block of each fast task
-    int K = 1;
-    for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) {
+    const int t_first = tr.level_off[L];
+    std::vector<std::pair<int, int>>& blk = level_blk[L];
+    blk.assign(tr.level_off[L + 1] - t_first, {0, 0});
+    for (int t = t_first; t < tr.level_off[L + 1]; ++t) {
       int up0 = 0, mt = 0;
       if (fast_task(p, tr, t, postorder, &up0, &mt)) {
         fast.push_back(t);
-        blk.push_back({up0, mt});
-        K = std::max(K, tr.task_off[t + 1] - tr.task_off[t]);
+        blk[t - t_first] = {up0, mt};
       } else {
         slow.push_back(t);
       }
@@ -231,46 +279,34 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
       slow.insert(slow.end(), fast.begin(), fast.end());
       std::sort(slow.begin(), slow.end());
       fast.clear();
-      blk.clear();
-      K = 1;
     }
     tr.level_nfast[L] = (int32_t)fast.size();
     tr.level_fbase[L] = (int64_t)tr.fentries.size();
-    tr.level_fk[L] = K;
-    for (size_t q = 0; q < fast.size(); ++q) {
-      const int t = fast[q];
-      const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];
-      const bool accum = postorder && (e1 - e0 > 1);
-      int provider = 0;
-      for (int w = 0; w < K; ++w) {
-        FEntry f{};
-        if (e0 + w < e1) {
-          const Entry& en = tr.entries[e0 + w];
-          const MsgDesc& m = p.msgs[en.msg];
-          f.from_off = m.from_off; f.to_off = m.to_off; f.sep_off = m.sep_off; f.res_off = m.res_off;
-          f.msg = en.msg; f.seq = en.seq; f.from_b = m.from_b; f.to_b = m.to_b;
-          f.valid = 1;
-          f.mf = (uint8_t)m.mf; f.mt = (uint8_t)m.mt; f.s = (uint8_t)m.s;
-          f.keep0 = (uint8_t)(m.keep0 < 0 ? 0 : m.keep0);
-          f.up0 = (uint8_t)(m.s > 0 ? m.up0 : 0);
-          if (!en.reuse) provider = w;
-          f.src_wave = (uint8_t)provider;
-          if (accum) {
-            // wave 0 owns the shared receiver block (even if its own message is g-only)
-            f.mode = (uint8_t)(kFAccum | (w == 0 ? kFOwn : 0));
-            if (w == 0 && m.s == 0) {
-              f.up0 = (uint8_t)blk[q].first;
-              f.mt = (uint8_t)(blk[q].second >= 0 ? blk[q].second : m.mt);
-            }
+    // first-fit-decreasing into groups of kFastMaxWaves wave slots; tasks of one size keep their order
+    {
+      std::vector<std::vector<int>> by_len(kFastMaxWaves + 1);
+      for (int t : fast) by_len[tr.task_off[t + 1] - tr.task_off[t]].push_back(t);
+      std::vector<size_t> next(kFastMaxWaves + 1, 0);
+      size_t left = fast.size();
+      std::vector<int> members;
+      while (left > 0) {
+        members.clear();
+        int room = kFastMaxWaves;
+        for (int len = kFastMaxWaves; len >= 1;) {
+          if (len <= room && next[len] < by_len[len].size()) {
+            members.push_back(by_len[len][next[len]++]);
+            room -= len;
+            --left;
           } else {
-            f.mode = kFOwn;
+            --len;
           }
-        } else if (accum) {
-          f.mode = kFAccum;  // padding record of an accumulate task: its wave still joins the barriers
         }
-        tr.fentries.push_back(f);
+        append_group(p, tr, members, blk, t_first, postorder, kFastMaxWaves, tr.fentries);
+        ++tr.level_ngroups[L];
       }
+      for (int t : fast) tr.level_nrecs[L] += tr.task_off[t + 1] - tr.task_off[t];
     }
+    level_fast[L] = fast;
     for (const auto* grp : {&fast, &slow})
       for (int t : *grp) {
         const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];
@@ -288,6 +324,20 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
         }
         new_task_off.push_back((int32_t)new_entries.size());
       }
+  }
+  // the tail: levels at the root end, all fast-class, at most kTailWaves messages each
+  auto tail_ok = [&](int L) {
+    const int nt = tr.level_off[L + 1] - tr.level_off[L];
+    return nt > 0 && tr.level_nfast[L] == nt && tr.level_nrecs[L] <= kTailWaves;
+  };
+  if (postorder) {
+    while (tr.tail_levels < nlev && tail_ok(nlev - 1 - tr.tail_levels)) ++tr.tail_levels;
+  } else {
+    while (tr.tail_levels < nlev && tail_ok(tr.tail_levels)) ++tr.tail_levels;
+  }
+  for (int q = 0; q < tr.tail_levels; ++q) {
+    const int L = postorder ? nlev - tr.tail_levels + q : q;
+    append_group(p, tr, level_fast[L], level_blk[L], tr.level_off[L], postorder, kTailWaves, tr.tentries);
   }
   tr.task_off.swap(new_task_off);
   tr.entries.swap(new_entries);
@@ -319,8 +369,9 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
     return fuse && it != nchild.end() && it->second == 1;
   };
   // ---- postorder: level = height of the child in the schedule tree (chains collapsed)
+  std::unordered_map<int, int> hnode;  // cluster -> level at which it can send (its height; leaves are absent: 0)
+  int post_levels = 0;
   {
-    std::unordered_map<int, int> hnode;  // cluster -> level at which it can send
     std::vector<int> lvl(n);
     int nlev = 0;
     for (int i = n - 1; i >= 0; --i) {
@@ -377,10 +428,23 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
       }
       if (!tasks.empty() || !fuse) tr.level_off.push_back((int)tr.task_off.size() - 1);
     }
+    post_levels = nlev;
     finalize_traversal(p, tr, true);
   }
-  // ---- preorder: level = depth of the parent (chains collapsed); tasks group by sender
+  // ---- preorder; tasks group by sender.  A sender may send as soon as it has received from its own parent (level =
+  // its depth: as soon as possible) and no later than its height allows (level = tree height - its height: as late as
+  // possible); both take as many levels as the tree is deep.  Default: AS LATE AS POSSIBLE, the mirror image of the
+  // postorder -- the levels near the root are then as narrow as the postorder's last ones (they join the single-workgroup
+  // tail launch), and the bulk of the messages sits in a few very wide levels at the leaf end (streamed by the
+  // persistent launch), instead of a bell of mid-sized levels that each pay a full launch latency.
+  // PGBP_PREORDER_ASAP=1 (or chain fusion) keeps the depth order.
   {
+    static const bool asap_env = getenv("PGBP_PREORDER_ASAP") != nullptr;
+    const bool alap = !fuse && !asap_env;
+    auto height = [&](int cluster) {
+      auto it = hnode.find(cluster);
+      return it == hnode.end() ? 0 : it->second;
+    };
     std::unordered_map<int, int> dnode;   // cluster -> level at which it sends
     std::unordered_map<int, int> head;    // cluster -> the cluster whose task carries its messages
     std::vector<int> lvl(n);
@@ -389,6 +453,7 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
       int dpt = 0;
       auto it = dnode.find(t.pa[i]);
       if (it != dnode.end()) dpt = it->second;
+      if (alap) dpt = post_levels - height(t.pa[i]);
       lvl[i] = dpt;
       const bool chained = unary(t.pa[i]);   // the child's task follows this message in the same wave
       dnode[t.ch[i]] = chained ? dpt : dpt + 1;
@@ -443,80 +508,6 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
     }
     finalize_traversal(p, tr, false);
   }
-}
-
-// DATAFLOW form of one traversal (Traversal::dfentries): all its tasks in one launch of the register-resident kernel.
-// A task may start as soon as the messages its operands depend on have arrived, which the kernel learns from one
-// arrival counter per cluster (messages received so far in this traversal); the level barrier -- a kernel boundary
-// plus the slowest wave of every level, 76 times per calibrate on a 50 000-tip tree -- is gone.  The order of the
-// grid makes waiting safe: a workgroup only ever waits for workgroups with a smaller index, and the hardware
-// dispatches in index order (per XCD), so the resident workgroup with the smallest index can always finish.
-//   postorder: tasks sorted by the depth of their receiver, deepest first (a task's senders are one deeper);
-//   preorder:  tasks sorted by the depth of their sender, root first (the sender's own receipt is one shallower);
-// ties keep the level order, so the order of the deltas added into one receiver is the one of the level schedule.
-// Returns false (and leaves the form empty) if the traversal is not all register-resident or a count does not fit.
-static bool build_dataflow(const Plan& p, const Tree& T, Traversal& tr, bool postorder) {
-  tr.dfentries.clear();
-  tr.df_k = tr.df_tasks = 0;
-  const int nlev = (int)tr.level_off.size() - 1;
-  if (nlev <= 0 || T.pa.empty()) return false;
-  std::vector<int32_t> depth(p.n_clusters, -1);
-  depth[T.pa[0]] = 0;
-  for (size_t i = 0; i < T.pa.size(); ++i) depth[T.ch[i]] = depth[T.pa[i]] + 1;
-  struct TaskRef { int64_t rec0; int32_t k, key; };
-  std::vector<TaskRef> tasks;
-  std::vector<int32_t> inbound(p.n_clusters, 0), delivered(p.n_clusters, 0);
-  int K = 1;
-  for (int L = 0; L < nlev; ++L) {
-    const int nt = tr.level_off[L + 1] - tr.level_off[L];
-    if (tr.level_nfast[L] != nt) return false;
-    const int k = tr.level_fk[L];
-    K = std::max(K, k);
-    for (int q = 0; q < nt; ++q) {
-      const int64_t r0 = tr.level_fbase[L] + (int64_t)q * k;
-      const FEntry& f0 = tr.fentries[r0];  // record 0 of a task is always valid
-      const int c = postorder ? f0.to_b : f0.from_b;
-      if (!f0.valid || depth[c] < 0) return false;
-      tasks.push_back({r0, k, postorder ? -depth[c] : depth[c]});
-      for (int w = 0; w < k; ++w)
-        if (tr.fentries[r0 + w].valid) ++inbound[tr.fentries[r0 + w].to_b];
-    }
-  }
-  std::stable_sort(tasks.begin(), tasks.end(), [](const TaskRef& x, const TaskRef& y) { return x.key < y.key; });
-  std::vector<FEntry> out;
-  out.reserve(tasks.size() * (size_t)K);
-  for (const TaskRef& t : tasks) {
-    int nvalid = 0;
-    bool accum = false;
-    for (int w = 0; w < t.k; ++w) {
-      nvalid += tr.fentries[t.rec0 + w].valid;
-      accum |= (tr.fentries[t.rec0 + w].mode & kFAccum) != 0;
-    }
-    for (int w = 0; w < K; ++w) {
-      FEntry f{};
-      if (w < t.k) f = tr.fentries[t.rec0 + w];
-      else if (accum) f.mode = kFAccum;  // padding wave of an accumulate task: joins the barriers, ends the list
-      f.wait_from = f.wait_sig = 0;
-      if (f.valid) {
-        if (f.src_wave == w) {  // this wave reads the sender: every message into the sender must have arrived
-          if (delivered[f.from_b] != inbound[f.from_b]) return false;  // (not a topological order: cannot happen)
-          f.wait_from = inbound[f.from_b];
-        }
-        if (f.mode & kFOwn) {
-          const int nsig = accum ? nvalid : 1;
-          if (delivered[f.to_b] >= (1 << 24) || nsig > 255) return false;
-          f.wait_sig = delivered[f.to_b] | (nsig << 24);
-        }
-      }
-      out.push_back(f);
-    }
-    for (int w = 0; w < t.k; ++w)
-      if (tr.fentries[t.rec0 + w].valid) ++delivered[tr.fentries[t.rec0 + w].to_b];
-  }
-  tr.dfentries.swap(out);
-  tr.df_k = K;
-  tr.df_tasks = (int32_t)tasks.size();
-  return true;
 }
 
 static bool tree_all_fast(const Tree& t) {
@@ -579,13 +570,6 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
     static const bool fuse_on = getenv("PGBP_CHAIN_FUSION") != nullptr;
     const bool uni_batch = p.max_dim <= 2 && p.n_sites >= 8;
     if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, true);
-    if (tree_all_fast(T)) {
-      if (!build_dataflow(p, T, T.post, true) || !build_dataflow(p, T, T.pre, false)) {
-        T.post.dfentries.clear();
-        T.pre.dfentries.clear();
-        T.post.df_tasks = T.pre.df_tasks = 0;
-      }
-    }
   }
   p.trees.swap(trees);
   p.all_fast = !p.trees.empty();
@@ -677,23 +661,21 @@ int pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* 
   return PGBP_OK;
 }
 
-int pgbp_plan_dataflow_sizes(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_tasks, int32_t* k) {
+int pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_ngroups, int32_t* tail_levels,
+                     int32_t* records, int32_t* tail_records) {
   const pgbp::Traversal* tr = get_trav(p, tree, dir);
-  if (!tr || !n_tasks || !k) return PGBP_ERR_INVALID;
-  *n_tasks = tr->df_tasks;
-  *k = tr->df_k;
-  return PGBP_OK;
-}
-
-int pgbp_plan_dataflow(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* records) {
-  const pgbp::Traversal* tr = get_trav(p, tree, dir);
-  if (!tr || !records) return PGBP_ERR_INVALID;
-  for (size_t i = 0; i < tr->dfentries.size(); ++i) {
-    const pgbp::FEntry& f = tr->dfentries[i];
-    int32_t* r = records + 7 * i;
-    r[0] = f.valid; r[1] = f.msg; r[2] = f.from_b; r[3] = f.to_b;
-    r[4] = f.wait_from; r[5] = f.wait_sig & 0xFFFFFF; r[6] = (int32_t)((uint32_t)f.wait_sig >> 24);
-  }
+  if (!tr) return PGBP_ERR_INVALID;
+  if (level_ngroups) std::copy(tr->level_ngroups.begin(), tr->level_ngroups.end(), level_ngroups);
+  if (tail_levels) *tail_levels = tr->tail_levels;
+  auto dump = [](const std::vector<pgbp::FEntry>& v, int32_t* out) {
+    for (size_t i = 0; i < v.size(); ++i) {
+      const pgbp::FEntry& f = v[i];
+      int32_t* r = out + 6 * i;
+      r[0] = f.valid; r[1] = f.msg; r[2] = f.grp_base; r[3] = f.grp_len; r[4] = f.src_wave; r[5] = f.mode;
+    }
+  };
+  if (records) dump(tr->fentries, records);
+  if (tail_records) dump(tr->tentries, tail_records);
   return PGBP_OK;
 }
 

@@ -1095,18 +1095,27 @@ def test_chain_fusion_opt_in_differential_fuzz(P):
     assert out.returncode == 0 and "80 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
-def test_dataflow_launch_opt_in_differential_fuzz(P):
-    """PGBP_DATAFLOW=1 (opt-in, read once per process -> child process): a traversal that the register-resident kernel
-    runs whole goes out as one launch whose tasks wait for arrival counters (pgbp_plan.cpp build_dataflow; write-through
-    stores, agent-scope counter adds, poll + acquire in pgbp_fast.hip).  The differential fuzz against the plain-C
-    sequential engine (beliefs 1e-8, flags, first failure of the reference's order, several sites) must hold unchanged."""
+@pytest.mark.parametrize("env", [
+    {"PGBP_STREAM": "1", "PGBP_STREAM_MIN": "1", "PGBP_STREAM_GRID": "3"},
+    {"PGBP_STREAM": "1", "PGBP_STREAM_MIN": "1", "PGBP_STREAM_GRID": "2", "PGBP_NO_TAIL": "1"},
+    {"PGBP_NO_TAIL": "1"},
+    {"PGBP_PREORDER_ASAP": "1", "PGBP_STREAM": "1", "PGBP_STREAM_MIN": "2", "PGBP_STREAM_GRID": "1"},
+], ids=["stream_everywhere_3wg", "stream_2wg_no_tail", "levels_only", "asap_stream_1wg"])
+def test_launch_modes_differential_fuzz(P, env):
+    """The three launch modes of the register-resident kernel (pgbp_fast.hip: one group per workgroup; persistent grid
+    with the next sender prefetched by LDS-DMA; single-workgroup tail) run the same message body.  The tuning variables
+    are read once per process, hence child processes: the streaming launch forced onto every level with a grid of 1-3
+    workgroups (so that every workgroup walks many groups: prefetch, slot reuse, a group's invalid records), with and
+    without the tail, the level launches alone, and the depth-ordered preorder.  Same differential fuzz against the
+    plain-C sequential engine as for the defaults: random trees (polytomies: tasks of 3 and 4 messages beside tasks of 1
+    and 2 in one group; caterpillars: the whole traversal in the tail), 1-16 traits (packed and plain layouts, odd
+    instances), 1-3 sites, injected non-positive-definite blocks (first failure of the reference's order)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, PGBP_DATAFLOW="1")
-    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "120", "91"], env=env,
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "120", "91"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 

@@ -711,13 +711,24 @@ def test_read_newick_gives_the_preorders_the_reference_tests_imply():
     assert [names[v - 1] for v in P.triangulate_minfill(P.moralize(net.node2family))] == g["minfill_order_names"]
 
 
-@pytest.mark.parametrize("ntips,p,kind", [(3, 2, "random"), (40, 4, "random"), (500, 16, "random"), (300, 8, "random"),
-                                          (30, 16, "caterpillar"), (70, 16, "poly4"), (120, 5, "random")])
-def test_dataflow_form_invariants(ntips, p, kind):
-    """The one-launch form of a traversal (build_dataflow in pgbp_plan.cpp): replaying the grid in index order, every
-    arrival count a record waits for has been signalled completely by workgroups with a SMALLER index (so a workgroup
-    never waits for one dispatched after it), the counts are the ones the data dependencies ask for, every message of
-    the level schedule appears once, and the messages into one receiver keep the order of the level schedule."""
+def _groups(lib, pl, tree, d, nlev):
+    ng = np.zeros(nlev, np.int32)
+    tl = C.c_int32()
+    assert lib.pgbp_plan_groups(pl, tree, d, L.i32p(ng), C.byref(tl), None, None) == 0
+    rec = np.zeros((max(1, int(ng.sum())), 4, 6), np.int32)
+    trec = np.zeros((max(1, tl.value), 8, 6), np.int32)
+    assert lib.pgbp_plan_groups(pl, tree, d, None, None, L.i32p(rec), L.i32p(trec)) == 0
+    return ng, tl.value, rec[:int(ng.sum())], trec[:tl.value]
+
+
+@pytest.mark.parametrize("ntips,p,kind", [(2, 3, "random"), (3, 2, "random"), (40, 4, "random"), (500, 16, "random"),
+                                          (300, 8, "random"), (30, 16, "caterpillar"), (70, 16, "poly4"),
+                                          (120, 5, "random"), (90, 2, "poly6")])
+def test_group_packing_and_tail_invariants(ntips, p, kind):
+    """Launch form of the fast-class tasks (finalize_traversal in pgbp_plan.cpp): every level's tasks are packed into
+    groups of 4 wavefront records, a task's messages consecutive and in schedule order inside ONE group, every message of
+    the level exactly once, no group emptier than first-fit allows; the tail repeats the levels at the root end of the
+    tree (last of a postorder, first of a preorder) as one group of 8 records per level, in level order."""
     rng = np.random.default_rng(ntips + p)
     if kind == "random":
         tr = S.random_tree(ntips, rng)
@@ -729,53 +740,63 @@ def test_dataflow_form_invariants(ntips, p, kind):
     lib, pl, code, keep = _plan(prob)
     assert code == 0, lib.pgbp_plan_last_error(pl)
     assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
-    nclusters = prob.nclusters
+
+    def check_group(grp, W, level_tasks):
+        """grp: [W][6] records; level_tasks: message tuple -> True for the tasks of the level not yet seen"""
+        w = 0
+        while w < W and grp[w, 0]:
+            base, ln = int(grp[w, 2]), int(grp[w, 3])
+            assert base == w and 1 <= ln <= 4 and w + ln <= W
+            msgs = tuple(int(grp[w + i, 1]) for i in range(ln))
+            assert level_tasks.pop(msgs, None) is not None, "a group's task is a task of its level, once"
+            for i in range(ln):
+                valid, msg, gb, gl, src, mode = (int(x) for x in grp[w + i])
+                assert valid == 1 and gb == base and gl == ln
+                assert base <= src <= w + i, "the marginal comes from an earlier (or the same) wave of the task"
+                if d == 0 and ln > 1:
+                    assert mode == (3 if i == 0 else 2) and src == w + i   # accumulate: first wave owns the block
+                else:
+                    assert mode == 1
+                    assert src == w + i or er_of[msg] == 1                 # reuse only where the planner said so
+            w += ln
+        assert not grp[w:, 0].any(), "invalid records only behind the last task"
+        return w
+
     for d in (0, 1):
         lo, to, em, ee, er = _traversal(lib, pl, 0, d)
-        nf = np.zeros(len(lo) - 1, np.int32)
+        er_of = {int(m): int(r) for m, r in zip(em, er)}
+        nlev = len(lo) - 1
+        nf = np.zeros(nlev, np.int32)
         assert lib.pgbp_plan_level_nfast(pl, 0, d, L.i32p(nf)) == 0
-        all_fast = all(nf[i] == lo[i + 1] - lo[i] for i in range(len(lo) - 1))
-        nt, k = C.c_int32(), C.c_int32()
-        assert lib.pgbp_plan_dataflow_sizes(pl, 0, d, C.byref(nt), C.byref(k)) == 0
-        if not all_fast:
-            assert nt.value == 0
-            continue
-        assert nt.value == len(to) - 1 and 1 <= k.value <= 4
-        rec = np.zeros((nt.value, k.value, 7), np.int32)
-        assert lib.pgbp_plan_dataflow(pl, 0, d, L.i32p(rec)) == 0
-        # what each cluster receives in this traversal, in level-schedule order
-        level_order = {}
-        for e in range(len(em)):
-            k_sep, side = divmod(int(em[e]), 2)
-            rcv = int(prob.sepset_clusters[k_sep][side])
-            level_order.setdefault(rcv, []).append(int(em[e]))
-        inbound = {c: len(v) for c, v in level_order.items()}
-        arrived = np.zeros(nclusters, int)
-        seen_order = {}
-        msgs = []
-        for t in range(nt.value):
-            pending = []
-            for w in range(k.value):
-                valid, msg, snd, rcv, wait_from, wait_to, nsig = (int(x) for x in rec[t, w])
-                if not valid:
-                    assert wait_from == 0 and wait_to == 0 and nsig == 0
-                    continue
-                msgs.append(msg)
-                seen_order.setdefault(rcv, []).append(msg)
-                # the sender is complete: everything it receives in this traversal has arrived already
-                assert arrived[snd] == inbound.get(snd, 0), (d, t, w)
-                assert wait_from in (0, inbound.get(snd, 0))            # 0: a wave that reuses another wave's marginal
-                if wait_from == 0 and inbound.get(snd, 0) > 0:
-                    assert any(int(rec[t, v, 2]) == snd and int(rec[t, v, 4]) > 0 for v in range(k.value))
-                if nsig:
-                    assert wait_to == arrived[rcv]                      # earlier tasks into the same receiver
-                    pending.append((rcv, nsig))
-            for rcv, nsig in pending:
-                arrived[rcv] += nsig
-        assert sorted(msgs) == sorted(int(m) for m in em)
-        for c, n_in in inbound.items():
-            assert arrived[c] == n_in
-            assert seen_order[c] == level_order[c]
+        ng, tail_levels, rec, trec = _groups(lib, pl, 0, d, nlev)
+        g0 = 0
+        level_msgs = []
+        for lv in range(nlev):
+            tasks = {tuple(int(m) for m in em[to[t]:to[t + 1]]): True for t in range(lo[lv], lo[lv] + nf[lv])}
+            n_msgs = sum(len(k) for k in tasks)
+            level_msgs.append(n_msgs)
+            used = 0
+            for g in range(g0, g0 + ng[lv]):
+                used += check_group(rec[g], 4, tasks)
+            assert not tasks and used == n_msgs
+            # first fit, largest first: at most one group of the level is less than half full
+            assert sum(1 for g in range(g0, g0 + ng[lv]) if rec[g, :, 0].sum() <= 1) <= 1 or n_msgs <= ng[lv]
+            assert ng[lv] * 4 < 2 * n_msgs + 4
+            g0 += ng[lv]
+        # the tail: the maximal run of all-fast levels with at most 8 messages at the root end
+        order = list(range(nlev - 1, -1, -1)) if d == 0 else list(range(nlev))
+        want = 0
+        for lv in order:
+            if nf[lv] == lo[lv + 1] - lo[lv] and nf[lv] > 0 and level_msgs[lv] <= 8:
+                want += 1
+            else:
+                break
+        assert tail_levels == want
+        for q in range(tail_levels):
+            lv = nlev - tail_levels + q if d == 0 else q
+            tasks = {tuple(int(m) for m in em[to[t]:to[t + 1]]): True for t in range(lo[lv], lo[lv + 1])}
+            check_group(trec[q], 8, tasks)
+            assert not tasks
     lib.pgbp_plan_destroy(pl)
 
 

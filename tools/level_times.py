@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Per-launch durations and kernel-to-kernel gaps of one calibrate! on the cfg3 workload, from a rocprofv3 kernel trace.
+
+  step 1 (under the profiler; the program itself after `--`):
+     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lt -- python3 tools/level_times.py run [ntips] [traits]
+  step 2 (plain): python3 tools/level_times.py parse gpurun_out/lt [out.json]
+
+`run` builds the workload, does 3 warm-up calibrates and 5 more, each bracketed by a device sync so that the
+calibrates are separable in the trace by their idle gaps.  `parse` reads the *_kernel_trace.csv, keeps the message-kernel
+dispatches of the LAST calibrate and prints, per launch: grid size (workgroups), duration, gap to the previous launch."""
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(ntips, p):
+    import numpy as np
+    import pgbp_amd as P
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(3)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    import time
+    for _ in range(8):
+        assert P.calibrate_(cgb, prob.schedule, 1, sync=False)[0]
+        time.sleep(0.003)
+    print("loglik", cgb.integratebelief_(prob.root_cluster)[1])
+
+
+def parse(d, out=None):
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    assert files, f"no kernel trace under {d}"
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                             int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)))
+    rows.sort()
+    msg = [r for r in rows if r[2].startswith("void pgbp::bp_") or "bp_level" in r[2] or "bp_tail" in r[2] or "bp_stream" in r[2]]
+    # the run does 8 identical calibrates: the last one = the last len/8 message-kernel dispatches
+    groups = [msg]
+    per = len(msg) // 8
+    g = msg[-per:]
+    t_first, t_last = g[0][0], g[-1][1]
+    res = []
+    prev_end = None
+    for (s, e, name, grid, wg) in g:
+        short = name.split("(")[0].replace("void pgbp::", "")
+        res.append({"kernel": short, "workgroups": grid // max(1, wg), "wg_size": wg, "us": (e - s) / 1e3,
+                    "gap_us": None if prev_end is None else (s - prev_end) / 1e3})
+        prev_end = e
+    tot = sum(r["us"] for r in res)
+    gaps = sum(r["gap_us"] or 0 for r in res)
+    summary = {"launches": len(res), "span_us": (t_last - t_first) / 1e3, "sum_kernel_us": tot, "sum_gap_us": gaps,
+               "calibrates_seen": len(groups)}
+    for i, r in enumerate(res):
+        print(f"{i:3d} {r['kernel'][:44]:44s} wgs {r['workgroups']:6d} x{r['wg_size']:4d}  {r['us']:8.2f} us  gap {r['gap_us'] if r['gap_us'] is not None else 0:6.2f}")
+    print(json.dumps(summary))
+    if out:
+        with open(out, "w") as fh:
+            json.dump({"summary": summary, "launches": res}, fh, indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 50000, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
+    else:
+        parse(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
