@@ -49,6 +49,19 @@ def build_workload(ntips, p, seed, graph):
     return tr, prob, packed, ll_check, (R, mu, X)
 
 
+def host_cores():
+    """Cores this process may really use: the scheduler affinity, cut down to the cgroup's CPU quota where there is one
+    (a GPU box hands a 1-GPU job 16 of its 256 logical CPUs), and never more than 16 per GPU without a quota to read."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline(prob, packed, budget_s=20.0):
     """The oracle's plain-C sequential engine (reference message order, 1 core) on a bounded sample:
     whole calibrate!() passes over the same workload until ~budget_s of CPU time is spent."""
@@ -71,11 +84,34 @@ def cpu_baseline(prob, packed, budget_s=20.0):
         passes += 1
         assert ok
     ll = eng.integrate(prob.root_cluster)[1]
-    return {"value": nmsg * passes / t_total, "unit": "messages/s", "cores": 1, "kind": "port",
-            "sample": f"{passes} full calibrate!() passes of the same workload ({nmsg} messages each), "
-                      f"oracle/c sequential engine (gcc -O3 -march=native, 1 thread of {os.cpu_count()} host cpus), "
-                      f"{t_total:.1f} s",
-            "loglik": ll}
+    out = {"value": nmsg * passes / t_total, "unit": "messages/s", "cores": 1, "kind": "port",
+           "sample": f"{passes} full calibrate!() passes of the same workload ({nmsg} messages each), "
+                     f"oracle/c sequential engine (gcc -O3 -march=native, 1 thread of {os.cpu_count()} host cpus), "
+                     f"{t_total:.1f} s",
+           "loglik": ll}
+    # secondary: the same engine level by level on every host core (OpenMP); the reference
+    # itself is single-threaded, so this is the socket-vs-GPU view, not the headline baseline
+    try:
+        ncores = host_cores()
+        levels = eng.levels_of_tree(pa, ch)
+        eng.reset()
+        assert eng.calibrate_levels(levels, 1, ncores)      # warm-up: thread pool, caches
+        t_all, passes_all = 0.0, 0
+        while t_all < max(2.0, budget_s / 4) and passes_all < 50:
+            eng.reset()
+            t0 = time.perf_counter()
+            ok = eng.calibrate_levels(levels, 1, ncores)
+            t_all += time.perf_counter() - t0
+            passes_all += 1
+            assert ok
+        ll_all = eng.integrate(prob.root_cluster)[1]
+        out["all_cores"] = {"value": nmsg * passes_all / t_all, "unit": "messages/s", "cores": ncores, "kind": "port",
+                            "sample": f"{passes_all} level-synchronous calibrate!() passes (OpenMP, {ncores} threads: tasks of a "
+                                      f"level in parallel, the reference's order inside a task), {t_all:.1f} s",
+                            "loglik_rel_diff_vs_1_core": abs(ll_all - ll) / max(1.0, abs(ll))}
+    except Exception as ex:  # an oracle build without OpenMP: say so
+        out["all_cores"] = {"value": None, "sample": f"unavailable: {ex}"}
+    return out
 
 
 def timed_region(enqueue_and_wait, dist, device_sync, reduce_device=None):
@@ -99,6 +135,23 @@ def timed_region(enqueue_and_wait, dist, device_sync, reduce_device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def make_comm(dist, torch, rank, world, local_rank):
+    """pgbp_comm (C ABI, RCCL bound inside libpgbp.so) for the one exchange of the sharded paths; rank 0's unique id
+    travels over the launcher's torch.distributed group.  None for a single rank or the one-GPU gloo rehearsal
+    (two RCCL ranks cannot share a device)."""
+    if world == 1 or dist is None or os.environ.get("PGBP_BENCH_REHEARSAL") == "1":
+        return None
+    from pgbp_amd.sharding import Comm
+
+    def bcast(raw):
+        t = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if raw is not None:
+            t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+    return Comm(world, rank, local_rank, bcast)
 
 
 def whole_job_rate(units_per_rank_step, steps, world, dt):
@@ -212,7 +265,18 @@ def run_sites(args, torch, dist, rank, world, local_rank):
     default_size = (world == 1 and args.sites == 1000 and args.site_traits == 8 and args.ntips == 20000 and ou
                     and args.seed == 3)
     # the one collective of this configuration: all ranks get every problem's log-likelihood
-    full = gather_sites(norm, nprob, dist, device="cpu" if os.environ.get("PGBP_BENCH_REHEARSAL") == "1" else f"cuda:{local_rank}")
+    comm = make_comm(dist, torch, rank, world, local_rank)
+    if comm is not None:
+        # behind the C ABI: ONE ncclAllGather carrying every rank's log-likelihoods, info words and (succ, iscal)
+        check(enqueue_ll(eng, 1, C.byref(opts)))
+        slot = -(-nprob // world)
+        g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, slot)
+        full = np.concatenate([g_norm[r, :shard_range(nprob, r, world)[1] - shard_range(nprob, r, world)[0]] for r in range(world)])
+        if g_info.any() or not all_succ:
+            raise SystemExit("sites workload: a rank reported a failed message")
+        comm.close()
+    else:
+        full = gather_sites(norm, nprob, dist, device="cpu" if os.environ.get("PGBP_BENCH_REHEARSAL") == "1" else f"cuda:{local_rank}")
     total_msgs = msgs_per_cal / max(1, ns) * nprob        # same per-problem count on every rank
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -411,6 +475,14 @@ def main():
     if args.blobs is None:
         args.blobs = (args.ntips + 11) // 12
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the launcher as a CHILD process (this process has not
+        # touched the GPU yet; never exec over a process that has) and hand its exit code back
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -420,8 +492,9 @@ def main():
     rehearsal = os.environ.get("PGBP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a figure for another number of GPUs than asked for "
+                         "is never printed")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -481,16 +554,30 @@ def main():
     check(lib.pgbp_enqueue_calibrate(eng, args.warmup, 0, C.byref(opts)))
 
     def k_steps():
-        check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
+        # one HIP event pair per calibrate around its message launches, INSIDE the timed steps: the kernel time below is
+        # a part of `dt` by construction
+        check(lib.pgbp_enqueue_calibrate_timed(eng, args.steps, 0, C.byref(opts)))
         check(lib.pgbp_sync(eng))
     dt = timed_region(k_steps, dist, torch.cuda.synchronize)
     value = whole_job_rate(msgs_per_cal, args.steps, world, dt)
+    ms_k, nl_k = C.c_float(), C.c_int32()
+    check(lib.pgbp_fetch_kernel_time(eng, C.byref(ms_k), C.byref(nl_k)))
 
-    # after the timed region: the calibrated beliefs still integrate to the right log-likelihood
+    # after the timed region: no message failed, and the calibrated beliefs still integrate to the right log-likelihood
+    res = (L.Result * 1)()
     mu_, n2, i2 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
     rel2 = abs(n2[0] - ll_check) / max(1.0, abs(ll_check))
     if not (i2[0] == 0 and rel2 <= 1e-8) and not skip_parity:
         raise SystemExit(f"post-run parity failed: {n2[0]!r} vs {ll_check!r}")
+    comm = make_comm(dist, torch, rank, world, local_rank)
+    ranks_loglik = None
+    if comm is not None:
+        # N > 1 (replicas): every rank's log-likelihood and success flag reach every rank in ONE ncclAllGather (C ABI)
+        g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, 1)
+        if g_info.any() or not all_succ:
+            raise SystemExit("a rank reported a failed message after the timed region")
+        ranks_loglik = [float(v) for v in g_norm[:, 0]]
+        comm.close()
 
     out = None
     if rank == 0:
@@ -511,13 +598,14 @@ def main():
         # same without the fill (factors copied from the resident factor pool)
         check(lib.pgbp_time_enqueued(eng, 1, nll, 1, C.byref(opts), C.byref(ms)))
         ll_evals_nofill = nll / (ms.value * 1e-3)
-        # ---- roofline of the dominant kernel: HIP events around every message-level launch
-        nl = C.c_int32()
-        reps = max(2, min(5, args.steps))
-        check(lib.pgbp_time_message_kernels(eng, reps, C.byref(opts), C.byref(ms), C.byref(nl)))
-        kern_ms = ms.value
+        # ---- roofline of the dominant kernel: the HIP events recorded inside the timed steps above
+        nl = nl_k
+        reps = args.steps
+        kern_ms = ms_k.value
         pmc = load_pmc_traffic()
         achieved = bytes_per_cal * reps / (kern_ms * 1e-3) / 1e9
+        traffic = (pmc or {}).get("hbm_bytes_per_launch")
+        launches_pmc = (pmc or {}).get("launches_per_calibrate") or 76   # (76: the round-1 file, one launch per level)
         copy_bw = measured_copy_bandwidth(torch, local_rank) if rank == 0 else None
         out = {
             "metric": "clique-tree messages/sec (calibrate!: postorder+preorder), 16-trait BM",
@@ -530,14 +618,18 @@ def main():
                        "messages_per_step": int(msgs_per_cal), "tree_depth": int(tr.depth().max()),
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
             "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel), "parity_skipped": skip_parity,
+            "ranks_loglik": ranks_loglik,
             "ll_evals_per_s": ll_evals, "ll_evals_per_s_without_factor_fill": ll_evals_nofill,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
+                         # the same with the HBM bytes the counters saw (the packed layout moves about half of the
+                         # algorithmic bytes): what fraction of the peak the chip actually streamed
+                         "frac_physical": (traffic * launches_pmc * reps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic": traffic,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
                                          "profiles/pmc_traffic_latest.json)",
                          "algorithmic_bytes_per_launch": bytes_per_cal / max(1, nl.value // reps),
-                         "kernel": "bp_level_fast16", "launches_per_step": nl.value // reps,
+                         "kernel": "bp_fast16", "launches_per_step": nl.value // reps,
                          "algorithmic_bytes_per_step": bytes_per_cal,
                          "kernel_ms_per_step": kern_ms / reps,
                          # context for `frac`: what a plain device-to-device copy of 1 GiB reaches on this box
@@ -566,6 +658,29 @@ def main():
                 "workload": "25001-tip tree = 50000 cliques, 16 traits, clique tree", "messages_per_step": int(m2),
                 "ms_per_step": ms.value / args.steps, "messages_per_s": m2 * args.steps / (ms.value * 1e-3),
                 "loglik_rel_err_vs_pruning": float(rel4)}
+            del cgb2
+        if world == 1 and not args.no_alt_reading and (args.traits, args.ntips, args.graph) == (16, 50000, "cliquetree"):
+            # BASELINE.json configs[1] (cfg2) as a secondary block: homogeneous BM, 8 traits, 10 000-tip tree, Bethe graph
+            tr2, prob2, packed2, ll2, _ = build_workload(10000, 8, 2, "bethe")
+            cgb2 = pgbp_amd.ClusterGraphBelief.from_arrays(prob2.dims, prob2.sepset_clusters, prob2.scope_off,
+                                                           prob2.scope_idx, packed2, device=local_rank)
+            cgb2.set_schedule(prob2.schedule)
+            b2, m2 = cgb2.traffic_model()
+            check2 = lambda code: code == 0 or (_ for _ in ()).throw(RuntimeError(lib.pgbp_last_error(cgb2._eng).decode()))
+            check2(lib.pgbp_enqueue_loglik(cgb2._eng, 1, C.byref(opts)))
+            check2(lib.pgbp_fetch_loglik(cgb2._eng, L.f64p(norm), L.i32p(info)))
+            rel5 = abs(norm[0] - ll2) / max(1.0, abs(ll2))
+            if not (info[0] == 0 and rel5 <= 1e-8) and not skip_parity:
+                raise SystemExit(f"parity gate failed (cfg2): {norm[0]!r} vs {ll2!r}")
+            check2(lib.pgbp_reset_from_factors(cgb2._eng))
+            check2(lib.pgbp_time_enqueued(cgb2._eng, 0, args.warmup, 0, C.byref(opts), C.byref(ms)))
+            check2(lib.pgbp_time_enqueued(cgb2._eng, 0, args.steps, 0, C.byref(opts), C.byref(ms)))
+            out["cfg2_bethe_10k_tips_8_traits"] = {
+                "workload": "cfg2: homogeneous BM, 8 traits, 10000-tip tree (seed 2), Bethe cluster graph",
+                "clusters": int(prob2.nclusters), "messages_per_step": int(m2), "ms_per_step": ms.value / args.steps,
+                "messages_per_s": m2 * args.steps / (ms.value * 1e-3),
+                "roofline_frac": b2 * args.steps / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "loglik_rel_err_vs_pruning": float(rel5)}
             del cgb2
         if world == 1 and args.ll_batch > 1:
             # several parameter sets per pass: the site dimension of one engine carries B candidate models (R, mu) over

@@ -133,6 +133,7 @@ const char* pgbp_last_error(const pgbp_engine* e); /* e == NULL: error of the la
 int64_t pgbp_packed_size(const pgbp_engine* e);
 int64_t pgbp_residual_size(const pgbp_engine* e);
 int32_t pgbp_n_messages(const pgbp_engine* e);
+int32_t pgbp_belief_dim(const pgbp_engine* e, int32_t belief); /* dimension of a cluster / sepset belief, -1: bad index */
 
 /* ---- state transfer ------------------------------------------------------------------- */
 /* Upload all beliefs of all sites (packed, site-major; host pointer). If snapshot_factors != 0 the
@@ -316,6 +317,61 @@ int  pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* op
 /* Algorithmic bytes of one full calibrate iteration over all sites (SURVEY.md section 8(d) formula:
  * 8*[(mf^2+mf+1) + 4*(s^2+s+1) + (s^2+s)] per message) and message count. */
 int  pgbp_traffic_model(const pgbp_engine* e, double* bytes_per_calibrate, int64_t* messages_per_calibrate);
+
+/* ---- several GPUs ---------------------------------------------------------------------------
+ * Independent sites are the dimension of the path that shards: calibrate!() of one site never reads another
+ * (src/calibration.jl:35-60 works on one ClusterGraphBelief).  One big tree or network on one site does not shard
+ * without an exchange step: run replicas (one engine per device).
+ *
+ * (1) ONE PROCESS, several devices.  A group = one engine (and stream) per listed device over contiguous site ranges
+ * (shard i gets sites [first, first + count): the first n_sites % n_devices shards hold one site more).  Every call
+ * fans out on one host thread per device and gathers in site order; buffers are the single-engine ones with
+ * desc->n_sites = the TOTAL number of sites (desc->device is ignored).  No collective: the host owns every result.
+ * A device may be listed more than once (two shards on one GPU: the rehearsal the tests run on a one-GPU box). */
+typedef struct pgbp_group pgbp_group;
+int  pgbp_group_create(const pgbp_desc* desc, int32_t n_devices, const int32_t* devices, pgbp_group** out);
+void pgbp_group_destroy(pgbp_group* g);
+const char* pgbp_group_last_error(const pgbp_group* g); /* g == NULL: error of the last failed create (this thread) */
+int32_t pgbp_group_size(const pgbp_group* g);
+pgbp_engine* pgbp_group_engine(pgbp_group* g, int32_t shard);  /* borrowed: any single-engine call on one shard */
+int  pgbp_group_range(const pgbp_group* g, int32_t shard, int32_t* first_site, int32_t* n_sites);
+int  pgbp_group_set_schedule(pgbp_group* g, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j, const int32_t* ch_j);
+int  pgbp_group_set_beliefs(pgbp_group* g, const double* packed, int32_t snapshot_factors);
+int  pgbp_group_get_beliefs(pgbp_group* g, double* packed);
+int  pgbp_group_reset_from_factors(pgbp_group* g);
+/* calibrate! on every site; results[n_sites_total].  With auto_stop each shard stops once all ITS sites are calibrated. */
+int  pgbp_group_calibrate(pgbp_group* g, int32_t niter, const pgbp_opts* opts, pgbp_result* results);
+int  pgbp_group_integrate(pgbp_group* g, int32_t belief, double* mu, double* norm, int32_t* info);
+/* f->data = [n_sites_total][n_rows][p]; per-site parameter sets (m->per_site) = [n_sites_total][...]; each shard takes its
+ * rows (n_rates, p: the strides of m->R). */
+int  pgbp_group_lg_setup(pgbp_group* g, const pgbp_lg_families* f);
+int  pgbp_group_lg_assignfactors(pgbp_group* g, const pgbp_lg_params* m, int32_t n_rates, int32_t p);
+int  pgbp_group_enqueue_calibrate(pgbp_group* g, int32_t reps, int32_t reset_each, const pgbp_opts* opts);
+int  pgbp_group_enqueue_loglik(pgbp_group* g, int32_t reps, const pgbp_opts* opts);
+int  pgbp_group_enqueue_loglik_lg(pgbp_group* g, int32_t reps, const pgbp_opts* opts);
+int  pgbp_group_fetch_loglik(pgbp_group* g, double* norm, int32_t* info); /* [n_sites_total] */
+int  pgbp_group_sync(pgbp_group* g);
+
+/* (2) ONE PROCESS PER GPU (torchrun / MPI / Distributed.jl).  Every rank owns an ordinary engine over its own sites;
+ * the only exchange is ONE ncclAllGather (RCCL over xGMI) per pgbp_comm_gather_loglik call.  RCCL is bound at run time
+ * (dlopen of librccl.so.1); without it the calls return PGBP_ERR_NO_DEVICE.
+ * Rank 0 calls pgbp_comm_unique_id and hands the PGBP_COMM_ID_BYTES to the other ranks by whatever channel launched
+ * them; every rank then calls pgbp_comm_create (ncclCommInitRank: collective, blocks until all ranks arrived). */
+#define PGBP_COMM_ID_BYTES 128
+typedef struct pgbp_comm pgbp_comm;
+int  pgbp_comm_unique_id(uint8_t* id /* [PGBP_COMM_ID_BYTES] */);
+int  pgbp_comm_create(const uint8_t* id, int32_t n_ranks, int32_t rank, int32_t device, pgbp_comm** out);
+void pgbp_comm_destroy(pgbp_comm* c);
+const char* pgbp_comm_last_error(const pgbp_comm* c);
+/* Every rank contributes, from its engine e (same device as the communicator), the per-site log-likelihoods and info
+ * words of its last pgbp_enqueue_loglik* / pgbp_integrate and its sites' (succ, iscal) of the last calibration, in a slot
+ * of slot_sites sites (>= the largest number of sites on any rank; the same value on every rank).  On return, on EVERY
+ * rank: norm_all[n_ranks * slot_sites] and info_all (may be NULL) hold rank r's sites at [r * slot_sites, ...) (unused
+ * tail of a slot: 0), *all_succ / *all_iscal (may be NULL) the minimum over all sites of all ranks -- the
+ * all-reduce(min) of the flags SURVEY.md section 8(e) asks for, carried by the same collective.  Enqueued on the engine's
+ * stream behind the kernels that produce the values; returns after the result reached the host. */
+int  pgbp_comm_gather_loglik(pgbp_comm* c, pgbp_engine* e, int32_t slot_sites, double* norm_all, int32_t* info_all,
+                             int32_t* all_succ, int32_t* all_iscal);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,9 @@
 /*
  * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
  *
- * Plain-C, single-threaded restatement of the reference's canonical-form belief propagation,
- * executing messages in the reference's exact sequential order.  Used (i) as the checker at sizes
+ * Plain-C restatement of the reference's canonical-form belief propagation, executing messages in the reference's
+ * exact sequential order on one thread (orc_calibrate: the checker and the primary CPU baseline) or, for the
+ * secondary all-core baseline only, level by level on every core (orc_calibrate_levels, OpenMP).  Used (i) as the checker at sizes
  * the numpy restatement cannot reach, (ii) as bench.py's `cpu_baseline` ("port": 1 core, the
  * reference is single-threaded).  Never linked into, or called by, the product.
  *
@@ -178,8 +179,13 @@ static int marginalize(orc_t* o, const double* J, const double* h, double g, int
   return 0;
 }
 
-/* propagate_belief!(to, sepset k, from, residual). Returns 0 or info. */
-int orc_propagate(orc_t* o, int to, int k, int from) {
+/* propagate_belief!(to, sepset k, from, residual) with the caller's scratch (work: 4 M^2 + 8 M + 8 doubles, M = the
+ * largest belief dimension).  Returns 0 or info. */
+static int propagate_w(orc_t* o, int to, int k, int from, double* work) {
+  orc_t view = *o;   /* marginalize() takes its scratch from the handle: a per-thread view with its own */
+  view.work = work;
+  orc_t* const oo = o;
+  o = &view;
   const int a = o->sepcl[2 * k], b = o->sepcl[2 * k + 1];
   const int dir = (to == a && from == b) ? 0 : ((to == b && from == a) ? 1 : -1);
   if (dir < 0) return -1;
@@ -218,8 +224,60 @@ int orc_propagate(orc_t* o, int to, int k, int from) {
   S[(size_t)s * s + s] = mg;
   T[(size_t)mt * mt + mt] += dg;
   /* iscalibrated_residnorm! */
-  o->flags[2 * k + dir] = (s == 0) || (!nanflag && maxh / sqrt((double)s) <= 1e-5 && maxJ / sqrt((double)s * (double)s) <= 1e-5);
+  oo->flags[2 * k + dir] = (s == 0) || (!nanflag && maxh / sqrt((double)s) <= 1e-5 && maxJ / sqrt((double)s * (double)s) <= 1e-5);
   return 0;
+}
+
+int orc_propagate(orc_t* o, int to, int k, int from) { return propagate_w(o, to, k, from, o->work); }
+
+/* ALL-CORE baseline (labelled "secondary"): the same messages, level-synchronous instead of
+ * sequential.  tasks of one level touch disjoint receivers / sepsets and read no belief written in that level (the
+ * caller -- oracle/cengine.py:levels_of_tree -- groups a postorder level's messages by receiver and gives every preorder
+ * message its own task), so they run on all cores (OpenMP); the entries of a task keep the reference's order.
+ * One (postorder, preorder) pass per iteration.  Returns succ; on a failure fail_* names ONE failing message (not
+ * necessarily the first of the reference's order: this entry point exists for timing). */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int orc_calibrate_levels(orc_t* o, int n_levels, const int32_t* level_off, const int32_t* task_off, const int32_t* ent_to,
+                         const int32_t* ent_k, const int32_t* ent_from, int niter, int nthreads, int* iscal) {
+  const size_t wlen = (size_t)(4 * o->maxdim * o->maxdim + 8 * o->maxdim + 8);
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  const int nt = omp_get_max_threads();
+#else
+  const int nt = 1;
+  (void)nthreads;
+#endif
+  double* works = (double*)xmalloc(sizeof(double) * wlen * (size_t)nt);
+  int failed = 0, cal = 0;
+  o->fail_edge = -1;
+  for (int it = 0; it < niter && !failed; ++it) {
+    for (int L = 0; L < n_levels && !failed; ++L) {
+      const int t0 = level_off[L], t1 = level_off[L + 1];
+#pragma omp parallel for schedule(dynamic, 16)
+      for (int t = t0; t < t1; ++t) {
+#ifdef _OPENMP
+        double* w = works + wlen * (size_t)omp_get_thread_num();
+#else
+        double* w = works;
+#endif
+        for (int e = task_off[t]; e < task_off[t + 1]; ++e) {
+          const int info = propagate_w(o, ent_to[e], ent_k[e], ent_from[e], w);
+          if (info) {
+#pragma omp critical
+            { failed = 1; o->fail_edge = e; o->fail_dir = 0; o->fail_info = info; }
+            break;
+          }
+        }
+      }
+    }
+    cal = 1;
+    for (int d = 0; d < 2 * o->ns; ++d) if (!o->flags[d]) { cal = 0; break; }
+  }
+  free(works);
+  if (iscal) *iscal = failed ? 0 : cal;
+  return !failed;
 }
 
 /* calibrate!(beliefs, [tree], niter): edges (pa, ch, sepset k) in preorder. Returns succ; *iscal. */

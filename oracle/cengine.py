@@ -20,7 +20,7 @@ def use_native_build():
     global _lib
     so = os.path.join(_HERE, "_build", "libpgbp_oracle_native.so")
     subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(_HERE, "c"), f"OUT={so}",
-                           "CFLAGS=-O3 -march=native -std=c99 -fPIC -shared -w"],
+                           "CFLAGS=-O3 -march=native -std=c99 -fPIC -shared -w -fopenmp"],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     _lib = None
     return _load(so)
@@ -92,6 +92,51 @@ class Engine:
         iscal = C.c_int(0)
         succ = lib().orc_calibrate(self.h, len(pa), _p(pa, C.c_int32), _p(ch, C.c_int32), _p(sk, C.c_int32),
                                    int(niter), int(post_only), C.byref(iscal))
+        return (bool(succ), bool(iscal.value)) if return_iscal else bool(succ)
+
+    def levels_of_tree(self, pa, ch):
+        """Level-synchronous form of one (postorder, preorder) pass over the schedule tree (pa, ch in preorder), for the
+        all-core baseline: (level_off, task_off, ent_to, ent_k, ent_from).  Postorder: level = height of the sender,
+        one task per (level, receiver) with its messages in the reference's order (decreasing edge index); preorder:
+        level = depth of the sender, one task per message."""
+        pa, ch, sk = self._edges(pa, ch)
+        n = len(pa)
+        height, depth = {}, {int(pa[0]): 0} if n else {}
+        lvl_post = np.zeros(n, np.int64)
+        for i in range(n - 1, -1, -1):
+            h = height.get(int(ch[i]), 0)
+            lvl_post[i] = h
+            height[int(pa[i])] = max(height.get(int(pa[i]), 0), h + 1)
+        lvl_pre = np.zeros(n, np.int64)
+        for i in range(n):
+            d = depth[int(pa[i])]
+            lvl_pre[i] = d
+            depth[int(ch[i])] = d + 1
+        level_off, task_off, e_to, e_k, e_from = [0], [0], [], [], []
+        for L in range(int(lvl_post.max()) + 1 if n else 0):
+            by_recv = {}
+            for i in np.nonzero(lvl_post == L)[0][::-1]:
+                by_recv.setdefault(int(pa[i]), []).append(int(i))
+            for recv, edges in by_recv.items():
+                for i in edges:
+                    e_to.append(recv); e_k.append(int(sk[i])); e_from.append(int(ch[i]))
+                task_off.append(len(e_to))
+            level_off.append(len(task_off) - 1)
+        for L in range(int(lvl_pre.max()) + 1 if n else 0):
+            for i in np.nonzero(lvl_pre == L)[0]:
+                e_to.append(int(ch[i])); e_k.append(int(sk[i])); e_from.append(int(pa[i]))
+                task_off.append(len(e_to))
+            level_off.append(len(task_off) - 1)
+        as32 = lambda v: np.ascontiguousarray(v, np.int32)
+        return as32(level_off), as32(task_off), as32(e_to), as32(e_k), as32(e_from)
+
+    def calibrate_levels(self, levels, niter=1, nthreads=0, return_iscal=False):
+        """All-core (OpenMP) level-synchronous calibrate!(): `levels` from levels_of_tree; nthreads 0 = every core."""
+        level_off, task_off, e_to, e_k, e_from = levels
+        iscal = C.c_int(0)
+        succ = lib().orc_calibrate_levels(self.h, len(level_off) - 1, _p(level_off, C.c_int32), _p(task_off, C.c_int32),
+                                          _p(e_to, C.c_int32), _p(e_k, C.c_int32), _p(e_from, C.c_int32), int(niter),
+                                          int(nthreads), C.byref(iscal))
         return (bool(succ), bool(iscal.value)) if return_iscal else bool(succ)
 
     def propagate(self, to, sepset_k, frm):

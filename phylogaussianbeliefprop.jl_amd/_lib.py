@@ -89,6 +89,7 @@ SYMBOLS = {
     "pgbp_packed_size": (C.c_int64, [_P]),
     "pgbp_residual_size": (C.c_int64, [_P]),
     "pgbp_n_messages": (C.c_int32, [_P]),
+    "pgbp_belief_dim": (C.c_int32, [_P, C.c_int32]),
     "pgbp_set_beliefs": (C.c_int, [_P, _F64P, C.c_int32]),
     "pgbp_get_beliefs": (C.c_int, [_P, _F64P]),
     "pgbp_set_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
@@ -120,6 +121,31 @@ SYMBOLS = {
     "pgbp_time_enqueued": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Opts), C.POINTER(C.c_float)]),
     "pgbp_time_message_kernels": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(C.c_float), _I32P]),
     "pgbp_traffic_model": (C.c_int, [_P, _F64P, _I64P]),
+    # several GPUs: one process / several devices (pgbp_group), one process per GPU (pgbp_comm: RCCL)
+    "pgbp_group_create": (C.c_int, [C.POINTER(Desc), C.c_int32, _I32P, C.POINTER(_P)]),
+    "pgbp_group_destroy": (None, [_P]),
+    "pgbp_group_last_error": (C.c_char_p, [_P]),
+    "pgbp_group_size": (C.c_int32, [_P]),
+    "pgbp_group_engine": (_P, [_P, C.c_int32]),
+    "pgbp_group_range": (C.c_int, [_P, C.c_int32, _I32P, _I32P]),
+    "pgbp_group_set_schedule": (C.c_int, [_P, C.c_int32, _I32P, _I32P, _I32P]),
+    "pgbp_group_set_beliefs": (C.c_int, [_P, _F64P, C.c_int32]),
+    "pgbp_group_get_beliefs": (C.c_int, [_P, _F64P]),
+    "pgbp_group_reset_from_factors": (C.c_int, [_P]),
+    "pgbp_group_calibrate": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
+    "pgbp_group_integrate": (C.c_int, [_P, C.c_int32, _F64P, _F64P, _I32P]),
+    "pgbp_group_lg_setup": (C.c_int, [_P, C.POINTER(LgFamilies)]),
+    "pgbp_group_lg_assignfactors": (C.c_int, [_P, C.POINTER(LgParams), C.c_int32, C.c_int32]),
+    "pgbp_group_enqueue_calibrate": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_group_enqueue_loglik": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_group_enqueue_loglik_lg": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_group_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),
+    "pgbp_group_sync": (C.c_int, [_P]),
+    "pgbp_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "pgbp_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "pgbp_comm_destroy": (None, [_P]),
+    "pgbp_comm_last_error": (C.c_char_p, [_P]),
+    "pgbp_comm_gather_loglik": (C.c_int, [_P, _P, C.c_int32, _F64P, _I32P, _I32P, _I32P]),
 }
 
 _lib = None

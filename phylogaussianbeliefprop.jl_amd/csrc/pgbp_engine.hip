@@ -18,7 +18,7 @@ using namespace pgbp;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // (per thread: pgbp_group creates its engines concurrently)
 
 // Kernel arguments in device memory: without it every launch of a narrow level pays a host-memory read for its
 // 0x90-byte argument segment (measured: cfg3 +7 %, cfg5 +20 % per calibrate).  The HIP runtime reads the variable
@@ -84,6 +84,8 @@ struct pgbp_engine {
   // HIP events of the last pgbp_enqueue_calibrate_timed call (resolved by pgbp_fetch_kernel_time)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
   int32_t kernel_launches = 0;
+  double* d_gather = nullptr;    // send slot of pgbp_comm_gather_loglik: [norm | info | succ, iscal]
+  int64_t gather_cap = 0;
   bool have_factors = false;
   // pgbp_bm_tree: static description + last parameters of the device factor fill
   int32_t bm_p = 0, bm_rows = 0, bm_per_site = 0;
@@ -111,6 +113,14 @@ struct pgbp_engine {
   } while (0)
 
 namespace {
+
+// Every entry point makes its engine's device current first: a host that drives several engines on several devices (one
+// host thread per engine: pgbp_group, pgbp_dist.hip) needs no hipSetDevice of its own.  The current device is per thread.
+struct DeviceScope {
+  explicit DeviceScope(const pgbp_engine* e) {
+    if (e) (void)hipSetDevice(e->plan.device);
+  }
+};
 
 // forget earlier failures: fail keys and the downstream-of-a-failure marks
 int reset_fail(pgbp_engine* e);
@@ -435,6 +445,7 @@ void pgbp_destroy(pgbp_engine* e) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)e->d_lg_R, (void*)e->d_lg_alpha, (void*)e->d_lg_theta, (void*)e->d_lg_mu})
     if (p) (void)hipFree(p);
+  if (e->d_gather) (void)hipFree(e->d_gather);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
 }
@@ -540,8 +551,12 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
 int64_t pgbp_packed_size(const pgbp_engine* e) { return e ? e->plan.packed_off.back() : -1; }
 int64_t pgbp_residual_size(const pgbp_engine* e) { return e ? e->plan.rpacked_off.back() : -1; }
 int32_t pgbp_n_messages(const pgbp_engine* e) { return e ? e->plan.n_msgs() : -1; }
+int32_t pgbp_belief_dim(const pgbp_engine* e, int32_t belief) {
+  return (e && belief >= 0 && belief < e->plan.n_beliefs()) ? e->plan.dims[belief] : -1;
+}
 
 int pgbp_sync(pgbp_engine* e) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipGetLastError());  // a launch that failed since the last check (bad grid, LDS size) surfaces here
@@ -549,6 +564,7 @@ int pgbp_sync(pgbp_engine* e) {
 }
 
 int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   if (e->layout_sm)
@@ -562,6 +578,7 @@ int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
 }
 
 int pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_factors) {
+  DeviceScope device_scope(e);
   if (!e || !packed) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   {
@@ -585,6 +602,7 @@ int pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_fact
 }
 
 int pgbp_get_beliefs(pgbp_engine* e, double* packed) {
+  DeviceScope device_scope(e);
   if (!e || !packed) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   {
@@ -613,6 +631,7 @@ static int belief_rec(pgbp_engine* e, int32_t site, int32_t b, double** dptr, in
 }
 
 int pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* rec) {
+  DeviceScope device_scope(e);
   if (!e || !rec) return PGBP_ERR_INVALID;
   double* d;
   int64_t len;
@@ -625,6 +644,7 @@ int pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* 
 }
 
 int pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec) {
+  DeviceScope device_scope(e);
   if (!e || !rec) return PGBP_ERR_INVALID;
   double* d;
   int64_t len;
@@ -636,6 +656,7 @@ int pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec) {
 }
 
 int pgbp_reset_from_factors(pgbp_engine* e) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = reset_from_factors_async(e);
   if (rc) return rc;
@@ -643,6 +664,7 @@ int pgbp_reset_from_factors(pgbp_engine* e) {
 }
 
 int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st, e->layout_sm ? 1 : 0);
   return pgbp_sync(e);
@@ -650,6 +672,7 @@ int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
 
 int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv,
                        int32_t* iscalibrated_kl) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   if (packed || e->layout_sm) {  // the word arrays are transposed in the site-minor layout
@@ -678,6 +701,7 @@ int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_res
 
 int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
                       const int32_t* ch_j) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = plan_set_schedule(e->plan, n_trees, tree_off, pa_j, ch_j);
   if (rc) return e->fail(rc, e->plan.err);  // the previous schedule (if any) stays in force
@@ -710,6 +734,7 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
 
 int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from, const pgbp_opts* opts,
                    int32_t* info) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -744,6 +769,7 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
 
 int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t cluster_from, const pgbp_opts* opts,
                         int32_t* iscalibrated_kl) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   int rc = check_opts(e, opts);
@@ -777,6 +803,7 @@ int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int3
 }
 
 int pgbp_regularize_bycluster(pgbp_engine* e) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   int rc = ensure_layout(e, false);
@@ -830,6 +857,7 @@ static int collect_results(pgbp_engine* e, pgbp_result* results, const std::vect
 }
 
 int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* opts, pgbp_result* results) {
+  DeviceScope device_scope(e);
   if (!e || !results || dir < 0 || dir > 1) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -844,6 +872,7 @@ int pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* op
 }
 
 int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_result* results) {
+  DeviceScope device_scope(e);
   if (!e || !results || niter < 0) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -928,6 +957,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
 }
 
 int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int32_t* info) {
+  DeviceScope device_scope(e);
   if (!e || !norm) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   if (belief < 0 || belief >= p.n_beliefs()) return e->fail(PGBP_ERR_INVALID, "belief index out of range");
@@ -954,6 +984,7 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
 // ---- scores ---------------------------------------------------------------------------------------------
 
 int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
+  DeviceScope device_scope(e);
   if (!e || !out3) return PGBP_ERR_INVALID;
   if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "pgbp_free_energy: no factors (pgbp_set_beliefs with snapshot, or pgbp_init_factors_frombeliefs)");
   if (e->layout_sm) {
@@ -988,6 +1019,7 @@ int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
 // ---- device factor assignment (homogeneous BM on a tree) ----------------------------------------
 
 int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
+  DeviceScope device_scope(e);
   if (!e || !t || !t->kind || !t->length || !t->data_row || t->p <= 0 || t->p > PGBP_MAX_DIM || t->n_rows < 0)
     return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
@@ -1062,6 +1094,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
 
 int pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double* logdetR, const double* mu,
                                int32_t per_site) {
+  DeviceScope device_scope(e);
   if (!e || !Rinv || !logdetR || !mu) return PGBP_ERR_INVALID;
   if (!e->d_bm_kind) return e->fail(PGBP_ERR_STATE, "pgbp_bm_tree_assignfactors: call pgbp_bm_tree_setup first");
   const size_t n = per_site ? (size_t)e->plan.n_sites : 1, pp = (size_t)e->bm_p;
@@ -1080,6 +1113,7 @@ int pgbp_bm_tree_assignfactors(pgbp_engine* e, const double* Rinv, const double*
 }
 
 int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -1103,6 +1137,7 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
 // ---- device factor assignment (any linear-Gaussian model, trees and networks) ---------------------------
 
 int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
+  DeviceScope device_scope(e);
   if (!e || !f || f->p <= 0 || f->p > PGBP_MAX_DIM || f->n_families < 0 || f->max_parents < 1 || f->n_rates < 1 ||
       f->n_rows < 0)
     return PGBP_ERR_INVALID;
@@ -1254,6 +1289,7 @@ static int lg_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
 }
 
 int pgbp_lg_assignfactors(pgbp_engine* e, const pgbp_lg_params* m) {
+  DeviceScope device_scope(e);
   if (!e || !m || !m->R || !m->mu) return PGBP_ERR_INVALID;
   if (!e->lg_ready) return e->fail(PGBP_ERR_STATE, "pgbp_lg_assignfactors: call pgbp_lg_setup first");
   if (m->model != PGBP_LG_BM && m->model != PGBP_LG_OU) return e->fail(PGBP_ERR_INVALID, "pgbp_lg_assignfactors: unknown model");
@@ -1280,6 +1316,7 @@ int pgbp_lg_assignfactors(pgbp_engine* e, const pgbp_lg_params* m) {
 }
 
 int pgbp_enqueue_loglik_lg(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -1331,6 +1368,7 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
 }
 
 int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -1353,6 +1391,7 @@ static void drop_kernel_events(pgbp_engine* e) {
 }
 
 int pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -1369,6 +1408,7 @@ int pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_eac
 }
 
 int pgbp_fetch_kernel_time(pgbp_engine* e, float* ms_kernels, int32_t* n_launches) {
+  DeviceScope device_scope(e);
   if (!e || !ms_kernels) return PGBP_ERR_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipGetLastError());
@@ -1398,6 +1438,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S0) {
 }
 
 int pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
+  DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
   int rc = check_opts(e, opts);
   if (rc) return rc;
@@ -1411,6 +1452,7 @@ int pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
 }
 
 int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
+  DeviceScope device_scope(e);
   if (!e || !norm) return PGBP_ERR_INVALID;
   const int ns = e->plan.n_sites;
   HIPCHK(e, hipMemcpyAsync(norm, e->d_norm, sizeof(double) * ns, hipMemcpyDeviceToHost, e->st));
@@ -1429,6 +1471,7 @@ int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
 
 int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each, const pgbp_opts* opts,
                        float* ms_total) {
+  DeviceScope device_scope(e);
   if (!e || !ms_total || kind < 0 || kind > 3) return PGBP_ERR_INVALID;
   hipEvent_t a, b;
   HIPCHK(e, hipEventCreate(&a));
@@ -1450,6 +1493,7 @@ int pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset
 
 int pgbp_time_message_kernels(pgbp_engine* e, int32_t reps, const pgbp_opts* opts, float* ms_kernels,
                               int32_t* n_launches) {
+  DeviceScope device_scope(e);
   if (!e || !ms_kernels) return PGBP_ERR_INVALID;
   int rc = pgbp_enqueue_calibrate_timed(e, reps, 1, opts);
   if (rc) return rc;
@@ -1466,3 +1510,57 @@ int pgbp_traffic_model(const pgbp_engine* e, double* bytes_per_calibrate, int64_
 }
 
 }  // extern "C"
+
+// ---- internal (pgbp_dist.hip): one rank's contribution to the all-gather of pgbp_comm_gather_loglik -----------------------
+namespace {
+__global__ void pack_gather_slot(const double* __restrict__ norm, const int32_t* __restrict__ info,
+                                 const unsigned long long* __restrict__ fail, const int32_t* __restrict__ iscal, int ns,
+                                 int slot_sites, double* __restrict__ out) {
+  // out[0 .. slot): log-likelihoods; out[slot .. 2 slot): info words; out[2 slot], out[2 slot + 1]: min over this rank's
+  // sites of succ (no failed message) and iscal.  One workgroup.
+  __shared__ int s_succ, s_iscal;
+  if (threadIdx.x == 0) { s_succ = 1; s_iscal = 1; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < slot_sites; i += blockDim.x) {
+    const bool in = i < ns;
+    const bool failed = in && pgbp::is_failure_key(fail[i]);
+    out[i] = in ? norm[i] : 0.0;
+    out[slot_sites + i] = in ? (double)(failed && info[i] == 0 ? (int)(fail[i] & ((1ull << pgbp::kInfoBits) - 1)) : info[i]) : 0.0;
+    if (failed) atomicMin(&s_succ, 0);
+    if (in && iscal[i] == 0) atomicMin(&s_iscal, 0);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * slot_sites] = (double)s_succ;
+    out[2 * slot_sites + 1] = (double)s_iscal;
+  }
+}
+}  // namespace
+
+namespace pgbp {
+int engine_pack_gather_slot(pgbp_engine* e, int32_t slot_sites, double** d_slot, hipStream_t* st, int32_t* n_sites) {
+  if (!e || !d_slot || !st) return PGBP_ERR_INVALID;
+  DeviceScope device_scope(e);
+  const int ns = e->plan.n_sites;
+  if (slot_sites < ns) return e->fail(PGBP_ERR_INVALID, "gather slot smaller than this rank's number of sites");
+  const int64_t need = 2 * (int64_t)slot_sites + 2;
+  if (need > e->gather_cap) {
+    if (e->d_gather) (void)hipFree(e->d_gather);
+    e->d_gather = nullptr;
+    e->gather_cap = 0;
+    int rc = dev_alloc(e, &e->d_gather, (size_t)need);
+    if (rc) return rc;
+    e->gather_cap = need;
+  }
+  hipLaunchKernelGGL(pack_gather_slot, dim3(1), dim3(256), 0, e->st, e->d_norm, e->d_info, e->d_fail, e->d_iscal, ns,
+                     slot_sites, e->d_gather);
+  HIPCHK(e, hipGetLastError());
+  *d_slot = e->d_gather;
+  *st = e->st;
+  if (n_sites) *n_sites = ns;
+  return PGBP_OK;
+}
+int engine_fail(pgbp_engine* e, int code, const std::string& msg) { return e->fail(code, msg); }
+int engine_device(const pgbp_engine* e) { return e->plan.device; }
+int engine_n_sites(const pgbp_engine* e) { return e->plan.n_sites; }
+}  // namespace pgbp

@@ -159,6 +159,12 @@ void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t*
 void launch_halt_if_calibrated(const int32_t* d_iscal, unsigned long long* d_fail, unsigned long long key, int n_sites,
                                hipStream_t st);
 // a fail word that reports a failed message (PosDefException.info in its low bits), as opposed to none / a halt key
-inline bool is_failure_key(unsigned long long key) { return key != kNoFail && (key & ((1ull << kInfoBits) - 1)) != 0; }
+__host__ __device__ inline bool is_failure_key(unsigned long long key) { return key != kNoFail && (key & ((1ull << kInfoBits) - 1)) != 0; }
+
+// engine internals used by pgbp_dist.hip (defined in pgbp_engine.hip)
+int engine_pack_gather_slot(pgbp_engine* e, int32_t slot_sites, double** d_slot, hipStream_t* st, int32_t* n_sites);
+int engine_fail(pgbp_engine* e, int code, const std::string& msg);
+int engine_device(const pgbp_engine* e);
+int engine_n_sites(const pgbp_engine* e);
 
 }  // namespace pgbp

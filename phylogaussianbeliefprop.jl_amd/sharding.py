@@ -33,3 +33,145 @@ def gather_sites(local, n_total: int, dist=None, device="cpu"):
         a, b = shard_range(n_total, r, world)
         full[a:b] = out[r, : b - a]
     return full
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Behind the C ABI (include/pgbp.h, "several GPUs"; csrc/pgbp_dist.hip): what a Julia host binds.  The two classes below
+# are thin ctypes mirrors used by bench.py and the tests.
+
+class EngineGroup:
+    """pgbp_group: ONE process, one engine per listed device over contiguous site ranges; every call fans out on one
+    host thread per device.  `devices` may repeat a device (rehearsal on a one-GPU box)."""
+
+    def __init__(self, dims, sepset_clusters, scope_off, scope_idx, n_sites, devices):
+        import ctypes as C
+        from . import _lib as L
+        self._C, self._L = C, L
+        self.lib = L.load()
+        desc, self._keep = L.make_desc(dims, sepset_clusters, scope_off, scope_idx, n_sites, 0)
+        self.n_sites = int(n_sites)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self._g = C.c_void_p()
+        code = self.lib.pgbp_group_create(C.byref(desc), len(dev), L.i32p(dev), C.byref(self._g))
+        if code != 0:
+            raise L.PgbpError(code, self.lib.pgbp_group_last_error(None).decode())
+        self.packed_size = int(self.lib.pgbp_packed_size(self.lib.pgbp_group_engine(self._g, 0)))
+
+    def _check(self, code):
+        if code != 0:
+            raise self._L.PgbpError(code, self.lib.pgbp_group_last_error(self._g).decode())
+
+    def close(self):
+        if self._g:
+            self.lib.pgbp_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return int(self.lib.pgbp_group_size(self._g))
+
+    def range(self, shard):
+        a, n = self._C.c_int32(), self._C.c_int32()
+        self._check(self.lib.pgbp_group_range(self._g, shard, self._C.byref(a), self._C.byref(n)))
+        return a.value, n.value
+
+    def engine(self, shard):
+        return self.lib.pgbp_group_engine(self._g, shard)
+
+    def set_schedule(self, schedule):
+        L = self._L
+        off = np.zeros(len(schedule) + 1, np.int32)
+        for i, s in enumerate(schedule):
+            off[i + 1] = off[i] + len(s[0])
+        pa = np.ascontiguousarray(np.concatenate([np.asarray(s[0]) for s in schedule]).astype(np.int32))
+        ch = np.ascontiguousarray(np.concatenate([np.asarray(s[1]) for s in schedule]).astype(np.int32))
+        self._check(self.lib.pgbp_group_set_schedule(self._g, len(schedule), L.i32p(off), L.i32p(pa), L.i32p(ch)))
+
+    def set_beliefs(self, packed, snapshot_factors=True):
+        packed = np.ascontiguousarray(packed, dtype=np.float64)
+        assert packed.shape == (self.n_sites, self.packed_size)
+        self._check(self.lib.pgbp_group_set_beliefs(self._g, self._L.f64p(packed), 1 if snapshot_factors else 0))
+
+    def get_beliefs(self):
+        out = np.zeros((self.n_sites, self.packed_size))
+        self._check(self.lib.pgbp_group_get_beliefs(self._g, self._L.f64p(out)))
+        return out
+
+    def calibrate(self, niter=1, opts=None):
+        L = self._L
+        res = (L.Result * self.n_sites)()
+        o = opts if opts is not None else L.Opts(0, 1, 0, 0, 1e-5)
+        self._check(self.lib.pgbp_group_calibrate(self._g, int(niter), self._C.byref(o), res))
+        return res
+
+    def integrate(self, belief, dim):
+        mu = np.zeros((self.n_sites, max(1, dim)))
+        norm = np.zeros(self.n_sites)
+        info = np.zeros(self.n_sites, np.int32)
+        self._check(self.lib.pgbp_group_integrate(self._g, int(belief), self._L.f64p(mu), self._L.f64p(norm), self._L.i32p(info)))
+        return mu, norm, info
+
+    def enqueue_calibrate(self, reps, reset_each=0, opts=None):
+        o = opts if opts is not None else self._L.Opts(0, 1, 0, 0, 1e-5)
+        self._check(self.lib.pgbp_group_enqueue_calibrate(self._g, int(reps), int(reset_each), self._C.byref(o)))
+
+    def enqueue_loglik(self, reps=1, opts=None, lg=False):
+        o = opts if opts is not None else self._L.Opts(0, 1, 0, 0, 1e-5)
+        fn = self.lib.pgbp_group_enqueue_loglik_lg if lg else self.lib.pgbp_group_enqueue_loglik
+        self._check(fn(self._g, int(reps), self._C.byref(o)))
+
+    def fetch_loglik(self):
+        norm = np.zeros(self.n_sites)
+        info = np.zeros(self.n_sites, np.int32)
+        self._check(self.lib.pgbp_group_fetch_loglik(self._g, self._L.f64p(norm), self._L.i32p(info)))
+        return norm, info
+
+    def sync(self):
+        self._check(self.lib.pgbp_group_sync(self._g))
+
+
+class Comm:
+    """pgbp_comm: one process per GPU; ONE ncclAllGather (RCCL) per gather_loglik call.  `bcast(bytes_or_None) -> bytes`
+    carries rank 0's unique id to the other ranks (e.g. a torch.distributed / MPI broadcast); unused for n_ranks == 1."""
+
+    def __init__(self, n_ranks, rank, device, bcast=None):
+        import ctypes as C
+        from . import _lib as L
+        self._C, self._L = C, L
+        self.lib = L.load()
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            code = self.lib.pgbp_comm_unique_id(ident)
+            if code != 0:
+                raise L.PgbpError(code, self.lib.pgbp_comm_last_error(None).decode())
+        if n_ranks > 1:
+            raw = bcast(bytes(ident) if rank == 0 else None)
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self._c = C.c_void_p()
+        code = self.lib.pgbp_comm_create(ident, self.n_ranks, self.rank, int(device), C.byref(self._c))
+        if code != 0:
+            raise L.PgbpError(code, self.lib.pgbp_comm_last_error(None).decode())
+
+    def close(self):
+        if self._c:
+            self.lib.pgbp_comm_destroy(self._c)
+            self._c = None
+
+    def gather_loglik(self, engine, slot_sites):
+        """-> (norm [n_ranks, slot_sites], info [n_ranks, slot_sites], all_succ, all_iscal) on every rank"""
+        C, L = self._C, self._L
+        norm = np.zeros((self.n_ranks, slot_sites))
+        info = np.zeros((self.n_ranks, slot_sites), np.int32)
+        succ, iscal = C.c_int32(), C.c_int32()
+        code = self.lib.pgbp_comm_gather_loglik(self._c, engine, int(slot_sites), L.f64p(norm), L.i32p(info),
+                                                C.byref(succ), C.byref(iscal))
+        if code != 0:
+            raise L.PgbpError(code, self.lib.pgbp_comm_last_error(self._c).decode())
+        return norm, info, bool(succ.value), bool(iscal.value)

@@ -98,3 +98,15 @@ def test_shard_range_properties():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_gpus_flag_never_prints_a_figure_for_another_world_size():
+    """`--gpus N` must mean N ranks: with a launcher environment of another size the run exits non-zero before touching
+    the GPU (without a launcher environment it starts torch.distributed.run itself; not exercised here: no GPU)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "--gpus 2 but WORLD_SIZE=1" in (out.stderr + out.stdout)
+    assert '"metric"' not in out.stdout

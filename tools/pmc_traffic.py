@@ -10,10 +10,12 @@ re-validated inside the same run on the reset-from-factors copy kernel, whose by
 (the cluster records, read once and written once: `copy_strided_kernel` in the plain layout,
 `copy_records_kernel` -- only the part of each slot in use -- in the packed layout).
 
-usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel [kernel]]
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel [kernel [calibrates]]]
   copy_kernel: calibration kernel with a known byte count each way (default copy_strided_kernel; a name without "pgbp::" is
                looked up as given, e.g. __amd_rocclr_copyBuffer for the site-minor reset of the sites workload)
-  kernel:      the message kernel to reduce (default bp_level_fast16; bp_level_uni for the sites workload)
+  kernel:      the message kernel to reduce (default bp_fast16: every launch mode of it; bp_level_uni for the sites workload)
+  calibrates:  how many calibrate!() iterations the profiled program ran and nothing else on that kernel (e.g.
+               `tools/level_times.py run` = 8): adds launches_per_calibrate and hbm_bytes_per_calibrate
 """
 import csv
 import json
@@ -35,7 +37,8 @@ def main():
     ck = sys.argv[5] if len(sys.argv) > 5 else "copy_strided_kernel"
     if not ck.startswith("__"):
         ck = "pgbp::" + ck
-    kname = sys.argv[6] if len(sys.argv) > 6 else "bp_level_fast16"
+    kname = sys.argv[6] if len(sys.argv) > 6 else "bp_fast16"
+    ncal = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     F = per_kernel(f_csv, "FETCH_SIZE")
     W = per_kernel(w_csv, "WRITE_SIZE")
     have_cal = copy_bytes > 0 and ck in F and ck in W   # copy_bytes 0: calibrated elsewhere (tools/copy8_microbench.hip)
@@ -56,6 +59,10 @@ def main():
                                     "WRITE_SIZE = bytes written, to three digits, for 8-B-per-lane and 16-B-per-lane accesses"),
         "note": "average over every %s launch of one bench.py run (postorder and preorder levels)" % kname,
     }
+    if ncal > 0:
+        res["calibrates"] = ncal
+        res["launches_per_calibrate"] = n / ncal
+        res["hbm_bytes_per_calibrate"] = (fetch + write) / ncal
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
