@@ -111,6 +111,14 @@ def cpu_baseline(prob, packed, budget_s=20.0):
                             "loglik_rel_diff_vs_1_core": abs(ll_all - ll) / max(1.0, abs(ll))}
     except Exception as ex:  # an oracle build without OpenMP: say so
         out["all_cores"] = {"value": None, "sample": f"unavailable: {ex}"}
+    # opportunistic: the real Julia calibrate!() where julia + the package already exist
+    try:
+        import subprocess
+        raw = subprocess.run(["sh", os.path.join(ROOT, "bench", "run_reference_calibrate.sh")], capture_output=True,
+                             text=True, timeout=600).stdout.strip().splitlines()
+        out["reference_julia"] = json.loads(raw[-1]) if raw else {"available": False, "reason": "no output"}
+    except Exception as ex:
+        out["reference_julia"] = {"available": False, "reason": str(ex)}
     return out
 
 
