@@ -317,7 +317,10 @@ def build_network_workload(args, rank):
     import pgbp_amd as P
     rng = np.random.default_rng(args.seed + rank)
     p = args.traits
-    net = P.random_level3_network(args.ntips, args.blobs, rng, n_colors=3)
+    if args.blob_style == "template":   # round-1 generator: copies of the reference's own level-3 test blob (treewidth 2)
+        net = P.random_level3_network(args.ntips, args.blobs, rng, n_colors=3)
+    else:                               # varied blobs of level <= 3, some with 4-node cliques (treewidth 3)
+        net = P.random_level3_network_varied(args.ntips, 3 * args.blobs, rng, n_colors=3)
     if args.graph == "joingraph":
         cn, ed, sn = P.joingraph(net.node2family, args.maxclustersize)
     elif args.graph == "cliquetree":
@@ -347,7 +350,6 @@ def run_network(args, torch, dist, rank, world, local_rank):
     lib = P.load()
     t0 = time.time()
     net, (cn, ed, sn), st, fam, X, rates, mu, sched = build_network_workload(args, rank)
-    t_host = time.time() - t0
     cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None, device=local_rank)
     cgb.lg_setup(fam, X)
     cgb.assignfactors_lg_(rates, mu)                      # assignfactors! on the device (heterogeneous BM, hybrid nodes)
@@ -357,9 +359,17 @@ def run_network(args, torch, dist, rank, world, local_rank):
         if code != 0:
             raise RuntimeError(lib.pgbp_last_error(eng).decode())
     loopy = len(ed) > len(cn) - 1
-    if loopy:
+    if loopy and args.graph == "joingraph":
+        # join graphs: regularizebeliefs_onschedule! (src/clustergraphbeliefs.jl:376-403) -- with the by-cluster or the
+        # by-node-subtree regulariser the first postorder over a spanning tree of this graph meets an ill-defined message
+        # (the plain-C engine fails at the same message with the same PosDefException.info); one-off host walk, the
+        # messages it sends are pgbp_propagate calls
+        from pgbp_amd.regularization import regularizebeliefs_onschedule_
+        regularizebeliefs_onschedule_(cgb)
+    elif loopy:
         check(lib.pgbp_regularize_bycluster(eng))         # regularizebeliefs_bycluster! (src/calibration.jl:335-343)
     cgb.pull()
+    t_host = time.time() - t0                             # network, cluster graph, scopes, factors, regularisation
     start = cgb._packed[0].copy()                         # the state every run starts from (clusters and sepsets)
     cgb.set_schedule(sched)
     # calibrate!(beliefs, sched, 100; auto=true): iterations to convergence, end to end with the host-driven auto stop
@@ -404,7 +414,8 @@ def run_network(args, torch, dist, rank, world, local_rank):
                                + (f"join-graph structuring (maxclustersize {args.maxclustersize})" if args.graph == "joingraph"
                                   else "clique tree" if args.graph == "cliquetree" else "LTRIP cluster graph (node families)"
                                   if args.graph == "ltrip" else "Bethe cluster graph")
-                               + (", regularizebeliefs_bycluster!" if loopy else " (a tree here)") + ", spanningtrees_clusterlist schedule",
+                               + ((", regularizebeliefs_onschedule!" if args.graph == "joingraph" else ", regularizebeliefs_bycluster!")
+                                  if loopy else " (a tree here)") + ", spanningtrees_clusterlist schedule",
                    "clusters": len(cn), "sepsets": len(ed), "schedule_trees": len(sched), "loopy": bool(loopy),
                    "messages_per_step": int(msgs_per_cal), "max_cluster_dimension": int(st.dims.max()),
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
@@ -413,7 +424,7 @@ def run_network(args, torch, dist, rank, world, local_rank):
                            "note": "calibrate!(beliefs, sched, 100; auto=true) end to end: the device halts itself at the first calibrated tree, one host round trip per 4 schedule trees"},
         "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "bp_level_generic + bp_level_fast16<4>", "algorithmic_bytes_per_step": bytes_per_cal,
+                     "kernel": "bp_level_generic + bp_fast16<4>", "algorithmic_bytes_per_step": bytes_per_cal,
                      "note": "algorithmic bytes of one calibrate iteration / its wall time; launch-latency-bound (levels per tree >> width)"},
         "host_setup_s": t_host,
     }
@@ -458,9 +469,12 @@ def main():
     ap.add_argument("--ntips", type=int, default=None, help="default: 50000 (tree workload), 20000 (sites workload)")
     ap.add_argument("--traits", type=int, default=None, help="default: 16 (tree workload), 4 (network workload)")
     ap.add_argument("--graph", default=None, choices=["cliquetree", "bethe", "joingraph", "ltrip"],
-                    help="default: cliquetree (tree workload), bethe (network workload)")
+                    help="default: cliquetree (tree workload), joingraph (network workload)")
     ap.add_argument("--blobs", type=int, default=None, help="network workload: level-3 blobs (3 reticulations each); default ntips / 12")
-    ap.add_argument("--maxclustersize", type=int, default=3, help="network workload, --graph joingraph")
+    ap.add_argument("--maxclustersize", type=int, default=3, help="network workload, --graph joingraph (a level-3 network's "
+                    "moral graph has cliques of at most 4 nodes: 3 is the largest bound under which the join graph is loopy)")
+    ap.add_argument("--blob-style", default="varied", choices=["varied", "template"], help="network workload: random blobs "
+                    "of level <= 3 (default) or copies of the reference's level-3 test blob")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-reading", action="store_true",
@@ -479,7 +493,7 @@ def main():
     if args.traits is None:
         args.traits = 4 if args.workload == "network" else 16
     if args.graph is None:
-        args.graph = "bethe" if args.workload == "network" else "cliquetree"
+        args.graph = "joingraph" if args.workload == "network" else "cliquetree"
     if args.blobs is None:
         args.blobs = (args.ntips + 11) // 12
 

@@ -167,56 +167,65 @@ def default_rootcluster(cg: ClusterGraph, net) -> int:
 
 
 def _graphs_jl_tree_order(n, nbrs, root):
-    """The vertex order `spanningtree_clusterlist` gets from Graphs.jl (src/clustergraph.jl:885-894):
-    `par = dfs_parents(g, root)` -- an iterative depth-first search that always follows the first unseen neighbour in
-    increasing vertex code -- then `topological_sort(tree(par))` = `topological_sort_by_dfs`: depth-first searches started
-    from every vertex in increasing code, vertices listed by REVERSE finishing time (so of two children the one with the
-    larger code comes first, and whatever hangs below vertex 0 ... comes last when vertex 0 is not the root).
-    nbrs[v]: neighbours of v in increasing code.  Returns (parents, vertices after the root in that order)."""
-    par = [-1] * n
-    seen = [False] * n
-    stack = [root]
-    seen[root] = True
-    par[root] = root
-    nxt = [0] * n
-    while stack:
-        v = stack[-1]
-        while nxt[v] < len(nbrs[v]) and seen[nbrs[v][nxt[v]]]:
-            nxt[v] += 1
-        if nxt[v] == len(nbrs[v]):
-            stack.pop()
-            continue
-        u = nbrs[v][nxt[v]]
-        seen[u] = True
-        par[u] = v
-        stack.append(u)
-    kids = [[] for _ in range(n)]
+    """Literal restatement of the two Graphs.jl routines behind `spanningtree_clusterlist` (src/clustergraph.jl:885-894;
+    Graphs.jl is a dependency of the reference, not vendored: algorithms as published in Graphs.jl 1.x,
+    src/traversals/dfs.jl).  (The product's version, pgbp_amd/clustergraph.py, keeps a scan pointer per vertex instead
+    of rescanning: the two are written independently and compared by tests/test_plan_cpu.py.)
+
+    dfs_parents(g, root) -> tree_dfs: `S = [root]; parents[root] = root; while S: v = S[end]; u = 0;
+    for n in outneighbors(g, v): if !seen[n]: u = n; break;  if u == 0: pop!(S) else: seen[u] = true; push!(S, u);
+    parents[u] = v`.
+    topological_sort_by_dfs(tree(parents)): for v in vertices: if vcolor[v] == 0: S = [v]; vcolor[v] = 1; while S:
+    u = S[end]; w = first out-neighbour with vcolor == 0 (a neighbour with vcolor == 1 is a cycle: error);
+    if w: vcolor[w] = 1; push!(S, w) else: vcolor[u] = 2; push!(verts, u); pop!(S);  return reverse(verts).
+    nbrs[v]: neighbours in increasing code (Graphs.jl adjacency lists are sorted).  Returns (parents, order after root)."""
+    seen = set([root])
+    parents = {root: root}
+    S = [root]
+    while S:
+        v = S[-1]
+        u = None
+        for cand in nbrs[v]:                 # rescanned from the start every time, as the library does
+            if cand not in seen:
+                u = cand
+                break
+        if u is None:
+            S.pop()
+        else:
+            seen.add(u)
+            S.append(u)
+            parents[u] = v
+    # tree(parents): directed graph with an edge parents[v] -> v for v != root
+    out = {v: [] for v in range(n)}
+    for v in sorted(parents):
+        if parents[v] != v:
+            out[parents[v]].append(v)
+    vcolor = {v: 0 for v in range(n)}
+    verts = []
     for v in range(n):
-        if par[v] >= 0 and par[v] != v:
-            kids[par[v]].append(v)          # increasing code
-    color = [0] * n
-    finished = []
-    pos = [0] * n
-    for s in range(n):
-        if color[s] or par[s] < 0:
+        if vcolor[v] != 0 or v not in parents:   # (vertices outside the component: isolated in tree(parents))
             continue
-        color[s] = 1
-        stack = [s]
-        while stack:
-            u = stack[-1]
-            while pos[u] < len(kids[u]) and color[kids[u][pos[u]]]:
-                pos[u] += 1
-            if pos[u] == len(kids[u]):
-                color[u] = 2
-                finished.append(u)
-                stack.pop()
+        S = [v]
+        vcolor[v] = 1
+        while S:
+            u = S[-1]
+            w = None
+            for cand in out[u]:
+                if vcolor[cand] == 1:
+                    raise ValueError("The input graph contains at least one loop.")
+                if vcolor[cand] == 0:
+                    w = cand
+                    break
+            if w is not None:
+                vcolor[w] = 1
+                S.append(w)
             else:
-                w = kids[u][pos[u]]
-                color[w] = 1
-                stack.append(w)
-    order = finished[::-1]
+                vcolor[u] = 2
+                verts.append(u)
+                S.pop()
+    order = list(reversed(verts))
     assert order and order[0] == root
-    return par, order[1:]
+    return [parents.get(v, -1) for v in range(n)], order[1:]
 
 
 def spanningtree_clusterlist(cg: ClusterGraph, rootj: int, edge_subset=None, vertices=None):
@@ -302,18 +311,34 @@ def nodefamilies(net):
 
 
 def _assign(bucket, new, maxsize):
-    """src/clustergraph.jl:705-736 assign!: bucket = dict size -> list of minibuckets (sorted lists)."""
-    for sz in sorted(bucket.keys(), reverse=True):
-        mbs = bucket[sz]
-        for i, mb in enumerate(mbs):
-            merged = sorted(set(new) | set(mb))
-            if len(merged) <= maxsize:
-                mbs.pop(i)
-                if not mbs:
+    """src/clustergraph.jl:705-736 assign!, statement by statement: `for sz in sort(collect(keys(bucket)), rev=true)`,
+    `for (i, minibucket) in enumerate(bucket[sz])`: `merged = sort(union(new, minibucket))`; if it fits: deleteat! the
+    old one (and the key when its vector empties), push the merged one under its own size, return (merged, old);
+    else the new minibucket is filed under its size and (new, []) returned.  bucket: dict size -> list of minibuckets."""
+    sizes = list(bucket.keys())
+    sizes.sort()
+    sizes.reverse()
+    for sz in sizes:
+        i = 0
+        while i < len(bucket[sz]):
+            old = bucket[sz][i]
+            union = list(new)
+            for x in old:
+                if x not in union:
+                    union.append(x)
+            union.sort()
+            if len(union) <= maxsize:
+                del bucket[sz][i]
+                if len(bucket[sz]) == 0:
                     del bucket[sz]
-                bucket.setdefault(len(merged), []).append(merged)
-                return merged, mb
-    bucket.setdefault(len(new), []).append(new)
+                if len(union) not in bucket:
+                    bucket[len(union)] = []
+                bucket[len(union)].append(union)
+                return union, old
+            i += 1
+    if len(new) not in bucket:
+        bucket[len(new)] = []
+    bucket[len(new)].append(new)
     return new, []
 
 

@@ -13,7 +13,8 @@ from .clustergraph import (bethe, cliquetree, default_rootcluster, ltrip, defaul
 from .clustergraphbeliefs import ClusterGraphBelief
 from .factors import lg_families
 from .optimize import calibrate_optimize_cliquetree_, calibrate_optimize_clustergraph_
-from .networks import NetArrays, allocate_scopes, random_level3_network, read_newick, simulate_bm_network
+from .networks import (NetArrays, allocate_scopes, random_level3_network, random_level3_network_varied, read_newick,
+                       simulate_bm_network)
 from .regularization import (regularizebeliefs_bycluster_, regularizebeliefs_bynodesubtree_,
                              regularizebeliefs_onschedule_)
 
@@ -23,5 +24,5 @@ __all__ = [
     "propagate_1traversal_preorder_", "propagate_belief_", "regularizebeliefs_bycluster_",
     "regularizebeliefs_bynodesubtree_", "regularizebeliefs_onschedule_", "default_rootcluster",
     "spanningtree_clusterlist", "spanningtrees_clusterlist", "joingraph", "bethe", "cliquetree", "ltrip", "moralize", "triangulate_minfill",
-    "nodesubtree_clusterlist", "default_rootcluster_nodes", "integratebelief_", "lg_families", "calibrate_optimize_cliquetree_", "calibrate_optimize_clustergraph_", "NetArrays", "allocate_scopes", "random_level3_network", "read_newick", "simulate_bm_network", "load", "LIB_PATH", "PgbpError",
+    "nodesubtree_clusterlist", "default_rootcluster_nodes", "integratebelief_", "lg_families", "calibrate_optimize_cliquetree_", "calibrate_optimize_clustergraph_", "NetArrays", "allocate_scopes", "random_level3_network", "random_level3_network_varied", "read_newick", "simulate_bm_network", "load", "LIB_PATH", "PgbpError",
 ]

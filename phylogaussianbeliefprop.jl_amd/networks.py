@@ -98,6 +98,117 @@ def random_level3_network(ntips: int, nblobs: int, rng: np.random.Generator, n_c
     return NetArrays(fam, ln, gm, col, np.array([is_leaf[v] for v in order], dtype=bool))
 
 
+def random_level3_network_varied(ntips: int, nret: int, rng: np.random.Generator, n_colors: int = 1, lo=0.1, hi=1.0,
+                                  max_level: int = 3) -> NetArrays:
+    """Random rooted network of level <= max_level with about `nret` reticulations in VARIED blobs (BASELINE.json
+    configs[4]).  A random bifurcating tree (uniform random joins); disjoint blob sites = an internal node with the
+    edges of its subtree down to depth 3; inside a site, 1 .. max_level reticulations are drawn between random pairs of
+    its (progressively subdivided) edges: the source edge gets a new tree node, the target edge a new hybrid node (minor
+    inheritance ~ U(0.1, 0.5), all lengths > 0), rejected if it would close a directed cycle.  The reticulations of a
+    site may interlock into one blob (level up to max_level; moral graphs with cliques of 4 nodes, treewidth 3) or stay
+    apart; sites are separated by cut edges, so no blob has more than max_level hybrids."""
+    tr: Tree = random_tree(ntips, rng, lo, hi)
+    N0 = tr.nnodes
+    parents: List[list] = [[] for _ in range(N0)]     # [(parent id, length, gamma)]
+    children: List[list] = [[] for _ in range(N0)]
+    is_leaf = list(tr.is_leaf)
+    for v in range(1, N0):
+        parents[v].append((int(tr.parent[v]), float(tr.length[v]), 1.0))
+        children[int(tr.parent[v])].append(v)
+
+    def new_node():
+        parents.append([])
+        children.append([])
+        is_leaf.append(False)
+        return len(parents) - 1
+
+    def subdivide(pa, ch):
+        """new node on the edge pa -> ch; returns it"""
+        k = next(i for i, q in enumerate(parents[ch]) if q[0] == pa)
+        _, t, g = parents[ch][k]
+        cut = float(rng.uniform(0.25, 0.75))
+        x = new_node()
+        parents[x].append((pa, t * cut, g))
+        parents[ch][k] = (x, t * (1.0 - cut), 1.0)
+        children[pa][children[pa].index(ch)] = x
+        children[x].append(ch)
+        return x
+
+    def reaches(a, b, limit=4096):
+        """is b a descendant of a (inside the small site)?"""
+        st, seen = [a], 0
+        while st and seen < limit:
+            x = st.pop()
+            if x == b:
+                return True
+            seen += 1
+            st.extend(children[x])
+        return False
+
+    used = np.zeros(N0, dtype=bool)
+    done = 0
+    for w in rng.permutation(np.nonzero(~tr.is_leaf)[0]):
+        if done >= nret:
+            break
+        w = int(w)
+        # the site: edges of the subtree of w down to depth 3, all of whose nodes are still free
+        nodes, frontier, edges = [w], [w], []
+        for _ in range(3):
+            nxt = []
+            for x in frontier:
+                for c in children[x]:
+                    if c < N0:
+                        edges.append((x, c))
+                        nodes.append(c)
+                        nxt.append(c)
+            frontier = nxt
+        if len(edges) < 4 or used[nodes].any():
+            continue
+        used[nodes] = True
+        want = int(rng.integers(1, max_level + 1))
+        site_edges = list(edges)
+        for _ in range(want):
+            for _attempt in range(20):
+                i, j = rng.choice(len(site_edges), size=2, replace=False)
+                (p1, c1), (p2, c2) = site_edges[i], site_edges[j]
+                if len(parents[c2]) > 1 or len(parents[c1]) > 1:      # keep every hybrid node at two parents
+                    continue
+                if c2 == c1 or reaches(c2, p1) or reaches(c2, c1):     # the hybrid would sit above its new parent
+                    continue
+                s_node = subdivide(p1, c1)
+                h_node = subdivide(p2, c2)
+                g = float(rng.uniform(0.1, 0.5))
+                k = next(q for q, e in enumerate(parents[h_node]) if e[0] == p2)
+                parents[h_node][k] = (p2, parents[h_node][k][1], 1.0 - g)
+                parents[h_node].append((s_node, float(rng.uniform(0.05, 0.3)), g))
+                children[s_node].append(h_node)
+                site_edges[i] = (p1, s_node); site_edges.append((s_node, c1))
+                site_edges[j] = (p2, h_node); site_edges.append((h_node, c2)); site_edges.append((s_node, h_node))
+                done += 1
+                break
+    n = len(parents)
+    indeg = [len(q) for q in parents]
+    order, stack = [], [0]
+    while stack:
+        v = stack.pop()
+        order.append(v)
+        for c in reversed(children[v]):
+            indeg[c] -= 1
+            if indeg[c] == 0:
+                stack.append(c)
+    assert len(order) == n, "the generated network has a directed cycle"
+    label = np.empty(n, dtype=np.int64)
+    label[np.array(order)] = np.arange(1, n + 1)
+    fam, ln, gm, col = [], [], [], []
+    for v in order:
+        ps = sorted(parents[v], key=lambda q: -label[q[0]])
+        fam.append([int(label[v])] + [int(label[q[0]]) for q in ps])
+        ln.append([q[1] for q in ps])
+        gm.append([q[2] for q in ps])
+        col.append([int(x) for x in rng.integers(0, n_colors, size=len(ps))])
+    return NetArrays(fam, ln, gm, col, np.array([is_leaf[v] for v in order], dtype=bool))
+
+
 def simulate_bm_network(net: NetArrays, rates: Sequence[np.ndarray], mu: np.ndarray, rng: np.random.Generator) -> np.ndarray:
     """Trait values at every node (N, p) under a heterogeneous BM on the network (weighted-average merging at hybrid
     nodes: src/evomodels/evomodels.jl:314-330), root fixed at mu."""

@@ -83,6 +83,79 @@ def regularizebeliefs_bynodesubtree_(beliefs, clustergraph=None):
     beliefs.push()
 
 
+def regularizebeliefs_bynodesubtree_arrays_(beliefs, cluster_nodes, edges, sepset_nodes, scopes):
+    """regularizebeliefs_bynodesubtree! (src/clustergraphbeliefs.jl:306-340) for cluster graphs built on plain arrays
+    (networks.py:allocate_scopes: `scopes.clusters[i]` = node labels + in-scope mask of cluster i), in time linear in
+    the total cluster membership: the per-node cluster and sepset lists are indexed once instead of searched per node
+    (50 000-node networks).  Nodes in increasing label order; every node's eps sees the edits of the nodes before it,
+    as in the reference's sequential loop."""
+    nc = beliefs.nclusters
+    beliefs.pull()
+    p_traits = scopes.clusters[0].inscope.shape[0] if nc else 0
+    # position of every node's in-scope block inside its clusters / sepsets
+    ndim = {}
+    cpos = []
+    for i, sc in enumerate(scopes.clusters):
+        acc, d = 0, {}
+        for j, lab in enumerate(sc.nodelabel):
+            k = int(sc.inscope[:, j].sum())
+            d[lab] = (acc, k)
+            ndim[lab] = k
+            acc += k
+        cpos.append(d)
+    spos = []
+    for nodes in sepset_nodes:
+        acc, d = 0, {}
+        for lab in nodes:
+            k = ndim.get(lab, 0)
+            d[lab] = (acc, k)
+            acc += k
+        spos.append(d)
+    holders, node_seps = {}, {}
+    for i, sc in enumerate(scopes.clusters):
+        for lab in sc.nodelabel:
+            holders.setdefault(lab, []).append(i)
+    for k, nodes in enumerate(sepset_nodes):
+        for lab in nodes:
+            node_seps.setdefault(lab, []).append(k)
+    for site in range(beliefs.n_sites):
+        Jc = [beliefs._views(site, i)[0] for i in range(nc)]
+        Js = [beliefs._views(site, nc + k)[0] for k in range(beliefs.nsepsets)]
+        maxabs = np.array([float(np.max(np.abs(J))) if J.size else 0.0 for J in Jc])
+        for v in sorted(holders):
+            cl = holders[v]
+            if len(cl) <= 1 or ndim.get(v, 0) == 0:
+                continue
+            root = max(cl, key=lambda i: scopes.clusters[i].nodelabel[0])
+            nbr = {i: [] for i in cl}
+            ne = 0
+            for k in node_seps.get(v, []):
+                a, c = int(edges[k][0]), int(edges[k][1])
+                nbr[a].append((c, k))
+                nbr[c].append((a, k))
+                ne += 1
+            order, seen, stack = [], {root}, [root]
+            while stack:
+                q = stack.pop()
+                for (c, k) in nbr[q]:
+                    if c not in seen:
+                        seen.add(c)
+                        stack.append(c)
+                        order.append((c, k))
+            if ne != len(cl) - 1 or len(seen) != len(cl):
+                raise ValueError(f"running intersection violated for node / variable {v}")
+            eps = max(_EPS, float(maxabs[cl].max()))
+            for (c, k) in order:
+                o, d = cpos[c][v]
+                idx = np.arange(o, o + d)
+                Jc[c][idx, idx] += eps
+                maxabs[c] = max(maxabs[c], float(np.max(np.abs(Jc[c][idx, idx]))))
+                o, d = spos[k][v]
+                idx = np.arange(o, o + d)
+                Js[k][idx, idx] += eps
+    beliefs.push()
+
+
 def _scopeindex_node(node_lab, sep, clu):
     """scopeindex(node_label, sepset, cluster) (src/beliefs.jl:418-436)."""
     if node_lab not in sep.nodelabel:

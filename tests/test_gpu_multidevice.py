@@ -124,3 +124,48 @@ def test_comm_single_rank_gather():
     with pytest.raises(L.PgbpError):
         comm.gather_loglik(cgb._eng, 3)                            # slot smaller than the rank's sites
     comm.close()
+
+
+@pytest.mark.gpu
+def test_nodesubtree_regulariser_on_plain_arrays_equals_the_object_walk():
+    """regularization.py:regularizebeliefs_bynodesubtree_arrays_ (indexed once, linear time: what the 50 000-node network
+    of BASELINE configs[4] needs) edits exactly what the per-node search of regularizebeliefs_bynodesubtree_ edits
+    (src/clustergraphbeliefs.jl:306-340), on a loopy join graph of a network with varied level-3 blobs."""
+    import pgbp_amd as P
+    from pgbp_amd.regularization import regularizebeliefs_bynodesubtree_, regularizebeliefs_bynodesubtree_arrays_
+    rng = np.random.default_rng(9)
+    net = P.random_level3_network_varied(120, 40, rng, n_colors=2)
+    cn, ed, sn = P.joingraph(net.node2family, 3)
+    assert len(ed) > len(cn) - 1                     # genuinely loopy
+    p = 2
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    rates = np.stack([np.eye(p) + 0.2, 2 * np.eye(p) + 0.4])
+    X = P.simulate_bm_network(net, rates, np.zeros(p), rng)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, list(range(net.nnodes)), p, n_rates=2)
+    out = []
+    for which in (0, 1):
+        cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+        cgb.lg_setup(fam, X)
+        cgb.assignfactors_lg_(rates, np.zeros(p))
+        cgb.pull()
+        if which == 0:
+            regularizebeliefs_bynodesubtree_arrays_(cgb, cn, ed, sn, st)
+        else:
+            class Obj:
+                pass
+            objs = []
+            for sc in st.clusters:
+                o = Obj(); o.nodelabel = list(sc.nodelabel); o.inscope = sc.inscope; objs.append(o)
+            insc = {lab: sc.inscope[:, j] for sc in st.clusters for j, lab in enumerate(sc.nodelabel)}
+            for nodes in sn:
+                o = Obj(); o.nodelabel = list(nodes); o.inscope = np.stack([insc[v] for v in nodes], axis=1); objs.append(o)
+            cgb._objs = objs
+            regularizebeliefs_bynodesubtree_(cgb)
+            cgb._objs = None
+        cgb.pull()
+        out.append(cgb._packed[0].copy())
+    assert np.array_equal(out[0], out[1])
+    start = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    start.lg_setup(fam, X); start.assignfactors_lg_(rates, np.zeros(p)); start.pull()
+    assert not np.array_equal(out[0], start._packed[0])

@@ -950,6 +950,133 @@ def test_full_size_config_against_c_oracle(P, ntips, p, graph):
     assert np.max(np.abs(pcgb._packed[0] - before)) <= 1e-9 * max(1.0, float(np.max(np.abs(before))))
 
 
+def test_full_size_cfg4_sites_against_pruning_and_c_oracle(P):
+    """BASELINE.json configs[3] at full size: 1000 sites x 8 traits = 8 000 independent univariate OU problems on a
+    20 000-tip tree (site-minor layout, thread-per-site kernel, OU factors assigned on the device).  Every problem's
+    log-likelihood against the independent pruning recursion (1e-8 relative); 4 sampled problems belief by belief,
+    flag by flag against the plain-C sequential engine on factors pulled from the device; size-independent properties:
+    a second calibration leaves the beliefs where they are, every flag is set, no message failed."""
+    from oracle import cengine
+    from pgbp_amd import synth as S
+    ntips, nprob = 20000, 8000
+    rng = np.random.default_rng(4)
+    tr = S.random_tree(ntips, rng)
+    sigma2 = rng.uniform(0.5, 2.0, size=nprob)
+    alpha = rng.uniform(0.1, 1.0, size=nprob)
+    theta = rng.normal(size=nprob)
+    mu = rng.normal(size=nprob)
+    X = S.simulate_ou_uni_sites(tr, sigma2, alpha, theta, mu, rng)
+    ll_ref = S.ou_loglik_pruning_uni_sites(tr, sigma2, alpha, theta, mu, X)
+    prob = S.cliquetree_of_tree(tr, 1)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, None, n_sites=nprob)
+    cgb.set_schedule(prob.schedule)
+    cgb.lg_setup(S.lg_tree_table(tr, prob, 1), X[:, :, None])
+    cgb.assignfactors_lg_((sigma2 / (2.0 * alpha)).reshape(nprob, 1, 1, 1), mu[:, None], model="ou", alpha=alpha, theta=theta[:, None])
+    lib = P.load()
+    from pgbp_amd import _lib as L
+    import ctypes as C
+    opts = cgb._opts()
+    norm, info = np.zeros(nprob), np.zeros(nprob, np.int32)
+    assert lib.pgbp_enqueue_loglik_lg(cgb._eng, 1, C.byref(opts)) == 0
+    assert lib.pgbp_fetch_loglik(cgb._eng, L.f64p(norm), L.i32p(info)) == 0
+    assert not info.any()
+    assert float(np.max(np.abs(norm - ll_ref) / np.maximum(1.0, np.abs(ll_ref)))) <= 1e-8
+    # factors of a sample of problems -> the sequential C engine
+    sample = np.random.default_rng(0).choice(nprob, size=4, replace=False)
+    assert lib.pgbp_reset_from_factors(cgb._eng) == 0
+    psz = int(lib.pgbp_packed_size(cgb._eng))
+    factors = {}
+    rec = np.zeros(psz)
+    nb = len(prob.dims)
+    for s_ in sample:
+        buf = np.zeros(psz)
+        for b in range(nb):
+            ln = int(prob.packed_off[b + 1] - prob.packed_off[b])
+            if ln:
+                assert lib.pgbp_get_belief(cgb._eng, int(s_), b, L.f64p(rec)) == 0
+                buf[prob.packed_off[b]:prob.packed_off[b + 1]] = rec[:ln]
+        factors[int(s_)] = buf
+    res = (L.Result * nprob)()
+    assert lib.pgbp_calibrate(cgb._eng, 2, C.byref(opts), res) == 0
+    assert all(res[i].succ == 1 and res[i].iscal == 1 for i in range(nprob))
+    pa, ch = prob.schedule[0]
+    for s_ in sample:
+        eng = cengine.Engine(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, factors[int(s_)])
+        assert eng.calibrate(pa, ch, 2, return_iscal=True) == (True, True)
+        ref = eng.packed()
+        got = np.zeros(psz)
+        for b in range(nb):
+            ln = int(prob.packed_off[b + 1] - prob.packed_off[b])
+            if ln:
+                assert lib.pgbp_get_belief(cgb._eng, int(s_), b, L.f64p(rec)) == 0
+                got[prob.packed_off[b]:prob.packed_off[b + 1]] = rec[:ln]
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert float(err.max()) <= 1e-8, (int(s_), float(err.max()))
+        assert rel_close(eng.integrate(prob.root_cluster)[1], ll_ref[s_])
+    # idempotence on calibrated clique trees, all 8 000 problems: the root's integral does not move
+    mu0, n0, i0 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
+    assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(opts), res) == 0
+    mu1, n1, i1 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
+    assert not i0.any() and not i1.any()
+    assert float(np.max(np.abs(n1 - n0) / np.maximum(1.0, np.abs(n0)))) <= 1e-10
+    assert float(np.max(np.abs(n0 - ll_ref) / np.maximum(1.0, np.abs(ll_ref)))) <= 1e-8
+
+
+@pytest.mark.parametrize("graph", ["joingraph", "bethe"])
+def test_full_size_cfg5_network_against_c_oracle(P, graph):
+    """BASELINE.json configs[4] at full size: heterogeneous BM (3 painted rates, 4 traits) on a level-3 network with
+    20 000 tips and 5 000 reticulations in varied blobs (networks.py:random_level3_network_varied), loopy cluster graph
+    (join-graph structuring with maxclustersize 3 -- the largest bound under which a level-3 network's join graph is
+    loopy: its moral graph has cliques of at most 4 nodes -- or Bethe), regularised, calibrate!(beliefs, schedule, 100;
+    auto=true) over the spanningtrees_clusterlist schedule.  Against the plain-C sequential engine from the same start:
+    the same (iteration, schedule tree) at which calibration is detected and EVERY belief to 1e-8 * max|.|."""
+    from oracle import cengine
+    from pgbp_amd.regularization import regularizebeliefs_onschedule_
+    rng = np.random.default_rng(3)
+    p = 4
+    net = P.random_level3_network_varied(20000, 5001, rng, n_colors=3)
+    assert net.nhybrids >= 4900
+    cn, ed, sn = P.joingraph(net.node2family, 3) if graph == "joingraph" else P.bethe(net.node2family)
+    assert len(ed) > len(cn) - 1 + 500                      # hundreds of independent cycles
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    base = P.synth.random_rate_matrix(p, rng)
+    base = (base + base.T) / 2
+    rates = np.stack([base * f for f in (0.5, 1.0, 2.0)])
+    mu = np.zeros(p)
+    X = P.simulate_bm_network(net, rates, mu, rng)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, list(range(net.nnodes)), p, n_rates=3)
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, mu)
+    if graph == "joingraph":
+        regularizebeliefs_onschedule_(cgb)
+    else:
+        assert P.load().pgbp_regularize_bycluster(cgb._eng) == 0
+    cgb.pull()
+    start = cgb._packed[0].copy()
+    cgb.init_messagecalibrationflags_reset_()
+    assert P.calibrate_(cgb, sched, 100, auto=True) == (True, True)
+    r = cgb.last_results[0]
+    ce = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+    reached = None
+    for it in range(1, 101):
+        for j, spt in enumerate(sched, start=1):
+            succ, iscal = ce.calibrate(spt[2], spt[3], 1, return_iscal=True)
+            assert succ
+            if iscal:
+                reached = (it, j)
+                break
+        if reached:
+            break
+    assert reached == (r.iter_reached, r.tree_reached) and reached[0] >= 5
+    got, ref = cgb._packed[0], ce.packed()
+    o = cgb._poff[:-1][np.diff(cgb._poff) > 0]
+    err = float(np.max(np.maximum.reduceat(np.abs(got - ref), o) / np.maximum(1.0, np.maximum.reduceat(np.abs(ref), o))))
+    assert err <= 1e-8, err
+
+
 @pytest.mark.parametrize("ntips,nhyb,python_bp", [(400, 80, True), (1500, 300, False)], ids=["400tips_80hybrids", "1500tips_300hybrids"])
 def test_cfg5_shaped_loopy_network(P, caplog, ntips, nhyb, python_bp):
     """BASELINE.json configs[4] at test size: heterogeneous BM (3 painted rates, 4 traits) on a random network with
