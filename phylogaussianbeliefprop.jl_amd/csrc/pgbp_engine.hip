@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -32,6 +33,8 @@ struct DevTraversal {
   int32_t* d_task_off = nullptr;
   Entry* d_entries = nullptr;
   FEntry* d_fentries = nullptr;
+  FEntry* d_centries = nullptr;      // Traversal::centries: the groups of the chunks of fused levels
+  int32_t* d_chunk_wg_off = nullptr; // Traversal::chunk_wg_off
 };
 
 }  // namespace
@@ -273,6 +276,8 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_task_off) (void)hipFree(d.d_task_off);
       if (d.d_entries) (void)hipFree(d.d_entries);
       if (d.d_fentries) (void)hipFree(d.d_fentries);
+      if (d.d_centries) (void)hipFree(d.d_centries);
+      if (d.d_chunk_wg_off) (void)hipFree(d.d_chunk_wg_off);
     }
     v->clear();
   }
@@ -323,7 +328,21 @@ int tail_levels(const pgbp_engine* e, const Traversal& tr, bool kl) {
 // levels [L0, L1) of one traversal: one launch per level (two where a level mixes fast-class and generic tasks)
 void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, const DevTraversal& d, int L0, int L1,
                     unsigned long long seq_base, unsigned long long stop_below, bool kl, int* launches) {
+  const bool chunks_on = !kl && !e->layout_sm && tuning().tail;
+  size_t next_chunk = 0;
   for (int L = L0; L < L1; ++L) {
+    if (chunks_on) {
+      // a chunk of fused levels starting here (and ending inside the range): one launch, one workgroup per tree of tasks
+      while (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 < L) ++next_chunk;
+      if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1) {
+        const Traversal::Chunk& ch = tr.chunks[next_chunk];
+        launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base,
+                      stop_below, stop_below, e->st, 0, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
+        if (launches) *launches += 1;
+        L = ch.level1 - 1;
+        continue;
+      }
+    }
     const int t0 = tr.level_off[L], nt = tr.level_off[L + 1] - t0;
     const int nf = tr.level_nfast[L], ng = tr.level_ngroups[L];
     const int mode = (tuning().stream && !kl && ng >= tuning().stream_min) ? kFastStream : kFastLevel;
@@ -716,6 +735,8 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_task_off, tr.task_off))) break;
       if ((rc = upload(e, &d.d_entries, tr.entries))) break;
       if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
+      if ((rc = upload(e, &d.d_centries, tr.centries))) break;
+      if ((rc = upload(e, &d.d_chunk_wg_off, tr.chunk_wg_off))) break;
     }
     if (rc == PGBP_OK) {
       std::vector<FEntry> tail(e->plan.trees[t].post.tentries);

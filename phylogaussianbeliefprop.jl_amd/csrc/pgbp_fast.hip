@@ -204,6 +204,15 @@ __device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double
 // ODD: the sepsets really have PR = P - 1 variables (an odd trait count): same lane grid, one phantom variable per
 // block, unit precision where it is integrated so that its pivot is 1 (log det and quadratic term unchanged).
 constexpr int kLevel = 0, kStream = 1, kTail = 2;
+
+#ifdef PGBP_STAMP  // experiment builds only (tools/stamp_passes.py): clock stamps of the phases of a pass
+constexpr int kStampSlots = 1 << 16, kStampN = 12;
+__device__ unsigned int g_stamp[kStampSlots][kStampN + 4];
+__device__ unsigned int g_stamp_n;
+#define PGBP_ST(i) do { stv[i] = (unsigned int)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PGBP_ST(i) do { } while (0)
+#endif
 // kStream, per wave: LDS image of a packed sender record (5 LDS-DMA pieces of 128 doubles; lanes past the record's end
 // stay idle, so 584 doubles hold the 577 of a 2P record) + the sepset tile + the receiver tile (144 doubles each)
 constexpr int kImgSender = 584, kImgTile = 144, kImgDoubles = kImgSender + 2 * kImgTile;
@@ -290,7 +299,7 @@ __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 64) void bp_fast16(
     DevState S_arg, const FEntry* __restrict__ recs_arg, int ngroups_arg, int split_arg, unsigned long long seq_base_arg,
-    unsigned long long stop_a_arg, unsigned long long stop_b_arg) {
+    unsigned long long stop_a_arg, unsigned long long stop_b_arg, const int32_t* __restrict__ wg_off) {
   constexpr int W = MODE == kTail ? kTailWaves : kFastMaxWaves;
   static_assert(!(ODD && BS), "odd dimensions run in the plain layout");
   static_assert(MODE != kStream || BS, "the streaming launch prefetches packed records");
@@ -322,13 +331,22 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
   double* const simg = img + kImgSender;
   double* const timg = simg + kImgTile;
 
-  int g = MODE == kTail ? 0 : blockIdx.x;
+  // kTail with wg_off: workgroup b walks the groups [wg_off[b], wg_off[b + 1]) -- its own dependency-closed piece of a
+  // run of fused levels (pgbp_plan.cpp: build_chunks); without: the one workgroup walks all of them
+  if constexpr (MODE == kTail) {
+    if (wg_off) ngroups = wg_off[blockIdx.x + 1];
+  }
+  int g = MODE == kTail ? (wg_off ? wg_off[blockIdx.x] : 0) : blockIdx.x;
   const int gstride = MODE == kStream ? gridDim.x : 1;
   FEntry en = load_record(recs + ((int64_t)g * W + wave));
   unsigned long long failkey = S.fail[site];
   if constexpr (MODE == kStream) prefetch_sender<P>(load_head(recs + ((int64_t)g * W + wave)), wave, pool, img, threadIdx.x & 63);
 
   for (;;) {
+#ifdef PGBP_STAMP
+    unsigned int stv[kStampN] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PGBP_ST(0);
     // lane geometry, re-derived per pass from an opaque copy of the lane id so that nothing of it is carried in
     // registers across the loop (the loop-free kLevel mode compiles to what it was)
     int lane = threadIdx.x & 63;
@@ -343,6 +361,12 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     const bool has_next = MODE != kLevel && g + gstride < ngroups;
     FHead nh{};
     if (MODE == kStream && has_next) nh = load_head(recs + ((int64_t)(g + gstride) * W + wave));
+    // kTail: the whole next record is requested here as a VECTOR load (lanes 0 .. 3 fetch 16 bytes each): the compiler
+    // tracks it like any other load and waits for it where it is used, at the end of the pass -- a scalar load pinned in
+    // SGPRs would be waited for on the spot, a dependent round trip (about 900 clocks) in every level of the tail
+    uint4 nxv = make_uint4(0, 0, 0, 0);
+    if (MODE == kTail && has_next)
+      nxv = reinterpret_cast<const uint4*>(recs + ((int64_t)(g + gstride) * W + wave))[lane & 3];
     if constexpr (MODE == kTail) {
       // a failure in the postorder part of this launch must stop its preorder part: at the first preorder level the fail
       // word is read again, coherently (every other level keeps the value read at the start: a dependent memory round
@@ -384,6 +408,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
       // the image of this pass's sender has landed (this also drains the previous pass's stores)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    PGBP_ST(1);
     if (state == 1) {
       // (kTail: the mark may have been set by an earlier level of this very launch -- by a wave of this workgroup, i.e.
       // through this CU's own vector L1, behind the level's barrier: a plain load sees it)
@@ -534,7 +559,9 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
             if (__any(nz)) {
               double mant = 1.0, quad = 0.0;
               int expo = 0;
+              PGBP_ST(2);
               info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
+              PGBP_ST(3);
               if (info == 0) {
                 const double logdet = log(mant) + (double)expo * PGBP_LN2;
                 gmsg += 0.5 * ((double)PR * PGBP_LOG2PI - logdet + quad);  // :81
@@ -569,7 +596,9 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         slot[kSlotStatus] = (double)state;
       }
     }
+    PGBP_ST(4);
     wg_barrier_lds();
+    PGBP_ST(5);
     if (!provider && state == 1) {
       const double* src = fast_lds + en.src_wave * kSlotDoubles;
       const int pst = (int)src[kSlotStatus];
@@ -591,6 +620,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     if constexpr (MODE == kStream) {
       // the tiles brought in by LDS-DMA (and, as it happens, the next sender) have landed; take them into registers
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PGBP_ST(6);
       if (state == 1 && has_block && !S.sep_zero) sJ = load_blk<true>(simg, P, a, b, up, kidx);
       if (state == 1 && own && (accum || has_block)) tJ = load_blk<true>(timg, P, a, b, up, kidx);
     }
@@ -644,9 +674,23 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         slot[kSlotStatus] = (double)state;
       }
     }
+    PGBP_ST(7);
     wg_barrier_lds();
+    PGBP_ST(8);
     FEntry nx{};
-    if (MODE != kLevel && has_next) nx = load_record(recs + ((int64_t)(g + gstride) * W + wave));
+    if (MODE == kStream && has_next) nx = load_record(recs + ((int64_t)(g + gstride) * W + wave));
+    if (MODE == kTail && has_next) {
+      unsigned int q[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        q[4 * i + 0] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.x, i);
+        q[4 * i + 1] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.y, i);
+        q[4 * i + 2] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.z, i);
+        q[4 * i + 3] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.w, i);
+      }
+      __builtin_memcpy(&nx, q, sizeof(FEntry));
+    }
+    PGBP_ST(9);
     if (state == 1) {
       tJ = Blk{tJ.x + dJ.x, tJ.y + dJ.y, tJ.z + dJ.z, tJ.w + dJ.w};
       th[0] += dh0; th[1] += dh1;
@@ -672,6 +716,19 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         if (lane == 0) to[tG0] = tg;
       }
     }
+    PGBP_ST(10);
+#ifdef PGBP_STAMP
+    if ((blockIdx.x & 63) == 0 && (threadIdx.x & 63) == 0) {  // a sample: every 64th workgroup
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stv[11] = (unsigned int)__builtin_amdgcn_s_memtime();
+      const unsigned int slot = atomicAdd(&g_stamp_n, 1u);
+      if (slot < kStampSlots) {
+        for (int i = 0; i < kStampN; ++i) g_stamp[slot][i] = stv[i];
+        g_stamp[slot][kStampN] = blockIdx.x; g_stamp[slot][kStampN + 1] = wave; g_stamp[slot][kStampN + 2] = g;
+        g_stamp[slot][kStampN + 3] = (unsigned int)(MODE * 1000000 + gridDim.x);
+      }
+    }
+#endif
     if constexpr (MODE == kLevel) break;
     g += gstride;
     if (g >= ngroups) break;
@@ -695,7 +752,9 @@ int g_stream_grid = 0;  // workgroups of a persistent streaming launch: what the
 template <int P, bool ODD>
 void launch_fast_p(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
                    unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
-                   int max_grid) {
+                   int max_grid, const int32_t* d_wg_off, int n_wg) {
+  const int32_t* no_wg = nullptr;
+  const int tail_grid = d_wg_off ? n_wg : 1;
   const size_t lds = fast_lds_bytes(mode);
   if constexpr (!ODD) {
     if (S.bs16) {
@@ -714,23 +773,23 @@ void launch_fast_p(const DevState& S, const FEntry* d_recs, int mode, int ngroup
         const int passes = (ngroups + cap - 1) / cap;
         const int grid = (ngroups + passes - 1) / passes;
         hipLaunchKernelGGL((bp_fast16<P, true, false, kStream>), dim3(grid, n_sites), dim3(kFastMaxWaves * 64), lds, st, S,
-                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b);
+                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b, no_wg);
       } else if (mode == kTail) {
-        hipLaunchKernelGGL((bp_fast16<P, true, false, kTail>), dim3(1, n_sites), dim3(kTailWaves * 64), lds, st, S, d_recs,
-                           ngroups, split, seq_base, stop_a, stop_b);
+        hipLaunchKernelGGL((bp_fast16<P, true, false, kTail>), dim3(tail_grid, n_sites), dim3(kTailWaves * 64), lds, st, S,
+                           d_recs, ngroups, split, seq_base, stop_a, stop_b, d_wg_off);
       } else {
         hipLaunchKernelGGL((bp_fast16<P, true, false, kLevel>), dim3(ngroups, n_sites), dim3(kFastMaxWaves * 64), lds, st, S,
-                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b);
+                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b, no_wg);
       }
       return;
     }
   }
   if (mode == kTail)
-    hipLaunchKernelGGL((bp_fast16<P, false, ODD, kTail>), dim3(1, n_sites), dim3(kTailWaves * 64), lds, st, S, d_recs, ngroups,
-                       split, seq_base, stop_a, stop_b);
+    hipLaunchKernelGGL((bp_fast16<P, false, ODD, kTail>), dim3(tail_grid, n_sites), dim3(kTailWaves * 64), lds, st, S, d_recs,
+                       ngroups, split, seq_base, stop_a, stop_b, d_wg_off);
   else  // plain layout: no streaming instance (a plain 2P record is 8.5 KB)
     hipLaunchKernelGGL((bp_fast16<P, false, ODD, kLevel>), dim3(ngroups, n_sites), dim3(kFastMaxWaves * 64),
-                       fast_lds_bytes(kLevel), st, S, d_recs, ngroups, ngroups, seq_base, stop_a, stop_b);
+                       fast_lds_bytes(kLevel), st, S, d_recs, ngroups, ngroups, seq_base, stop_a, stop_b, no_wg);
 }
 
 }  // namespace
@@ -888,16 +947,17 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
 // the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
 // mode: kLevel (0) one group of kFastMaxWaves records per workgroup; kStream (1) persistent grid with LDS-DMA prefetch
 // (packed layout only: falls back to kLevel otherwise); kTail (2) one workgroup walks `ngroups` groups of kTailWaves
-// records, groups >= split stop below stop_b instead of stop_a (a postorder's tail followed by a preorder's head).
+// records, groups >= split stop below stop_b instead of stop_a (a postorder's tail followed by a preorder's head);
+// with d_wg_off (n_wg + 1 group offsets) n_wg workgroups each walk their own range of groups (a chunk of fused levels).
 void launch_fast16(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
                    unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
-                   int max_grid) {
+                   int max_grid, const int32_t* d_wg_off, int n_wg) {
   if (ngroups <= 0) return;
   if (mode == kStream && !(S.bs16 && S.fast_p % 2 == 0)) mode = kLevel;
 #ifdef PGBP_ONLY_P16  // experiment builds: one instance, seconds to compile
-  if (S.fast_p == 16) launch_fast_p<16, false>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid);
+  if (S.fast_p == 16) launch_fast_p<16, false>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid, d_wg_off, n_wg);
 #else
-#define PGBP_FAST(PP, OD) launch_fast_p<PP, OD>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid); break
+#define PGBP_FAST(PP, OD) launch_fast_p<PP, OD>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid, d_wg_off, n_wg); break
   switch (S.fast_p) {  // the real sepset dimension; odd ones run on the next even instance with a phantom variable
     case 16: PGBP_FAST(16, false);
     case 15: PGBP_FAST(16, true);
@@ -922,3 +982,14 @@ void launch_fast16(const DevState& S, const FEntry* d_recs, int mode, int ngroup
 
 }  // namespace pgbp
 
+#ifdef PGBP_STAMP
+extern "C" int pgbp_debug_stamps(unsigned int* out, unsigned int cap, unsigned int* n) {
+  if (hipDeviceSynchronize() != hipSuccess) return 4;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(pgbp::g_stamp_n), sizeof(unsigned int)) != hipSuccess) return 1;
+  const unsigned int k = *n < cap ? *n : cap;
+  if (k && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgbp::g_stamp), sizeof(unsigned int) * (size_t)k * 16) != hipSuccess) return 2;
+  unsigned int z = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_stamp_n), &z, sizeof(z)) != hipSuccess) return 3;
+  return 0;
+}
+#endif

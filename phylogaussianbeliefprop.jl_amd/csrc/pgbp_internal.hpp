@@ -59,6 +59,8 @@ static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
 constexpr int kFOwn = 1, kFAccum = 2;
 constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = records per group of a level launch
 constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
+constexpr int kChunkMaxTasks = 384;   // a level joins a chunk of fused levels if it has at most this many tasks, all fast-class
+constexpr int kChunkDepth = 4;        // levels per chunk
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
 
 struct Traversal {
@@ -73,6 +75,21 @@ struct Traversal {
   // them with a workgroup barrier per level instead of a kernel boundary.  tentries = tail_levels groups of kTailWaves.
   int32_t tail_levels = 0;
   std::vector<FEntry> tentries;
+  // CHUNKS: runs of consecutive narrow all-fast levels below the tail, fused into one launch each.  Inside a chunk the
+  // tasks form a forest (a task hangs below the task that carries its receiver's own message -- postorder -- or that
+  // delivers its sender's message -- preorder); every tree of it is ONE workgroup of kTailWaves wavefronts that walks
+  // its levels one after the other with a workgroup barrier in between, and no workgroup depends on another one of the
+  // same launch.  centries = groups of kTailWaves records; chunk c owns the groups [group0, group0 + n_groups) and its
+  // workgroup b the groups [wg_off[wg0 + b], wg_off[wg0 + b + 1]) (offsets relative to group0).
+  struct Chunk {
+    int32_t level0 = 0, level1 = 0;   // levels [level0, level1) of this traversal
+    int32_t n_wg = 0, wg0 = 0;        // workgroups; first entry of this chunk in chunk_wg_off (n_wg + 1 entries)
+    int64_t group0 = 0;
+    int32_t n_groups = 0;
+  };
+  std::vector<Chunk> chunks;
+  std::vector<int32_t> chunk_wg_off;
+  std::vector<FEntry> centries;
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;

@@ -240,6 +240,8 @@ static void append_group(const Plan& p, const Traversal& tr, const std::vector<i
   for (; fill < W; ++fill) out.push_back(FEntry{});
 }
 
+static void build_chunks(const Plan& p, Traversal& tr, bool postorder);
+
 // Reorder the tasks of every level so that fast-class tasks come first, pack them into groups of kFastMaxWaves records
 // (first fit, largest task first: no wave of a workgroup idles beside a shorter task), set the receiver load/store
 // flags of the generic tasks, and cut the tail (Traversal::tail_levels).
@@ -341,6 +343,134 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   }
   tr.task_off.swap(new_task_off);
   tr.entries.swap(new_entries);
+  build_chunks(p, tr, postorder);
+}
+
+// CHUNKS of fused levels (Traversal::chunks).  Called on the final task / entry arrays of a traversal.
+static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
+  tr.chunks.clear();
+  tr.chunk_wg_off.clear();
+  tr.centries.clear();
+  static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr;
+  static const int depth = [] { const char* v = getenv("PGBP_CHUNK_DEPTH"); return v ? std::max(2, atoi(v)) : kChunkDepth; }();
+  static const int max_tasks = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkMaxTasks; }();
+  const int nlev = (int)tr.level_off.size() - 1;
+  if (off || nlev <= 0) return;
+  const int ntasks = (int)tr.task_off.size() - 1;
+  std::vector<int32_t> task_level(ntasks, 0);
+  for (int L = 0; L < nlev; ++L)
+    for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) task_level[t] = L;
+  // the task in which a cluster sends (postorder) / receives (preorder) in this traversal
+  std::vector<int32_t> task_of(p.n_clusters, -1);
+  for (int t = 0; t < ntasks; ++t)
+    for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e) {
+      const MsgDesc& m = p.msgs[tr.entries[e].msg];
+      task_of[postorder ? m.from_b : m.to_b] = t;
+    }
+  // levels below the tail that may be fused
+  const int lo = postorder ? 0 : tr.tail_levels, hi = postorder ? nlev - tr.tail_levels : nlev;
+  auto eligible = [&](int L) {
+    const int nt = tr.level_off[L + 1] - tr.level_off[L];
+    return nt > 0 && nt <= max_tasks && tr.level_nfast[L] == nt;
+  };
+  std::vector<std::pair<int, int>> spans;  // chunks as level ranges
+  for (int L = lo; L < hi;) {
+    if (!eligible(L)) { ++L; continue; }
+    int R = L;
+    while (R < hi && eligible(R)) ++R;
+    // the run [L, R): cut into chunks of `depth` levels from the root end, so that the odd short chunk is the wide one
+    if (postorder) {
+      for (int b = R; b > L; b -= depth) spans.push_back({std::max(L, b - depth), b});
+    } else {
+      for (int a = L; a < R; a += depth) spans.push_back({a, std::min(R, a + depth)});
+    }
+    L = R;
+  }
+  std::sort(spans.begin(), spans.end());
+  std::vector<int32_t> wg_of(ntasks, -1);
+  for (const auto& sp : spans) {
+    const int L0 = sp.first, L1 = sp.second;
+    if (L1 - L0 < 2) continue;  // a single level: the level launch does as well
+    // workgroup of every task: the tree of the chunk's forest it belongs to (roots first)
+    int n_wg = 0;
+    auto parent_task = [&](int t) -> int {
+      const MsgDesc& m = p.msgs[tr.entries[tr.task_off[t]].msg];
+      const int c = postorder ? m.to_b : m.from_b;  // the cluster whose own message (post) / receipt (pre) is the parent
+      const int q = task_of[c];
+      if (q < 0) return -1;
+      const int Lq = task_level[q];
+      return (Lq >= L0 && Lq < L1 && Lq != task_level[t]) ? q : -1;
+    };
+    if (postorder) {
+      // a receiver that sends only after this chunk may still receive at several of its levels (children of different
+      // heights): those tasks write the same belief and must stay in one workgroup, in level order
+      std::unordered_map<int, int> wg_of_receiver;
+      for (int L = L1 - 1; L >= L0; --L)
+        for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) {
+          const int q = parent_task(t);
+          if (q >= 0) {
+            wg_of[t] = wg_of[q];
+          } else {
+            const int R = p.msgs[tr.entries[tr.task_off[t]].msg].to_b;
+            auto it = wg_of_receiver.find(R);
+            if (it == wg_of_receiver.end()) it = wg_of_receiver.emplace(R, n_wg++).first;
+            wg_of[t] = it->second;
+          }
+        }
+    } else {
+      for (int L = L0; L < L1; ++L)
+        for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) {
+          const int q = parent_task(t);
+          wg_of[t] = q < 0 ? n_wg++ : wg_of[q];
+        }
+    }
+    // per workgroup, per level: its tasks, in level order; groups of kTailWaves records (a task never straddles two)
+    std::vector<std::vector<int>> tasks_of_wg(n_wg);
+    for (int L = L0; L < L1; ++L)
+      for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) tasks_of_wg[wg_of[t]].push_back(t);  // ascending level
+    std::vector<int> order(n_wg);
+    for (int w = 0; w < n_wg; ++w) order[w] = w;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int x, int y) { return tasks_of_wg[x].size() > tasks_of_wg[y].size(); });  // long ones first
+    Traversal::Chunk ch;
+    ch.level0 = L0; ch.level1 = L1; ch.n_wg = n_wg; ch.wg0 = (int32_t)tr.chunk_wg_off.size();
+    ch.group0 = (int64_t)(tr.centries.size() / kTailWaves);
+    int32_t ngroups = 0;
+    for (int w : order) {
+      tr.chunk_wg_off.push_back(ngroups);
+      const std::vector<int>& ts = tasks_of_wg[w];
+      size_t i = 0;
+      while (i < ts.size()) {
+        const int L = task_level[ts[i]];
+        std::vector<int> members;
+        int fill = 0;
+        while (i < ts.size() && task_level[ts[i]] == L) {
+          const int len = tr.task_off[ts[i] + 1] - tr.task_off[ts[i]];
+          if (fill + len > kTailWaves) break;
+          members.push_back(ts[i]);
+          fill += len;
+          ++i;
+        }
+        // receiver blocks of the members (fast_task is cheap: recomputed instead of stored per task)
+        int tmin = members[0], tmax = members[0];
+        for (int t : members) {
+          tmin = std::min(tmin, t);
+          tmax = std::max(tmax, t);
+        }
+        std::vector<std::pair<int, int>> blk_by_task(tmax - tmin + 1, {0, 0});
+        for (int t : members) {
+          int up0 = 0, mt = 0;
+          (void)fast_task(p, tr, t, postorder, &up0, &mt);
+          blk_by_task[t - tmin] = {up0, mt};
+        }
+        append_group(p, tr, members, blk_by_task, tmin, postorder, kTailWaves, tr.centries);
+        ++ngroups;
+      }
+    }
+    tr.chunk_wg_off.push_back(ngroups);
+    ch.n_groups = ngroups;
+    tr.chunks.push_back(ch);
+  }
 }
 
 // Level-synchronous schedules of one spanning tree.
@@ -676,6 +806,28 @@ int pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* lev
   };
   if (records) dump(tr->fentries, records);
   if (tail_records) dump(tr->tentries, tail_records);
+  return PGBP_OK;
+}
+
+int pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_chunks, int32_t* info, int32_t* wg_off,
+                     int32_t* records) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr || !n_chunks) return PGBP_ERR_INVALID;
+  *n_chunks = (int32_t)tr->chunks.size();
+  for (size_t c = 0; c < tr->chunks.size(); ++c) {
+    const auto& ch = tr->chunks[c];
+    if (info) {
+      int32_t* r = info + 4 * c;
+      r[0] = ch.level0; r[1] = ch.level1; r[2] = ch.n_wg; r[3] = ch.n_groups;
+    }
+  }
+  if (wg_off) std::copy(tr->chunk_wg_off.begin(), tr->chunk_wg_off.end(), wg_off);
+  if (records)
+    for (size_t i = 0; i < tr->centries.size(); ++i) {
+      const pgbp::FEntry& f = tr->centries[i];
+      int32_t* r = records + 6 * i;
+      r[0] = f.valid; r[1] = f.msg; r[2] = f.grp_base; r[3] = f.grp_len; r[4] = f.src_wave; r[5] = f.mode;
+    }
   return PGBP_OK;
 }
 

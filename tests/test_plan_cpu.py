@@ -948,3 +948,130 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         assert [total] + offs == want[cname], (jname, cname, [total] + offs, want[cname])
         seen += 1
     assert seen >= 5
+
+
+def _chunks(lib, pl, tree, d):
+    n = C.c_int32()
+    assert lib.pgbp_plan_chunks(pl, tree, d, C.byref(n), None, None, None) == 0
+    info = np.zeros((max(1, n.value), 4), np.int32)
+    assert lib.pgbp_plan_chunks(pl, tree, d, C.byref(n), L.i32p(info), None, None) == 0
+    info = info[:n.value]
+    wg = np.zeros(max(1, int((info[:, 2] + 1).sum())), np.int32)
+    rec = np.zeros((max(1, int(info[:, 3].sum())), 8, 6), np.int32)
+    assert lib.pgbp_plan_chunks(pl, tree, d, C.byref(n), None, L.i32p(wg), L.i32p(rec)) == 0
+    out, w0, g0 = [], 0, 0
+    for (l0, l1, nwg, ng) in info:
+        offs = wg[w0:w0 + nwg + 1]
+        out.append((int(l0), int(l1), [rec[g0 + offs[b]:g0 + offs[b + 1]] for b in range(nwg)]))
+        assert offs[0] == 0 and offs[-1] == ng and np.all(np.diff(offs) > 0)
+        w0 += nwg + 1
+        g0 += ng
+    return out
+
+
+@pytest.mark.parametrize("ntips,p,kind,graph", [(3000, 16, "random", "cliquetree"), (800, 4, "random", "cliquetree"),
+                                                (60, 16, "caterpillar", "cliquetree"), (900, 8, "random", "bethe"),
+                                                (400, 3, "poly4", "cliquetree")])
+def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
+    """Chunks of fused levels (build_chunks in pgbp_plan.cpp): replaying one calibrate iteration launch by launch --
+    level launches, chunk launches (their workgroups in ANY order: checked forwards and backwards), the tail -- every
+    message finds what it depends on done either by an earlier launch or by an earlier step of its OWN workgroup; two
+    workgroups of one launch never touch the same cluster or sepset; every message runs exactly once."""
+    rng = np.random.default_rng(ntips + p)
+    if kind == "random":
+        tr = S.random_tree(ntips, rng)
+    elif kind == "caterpillar":
+        tr = S.caterpillar_tree(ntips, rng)
+    else:
+        tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
+    prob = S.cliquetree_of_tree(tr, p) if graph == "cliquetree" else S.bethe_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0, lib.pgbp_plan_last_error(pl)
+    assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
+    pa, ch = (np.asarray(x) for x in prob.schedule[0])
+    sc = np.asarray(prob.sepset_clusters).reshape(-1, 2)
+    parent = {int(c): int(a) for a, c in zip(pa, ch)}
+    children = {}
+    for a, c in zip(pa, ch):
+        children.setdefault(int(a), []).append(int(c))
+    edge_of = {(int(a), int(c)): i for i, (a, c) in enumerate(zip(pa, ch))}
+
+    def ends(m):
+        k, side = divmod(int(m), 2)
+        return int(sc[k][1 - side]), int(sc[k][side]), k     # sender, receiver, sepset
+
+    def group_tasks(grp):
+        w, tasks = 0, []
+        while w < grp.shape[0] and grp[w, 0]:
+            ln = int(grp[w, 3])
+            tasks.append([int(grp[w + i, 1]) for i in range(ln)])
+            w += ln
+        assert not grp[w:, 0].any()
+        return tasks
+
+    n_chunk_launches = 0
+    done = set()
+    recv_order = {}
+    for d in (0, 1):
+        lo, to, em, ee, er = _traversal(lib, pl, 0, d)
+        nlev = len(lo) - 1
+        ng, tl, rec, trec = _groups(lib, pl, 0, d, nlev)
+        chunks = {c[0]: c for c in _chunks(lib, pl, 0, d)}
+        tail = set(range(nlev - tl, nlev)) if d == 0 else set(range(tl))
+        launches = []      # each: list of workgroups; a workgroup: list of steps; a step: list of tasks
+        Lv = 0
+        while Lv < nlev:
+            if Lv in chunks:
+                l0, l1, wgs = chunks[Lv]
+                assert not (set(range(l0, l1)) & tail), "chunks lie below the tail"
+                want = sorted(sorted(int(m) for m in em[to[t]:to[t + 1]]) for t in range(lo[l0], lo[l1]))
+                got = sorted(sorted(tk) for w in wgs for g in w for tk in group_tasks(g))
+                assert want == got, "a chunk runs exactly the tasks of its levels"
+                launches.append([[group_tasks(g) for g in w] for w in wgs])
+                n_chunk_launches += 1
+                Lv = l1
+            else:
+                launches.append([[[[int(m) for m in em[to[t]:to[t + 1]]]] for t in range(lo[Lv], lo[Lv + 1])]])
+                Lv += 1
+        for launch in launches:
+            for wg_order in (launch, launch[::-1]):
+                touched = {}
+                for wi, wg in enumerate(wg_order):
+                    local = set()
+                    for step in wg:
+                        readers, writers = set(), {}
+                        for ti, tk in enumerate(step):
+                            for m in tk:
+                                s_, r_, k_ = ends(m)
+                                pre = [(c, s_) for c in children.get(s_, []) if c != r_]
+                                if parent.get(s_) != r_:                       # a preorder message: parent first, all children
+                                    pre = [(c, s_) for c in children.get(s_, [])]
+                                    if s_ in parent:
+                                        pre.append((parent[s_], s_))
+                                for q in pre:
+                                    assert q in done or q in local, (d, m, q)
+                                readers.add(s_)
+                                assert writers.setdefault(r_, ti) == ti
+                                for obj in (("c", s_), ("c", r_), ("s", k_)):
+                                    assert touched.setdefault(obj, wi) == wi, "two workgroups of one launch share a belief"
+                        assert not (readers & set(writers))
+                        for tk in step:
+                            for m in tk:
+                                local.add(ends(m)[:2])
+            for wg in launch:
+                for step in wg:
+                    for tk in step:
+                        for m in tk:
+                            s_, r_, _ = ends(m)
+                            assert (s_, r_) not in done
+                            done.add((s_, r_))
+                            recv_order.setdefault((d, r_), []).append(m)
+    assert len(done) == 2 * len(pa)
+    # messages into one receiver: every one of them once (within a task the planner keeps the reference's order, which
+    # test_level_schedule_invariants checks; across levels the level schedule itself reorders: DESIGN.md section 3)
+    for (d, r_), msgs in recv_order.items():
+        want = len(children.get(r_, [])) if d == 0 else 1
+        assert len(msgs) == want and len(set(msgs)) == len(msgs)
+    if ntips >= 800:
+        assert n_chunk_launches >= 2
+    lib.pgbp_plan_destroy(pl)
