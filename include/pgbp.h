@@ -34,7 +34,9 @@ extern "C" {
 #endif
 
 #define PGBP_VERSION 1
-#define PGBP_MAX_DIM 64 /* largest belief dimension the kernels accept (refused above) */
+#define PGBP_MAX_DIM 128 /* largest belief dimension the kernels accept (refused above): a 128 x 129 working matrix is
+                            132 KB of a CU's 160 KB of LDS; update_residualkldiv / pgbp_residual_kldiv need sepsets of
+                            dimension <= 96 (two systems side by side) */
 
 enum pgbp_status {
   PGBP_OK = 0,

@@ -288,6 +288,9 @@ void free_traversals(pgbp_engine* e) {
 
 int check_opts(pgbp_engine* e, const pgbp_opts* o) {
   if (o && !(o->atol >= 0.0)) return e->fail(PGBP_ERR_INVALID, "pgbp_opts.atol must be >= 0");
+  if (o && o->update_residualkldiv && e->max_s > 96)
+    return e->fail(PGBP_ERR_TOO_LARGE, "update_residualkldiv needs sepsets of dimension <= 96 (this graph: " +
+                                           std::to_string(e->max_s) + ")");
   return PGBP_OK;
 }
 
@@ -348,12 +351,16 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
     const int mode = (tuning().stream && !kl && ng >= tuning().stream_min) ? kFastStream : kFastLevel;
     launch_fast16(S, d.d_fentries + tr.level_fbase[L], mode, ng, ng, e->plan.n_sites, seq_base, stop_below, stop_below,
                   e->st, tuning().stream_grid);
+    const int nbig = tr.level_nbig[L];
     if (e->plan.max_dim <= 2 && e->plan.n_sites >= 8)  // many tiny problems: lanes = sites
       launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->st);
-    else
-      launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below,
+    else {
+      launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, e->st);
-    if (launches) *launches += (nf > 0) + (nt - nf > 0);
+      launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
+                       tr.max_mf_big, e->st);
+    }
+    if (launches) *launches += (nf > 0) + (nt - nf - nbig > 0) + (nbig > 0);
     if (kl) {  // residual_kldiv! right after the messages of the level (src/calibration.jl:128,154)
       const int e0 = tr.task_off[t0], e1 = tr.task_off[t0 + nt];
       launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, e->max_s, e->d_kldiv, e->d_klflags, e->plan.n_sites,
@@ -777,7 +784,10 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
   if ((rc = reset_fail(e))) return rc;
   DevState S = dev_state(e, opts);
-  launch_level_generic(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+  if (p.msgs[en.msg].mf > kGenericMaxDim)
+    launch_level_big(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+  else
+    launch_level_generic(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
   std::vector<unsigned long long> keys(p.n_sites);
   HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * p.n_sites, hipMemcpyDeviceToHost, e->st));
   HIPCHK(e, hipStreamSynchronize(e->st));

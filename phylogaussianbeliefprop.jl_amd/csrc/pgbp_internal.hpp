@@ -59,6 +59,7 @@ static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
 constexpr int kFOwn = 1, kFAccum = 2;
 constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = records per group of a level launch
 constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
+constexpr int kGenericMaxDim = 64;    // largest sender the wave-per-task generic kernel's lane grids handle
 constexpr int kChunkMaxTasks = 384;   // a level joins a chunk of fused levels if it has at most this many tasks, all fast-class
 constexpr int kChunkDepth = 4;        // levels per chunk
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
@@ -66,6 +67,8 @@ constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first
   std::vector<int32_t> level_nfast;  // [n_levels] how many of the level's tasks run on the register-resident kernel
+  std::vector<int32_t> level_nbig;   // [n_levels] how many of its LAST tasks hold a sender of dimension > 64 (bp_level_big)
+  int32_t max_mf_big = 0;            // largest sender dimension among those
   std::vector<FEntry> fentries;      // packed groups of the fast tasks (kFastMaxWaves records each), level after level
   std::vector<int64_t> level_fbase;  // [n_levels] first record of the level in fentries
   std::vector<int32_t> level_ngroups;  // [n_levels] groups of the level

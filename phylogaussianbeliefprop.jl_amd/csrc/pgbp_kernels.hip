@@ -20,7 +20,7 @@ namespace pgbp {
 #define PGBP_LOG2PI 1.8378770664093454835606594728112
 #define PGBP_EPS 2.220446049250313e-16
 
-static constexpr int kPermDoubles = 32;  // PGBP_MAX_DIM int32 = 256 B at the front of LDS
+static constexpr int kPermDoubles = PGBP_MAX_DIM / 2;  // PGBP_MAX_DIM int32 at the front of LDS
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -33,6 +33,8 @@ __device__ __forceinline__ int pow2_at_least(int n) {  // n in [1, 64] -> smalle
 }
 
 extern __shared__ double lds[];
+
+size_t generic_lds_bytes(int max_mf);
 
 #ifdef PGBP_GTRACE
 // experiment-only instrumentation of the generic kernel (tools/trace_generic.py, never in the shipped build):
@@ -329,6 +331,186 @@ namespace pgbp {
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
+// LARGE beliefs (a sender, receiver or sepset of dimension 65 .. PGBP_MAX_DIM): one workgroup of 256 threads per task,
+// the augmented sender [J | h] (up to 128 x 129 doubles = 132 KB of the CU's 160 KB of LDS) eliminated in place, flat index
+// loops instead of the power-of-two lane grids of bp_level_generic.  The clique trees of real networks have a few such
+// cliques (the 54-node clique of docs/src/man/clustergraphs.md:40-89); everything about the message itself is as in
+// bp_level_generic: both early exits of marginalize, Symmetric(J_I) = upper triangle, potrf-style info, poison marks,
+// first-failure key, residual-norm flag (src/beliefupdates.jl:55-83, 579-587, 483-488; src/beliefs.jl:994-1003).
+constexpr int kBigThreads = 256;
+__global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const int32_t* __restrict__ task_off,
+                                                            const Entry* __restrict__ entries, int task0,
+                                                            unsigned long long seq_base, unsigned long long stop_below) {
+  const int tid = threadIdx.x;
+  const int site = blockIdx.y;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  const int task = task0 + blockIdx.x;
+  double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
+  double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  int32_t* perm = reinterpret_cast<int32_t*>(lds);
+  double* W = lds + kPermDoubles;
+  __shared__ int s_info;
+  __shared__ double s_red[kBigThreads];
+  __shared__ int s_flag;
+  const int e0 = task_off[task], e1 = task_off[task + 1];
+  int mf = 0, ni = 0, ld = 1;
+  double gmsg = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const Entry en = entries[e];
+    const MsgDesc m = S.msgs[en.msg];
+    if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
+      if (tid == 0)
+        for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
+      return;
+    }
+    const int s = m.s, mt = m.mt;
+    double* __restrict__ sep = pool + m.sep_off;
+    double* __restrict__ to = pool + m.to_off;
+    double* __restrict__ res = rpool + m.res_off;
+    const int32_t* __restrict__ up = S.idx + m.up_map;
+    if (!en.reuse) {
+      const double* __restrict__ from = pool + m.from_off;
+      mf = m.mf;
+      ni = m.ni;
+      ld = (mf + 1) | 1;
+      __syncthreads();  // W / perm of the previous entry no longer needed
+      for (int i = tid; i < mf; i += kBigThreads)
+        perm[i] = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];  // integrated first, kept last
+      __syncthreads();
+      for (int idx = tid; idx < mf * mf; idx += kBigThreads) {
+        const int j = idx / mf, i = idx - j * mf;
+        W[i * ld + j] = from[perm[i] + (int64_t)perm[j] * mf];
+      }
+      for (int i = tid; i < mf; i += kBigThreads) W[i * ld + mf] = from[(int64_t)mf * mf + perm[i]];
+      {
+        int z = 0;
+        asm volatile("" : "+v"(z));   // vector load: the sender may have been written by this workgroup (an earlier entry)
+        gmsg = from[(int64_t)mf * mf + mf + z];
+      }
+      if (tid == 0) { s_info = 0; s_flag = 0; }
+      __syncthreads();
+      if (ni > 0) {
+        // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66): rows 0 .. mf-1, columns 0 .. ni-1, and h_I
+        bool nz = false;
+        for (int idx = tid; idx < mf * ni; idx += kBigThreads) {
+          const int j = idx / mf, i = idx - j * mf;
+          nz |= fabs(W[i * ld + j]) > PGBP_EPS;
+        }
+        for (int i = tid; i < ni; i += kBigThreads) nz |= fabs(W[i * ld + mf]) > PGBP_EPS;
+        if (nz) s_flag = 1;
+        __syncthreads();
+        if (s_flag) {
+          // Symmetric(J_I): upper triangle only (:68); pivot rows get J_SI' for the kept columns (:77)
+          for (int idx = tid; idx < ni * mf; idx += kBigThreads) {
+            const int i = idx / mf, j = idx - i * mf;   // i < ni
+            if (j > i && j >= ni) W[i * ld + j] = W[j * ld + i];
+          }
+          __syncthreads();
+          for (int idx = tid; idx < ni * ni; idx += kBigThreads) {
+            const int i = idx / ni, j = idx - i * ni;
+            if (j > i) W[j * ld + i] = W[i * ld + j];
+          }
+          __syncthreads();
+          // right-looking elimination of the ni leading variables on [J | h]
+          double mant = 1.0, quad = 0.0;
+          int expo = 0;
+          for (int k = 0; k < ni; ++k) {
+            const double d = W[k * ld + k];
+            if (!(d > 0.0)) {
+              if (tid == 0) s_info = k + 1;
+              break;
+            }
+            const double rd = 1.0 / d;
+            const double hk = W[k * ld + mf];
+            int ex;
+            mant *= frexp(d, &ex);
+            expo += ex;
+            if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
+            quad += hk * hk * rd;
+            const int nr = mf - (k + 1), ncol = mf - k;   // rows k+1 .. mf-1, columns k+1 .. mf (h)
+            for (int idx = tid; idx < nr * ncol; idx += kBigThreads) {
+              const int ii = idx / ncol, jj = idx - ii * ncol;
+              const int i = k + 1 + ii, j = k + 1 + jj;
+              W[i * ld + j] -= (W[i * ld + k] * rd) * W[k * ld + j];
+            }
+            __syncthreads();
+          }
+          __syncthreads();
+          if (s_info != 0) {
+            if (tid == 0) {
+              S.status[(int64_t)site * S.n_msgs + en.msg] = s_info;
+              for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
+              atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)s_info);
+            }
+            return;
+          }
+          const double logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
+          gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);  // :81
+        }
+      }
+    }
+    __syncthreads();
+    // ---- divide! and mult!
+    double maxJ = 0.0, maxh = 0.0;
+    for (int idx = tid; idx < s * s; idx += kBigThreads) {
+      const int b = idx / s, a = idx - b * s;
+      const double msg = W[(ni + a) * ld + ni + b];
+      const int64_t o = a + (int64_t)b * s;
+      const double dJ = msg - sep[o];
+      sep[o] = msg;
+      res[o] = dJ;
+      to[up[a] + (int64_t)up[b] * mt] += dJ;
+      maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+    }
+    for (int a = tid; a < s; a += kBigThreads) {
+      const double msg = W[(ni + a) * ld + mf];
+      const int64_t o = (int64_t)s * s + a;
+      const double dh = msg - sep[o];
+      sep[o] = msg;
+      res[o] = dh;
+      to[(int64_t)mt * mt + up[a]] += dh;
+      maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
+    }
+    if (tid == 0) {
+      const double dg = gmsg - sep[(int64_t)s * s + s];
+      sep[(int64_t)s * s + s] = gmsg;
+      to[(int64_t)mt * mt + mt] += dg;
+      S.status[(int64_t)site * S.n_msgs + en.msg] = 0;
+    }
+    if (S.update_resnorm) {
+      // iscalibrated_residnorm! (src/beliefs.jl:994-1003): x -> fl(x / c) is monotone, every thread tests its own maximum
+      const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+      s_red[tid] = ok ? 1.0 : 0.0;
+      __syncthreads();
+      if (tid == 0) {
+        bool all = true;
+        for (int t = 0; t < kBigThreads; ++t) all &= s_red[t] != 0.0;
+        S.flags[(int64_t)site * S.n_msgs + en.msg] = all ? 1 : 0;
+      }
+    }
+    __syncthreads();  // the next entry of the task may read or read-modify-write what this one wrote
+  }
+}
+
+static void allow_large_lds(const void* kernel, size_t bytes) {
+  // more than 64 KB of dynamic LDS is asked for explicitly (what the launch needs, not the device maximum: a kernel
+  // with static LDS of its own would be refused the full 160 KB, and a refused attribute call is a sticky HIP error)
+  if (bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    (void)hipGetLastError();
+  }
+}
+
+void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st) {
+  if (ntasks <= 0) return;
+  const size_t bytes = generic_lds_bytes(max_mf);
+  allow_large_lds(reinterpret_cast<const void*>(bp_level_big), bytes);
+  hipLaunchKernelGGL(bp_level_big, dim3(ntasks, n_sites), dim3(kBigThreads), bytes, st, S, d_task_off, d_entries, task0,
+                     seq_base, stop_below);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Univariate / tiny beliefs (every dimension <= 2): ONE THREAD per (site, task), lanes = sites.
 // The message descriptors are wave-uniform (scalar loads); each lane reads its own site's records.  This is the
 // batch-of-independent-sites case (cfg4: thousands of univariate problems on one tree), where a wavefront per
@@ -562,6 +744,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
                       double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
+  allow_large_lds(reinterpret_cast<const void*>(integrate_kernel), generic_lds_bytes(m));
   hipLaunchKernelGGL(integrate_kernel, dim3(n_sites), dim3(kWave), generic_lds_bytes(m), st, pool, pool_stride,
                      rec_off, m, bs16, fast_p, d_mu, mu_stride, d_norm, d_info);
 }
@@ -693,11 +876,13 @@ __device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int l
   return true;
 }
 
+// kb: columns of J_t per pass (m: one pass, the whole [J | J_t | h] at once; fewer when m x (2m + 1) doubles exceed the
+// LDS a workgroup may have: the elimination of J is then repeated per block of columns, mu kept from the first pass)
 __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restrict__ pool, int64_t pool_stride,
                                                          const double* __restrict__ fpool, int64_t fpool_stride,
                                                          const int64_t* __restrict__ boff,
                                                          const int32_t* __restrict__ dim, int n_clusters,
-                                                         int n_beliefs, int bs, int fp,
+                                                         int n_beliefs, int bs, int fp, int kb_max,
                                                          double2* __restrict__ contrib, int32_t* __restrict__ info) {
   const int lane = threadIdx.x, b = blockIdx.x, site = blockIdx.y;
   const int m = dim[b];
@@ -711,38 +896,51 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
     return;
   }
   const bool packed = bs && bs16::applies(m, fp);
-  const int nrhs = is_cluster ? m + 1 : 0;
-  const int nc = m + nrhs;
-  const int ld = nc | 1;
+  const int kb = is_cluster ? (m < kb_max ? m : kb_max) : 0;   // columns of J_t per pass
+  const int ld = (m + kb + 1) | 1;
   double* W = lds;
-  for (int idx = lane; idx < m * m; idx += kWave) {
-    const int j = idx / m, i = idx - j * m;
-    W[i * ld + j] = fe_elem(rec, m, packed, fp, i, j);  // Symmetric(J): upper triangle
-    if (is_cluster) W[i * ld + m + j] = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
+  double* mu = lds + (size_t)m * ld;                            // m doubles behind the working matrix
+  double acc = 0.0, logdet = 0.0;
+  for (int c0 = 0; c0 == 0 || c0 < (is_cluster ? m : 0); c0 += (kb > 0 ? kb : m)) {
+    const int nb = is_cluster ? (m - c0 < kb ? m - c0 : kb) : 0;  // columns of J_t in this pass
+    const int nc = m + nb + (c0 == 0 && is_cluster ? 1 : 0);      // + h in the first pass
+    __syncthreads();
+    for (int idx = lane; idx < m * m; idx += kWave) {
+      const int j = idx / m, i = idx - j * m;
+      W[i * ld + j] = fe_elem(rec, m, packed, fp, i, j);  // Symmetric(J): upper triangle
+    }
+    for (int idx = lane; idx < m * nb; idx += kWave) {
+      const int jj = idx / m, i = idx - jj * m, j = c0 + jj;
+      W[i * ld + m + jj] = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
+    }
+    if (c0 == 0 && is_cluster)
+      for (int i = lane; i < m; i += kWave) W[i * ld + m + nb] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
+    __syncthreads();
+    double ld_pass;
+    if (!gauss_jordan_spd(W, m, nc, ld, lane, ld_pass)) {
+      if (lane == 0) { atomicMin(&info[site], b + 1); *out = make_double2(NAN, NAN); }
+      return;
+    }
+    if (c0 == 0) logdet = ld_pass;
+    if (!is_cluster) break;
+    // right block: J^-1 J_t[:, c0 .. c0 + nb) and, in the first pass, mu = J^-1 h behind it
+    for (int jj = lane; jj < nb; jj += kWave) acc += 0.5 * W[(c0 + jj) * ld + m + jj];  // tr(J^-1 J_t) / 2
+    if (c0 == 0)
+      for (int i = lane; i < m; i += kWave) mu[i] = W[i * ld + m + nb];
   }
-  if (is_cluster)
-    for (int i = lane; i < m; i += kWave) W[i * ld + 2 * m] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
   __syncthreads();
-  double logdet;
-  if (!gauss_jordan_spd(W, m, nc, ld, lane, logdet)) {
-    if (lane == 0) { atomicMin(&info[site], b + 1); *out = make_double2(NAN, NAN); }
-    return;
-  }
   const double ent = 0.5 * ((double)m * (PGBP_LOG2PI + 1.0) - logdet);
   if (!is_cluster) {
     if (lane == 0) *out = make_double2(0.0, -ent);
     return;
   }
-  // right block now holds J^-1 J_t (columns m .. 2m-1) and mu = J^-1 h (column 2m)
-  double acc = 0.0;
-  for (int i = lane; i < m; i += kWave) acc += 0.5 * W[i * ld + m + i];  // tr(J^-1 J_t) / 2
   for (int idx = lane; idx < m * m; idx += kWave) {
     const int j = idx / m, i = idx - j * m;
     const double jt = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
-    acc += 0.5 * W[i * ld + 2 * m] * jt * W[j * ld + 2 * m];             // mu'J_t mu / 2
+    acc += 0.5 * mu[i] * jt * mu[j];                                     // mu'J_t mu / 2
   }
   for (int i = lane; i < m; i += kWave)
-    acc -= (packed ? frec[bs16::h_off(m, i, fp)] : frec[(int64_t)m * m + i]) * W[i * ld + 2 * m];  // - h_t'mu
+    acc -= (packed ? frec[bs16::h_off(m, i, fp)] : frec[(int64_t)m * m + i]) * mu[i];  // - h_t'mu
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) *out = make_double2(acc - (packed ? frec[bs16::g_off(m, fp)] : frec[(int64_t)m * m + m]), ent);
@@ -776,15 +974,14 @@ void launch_free_energy(const double* pool, int64_t pool_stride, const double* f
                         const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
                         int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st) {
   const int mm = max_dim < 1 ? 1 : max_dim;
-  const size_t ldsb = sizeof(double) * (size_t)mm * (size_t)((2 * mm + 1) | 1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(free_energy_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-    attr_set = true;
-  }
+  // columns of J_t per pass: all of them while m x (2m + 1) + m doubles fit in 150 KB of LDS (m <= 96), else a block
+  const size_t cap = 150 * 1024 / sizeof(double);
+  int kb = mm;
+  while (kb > 1 && (size_t)mm * (size_t)((mm + kb + 1) | 1) + (size_t)mm > cap) --kb;
+  const size_t ldsb = sizeof(double) * ((size_t)mm * (size_t)((mm + kb + 1) | 1) + (size_t)mm);
+  allow_large_lds(reinterpret_cast<const void*>(free_energy_kernel), ldsb);
   hipLaunchKernelGGL(free_energy_kernel, dim3(n_beliefs, n_sites), dim3(kWave), ldsb, st, pool, pool_stride, fpool,
-                     fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p,
+                     fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p, kb,
                      reinterpret_cast<double2*>(d_contrib), d_info);
   hipLaunchKernelGGL(free_energy_reduce_kernel, dim3(n_sites), dim3(256), 0, st,
                      reinterpret_cast<const double2*>(d_contrib), n_beliefs, d_out3);
@@ -876,12 +1073,7 @@ void launch_residual_kldiv(const DevState& S, const Entry* d_entries, int e0, in
                            int32_t* d_klflags, int n_sites, unsigned long long stop_below, hipStream_t st) {
   if (n_entries <= 0 || max_s <= 0) return;
   const size_t ldsb = sizeof(double) * ((size_t)max_s * (size_t)((2 * max_s + 1) | 1) + (size_t)max_s);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(residual_kldiv_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-    attr_set = true;
-  }
+  allow_large_lds(reinterpret_cast<const void*>(residual_kldiv_kernel), ldsb);
   hipLaunchKernelGGL(residual_kldiv_kernel, dim3(n_entries, n_sites), dim3(kWave), ldsb, st, S, d_entries, e0, d_kldiv,
                      d_klflags, stop_below);
 }

@@ -44,6 +44,10 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
                           int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
                           hipStream_t st);
 
+// tasks with a belief of dimension 65 .. PGBP_MAX_DIM: one workgroup of 256 threads per task, the sender in up to 132 KB of LDS
+void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st);
+
 // thread-per-(site, task) kernel for graphs whose beliefs all have dimension <= 2 (univariate batches)
 void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
                       int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);

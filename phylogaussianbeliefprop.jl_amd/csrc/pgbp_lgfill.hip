@@ -305,11 +305,10 @@ void launch_lg_fill(const LgStatic& F, const LgParams& M, double* pool, int64_t 
   const int rec_cap = (mm * mm + mm + 1 + 1) & ~1;
   const int ld = (2 * F.p + 1) | 1;
   const size_t doubles = (size_t)rec_cap + (size_t)F.p * ld + (size_t)(F.K + 1) + (size_t)(F.K + 2 + F.p) / 2 + 2;
-  static bool attr_set = false;
-  if (!attr_set) {  // up to 64-dimensional clusters with 64 traits: about 100 KB of the CU's 160 KB
+  if (doubles * sizeof(double) > 64 * 1024) {  // a 128-dimensional cluster record is 132 KB of the CU's 160 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              128 * 1024);
-    attr_set = true;
+                              (int)(doubles * sizeof(double)));
+    (void)hipGetLastError();
   }
   hipLaunchKernelGGL(lg_fill_kernel, dim3(n_clusters, n_sites), dim3(kWave), doubles * sizeof(double), st, F, M, pool,
                      pool_stride, fpool, fpool_stride, d_boff, d_dim, bs16, fast_p, rec_cap);

@@ -251,6 +251,8 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   std::vector<Entry> new_entries;
   new_entries.reserve(tr.entries.size());
   tr.level_nfast.assign(nlev, 0);
+  tr.level_nbig.assign(nlev, 0);
+  tr.max_mf_big = 0;
   tr.level_fbase.assign(nlev, 0);
   tr.level_ngroups.assign(nlev, 0);
   tr.level_nrecs.assign(nlev, 0);
@@ -281,6 +283,17 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
       slow.insert(slow.end(), fast.begin(), fast.end());
       std::sort(slow.begin(), slow.end());
       fast.clear();
+    }
+    // tasks with a sender of more than kGenericMaxDim variables go last: they run on bp_level_big
+    {
+      auto is_big = [&](int t) {
+        for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e)
+          if (p.msgs[tr.entries[e].msg].mf > kGenericMaxDim) return true;
+        return false;
+      };
+      std::stable_partition(slow.begin(), slow.end(), [&](int t) { return !is_big(t); });
+      for (int t : slow)
+        if (is_big(t)) ++tr.level_nbig[L];
     }
     tr.level_nfast[L] = (int32_t)fast.size();
     tr.level_fbase[L] = (int64_t)tr.fentries.size();
@@ -318,11 +331,17 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
           const MsgDesc& y = p.msgs[tr.entries[e].msg];
           same_block = x.to_b == y.to_b && x.up0 == y.up0 && x.s == y.s && x.up0 >= 0;
         }
+        bool task_is_big = false;
+        for (int e = e0; e < e1; ++e) task_is_big |= p.msgs[tr.entries[e].msg].mf > kGenericMaxDim;
         for (int e = e0; e < e1; ++e) {
           Entry en = tr.entries[e];
           en.tflags = same_block ? ((e == e0 ? kTLoad : 0) | (e == e1 - 1 ? kTStore : 0)) : (kTLoad | kTStore);
           new_entries.push_back(en);
-          if (grp == &slow) tr.max_mf = std::max(tr.max_mf, p.msgs[en.msg].mf);
+          if (grp == &slow) {
+            const int mfe = p.msgs[en.msg].mf;
+            if (task_is_big) tr.max_mf_big = std::max(tr.max_mf_big, mfe);
+            else tr.max_mf = std::max(tr.max_mf, mfe);
+          }
         }
         new_task_off.push_back((int32_t)new_entries.size());
       }

@@ -169,3 +169,69 @@ def test_nodesubtree_regulariser_on_plain_arrays_equals_the_object_walk():
     start = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
     start.lg_setup(fam, X); start.assignfactors_lg_(rates, np.zeros(p)); start.pull()
     assert not np.array_equal(out[0], start._packed[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [2, 1])
+def test_muller_clique_tree_with_beliefs_beyond_64_dimensions(p):
+    """The reference's documented clique tree of the Mueller et al. network (docs/src/man/clustergraphs.md:40-89: 664
+    cliques, the largest holds 54 nodes) with p = 2 traits: beliefs of up to 108 variables, sepsets of up to 106 --
+    beyond the 64 the wave-per-task kernel's lane grids hold, on bp_level_big (a workgroup per task, the sender in up to
+    132 KB of LDS).  calibrate!() against the plain-C sequential engine: every belief to 1e-8 * max|.|, every residual
+    flag; the log-likelihood is the same at every belief (exact on a clique tree); free_energy (blocked right-hand
+    sides above dimension 96) equals minus the log-likelihood; a single pgbp_propagate of the largest message; p = 1
+    (54 dimensions) runs the same graph on the wave-per-task kernel."""
+    import pgbp_amd as P
+    from oracle import cengine
+    path = os.path.join(ROOT, "tests", "golden", "muller_2022.phy")
+    net, names = P.read_newick(open(path).read())
+    cn, ed, sn = P.cliquetree(net.node2family)
+    assert len(cn) == 664 and max(len(c) for c in cn) == 54
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    assert st.dims.max() >= 50 * p           # (tips and the fixed root are out of scope)
+    rng = np.random.default_rng(2)
+    rates = np.stack([np.eye(p) + 0.3])
+    X = P.simulate_bm_network(net, rates, np.zeros(p), rng)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, list(range(net.nnodes)), p, n_rates=1)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, np.zeros(p))
+    cgb.pull()
+    start = cgb._packed[0].copy()
+    root = P.default_rootcluster(cn, net.is_leaf)
+    spt = P.spanningtree_clusterlist(len(cn), ed, root)
+    sched = [(np.asarray(spt[2]), np.asarray(spt[3]))]
+    assert P.calibrate_(cgb, sched, 2) == (True, True)
+    ce = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+    assert ce.calibrate(sched[0][0], sched[0][1], 2, return_iscal=True) == (True, True)
+    got, ref = cgb._packed[0], ce.packed()
+    off = cgb._poff
+    worst = 0.0
+    for i in range(len(st.dims)):
+        a, b = got[off[i]:off[i + 1]], ref[off[i]:off[i + 1]]
+        if a.size:
+            worst = max(worst, float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b)))))
+    assert worst <= 1e-8, worst
+    assert np.array_equal(cgb._flags().astype(bool), ce.residuals()[1].astype(bool))
+    ll = ce.integrate(root)[1]
+    big = int(np.argmax(st.dims[:len(cn)]))
+    for i in (root, big, 0, len(cn) - 1, len(cn) + 5):
+        if st.dims[i] > 0:
+            v = cgb.integratebelief_(int(i))[1]
+            assert abs(v - ll) <= 1e-8 * max(1.0, abs(ll)), (i, v, ll)
+    fe = cgb.free_energy()
+    assert abs(fe[2] + ll) <= 1e-8 * max(1.0, abs(ll)), (fe, ll)
+    # one message on its own, from the start state: the largest sender towards one of its neighbours
+    cgb._packed[0][:] = start
+    cgb.push()
+    k = next(k for k, (a, b) in enumerate(ed) if big in (a, b))
+    a, b = ed[k]
+    to = b if a == big else a
+    assert cgb._propagate(to, len(cn) + k, big, sync=True) is None
+    ce2 = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+    assert ce2.propagate(to, k, big) == 0
+    r2 = ce2.packed()
+    for i in (to, len(cn) + k):
+        x, y = cgb._packed[0][off[i]:off[i + 1]], r2[off[i]:off[i + 1]]
+        assert float(np.max(np.abs(x - y))) <= 1e-8 * max(1.0, float(np.max(np.abs(y))))
