@@ -1078,3 +1078,29 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
     if ntips >= 800:
         assert n_chunk_launches >= 2
     lib.pgbp_plan_destroy(pl)
+
+
+def test_level3_networks_have_moral_cliques_of_at_most_4_nodes():
+    """Why BASELINE configs[4] runs join-graph structuring with maxclustersize 3: the moral graph of a network of level
+    <= 3 (a tree plus at most 3 reticulations per blob, plus one marrying edge per hybrid) triangulates (min-fill) into
+    cliques of at most 4 nodes on every blob the varied generator draws, so JoinGraphStructuring(6) never splits a bucket
+    (its join graph is a clique tree) while JoinGraphStructuring(3) is loopy as soon as one 4-clique exists."""
+    import pgbp_amd as P
+    seen4 = 0
+    for seed in range(12):
+        rng = np.random.default_rng(100 + seed)
+        net = P.random_level3_network_varied(300, 120, rng, n_colors=2)
+        assert net.nhybrids >= 60
+        # level: no node has more than two parents, and the generator's sites hold at most 3 hybrids each
+        assert max(len(nf) for nf in net.node2family) <= 3
+        cn, ed, sn = P.cliquetree(net.node2family)
+        sizes = [len(c) for c in cn]
+        assert max(sizes) <= 4
+        seen4 += sum(1 for x in sizes if x == 4)
+        cn6, ed6, sn6 = P.joingraph(net.node2family, 6)
+        assert len(ed6) == len(cn6) - 1                      # a tree
+        cn3, ed3, sn3 = P.joingraph(net.node2family, 3)
+        assert max(len(c) for c in cn3) <= 3
+        if 4 in sizes:
+            assert len(ed3) > len(cn3) - 1                   # loopy
+    assert seen4 >= 10
