@@ -125,9 +125,11 @@ int  pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* le
                       int32_t* records, int32_t* tail_records);
 /* Chunks of fused levels of one traversal: runs of narrow levels below the tail that go out as ONE launch each, one
  * workgroup per dependency-closed tree of tasks, a workgroup barrier between its levels.  *n_chunks; then (any may be
- * NULL) info[4 * n_chunks] = {first level, one past the last level, workgroups, groups} per chunk;
- * wg_off[sum(workgroups + 1)]: per chunk, the group range of each of its workgroups (relative to the chunk's first
- * group); records[6 * 8 * sum(groups)]: as for pgbp_plan_groups, 8 records per group, chunk after chunk. */
+ * NULL) info[4 * n_chunks] = {first level, one past the last level, workgroups, groups} per chunk (groups < 0: a chunk
+ * of generic-class tasks, |groups| groups of 8 TASK ids); wg_off[sum(workgroups + 1)]: per chunk, the group range of each of
+ * its workgroups (relative to the chunk's first group); records[6 * 8 * sum(|groups|)]: chunk after chunk, 8 records per
+ * group -- as for pgbp_plan_groups, or {1, task index in pgbp_plan_traversal's task_off, 0, 0, 0, 0} / all 0 for a generic
+ * chunk. */
 int  pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_chunks, int32_t* info, int32_t* wg_off,
                       int32_t* records);
 const char* pgbp_plan_last_error(const pgbp_plan* p);

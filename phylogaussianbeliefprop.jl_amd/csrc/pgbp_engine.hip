@@ -35,6 +35,7 @@ struct DevTraversal {
   FEntry* d_fentries = nullptr;
   FEntry* d_centries = nullptr;      // Traversal::centries: the groups of the chunks of fused levels
   int32_t* d_chunk_wg_off = nullptr; // Traversal::chunk_wg_off
+  int32_t* d_cgroups = nullptr;      // Traversal::cgroups: task ids of the generic-class chunks
 };
 
 }  // namespace
@@ -278,6 +279,7 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_fentries) (void)hipFree(d.d_fentries);
       if (d.d_centries) (void)hipFree(d.d_centries);
       if (d.d_chunk_wg_off) (void)hipFree(d.d_chunk_wg_off);
+      if (d.d_cgroups) (void)hipFree(d.d_cgroups);
     }
     v->clear();
   }
@@ -339,8 +341,12 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
       while (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 < L) ++next_chunk;
       if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1) {
         const Traversal::Chunk& ch = tr.chunks[next_chunk];
-        launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base,
-                      stop_below, stop_below, e->st, 0, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
+        if (ch.generic)
+          launch_chunk_generic(S, d.d_task_off, d.d_entries, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0,
+                               ch.n_wg, e->plan.n_sites, seq_base, stop_below, ch.max_mf, e->st);
+        else
+          launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base,
+                        stop_below, stop_below, e->st, 0, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
         if (launches) *launches += 1;
         L = ch.level1 - 1;
         continue;
@@ -744,6 +750,7 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
       if ((rc = upload(e, &d.d_centries, tr.centries))) break;
       if ((rc = upload(e, &d.d_chunk_wg_off, tr.chunk_wg_off))) break;
+      if ((rc = upload(e, &d.d_cgroups, tr.cgroups))) break;
     }
     if (rc == PGBP_OK) {
       std::vector<FEntry> tail(e->plan.trees[t].post.tentries);

@@ -61,6 +61,7 @@ constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = rec
 constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
 constexpr int kGenericMaxDim = 64;    // largest sender the wave-per-task generic kernel's lane grids handle
 constexpr int kChunkMaxTasks = 384;   // a level joins a chunk of fused levels if it has at most this many tasks, all fast-class
+constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x (perm + mf x (mf + 1)) doubles of LDS per workgroup
 constexpr int kChunkDepth = 4;        // levels per chunk
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
 
@@ -89,10 +90,13 @@ struct Traversal {
     int32_t n_wg = 0, wg0 = 0;        // workgroups; first entry of this chunk in chunk_wg_off (n_wg + 1 entries)
     int64_t group0 = 0;
     int32_t n_groups = 0;
+    int32_t generic = 0;              // 1: its groups are kTailWaves task ids each (cgroups), run by bp_chunk_generic
+    int32_t max_mf = 0;               // largest sender among its tasks (LDS scratch per wavefront of bp_chunk_generic)
   };
   std::vector<Chunk> chunks;
   std::vector<int32_t> chunk_wg_off;
   std::vector<FEntry> centries;
+  std::vector<int32_t> cgroups;      // generic chunks: kTailWaves task ids per group (-1: none); Chunk::group0 indexes groups
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;

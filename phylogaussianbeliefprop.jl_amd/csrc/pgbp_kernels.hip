@@ -36,16 +36,6 @@ extern __shared__ double lds[];
 
 size_t generic_lds_bytes(int max_mf);
 
-#ifdef PGBP_GTRACE
-// experiment-only instrumentation of the generic kernel (tools/trace_generic.py, never in the shipped build):
-// per-phase timestamps of launches with at most 4 tasks
-__device__ unsigned long long g_gtrace[1u << 16][14];
-__device__ unsigned int g_gtrace_n;
-#define GTR(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); gtr[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GTR(i) do { } while (0)
-#endif
-
 // lane -> (lane & (L - 1), lane >> lg) grids with L = 2^lg >= n: index arithmetic without integer division
 __device__ __forceinline__ int log2_ceil(int n) {  // n in [1, 64]
   return n <= 1 ? 0 : 32 - __clz(n - 1);
@@ -55,6 +45,20 @@ __device__ __forceinline__ int log2_ceil(int n) {  // n in [1, 64]
 // (leading dimension ld): W[i][j] -= (W[i][k] / W[k][k]) * W[k][j].  Returns 0 or the 1-based index of
 // the first non-positive pivot (LAPACK potrf `info`, src/beliefupdates.jl:68-76). Accumulates
 // sum log(d_k) and sum h~_k^2 / d_k.  All 64 lanes take part; results are wave-uniform.
+// WAVE: the working matrix belongs to this wavefront alone (several tasks per workgroup): the barrier between pivots is
+// the wave-local ordering of LDS accesses; else the workgroup is the one wavefront and __syncthreads() says the same.
+__device__ __forceinline__ void wave_local_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool WAVE>
+__device__ __forceinline__ void task_sync() {
+  if constexpr (WAVE) wave_local_sync();
+  else __syncthreads();
+}
+
+template <bool WAVE = false>
 __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int ni, int lane, double& logdet,
                                                  double& quad) {
   logdet = 0.0;
@@ -85,56 +89,44 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
         for (int i = k + 1 + i0; i < mf; i += R) W[i * ld + j] -= (W[i * ld + k] * rd) * pkj;
       }
     }
-    __syncthreads();
+    task_sync<WAVE>();
   }
   logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
   return 0;
 }
 
-__global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t* __restrict__ task_off,
-                                                       const Entry* __restrict__ entries, int task0,
-                                                       unsigned long long seq_base,
-                                                       unsigned long long stop_below) {
-  const int lane = threadIdx.x;
-  const int site = blockIdx.y;
-#ifdef PGBP_GTRACE
-  unsigned long long gtr[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  gtr[12] = __builtin_amdgcn_s_memrealtime();
-  gtr[0] = __builtin_amdgcn_s_memtime();
-#endif
-  // A message of an EARLIER traversal failed: the reference has stopped (src/calibration.jl:82,129-132).
-  // Failures inside the current traversal only stop what is downstream of them (poison), so that the
-  // minimum fail key is the first failure of the reference's sequential order.
-  if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  GTR(1);
-  const int task = task0 + blockIdx.x;
+// One task (its messages in order) by ONE wavefront; perm / W: that wavefront's scratch in LDS.  WAVE: other wavefronts
+// of the workgroup run other tasks beside it (the loop mode below), so every synchronisation in here is wave-local and
+// nothing in here may be a workgroup barrier; a `return` ends the task (not the kernel).
+template <bool WAVE>
+__device__ __forceinline__ void generic_task(const DevState& S, const int32_t* __restrict__ task_off,
+                                             const Entry* __restrict__ entries, const int task, const int site,
+                                             const int lane, unsigned long long seq_base, int32_t* perm, double* W) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
-  int32_t* perm = reinterpret_cast<int32_t*>(lds);
-  double* W = lds + kPermDoubles;
 
   const int e0 = task_off[task], e1 = task_off[task + 1];
   int mf = 0, ni = 0, ld = 1;
   double gmsg = 0.0;
-  GTR(2);
   // entry / descriptor of the NEXT message are fetched while the current one is worked on (a task is a chain of
   // dependent loads otherwise: entry -> descriptor -> operands, about half a microsecond per hop)
   int en_msg = entries[e0].msg, en_reuse = entries[e0].reuse, en_seq = entries[e0].seq;
-  GTR(3);
   MsgDesc m = S.msgs[en_msg];
-  GTR(4);
   for (int e = e0; e < e1; ++e) {
     const bool more = e + 1 < e1;
     int nx_msg = en_msg, nx_reuse = 0, nx_seq = 0;
     if (more) { nx_msg = entries[e + 1].msg; nx_reuse = entries[e + 1].reuse; nx_seq = entries[e + 1].seq; }
-    if (S.poison[(int64_t)site * S.n_clusters + m.from_b]) {
+    // (loop mode: a mark may have been stored by another wavefront of this workgroup one level ago -- a vector load,
+    // the scalar cache does not see those stores)
+    int pz = 0;
+    if constexpr (WAVE) asm volatile("" : "+v"(pz));
+    if (__builtin_amdgcn_readfirstlane((int)S.poison[(int64_t)site * S.n_clusters + m.from_b + pz])) {
       // nothing downstream of a failed message runs: every receiver the rest of this task would have reached
       // (a fused chain passes through several) is marked
       if (lane == 0)
         for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
       return;
     }
-    if (e == e0) GTR(5);
     const int s = m.s, mt = m.mt;
     double* __restrict__ sep = pool + m.sep_off;
     double* __restrict__ to = pool + m.to_off;
@@ -177,7 +169,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
       ld = (mf + 1) | 1;  // odd leading dimension: conflict-free column walks
       const int lgm = log2_ceil(mf > 0 ? mf : 1);
       const int ci = lane & ((1 << lgm) - 1), r0 = lane >> lgm, Rm = kWave >> lgm;
-      __syncthreads();    // W / perm of the previous entry no longer needed
+      task_sync<WAVE>();    // W / perm of the previous entry no longer needed
       // integrated variables first, kept variables last.  Kept indices contiguous (keep0 >= 0; every single-node
       // sepset): the permutation is arithmetic, no index loads
       const int k0 = m.keep0;
@@ -187,8 +179,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
         else pv = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];
         perm[i] = pv;
       }
-      __syncthreads();
-      if (e == e0) GTR(6);
+      task_sync<WAVE>();
       // gather; h as the extra column
       if (ci < mf) {
         const int pi = perm[ci];
@@ -202,8 +193,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
         asm volatile("" : "+v"(z));
         gmsg = from[(int64_t)mf * mf + mf + z];
       }
-      __syncthreads();
-      if (e == e0) GTR(7);
+      task_sync<WAVE>();
       if (ni > 0) {
         // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
         bool nz = false;
@@ -224,9 +214,9 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
               }
             }
           }
-          __syncthreads();
+          task_sync<WAVE>();
           double logdet, quad;
-          const int info = eliminate_leading(W, ld, mf, ni, lane, logdet, quad);
+          const int info = eliminate_leading<WAVE>(W, ld, mf, ni, lane, logdet, quad);
           if (info != 0) {
             if (lane == 0) {
               S.status[(int64_t)site * S.n_msgs + en_msg] = info;
@@ -240,7 +230,6 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
         }
       }
     }
-    if (e == e0) GTR(8);
     MsgDesc m_next = m;
     if (more) m_next = S.msgs[nx_msg];   // its entry was requested at the top of this iteration
     // ---- divide! and mult!
@@ -295,40 +284,50 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
       if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en_msg] = ok ? 1 : 0;
     }
     if (more) __threadfence_block();  // next entry of the task may read or read-modify-write what this one wrote
-#ifdef PGBP_GTRACE
-    if (e == e0) { gtr[9] = __builtin_amdgcn_s_memtime(); GTR(10); }
-#endif
     en_msg = nx_msg;
     en_reuse = nx_reuse;
     en_seq = nx_seq;
     m = m_next;
   }
-#ifdef PGBP_GTRACE
-  GTR(11);
-  gtr[13] = __builtin_amdgcn_s_memrealtime();
-  if (gridDim.x <= 4 && lane == 0) {
-    const unsigned int slot = atomicAdd(&g_gtrace_n, 1u);
-    if (slot < (1u << 16)) {
-      for (int q = 0; q < 14; ++q) g_gtrace[slot][q] = gtr[q];
-      g_gtrace[slot][12] = (gtr[13] - gtr[12]) | ((unsigned long long)(e1 - e0) << 32);
-      g_gtrace[slot][13] = (unsigned long long)mf | ((unsigned long long)ni << 8) | ((unsigned long long)gridDim.x << 16);
-    }
-  }
-#endif
 }
 
-#ifdef PGBP_GTRACE
-}  // namespace pgbp
-extern "C" int pgbp_debug_gtrace(unsigned long long* out, unsigned int cap, unsigned int* n, int reset) {
-  if (hipDeviceSynchronize() != hipSuccess) return 4;
-  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(pgbp::g_gtrace_n), sizeof(unsigned int)) != hipSuccess) return 1;
-  const unsigned int m = *n < cap ? *n : cap;
-  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgbp::g_gtrace), (size_t)m * 14 * sizeof(unsigned long long)) != hipSuccess) return 2;
-  if (reset) { unsigned int z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_gtrace_n), &z, sizeof(z)) != hipSuccess) return 3; }
-  return 0;
+__global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t* __restrict__ task_off,
+                                                       const Entry* __restrict__ entries, int task0,
+                                                       unsigned long long seq_base,
+                                                       unsigned long long stop_below) {
+  const int site = blockIdx.y;
+  // A message of an EARLIER traversal failed: the reference has stopped (src/calibration.jl:82,129-132).
+  // Failures inside the current traversal only stop what is downstream of them (poison), so that the
+  // minimum fail key is the first failure of the reference's sequential order.
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  generic_task<false>(S, task_off, entries, task0 + blockIdx.x, site, threadIdx.x, seq_base,
+                      reinterpret_cast<int32_t*>(lds), lds + kPermDoubles);
 }
-namespace pgbp {
-#endif
+
+// LOOP MODE of the same task body: a chunk of fused narrow levels (pgbp_plan.cpp: build_chunks) of generic-class tasks.
+// Workgroup b = one dependency-closed tree of tasks; it walks its groups [wg_off[b], wg_off[b + 1]) of up to
+// kTailWaves task ids (one wavefront per task, -1: none) with a workgroup barrier in between: the stores of a level are
+// complete (vmcnt) and visible (same CU, same vector L1) before the next level's loads.  No workgroup of a launch depends
+// on another.  per_wave: doubles of LDS scratch per wavefront (perm + the largest working matrix of the traversal).
+__global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, const int32_t* __restrict__ task_off,
+                                                                    const Entry* __restrict__ entries,
+                                                                    const int32_t* __restrict__ grp_tasks,
+                                                                    const int32_t* __restrict__ wg_off, int per_wave,
+                                                                    unsigned long long seq_base,
+                                                                    unsigned long long stop_below) {
+  const int site = blockIdx.y;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;   // (uniform over the workgroup: no barrier is skipped by a few)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* scratch = lds + (size_t)wave * per_wave;
+  const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
+  for (int g = g0; g < g1; ++g) {
+    const int task = grp_tasks[(int64_t)g * kTailWaves + wave];
+    if (task >= 0)
+      generic_task<true>(S, task_off, entries, task, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch),
+                         scratch + kPermDoubles);
+    if (g + 1 < g1) __syncthreads();
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // LARGE beliefs (a sender, receiver or sepset of dimension 65 .. PGBP_MAX_DIM): one workgroup of 256 threads per task,
@@ -672,6 +671,15 @@ void launch_level_generic(const DevState& S, const int32_t* d_task_off, const En
   if (ntasks <= 0) return;
   hipLaunchKernelGGL(bp_level_generic, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S,
                      d_task_off, d_entries, task0, seq_base, stop_below);
+}
+
+void launch_chunk_generic(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const int32_t* d_grp_tasks,
+                          const int32_t* d_wg_off, int n_wg, int n_sites, unsigned long long seq_base,
+                          unsigned long long stop_below, int max_mf, hipStream_t st) {
+  if (n_wg <= 0) return;
+  const size_t per_wave = generic_lds_bytes(max_mf) / sizeof(double);
+  hipLaunchKernelGGL(bp_chunk_generic, dim3(n_wg, n_sites), dim3(kTailWaves * 64), per_wave * sizeof(double) * kTailWaves, st,
+                     S, d_task_off, d_entries, d_grp_tasks, d_wg_off, (int)per_wave, seq_base, stop_below);
 }
 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2

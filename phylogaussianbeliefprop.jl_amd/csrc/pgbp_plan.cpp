@@ -370,7 +370,9 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   tr.chunks.clear();
   tr.chunk_wg_off.clear();
   tr.centries.clear();
-  static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr;
+  tr.cgroups.clear();
+  // (chain fusion makes tasks that pass through several receivers: the forest below assumes one receiver / sender per task)
+  static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
   static const int depth = [] { const char* v = getenv("PGBP_CHUNK_DEPTH"); return v ? std::max(2, atoi(v)) : kChunkDepth; }();
   static const int max_tasks = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkMaxTasks; }();
   const int nlev = (int)tr.level_off.size() - 1;
@@ -388,20 +390,43 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     }
   // levels below the tail that may be fused
   const int lo = postorder ? 0 : tr.tail_levels, hi = postorder ? nlev - tr.tail_levels : nlev;
+  // a level may be fused if it is narrow and holds no large-belief task; generic-class tasks need their working matrix
+  // eight times over in one workgroup's LDS
+  std::vector<int32_t> level_mf(nlev, 0);  // largest sender of the level
+  for (int t = 0; t < ntasks; ++t)
+    for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e)
+      level_mf[task_level[t]] = std::max(level_mf[task_level[t]], p.msgs[tr.entries[e].msg].mf);
+  auto all_fast = [&](int L) { return tr.level_nfast[L] == tr.level_off[L + 1] - tr.level_off[L]; };
   auto eligible = [&](int L) {
     const int nt = tr.level_off[L + 1] - tr.level_off[L];
-    return nt > 0 && nt <= max_tasks && tr.level_nfast[L] == nt;
+    return nt > 0 && nt <= max_tasks && tr.level_nbig[L] == 0 && (all_fast(L) || level_mf[L] <= kChunkGenericMaxMf);
   };
+  auto width = [&](int L) { return tr.level_off[L + 1] - tr.level_off[L]; };
+  // levels per chunk, counted from the root-most level (width w0): `depth` of them, and beyond that (up to 4 x depth)
+  // only while the levels stay no wider than 2 x w0 -- a chain of narrow levels is as long as it is whatever the launch
+  // count, but a workgroup that owns a widening subtree serialises its lower levels (measured: blind depth 16 on the
+  // root end of cfg3 costs 0.25 ms)
+  auto extend = [&](int w0, int n, int w) { return n < depth || (n < 4 * depth && w <= 2 * w0); };
   std::vector<std::pair<int, int>> spans;  // chunks as level ranges
   for (int L = lo; L < hi;) {
     if (!eligible(L)) { ++L; continue; }
     int R = L;
-    while (R < hi && eligible(R)) ++R;
-    // the run [L, R): cut into chunks of `depth` levels from the root end, so that the odd short chunk is the wide one
+    while (R < hi && eligible(R) && all_fast(R) == all_fast(L)) ++R;   // one kernel class per run (and per chunk)
+    // the run [L, R): cut into chunks from the root end, so that the odd short chunk is the wide one
     if (postorder) {
-      for (int b = R; b > L; b -= depth) spans.push_back({std::max(L, b - depth), b});
+      for (int b = R; b > L;) {
+        int a = b - 1;
+        while (a > L && extend(width(b - 1), b - a, width(a - 1))) --a;
+        spans.push_back({a, b});
+        b = a;
+      }
     } else {
-      for (int a = L; a < R; a += depth) spans.push_back({a, std::min(R, a + depth)});
+      for (int a = L; a < R;) {
+        int b = a + 1;
+        while (b < R && extend(width(a), b - a, width(b))) ++b;
+        spans.push_back({a, b});
+        a = b;
+      }
     }
     L = R;
   }
@@ -453,12 +478,23 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
                      [&](int x, int y) { return tasks_of_wg[x].size() > tasks_of_wg[y].size(); });  // long ones first
     Traversal::Chunk ch;
     ch.level0 = L0; ch.level1 = L1; ch.n_wg = n_wg; ch.wg0 = (int32_t)tr.chunk_wg_off.size();
-    ch.group0 = (int64_t)(tr.centries.size() / kTailWaves);
+    ch.generic = all_fast(L0) ? 0 : 1;
+    ch.max_mf = 0;
+    for (int L = L0; L < L1; ++L) ch.max_mf = std::max(ch.max_mf, level_mf[L]);
+    ch.group0 = ch.generic ? (int64_t)(tr.cgroups.size() / kTailWaves) : (int64_t)(tr.centries.size() / kTailWaves);
     int32_t ngroups = 0;
     for (int w : order) {
       tr.chunk_wg_off.push_back(ngroups);
       const std::vector<int>& ts = tasks_of_wg[w];
       size_t i = 0;
+      while (ch.generic && i < ts.size()) {
+        // generic-class chunk: one wavefront per TASK, up to kTailWaves tasks of one level per group
+        const int L = task_level[ts[i]];
+        int fill = 0;
+        for (; i < ts.size() && task_level[ts[i]] == L && fill < kTailWaves; ++i, ++fill) tr.cgroups.push_back(ts[i]);
+        for (; fill < kTailWaves; ++fill) tr.cgroups.push_back(-1);
+        ++ngroups;
+      }
       while (i < ts.size()) {
         const int L = task_level[ts[i]];
         std::vector<int> members;
@@ -837,16 +873,27 @@ int pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_c
     const auto& ch = tr->chunks[c];
     if (info) {
       int32_t* r = info + 4 * c;
-      r[0] = ch.level0; r[1] = ch.level1; r[2] = ch.n_wg; r[3] = ch.n_groups;
+      r[0] = ch.level0; r[1] = ch.level1; r[2] = ch.n_wg; r[3] = ch.generic ? -ch.n_groups : ch.n_groups;
     }
   }
   if (wg_off) std::copy(tr->chunk_wg_off.begin(), tr->chunk_wg_off.end(), wg_off);
-  if (records)
-    for (size_t i = 0; i < tr->centries.size(); ++i) {
-      const pgbp::FEntry& f = tr->centries[i];
-      int32_t* r = records + 6 * i;
-      r[0] = f.valid; r[1] = f.msg; r[2] = f.grp_base; r[3] = f.grp_len; r[4] = f.src_wave; r[5] = f.mode;
-    }
+  if (records) {
+    // chunk after chunk: a register-resident chunk's groups as 8 records of 6 words; a generic one's as 8 "records"
+    // {1 or 0, task id, 0, 0, 0, 0}
+    size_t o = 0;
+    for (const auto& ch : tr->chunks)
+      for (int g = 0; g < ch.n_groups; ++g)
+        for (int w = 0; w < pgbp::kTailWaves; ++w, ++o) {
+          int32_t* r = records + 6 * o;
+          if (ch.generic) {
+            const int32_t t = tr->cgroups[(size_t)(ch.group0 + g) * pgbp::kTailWaves + w];
+            r[0] = t >= 0; r[1] = t; r[2] = r[3] = r[4] = r[5] = 0;
+          } else {
+            const pgbp::FEntry& f = tr->centries[(size_t)(ch.group0 + g) * pgbp::kTailWaves + w];
+            r[0] = f.valid; r[1] = f.msg; r[2] = f.grp_base; r[3] = f.grp_len; r[4] = f.src_wave; r[5] = f.mode;
+          }
+        }
+  }
   return PGBP_OK;
 }
 

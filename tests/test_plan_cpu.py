@@ -960,12 +960,14 @@ def _chunks(lib, pl, tree, d):
     assert lib.pgbp_plan_chunks(pl, tree, d, C.byref(n), L.i32p(info), None, None) == 0
     info = info[:n.value]
     wg = np.zeros(max(1, int((info[:, 2] + 1).sum())), np.int32)
-    rec = np.zeros((max(1, int(info[:, 3].sum())), 8, 6), np.int32)
+    rec = np.zeros((max(1, int(np.abs(info[:, 3]).sum())), 8, 6), np.int32)
     assert lib.pgbp_plan_chunks(pl, tree, d, C.byref(n), None, L.i32p(wg), L.i32p(rec)) == 0
     out, w0, g0 = [], 0, 0
     for (l0, l1, nwg, ng) in info:
+        generic = ng < 0          # groups of 8 task ids instead of 8 message records
+        ng = abs(int(ng))
         offs = wg[w0:w0 + nwg + 1]
-        out.append((int(l0), int(l1), [rec[g0 + offs[b]:g0 + offs[b + 1]] for b in range(nwg)]))
+        out.append((int(l0), int(l1), [rec[g0 + offs[b]:g0 + offs[b + 1]] for b in range(nwg)], generic))
         assert offs[0] == 0 and offs[-1] == ng and np.all(np.diff(offs) > 0)
         w0 += nwg + 1
         g0 += ng
@@ -974,20 +976,35 @@ def _chunks(lib, pl, tree, d):
 
 @pytest.mark.parametrize("ntips,p,kind,graph", [(3000, 16, "random", "cliquetree"), (800, 4, "random", "cliquetree"),
                                                 (60, 16, "caterpillar", "cliquetree"), (900, 8, "random", "bethe"),
-                                                (400, 3, "poly4", "cliquetree")])
+                                                (400, 3, "poly4", "cliquetree"), (700, 4, "network", "joingraph"),
+                                                (500, 2, "network", "bethe"), (300, 3, "poly7", "cliquetree"),
+                                                (80, 16, "poly3", "cliquetree"), (120, 6, "poly7", "cliquetree")])
 def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
     """Chunks of fused levels (build_chunks in pgbp_plan.cpp): replaying one calibrate iteration launch by launch --
     level launches, chunk launches (their workgroups in ANY order: checked forwards and backwards), the tail -- every
     message finds what it depends on done either by an earlier launch or by an earlier step of its OWN workgroup; two
     workgroups of one launch never touch the same cluster or sepset; every message runs exactly once."""
     rng = np.random.default_rng(ntips + p)
-    if kind == "random":
-        tr = S.random_tree(ntips, rng)
-    elif kind == "caterpillar":
-        tr = S.caterpillar_tree(ntips, rng)
+    if kind == "network":
+        # loopy cluster graphs of a level-3 network: generic-class tasks (hybrid families, 2-node sepsets), several trees
+        import pgbp_amd as P
+
+        class Prob:
+            pass
+        net = P.random_level3_network_varied(ntips, ntips // 4, rng, n_colors=2)
+        cn, ed, sn = P.joingraph(net.node2family, 3) if graph == "joingraph" else P.bethe(net.node2family)
+        st = P.allocate_scopes(cn, ed, sn, net, p)
+        prob = Prob()
+        prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx = st.dims, st.sepset_clusters, st.scope_off, st.scope_idx
+        prob.schedule = [(np.asarray(t[2]), np.asarray(t[3])) for t in P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)][:1]
     else:
-        tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
-    prob = S.cliquetree_of_tree(tr, p) if graph == "cliquetree" else S.bethe_of_tree(tr, p)
+        if kind == "random":
+            tr = S.random_tree(ntips, rng)
+        elif kind == "caterpillar":
+            tr = S.caterpillar_tree(ntips, rng)
+        else:
+            tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
+        prob = S.cliquetree_of_tree(tr, p) if graph == "cliquetree" else S.bethe_of_tree(tr, p)
     lib, pl, code, keep = _plan(prob)
     assert code == 0, lib.pgbp_plan_last_error(pl)
     assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
@@ -1025,12 +1042,21 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
         Lv = 0
         while Lv < nlev:
             if Lv in chunks:
-                l0, l1, wgs = chunks[Lv]
+                l0, l1, wgs, generic = chunks[Lv]
                 assert not (set(range(l0, l1)) & tail), "chunks lie below the tail"
+
+                def tasks_of(g):
+                    if not generic:
+                        return group_tasks(g)
+                    ids = [int(r[1]) for r in g if r[0]]
+                    assert all(r[0] for r in g[:len(ids)]) and len(ids) >= 1
+                    # eight working matrices share one workgroup's LDS: small senders only (kChunkGenericMaxMf)
+                    assert all(int(prob.dims[ends(m)[0]]) <= 24 for t in ids for m in em[to[t]:to[t + 1]])
+                    return [[int(m) for m in em[to[t]:to[t + 1]]] for t in ids]
                 want = sorted(sorted(int(m) for m in em[to[t]:to[t + 1]]) for t in range(lo[l0], lo[l1]))
-                got = sorted(sorted(tk) for w in wgs for g in w for tk in group_tasks(g))
+                got = sorted(sorted(tk) for w in wgs for g in w for tk in tasks_of(g))
                 assert want == got, "a chunk runs exactly the tasks of its levels"
-                launches.append([[group_tasks(g) for g in w] for w in wgs])
+                launches.append([[tasks_of(g) for g in w] for w in wgs])
                 n_chunk_launches += 1
                 Lv = l1
             else:
