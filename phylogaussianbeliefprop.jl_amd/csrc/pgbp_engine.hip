@@ -35,7 +35,8 @@ struct DevTraversal {
   FEntry* d_fentries = nullptr;
   FEntry* d_centries = nullptr;      // Traversal::centries: the groups of the chunks of fused levels
   int32_t* d_chunk_wg_off = nullptr; // Traversal::chunk_wg_off
-  int32_t* d_cgroups = nullptr;      // Traversal::cgroups: task ids of the generic-class chunks
+  int32_t* d_cgroups = nullptr;      // Traversal::cgroups as first records of the tasks (Traversal::task_grec)
+  GRec* d_grecs = nullptr;           // Traversal::grecs
 };
 
 }  // namespace
@@ -83,6 +84,7 @@ struct pgbp_engine {
   bool sym_known = false, sym_ok = false;
   int32_t* d_one_task_off = nullptr;  // single-message task for pgbp_propagate
   Entry* d_one_entry = nullptr;
+  GRec* d_one_rec = nullptr;
   std::vector<DevTraversal> dpost, dpre;
   std::vector<FEntry*> d_tail;   // per tree: the tail groups of its postorder followed by those of its preorder
   // HIP events of the last pgbp_enqueue_calibrate_timed call (resolved by pgbp_fetch_kernel_time)
@@ -280,6 +282,7 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_centries) (void)hipFree(d.d_centries);
       if (d.d_chunk_wg_off) (void)hipFree(d.d_chunk_wg_off);
       if (d.d_cgroups) (void)hipFree(d.d_cgroups);
+      if (d.d_grecs) (void)hipFree(d.d_grecs);
     }
     v->clear();
   }
@@ -334,16 +337,18 @@ int tail_levels(const pgbp_engine* e, const Traversal& tr, bool kl) {
 void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, const DevTraversal& d, int L0, int L1,
                     unsigned long long seq_base, unsigned long long stop_below, bool kl, int* launches) {
   const bool chunks_on = !kl && !e->layout_sm && tuning().tail;
+  const bool uni = e->plan.max_dim <= 2 && e->plan.n_sites >= 8;  // many tiny problems: lanes = sites (bp_level_uni), no loop mode
   size_t next_chunk = 0;
   for (int L = L0; L < L1; ++L) {
     if (chunks_on) {
       // a chunk of fused levels starting here (and ending inside the range): one launch, one workgroup per tree of tasks
       while (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 < L) ++next_chunk;
-      if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1) {
+      if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1 &&
+          !(tr.chunks[next_chunk].generic && uni)) {
         const Traversal::Chunk& ch = tr.chunks[next_chunk];
         if (ch.generic)
-          launch_chunk_generic(S, d.d_task_off, d.d_entries, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0,
-                               ch.n_wg, e->plan.n_sites, seq_base, stop_below, ch.max_mf, e->st);
+          launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
+                               e->plan.n_sites, seq_base, stop_below, ch.max_mf, e->st);
         else
           launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base,
                         stop_below, stop_below, e->st, 0, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
@@ -358,10 +363,10 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
     launch_fast16(S, d.d_fentries + tr.level_fbase[L], mode, ng, ng, e->plan.n_sites, seq_base, stop_below, stop_below,
                   e->st, tuning().stream_grid);
     const int nbig = tr.level_nbig[L];
-    if (e->plan.max_dim <= 2 && e->plan.n_sites >= 8)  // many tiny problems: lanes = sites
+    if (uni)
       launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->st);
     else {
-      launch_level_generic(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
+      launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, e->st);
       launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
                        tr.max_mf_big, e->st);
@@ -469,7 +474,7 @@ void pgbp_destroy(pgbp_engine* e) {
                   (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
-                  (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_bdim, (void*)e->d_rdim,
+                  (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_one_rec, (void*)e->d_bdim, (void*)e->d_rdim,
                   (void*)e->d_symflag, (void*)e->d_bm_kind, (void*)e->d_bm_row, (void*)e->d_bm_length,
                   (void*)e->d_bm_data, (void*)e->d_bm_Rinv, (void*)e->d_bm_logdet, (void*)e->d_bm_mu})
     if (p) (void)hipFree(p);
@@ -560,6 +565,7 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   }
   if ((rc = dev_alloc(e, &e->d_one_task_off, 2))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_one_entry, 1))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_one_rec, 1))) return bail(rc);
   // beliefs = constant function 1 (h, J, g all 0: src/beliefs.jl:108-132); residuals 0;
   // flags false / kldiv -1, empty messages born calibrated (src/beliefs.jl:914-924)
   if (hipMemsetAsync(e->d_pool, 0, ns * p.pool_stride() * sizeof(double), e->st) != hipSuccess ||
@@ -750,7 +756,11 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
       if ((rc = upload(e, &d.d_centries, tr.centries))) break;
       if ((rc = upload(e, &d.d_chunk_wg_off, tr.chunk_wg_off))) break;
-      if ((rc = upload(e, &d.d_cgroups, tr.cgroups))) break;
+      std::vector<int32_t> grp_recs(tr.cgroups);
+      for (int32_t& t : grp_recs)
+        if (t >= 0) t = tr.task_grec[t];
+      if ((rc = upload(e, &d.d_cgroups, grp_recs))) break;
+      if ((rc = upload(e, &d.d_grecs, tr.grecs))) break;
     }
     if (rc == PGBP_OK) {
       std::vector<FEntry> tail(e->plan.trees[t].post.tentries);
@@ -791,10 +801,13 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
   if ((rc = reset_fail(e))) return rc;
   DevState S = dev_state(e, opts);
-  if (p.msgs[en.msg].mf > kGenericMaxDim)
+  if (p.msgs[en.msg].mf > kGenericMaxDim) {
     launch_level_big(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
-  else
-    launch_level_generic(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+  } else {
+    const GRec rec = make_grec(p, en, -1);
+    HIPCHK(e, hipMemcpyAsync(e->d_one_rec, &rec, sizeof(rec), hipMemcpyHostToDevice, e->st));
+    launch_level_generic(S, e->d_one_rec, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+  }
   std::vector<unsigned long long> keys(p.n_sites);
   HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * p.n_sites, hipMemcpyDeviceToHost, e->st));
   HIPCHK(e, hipStreamSynchronize(e->st));

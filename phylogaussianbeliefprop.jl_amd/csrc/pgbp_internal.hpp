@@ -1,6 +1,7 @@
 // Internal structures shared by the host planner (pgbp_plan.cpp), the engine
 // (pgbp_engine.hip) and the kernels (pgbp_kernels.hip).  Not part of the ABI.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -34,6 +35,28 @@ struct Entry {
   int32_t pad[3];
 };
 constexpr int kTLoad = 1, kTStore = 2;
+
+// Self-contained record of one message for the wave-per-task kernels (bp_level_generic, bp_chunk_generic in
+// pgbp_kernels.hip): descriptor, position in its task and -- for senders of up to kGInlPerm variables and sepsets of
+// up to kGInlUp -- the two index maps, in ONE 128-byte line.  A wavefront fetches it with one dword load per lane
+// (fields by v_readlane) and two byte loads, so the chain of dependent loads of a message is  record -> operands
+// instead of  task -> entry -> descriptor -> index maps -> operands  (about a microsecond per hop on a narrow level).
+// Records of one traversal: per level the FIRST record of each of its generic-class tasks, in task order
+// (Traversal::level_gbase), then the later records of those tasks, chained through `next`.
+constexpr int kGInlPerm = 40, kGInlUp = 16;
+struct GRec {
+  int64_t from_off, to_off, sep_off, res_off;  // dwords 0 .. 7: doubles, inside one site's pools
+  int32_t msg, seq, from_b, to_b;              // 8 .. 11
+  int32_t keep_map, up_map, int_map;           // 12 .. 14: offsets into the index pool (the maps when not inline)
+  int32_t next;                                // 15: record of the task's next message, -1: this is the last
+  uint8_t mf, mt, s, ni;                       // 16
+  uint8_t keep0, up0;                          // 17: first kept / updated index when contiguous, 255: not
+  uint8_t reuse;                               //     same sender and kept indices as the previous message of the task
+  uint8_t inl;                                 //     bit 0: perm[] holds the sender's order, bit 1: up[] the receiver's positions
+  uint8_t perm[kGInlPerm];                     // 18 .. 27: integrated variables first, kept last
+  uint8_t up[kGInlUp];                         // 28 .. 31
+};
+static_assert(sizeof(GRec) == 128 && offsetof(GRec, perm) == 72 && offsetof(GRec, up) == 112, "GRec is one 128-byte record");
 
 // Self-contained message record of the register-resident kernel (pgbp_fast.hip): everything a wavefront
 // needs is in ONE 64-byte line, so the dependent-load chain is  record -> data.  The fast-class tasks of a level
@@ -97,6 +120,9 @@ struct Traversal {
   std::vector<int32_t> chunk_wg_off;
   std::vector<FEntry> centries;
   std::vector<int32_t> cgroups;      // generic chunks: kTailWaves task ids per group (-1: none); Chunk::group0 indexes groups
+  std::vector<GRec> grecs;           // records of the generic-class tasks (see GRec)
+  std::vector<int32_t> level_gbase;  // [n_levels] record of the level's first generic-class task (its tasks follow in order)
+  std::vector<int32_t> task_grec;    // [n_tasks] first record of the task (-1: a fast-class task)
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;
@@ -134,6 +160,7 @@ struct Plan {
 };
 
 int plan_build(Plan& p, const pgbp_desc* d);
+GRec make_grec(const Plan& p, const Entry& en, int32_t next);  // the record of one message (next: see GRec)
 int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
                       const int32_t* ch_j);
 double plan_bytes_per_calibrate(const Plan& p, int64_t* n_messages);

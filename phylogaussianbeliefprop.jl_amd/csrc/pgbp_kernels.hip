@@ -95,64 +95,88 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
   return 0;
 }
 
-// One task (its messages in order) by ONE wavefront; perm / W: that wavefront's scratch in LDS.  WAVE: other wavefronts
-// of the workgroup run other tasks beside it (the loop mode below), so every synchronisation in here is wave-local and
-// nothing in here may be a workgroup barrier; a `return` ends the task (not the kernel).
+// ---- the record of a message (GRec, pgbp_internal.hpp) as a wavefront holds it: one dword per lane (lanes 0 .. 31 =
+// the 128 bytes of the record) and this lane's byte of the two inline index maps.  Three vector loads with addresses
+// that depend on the record index alone, so the record of the NEXT message (of the task, or of the workgroup's next step
+// in the loop mode) is in flight beside the current message at the cost of three registers.
+struct GLoad {
+  unsigned int rv;
+  int pb, ub;
+};
+__device__ __forceinline__ GLoad load_grec(const GRec* __restrict__ recs, int ri, int lane) {
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(recs + ri);
+  GLoad l;
+  l.rv = reinterpret_cast<const unsigned int*>(b)[lane & 31];
+  l.pb = b[offsetof(GRec, perm) + (lane < kGInlPerm ? lane : 0)];
+  l.ub = b[offsetof(GRec, up) + (lane & (kGInlUp - 1))];
+  return l;
+}
+__device__ __forceinline__ int grec_dw(unsigned int rv, int k) { return __builtin_amdgcn_readlane((int)rv, k); }
+__device__ __forceinline__ int64_t grec_i64(unsigned int rv, int k) {
+  return (int64_t)(((unsigned long long)(unsigned int)grec_dw(rv, k + 1) << 32) | (unsigned int)grec_dw(rv, k));
+}
+
+// One task (its messages in order) by ONE wavefront, from the task's first record; perm / W: that wavefront's scratch in
+// LDS.  WAVE: other wavefronts of the workgroup run other tasks beside it (the loop mode below), so every
+// synchronisation in here is wave-local and nothing in here may be a workgroup barrier; a `return` ends the task (not
+// the kernel).  Dependent loads of a message: record (fetched ahead) -> operands.
 template <bool WAVE>
-__device__ __forceinline__ void generic_task(const DevState& S, const int32_t* __restrict__ task_off,
-                                             const Entry* __restrict__ entries, const int task, const int site,
+__device__ __forceinline__ void generic_task(const DevState& S, const GRec* __restrict__ recs, GLoad cur, const int site,
                                              const int lane, unsigned long long seq_base, int32_t* perm, double* W) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
-
-  const int e0 = task_off[task], e1 = task_off[task + 1];
   int mf = 0, ni = 0, ld = 1;
   double gmsg = 0.0;
-  // entry / descriptor of the NEXT message are fetched while the current one is worked on (a task is a chain of
-  // dependent loads otherwise: entry -> descriptor -> operands, about half a microsecond per hop)
-  int en_msg = entries[e0].msg, en_reuse = entries[e0].reuse, en_seq = entries[e0].seq;
-  MsgDesc m = S.msgs[en_msg];
-  for (int e = e0; e < e1; ++e) {
-    const bool more = e + 1 < e1;
-    int nx_msg = en_msg, nx_reuse = 0, nx_seq = 0;
-    if (more) { nx_msg = entries[e + 1].msg; nx_reuse = entries[e + 1].reuse; nx_seq = entries[e + 1].seq; }
-    // (loop mode: a mark may have been stored by another wavefront of this workgroup one level ago -- a vector load,
-    // the scalar cache does not see those stores)
+  for (;;) {
+    const unsigned int rv = cur.rv;
+    const int next = grec_dw(rv, 15);
+    GLoad nxt = cur;
+    if (next >= 0) nxt = load_grec(recs, next, lane);   // beside everything below
+    const int en_msg = grec_dw(rv, 8), en_seq = grec_dw(rv, 9), from_b = grec_dw(rv, 10);
+    const int dims = grec_dw(rv, 16), fl = grec_dw(rv, 17);
+    const int s = (dims >> 16) & 255, mt = (dims >> 8) & 255;
+    const int k0 = (fl & 255) == 255 ? -1 : (fl & 255), u0 = ((fl >> 8) & 255) == 255 ? -1 : ((fl >> 8) & 255);
+    const bool en_reuse = ((fl >> 16) & 255) != 0;
+    const int inl = (fl >> 24) & 255;
+    // the sender sits downstream of a failed message?  Requested with the operands (a vector load: in the loop mode the
+    // mark may have been stored by another wavefront of this workgroup one level ago, which the scalar cache does not
+    // see), looked at before anything of this message is recorded or stored
     int pz = 0;
-    if constexpr (WAVE) asm volatile("" : "+v"(pz));
-    if (__builtin_amdgcn_readfirstlane((int)S.poison[(int64_t)site * S.n_clusters + m.from_b + pz])) {
-      // nothing downstream of a failed message runs: every receiver the rest of this task would have reached
-      // (a fused chain passes through several) is marked
-      if (lane == 0)
-        for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
-      return;
-    }
-    const int s = m.s, mt = m.mt;
-    double* __restrict__ sep = pool + m.sep_off;
-    double* __restrict__ to = pool + m.to_off;
-    double* __restrict__ res = rpool + m.res_off;
-    const int32_t* __restrict__ up = S.idx + m.up_map;
-    const bool upc = m.up0 >= 0;                      // update indices contiguous: no index loads
+    asm volatile("" : "+v"(pz));
+    const int poisoned = S.poison[(int64_t)site * S.n_clusters + from_b + pz];
+    double* __restrict__ sep = pool + grec_i64(rv, 4);
+    double* __restrict__ to = pool + grec_i64(rv, 2);
+    double* __restrict__ res = rpool + grec_i64(rv, 6);
+    const bool upc = u0 >= 0;                         // update indices contiguous: no index map
+    const bool upi = (inl & 2) != 0;                  // ... or in the record
+    const int32_t* __restrict__ up = S.idx + grec_dw(rv, 13);
     // lane grid of the sepset block: a = row, b = b0, b0 + Rs, ...
     const int lgs = log2_ceil(s > 0 ? s : 1);
     const int a = lane & ((1 << lgs) - 1), b0 = lane >> lgs, Rs = kWave >> lgs;
-    const int ua = (s > 0 && a < s) ? (upc ? m.up0 + a : up[a]) : 0;
-    // sepset and receiver operands of this lane, requested BEFORE the gather / elimination so that their HBM latency
+    int ua = 0;
+    if (upc) ua = u0 + a;
+    else if (upi) ua = __shfl(cur.ub, a);
+    else if (s > 0 && a < s) ua = up[a];
+    // sepset and receiver operands of this lane, requested BEFORE the gather / elimination so that their latency
     // runs beside it (small sepsets only: at most 4 (a, b) pairs per lane; larger ones are read after the elimination)
     const bool pre = s > 0 && s <= 16;
     double pre_sep[4] = {0, 0, 0, 0}, pre_to[4] = {0, 0, 0, 0}, pre_seph = 0.0, pre_toh = 0.0;
     int ubq[4] = {0, 0, 0, 0};
-    if (pre && a < s) {
+    if (pre) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int b = b0 + q * Rs;
-        if (b < s) {
-          ubq[q] = upc ? m.up0 + b : up[b];
+        int ub = 0;
+        if (upc) ub = u0 + b;
+        else if (upi) ub = __shfl(cur.ub, b & (kGInlUp - 1));
+        else if (a < s && b < s) ub = up[b];
+        ubq[q] = ub;
+        if (a < s && b < s) {
           pre_sep[q] = sep[a + (int64_t)b * s];
-          pre_to[q] = to[ua + (int64_t)ubq[q] * mt];
+          pre_to[q] = to[ua + (int64_t)ub * mt];
         }
       }
-      if (b0 == 0) {
+      if (a < s && b0 == 0) {
         pre_seph = sep[(int64_t)s * s + a];
         pre_toh = to[(int64_t)mt * mt + ua];
       }
@@ -163,21 +187,22 @@ __device__ __forceinline__ void generic_task(const DevState& S, const int32_t* _
       pre_tog = to[(int64_t)mt * mt + mt];
     }
     if (!en_reuse) {
-      const double* __restrict__ from = pool + m.from_off;
-      mf = m.mf;
-      ni = m.ni;
+      const double* __restrict__ from = pool + grec_i64(rv, 0);
+      mf = dims & 255;
+      ni = (dims >> 24) & 255;
       ld = (mf + 1) | 1;  // odd leading dimension: conflict-free column walks
       const int lgm = log2_ceil(mf > 0 ? mf : 1);
       const int ci = lane & ((1 << lgm) - 1), r0 = lane >> lgm, Rm = kWave >> lgm;
-      task_sync<WAVE>();    // W / perm of the previous entry no longer needed
-      // integrated variables first, kept variables last.  Kept indices contiguous (keep0 >= 0; every single-node
-      // sepset): the permutation is arithmetic, no index loads
-      const int k0 = m.keep0;
-      for (int i = lane; i < mf; i += kWave) {
-        int pv;
-        if (k0 >= 0) pv = (i < ni) ? (i < k0 ? i : i + s) : k0 + (i - ni);
-        else pv = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];
-        perm[i] = pv;
+      task_sync<WAVE>();    // W / perm of the previous message no longer needed
+      // integrated variables first, kept variables last.  Kept indices contiguous (every single-node sepset): the
+      // permutation is arithmetic; else it came with the record, or (large senders) sits in the index pool
+      if (k0 >= 0) {
+        if (lane < mf) perm[lane] = (lane < ni) ? (lane < k0 ? lane : lane + s) : k0 + (lane - ni);
+      } else if (inl & 1) {
+        if (lane < mf) perm[lane] = cur.pb;
+      } else {
+        const int int_map = grec_dw(rv, 14), keep_map = grec_dw(rv, 12);
+        for (int i = lane; i < mf; i += kWave) perm[i] = (i < ni) ? S.idx[int_map + i] : S.idx[keep_map + (i - ni)];
       }
       task_sync<WAVE>();
       // gather; h as the extra column
@@ -187,51 +212,60 @@ __device__ __forceinline__ void generic_task(const DevState& S, const int32_t* _
         if (r0 == 0) W[ci * ld + mf] = from[(int64_t)mf * mf + pi];
       }
       {
-        // vector load on purpose: in a fused chain the sender was written by THIS wave a moment ago (vector stores);
-        // a wave-uniform address would be fetched through the scalar cache, which those stores do not update
+        // vector load on purpose: the sender may have been written through the vector cache a moment ago (a fused
+        // chain, the previous step of the loop mode); a wave-uniform address would go through the scalar cache
         int z = 0;
         asm volatile("" : "+v"(z));
         gmsg = from[(int64_t)mf * mf + mf + z];
       }
       task_sync<WAVE>();
-      if (ni > 0) {
-        // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
-        bool nz = false;
+    }
+    if (__builtin_amdgcn_readfirstlane(poisoned)) {
+      // nothing downstream of a failed message runs: every receiver the rest of this task would have reached is marked
+      if (lane == 0) {
+        S.poison[(int64_t)site * S.n_clusters + grec_dw(rv, 11)] = 1;
+        for (int q = next; q >= 0; q = recs[q].next) S.poison[(int64_t)site * S.n_clusters + recs[q].to_b] = 1;
+      }
+      return;
+    }
+    if (!en_reuse && ni > 0) {
+      const int lgm = log2_ceil(mf > 0 ? mf : 1);
+      const int ci = lane & ((1 << lgm) - 1), r0 = lane >> lgm, Rm = kWave >> lgm;
+      // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
+      bool nz = false;
+      if (ci < mf) {
+        for (int j = r0; j < ni; j += Rm) nz |= fabs(W[ci * ld + j]) > PGBP_EPS;
+        if (r0 == 0 && ci < ni) nz |= fabs(W[ci * ld + mf]) > PGBP_EPS;
+      }
+      const bool fake = !__any(nz);
+      if (!fake) {
+        // Symmetric(J_I): upper triangle only (:68); pivot rows get J_SI' for the kept columns (:77)
         if (ci < mf) {
-          for (int j = r0; j < ni; j += Rm) nz |= fabs(W[ci * ld + j]) > PGBP_EPS;
-          if (r0 == 0 && ci < ni) nz |= fabs(W[ci * ld + mf]) > PGBP_EPS;
-        }
-        const bool fake = !__any(nz);
-        if (!fake) {
-          // Symmetric(J_I): upper triangle only (:68); pivot rows get J_SI' for the kept columns (:77)
-          if (ci < mf) {
-            const int j = ci;
-            for (int i = r0; i < ni; i += Rm) {
-              if (j > i) {
-                const double v = (j < ni) ? W[i * ld + j] : W[j * ld + i];
-                W[i * ld + j] = v;
-                if (j < ni) W[j * ld + i] = v;
-              }
+          const int j = ci;
+          for (int i = r0; i < ni; i += Rm) {
+            if (j > i) {
+              const double v = (j < ni) ? W[i * ld + j] : W[j * ld + i];
+              W[i * ld + j] = v;
+              if (j < ni) W[j * ld + i] = v;
             }
           }
-          task_sync<WAVE>();
-          double logdet, quad;
-          const int info = eliminate_leading<WAVE>(W, ld, mf, ni, lane, logdet, quad);
-          if (info != 0) {
-            if (lane == 0) {
-              S.status[(int64_t)site * S.n_msgs + en_msg] = info;
-              for (int e2 = e; e2 < e1; ++e2) S.poison[(int64_t)site * S.n_clusters + S.msgs[entries[e2].msg].to_b] = 1;
-              atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en_seq) << kInfoBits) |
-                                           (unsigned long long)info);
-            }
-            return;  // nothing of this message is applied; later messages of the task do not run
-          }
-          gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);  // :81
         }
+        task_sync<WAVE>();
+        double logdet, quad;
+        const int info = eliminate_leading<WAVE>(W, ld, mf, ni, lane, logdet, quad);
+        if (info != 0) {
+          if (lane == 0) {
+            S.status[(int64_t)site * S.n_msgs + en_msg] = info;
+            S.poison[(int64_t)site * S.n_clusters + grec_dw(rv, 11)] = 1;
+            for (int q = next; q >= 0; q = recs[q].next) S.poison[(int64_t)site * S.n_clusters + recs[q].to_b] = 1;
+            atomicMin(&S.fail[site], ((seq_base + (unsigned long long)(unsigned int)en_seq) << kInfoBits) |
+                                         (unsigned long long)(unsigned int)info);
+          }
+          return;  // nothing of this message is applied; later messages of the task do not run
+        }
+        gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);  // :81
       }
     }
-    MsgDesc m_next = m;
-    if (more) m_next = S.msgs[nx_msg];   // its entry was requested at the top of this iteration
     // ---- divide! and mult!
     double maxJ = 0.0, maxh = 0.0;
     if (s > 0 && a < s) {
@@ -256,7 +290,7 @@ __device__ __forceinline__ void generic_task(const DevState& S, const int32_t* _
           const double dJ = msg - sep[o];
           sep[o] = msg;
           res[o] = dJ;
-          to[ua + (int64_t)(upc ? m.up0 + b : up[b]) * mt] += dJ;
+          to[ua + (int64_t)(upc ? u0 + b : up[b]) * mt] += dJ;
           maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
         }
       }
@@ -283,16 +317,13 @@ __device__ __forceinline__ void generic_task(const DevState& S, const int32_t* _
       const bool ok = __all(lane_ok);
       if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en_msg] = ok ? 1 : 0;
     }
-    if (more) __threadfence_block();  // next entry of the task may read or read-modify-write what this one wrote
-    en_msg = nx_msg;
-    en_reuse = nx_reuse;
-    en_seq = nx_seq;
-    m = m_next;
+    if (next < 0) return;
+    __threadfence_block();  // the next message of the task may read or read-modify-write what this one wrote
+    cur = nxt;
   }
 }
 
-__global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t* __restrict__ task_off,
-                                                       const Entry* __restrict__ entries, int task0,
+__global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* __restrict__ recs, int rec0,
                                                        unsigned long long seq_base,
                                                        unsigned long long stop_below) {
   const int site = blockIdx.y;
@@ -300,32 +331,41 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const int32_t
   // Failures inside the current traversal only stop what is downstream of them (poison), so that the
   // minimum fail key is the first failure of the reference's sequential order.
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  generic_task<false>(S, task_off, entries, task0 + blockIdx.x, site, threadIdx.x, seq_base,
+  generic_task<false>(S, recs, load_grec(recs, rec0 + blockIdx.x, threadIdx.x), site, threadIdx.x, seq_base,
                       reinterpret_cast<int32_t*>(lds), lds + kPermDoubles);
 }
 
 // LOOP MODE of the same task body: a chunk of fused narrow levels (pgbp_plan.cpp: build_chunks) of generic-class tasks.
 // Workgroup b = one dependency-closed tree of tasks; it walks its groups [wg_off[b], wg_off[b + 1]) of up to
-// kTailWaves task ids (one wavefront per task, -1: none) with a workgroup barrier in between: the stores of a level are
-// complete (vmcnt) and visible (same CU, same vector L1) before the next level's loads.  No workgroup of a launch depends
-// on another.  per_wave: doubles of LDS scratch per wavefront (perm + the largest working matrix of the traversal).
-__global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, const int32_t* __restrict__ task_off,
-                                                                    const Entry* __restrict__ entries,
-                                                                    const int32_t* __restrict__ grp_tasks,
+// kTailWaves first records of tasks (one wavefront per task, -1: none) with a workgroup barrier in between: the stores
+// of a level are complete (vmcnt) and visible (same CU, same vector L1) before the next level's loads.  No workgroup of
+// a launch depends on another.  per_wave: doubles of LDS scratch per wavefront (perm + the largest working matrix of
+// the chunk).  The record of a wavefront's next task is fetched while it works on the current one.
+__global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, const GRec* __restrict__ recs,
+                                                                    const int32_t* __restrict__ grp_recs,
                                                                     const int32_t* __restrict__ wg_off, int per_wave,
                                                                     unsigned long long seq_base,
                                                                     unsigned long long stop_below) {
   const int site = blockIdx.y;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;   // (uniform over the workgroup: no barrier is skipped by a few)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* scratch = lds + (size_t)wave * per_wave;
   const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
+  int ri = grp_recs[(int64_t)g0 * kTailWaves + wave];
+  GLoad cur = {0u, 0, 0};
+  if (ri >= 0) cur = load_grec(recs, ri, lane);
   for (int g = g0; g < g1; ++g) {
-    const int task = grp_tasks[(int64_t)g * kTailWaves + wave];
-    if (task >= 0)
-      generic_task<true>(S, task_off, entries, task, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch),
-                         scratch + kPermDoubles);
+    int ri_next = -1;
+    GLoad nxt = {0u, 0, 0};
+    if (g + 1 < g1) {
+      ri_next = grp_recs[(int64_t)(g + 1) * kTailWaves + wave];
+      if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
+    }
+    if (ri >= 0)
+      generic_task<true>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles);
     if (g + 1 < g1) __syncthreads();
+    ri = ri_next;
+    cur = nxt;
   }
 }
 
@@ -665,21 +705,20 @@ size_t generic_lds_bytes(int max_mf) {
   return sizeof(double) * (size_t)(kPermDoubles + mf * ld);
 }
 
-void launch_level_generic(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0,
-                          int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below,
-                          int max_mf, hipStream_t st) {
+void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
+                          unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(bp_level_generic, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S,
-                     d_task_off, d_entries, task0, seq_base, stop_below);
+  hipLaunchKernelGGL(bp_level_generic, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S, d_recs, rec0,
+                     seq_base, stop_below);
 }
 
-void launch_chunk_generic(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const int32_t* d_grp_tasks,
-                          const int32_t* d_wg_off, int n_wg, int n_sites, unsigned long long seq_base,
-                          unsigned long long stop_below, int max_mf, hipStream_t st) {
+void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* d_grp_recs, const int32_t* d_wg_off, int n_wg,
+                          int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
+                          hipStream_t st) {
   if (n_wg <= 0) return;
   const size_t per_wave = generic_lds_bytes(max_mf) / sizeof(double);
   hipLaunchKernelGGL(bp_chunk_generic, dim3(n_wg, n_sites), dim3(kTailWaves * 64), per_wave * sizeof(double) * kTailWaves, st,
-                     S, d_task_off, d_entries, d_grp_tasks, d_wg_off, (int)per_wave, seq_base, stop_below);
+                     S, d_recs, d_grp_recs, d_wg_off, (int)per_wave, seq_base, stop_below);
 }
 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2

@@ -241,13 +241,14 @@ static void append_group(const Plan& p, const Traversal& tr, const std::vector<i
 }
 
 static void build_chunks(const Plan& p, Traversal& tr, bool postorder);
+static void build_grecs(const Plan& p, Traversal& tr);
 
 // Reorder the tasks of every level so that fast-class tasks come first, pack them into groups of kFastMaxWaves records
 // (first fit, largest task first: no wave of a workgroup idles beside a shorter task), set the receiver load/store
 // flags of the generic tasks, and cut the tail (Traversal::tail_levels).
 static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   const int nlev = (int)tr.level_off.size() - 1;
-  std::vector<int32_t> new_task_off{0};
+  std::vector<int32_t> new_task_off{0}, new_level_off{0};
   std::vector<Entry> new_entries;
   new_entries.reserve(tr.entries.size());
   tr.level_nfast.assign(nlev, 0);
@@ -333,18 +334,28 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
         }
         bool task_is_big = false;
         for (int e = e0; e < e1; ++e) task_is_big |= p.msgs[tr.entries[e].msg].mf > kGenericMaxDim;
+        // A generic-class PREORDER task (one sender, a message to each of its children: different receivers, different
+        // sepsets, the sender itself untouched) becomes one task per message: a wavefront works through its messages
+        // one after the other at several microseconds each, and on the narrow levels that latency is the level's time.
+        // (Not in the univariate site-minor engines, whose tasks are spread over sites, not over messages.)
+        bool split = grp == &slow && !postorder && !task_is_big && p.max_dim > 2;
+        for (int e = e0 + 1; e < e1; ++e)   // (a chain-fused task passes through several senders: its messages depend on each other)
+          split = split && p.msgs[tr.entries[e].msg].from_b == p.msgs[tr.entries[e0].msg].from_b;
         for (int e = e0; e < e1; ++e) {
           Entry en = tr.entries[e];
           en.tflags = same_block ? ((e == e0 ? kTLoad : 0) | (e == e1 - 1 ? kTStore : 0)) : (kTLoad | kTStore);
+          if (split) en.reuse = 0;
           new_entries.push_back(en);
           if (grp == &slow) {
             const int mfe = p.msgs[en.msg].mf;
             if (task_is_big) tr.max_mf_big = std::max(tr.max_mf_big, mfe);
             else tr.max_mf = std::max(tr.max_mf, mfe);
           }
+          if (split && e + 1 < e1) new_task_off.push_back((int32_t)new_entries.size());
         }
         new_task_off.push_back((int32_t)new_entries.size());
       }
+    new_level_off.push_back((int32_t)new_task_off.size() - 1);
   }
   // the tail: levels at the root end, all fast-class, at most kTailWaves messages each
   auto tail_ok = [&](int L) {
@@ -362,7 +373,56 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   }
   tr.task_off.swap(new_task_off);
   tr.entries.swap(new_entries);
+  tr.level_off.swap(new_level_off);
+  build_grecs(p, tr);
   build_chunks(p, tr, postorder);
+}
+
+GRec make_grec(const Plan& p, const Entry& en, int32_t next) {
+  const MsgDesc& m = p.msgs[en.msg];
+  GRec r;
+  std::memset(&r, 0, sizeof(r));
+  r.from_off = m.from_off; r.to_off = m.to_off; r.sep_off = m.sep_off; r.res_off = m.res_off;
+  r.msg = en.msg; r.seq = en.seq; r.from_b = m.from_b; r.to_b = m.to_b;
+  r.keep_map = m.keep_map; r.up_map = m.up_map; r.int_map = m.int_map;
+  r.next = next;
+  r.mf = (uint8_t)m.mf; r.mt = (uint8_t)m.mt; r.s = (uint8_t)m.s; r.ni = (uint8_t)m.ni;
+  r.keep0 = m.keep0 < 0 ? 255 : (uint8_t)m.keep0;
+  r.up0 = m.up0 < 0 ? 255 : (uint8_t)m.up0;
+  r.reuse = (uint8_t)(en.reuse != 0);
+  if (m.keep0 < 0 && m.mf <= kGInlPerm) {
+    for (int i = 0; i < m.ni; ++i) r.perm[i] = (uint8_t)p.idxpool[m.int_map + i];
+    for (int i = 0; i < m.s; ++i) r.perm[m.ni + i] = (uint8_t)p.idxpool[m.keep_map + i];
+    r.inl |= 1;
+  }
+  if (m.up0 < 0 && m.s <= kGInlUp) {
+    for (int i = 0; i < m.s; ++i) r.up[i] = (uint8_t)p.idxpool[m.up_map + i];
+    r.inl |= 2;
+  }
+  return r;
+}
+
+// Records of the generic-class tasks (GRec), on the final task / entry arrays of a traversal.
+static void build_grecs(const Plan& p, Traversal& tr) {
+  const int nlev = (int)tr.level_off.size() - 1;
+  const int ntasks = (int)tr.task_off.size() - 1;
+  tr.grecs.clear();
+  tr.level_gbase.assign(nlev, 0);
+  tr.task_grec.assign(ntasks, -1);
+  for (int L = 0; L < nlev; ++L) {
+    const int t0 = tr.level_off[L] + tr.level_nfast[L], t1 = tr.level_off[L + 1];
+    tr.level_gbase[L] = (int32_t)tr.grecs.size();
+    int32_t later = (int32_t)tr.grecs.size() + (t1 - t0);   // where the tasks' later records go
+    for (int t = t0; t < t1; ++t) {
+      tr.task_grec[t] = (int32_t)tr.grecs.size();
+      const int n = tr.task_off[t + 1] - tr.task_off[t];
+      tr.grecs.push_back(make_grec(p, tr.entries[tr.task_off[t]], n > 1 ? later : -1));
+      later += n - 1;
+    }
+    for (int t = t0; t < t1; ++t)
+      for (int e = tr.task_off[t] + 1; e < tr.task_off[t + 1]; ++e)
+        tr.grecs.push_back(make_grec(p, tr.entries[e], e + 1 < tr.task_off[t + 1] ? (int32_t)tr.grecs.size() + 1 : -1));
+  }
 }
 
 // CHUNKS of fused levels (Traversal::chunks).  Called on the final task / entry arrays of a traversal.

@@ -982,8 +982,8 @@ def _chunks(lib, pl, tree, d):
 def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
     """Chunks of fused levels (build_chunks in pgbp_plan.cpp): replaying one calibrate iteration launch by launch --
     level launches, chunk launches (their workgroups in ANY order: checked forwards and backwards), the tail -- every
-    message finds what it depends on done either by an earlier launch or by an earlier step of its OWN workgroup; two
-    workgroups of one launch never touch the same cluster or sepset; every message runs exactly once."""
+    message finds what it depends on done either by an earlier launch or by an earlier step of its OWN workgroup; what a
+    workgroup writes no other workgroup of the launch reads or writes; every message runs exactly once."""
     rng = np.random.default_rng(ntips + p)
     if kind == "network":
         # loopy cluster graphs of a level-3 network: generic-class tasks (hybrid families, 2-node sepsets), several trees
@@ -1064,7 +1064,7 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                 Lv += 1
         for launch in launches:
             for wg_order in (launch, launch[::-1]):
-                touched = {}
+                touched, read_by = {}, {}
                 for wi, wg in enumerate(wg_order):
                     local = set()
                     for step in wg:
@@ -1081,8 +1081,14 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                                     assert q in done or q in local, (d, m, q)
                                 readers.add(s_)
                                 assert writers.setdefault(r_, ti) == ti
-                                for obj in (("c", s_), ("c", r_), ("s", k_)):
+                                # what a workgroup WRITES (the receiver, the sepset) no other workgroup of the launch
+                                # touches; a sender that nobody writes may be read by several (preorder: one task
+                                # per message of a generic-class sender)
+                                for obj in (("c", r_), ("s", k_)):
                                     assert touched.setdefault(obj, wi) == wi, "two workgroups of one launch share a belief"
+                                    assert read_by.get(obj, {wi}) == {wi}, "a workgroup writes what another one reads"
+                                assert touched.get(("c", s_), wi) == wi, "a workgroup reads what another one writes"
+                                read_by.setdefault(("c", s_), set()).add(wi)
                         assert not (readers & set(writers))
                         for tk in step:
                             for m in tk:

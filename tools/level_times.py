@@ -3,6 +3,7 @@
 
   step 1 (under the profiler; the program itself after `--`):
      rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lt -- python3 tools/level_times.py run [ntips] [traits]
+     (or `run-network [joingraph|bethe] [ntips]`: the cfg5 network workload of bench.py)
   step 2 (plain): python3 tools/level_times.py parse gpurun_out/lt [out.json]
 
 `run` builds the workload, does 3 warm-up calibrates and 5 more, each bracketed by a device sync so that the
@@ -33,6 +34,33 @@ def run(ntips, p):
         assert P.calibrate_(cgb, prob.schedule, 1, sync=False)[0]
         time.sleep(0.003)
     print("loglik", cgb.integratebelief_(prob.root_cluster)[1])
+
+
+def run_network(graph, ntips):
+    """the cfg5 network workload (bench.py --workload network): 8 calibrate iterations from the regularised start"""
+    import argparse
+    import ctypes as C
+    import time
+    import pgbp_amd as P
+    import bench as B
+    args = argparse.Namespace(seed=0, traits=4, blob_style="varied", ntips=ntips, blobs=ntips // 12, graph=graph, maxclustersize=3)
+    net, (cn, ed, sn), st, fam, X, rates, mu, sched = B.build_network_workload(args, 0)
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, mu)
+    lib = P.load()
+    if graph == "joingraph":
+        from pgbp_amd.regularization import regularizebeliefs_onschedule_
+        regularizebeliefs_onschedule_(cgb)
+    else:
+        assert lib.pgbp_regularize_bycluster(cgb._eng) == 0
+    cgb.set_schedule(sched)
+    opts = cgb._opts()
+    for _ in range(8):
+        assert lib.pgbp_enqueue_calibrate(cgb._eng, 1, 0, C.byref(opts)) == 0
+        assert lib.pgbp_sync(cgb._eng) == 0
+        time.sleep(0.003)
+    print("trees", len(sched), "messages per iteration", sum(2 * len(s[2]) for s in sched))
 
 
 def parse(d, out=None):
@@ -71,7 +99,9 @@ def parse(d, out=None):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
+    if sys.argv[1] == "run-network":
+        run_network(sys.argv[2] if len(sys.argv) > 2 else "joingraph", int(sys.argv[3]) if len(sys.argv) > 3 else 20000)
+    elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 50000, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
     else:
         parse(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
