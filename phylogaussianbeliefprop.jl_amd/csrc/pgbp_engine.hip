@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <limits>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -58,6 +59,11 @@ struct pgbp_engine {
   int32_t* d_nb_msg = nullptr;
   int32_t* d_sepcl = nullptr;       // [2*n_sepsets] sepset -> its two clusters
   double* d_eps = nullptr;          // [n_sites][n_clusters] regularisation scratch
+  double* d_thr = nullptr;          // DevState::thr: residual-norm thresholds of the current tolerance
+  double* d_logtab = nullptr;       // DevState::logtab
+  std::vector<double> h_thr;
+  double thr_atol = 0.0;
+  bool thr_valid = false;
   unsigned long long* d_fail = nullptr;
   int32_t* d_poison = nullptr;      // [n_sites][n_clusters]
   int32_t* d_iscal = nullptr;       // [n_sites]
@@ -147,7 +153,33 @@ int upload(pgbp_engine* e, T** p, const std::vector<T>& v) {
   return PGBP_OK;
 }
 
-DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
+// the largest x with fl(x / c) <= atol (x -> fl(x / c) is monotone; IEEE division on the host = the device's)
+double quotient_threshold(double c, double atol) {
+  if (!(atol >= 0.0)) return -1.0;                 // NaN or negative tolerance: nothing passes (the maxima are >= 0)
+  if (std::isinf(atol) || c == 0.0) return INFINITY;
+  double x = atol * c;
+  if (std::isinf(x)) x = std::numeric_limits<double>::max();
+  while (x / c > atol) x = std::nextafter(x, -INFINITY);
+  while (std::nextafter(x, INFINITY) / c <= atol) x = std::nextafter(x, INFINITY);
+  return x;
+}
+
+// DevState::thr for the tolerance of this call (rebuilt and uploaded only when the tolerance changes)
+int ensure_thresholds(pgbp_engine* e, double atol) {
+  if (e->thr_valid && std::memcmp(&atol, &e->thr_atol, sizeof(double)) == 0) return PGBP_OK;
+  HIPCHK(e, hipStreamSynchronize(e->st));   // (an earlier upload may still read the host copy)
+  e->h_thr.assign(2 * (PGBP_MAX_DIM + 1), INFINITY);
+  for (int s = 1; s <= PGBP_MAX_DIM; ++s) {
+    e->h_thr[s] = quotient_threshold(std::sqrt((double)s), atol);
+    e->h_thr[PGBP_MAX_DIM + 1 + s] = quotient_threshold(std::sqrt((double)s * (double)s), atol);
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_thr, e->h_thr.data(), sizeof(double) * e->h_thr.size(), hipMemcpyHostToDevice, e->st));
+  e->thr_atol = atol;
+  e->thr_valid = true;
+  return PGBP_OK;
+}
+
+DevState dev_state(pgbp_engine* e, const pgbp_opts* o) {
   DevState S;
   S.pool = e->d_pool;
   S.pool_stride = e->plan.pool_stride();
@@ -163,6 +195,14 @@ DevState dev_state(const pgbp_engine* e, const pgbp_opts* o) {
   S.n_msgs = e->plan.n_msgs();
   S.update_resnorm = o ? o->update_residualnorm : 1;
   S.atol = o ? o->atol : 1e-5;
+  if (ensure_thresholds(e, S.atol) != PGBP_OK) {  // (the error text is set; the launch that follows reports it through hipGetLastError)
+    e->thr_valid = false;
+  }
+  S.thr = e->d_thr;
+  S.logtab = reinterpret_cast<const double2*>(e->d_logtab);
+  const int sp = e->plan.fast_p > 0 ? e->plan.fast_p : 0;
+  S.thr_h_p = e->h_thr.empty() ? 0.0 : e->h_thr[sp];
+  S.thr_J_p = e->h_thr.empty() ? 0.0 : e->h_thr[PGBP_MAX_DIM + 1 + sp];
   S.bs16 = e->layout_bs16 ? 1 : 0;
   S.fast_p = e->plan.fast_p;
   S.sm = e->layout_sm ? 1 : 0;
@@ -469,7 +509,7 @@ void pgbp_destroy(pgbp_engine* e) {
     (void)hipEventDestroy(pr.second);
   }
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
-                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_flags_alt, (void*)e->d_status_alt,
+                  (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_thr, (void*)e->d_logtab, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_flags_alt, (void*)e->d_status_alt,
                   (void*)e->d_klflags_alt, (void*)e->d_poison_alt, (void*)e->d_kldiv_alt, (void*)e->d_fail, (void*)e->d_poison,
                   (void*)e->d_iscal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
@@ -544,6 +584,19 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
     if ((rc = upload(e, &e->d_nb_msg, nb_msg))) return bail(rc);
     if ((rc = upload(e, &e->d_sepcl, p.sepset_clusters))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_eps, ns * (size_t)std::max(1, p.n_clusters)))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_thr, 2 * (size_t)(PGBP_MAX_DIM + 1)))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_logtab, 256))) return bail(rc);
+    {
+      // DevState::logtab, in the host's extended precision
+      double tab[256];
+      for (int i = 0; i < 128; ++i) {
+        const long double c = 0.5L + ((long double)i + 0.5L) / 256.0L;
+        const double inv = (double)(1.0L / c);
+        tab[2 * i] = inv;
+        tab[2 * i + 1] = (double)(-logl((long double)inv));
+      }
+      if (hipMemcpy(e->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) return bail(PGBP_ERR_HIP);
+    }
   }
   if ((rc = dev_alloc(e, &e->d_fail, ns))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_poison, ns * (size_t)p.n_clusters))) return bail(rc);

@@ -312,11 +312,12 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
   int ngroups = ngroups_arg, split = split_arg;
   unsigned long long seq_base = seq_base_arg, stop_a = stop_a_arg, stop_b = stop_b_arg;
   {
-    unsigned long long atol_bits = __double_as_longlong(S.atol);
+    unsigned long long th_bits = __double_as_longlong(S.thr_h_p), tj_bits = __double_as_longlong(S.thr_J_p);
     asm("; kernel arguments resident"
         : "+s"(S.pool_stride), "+s"(S.rpool_stride), "+s"(S.n_clusters), "+s"(S.n_msgs), "+s"(S.update_resnorm),
-          "+s"(atol_bits), "+s"(ngroups), "+s"(split), "+s"(seq_base), "+s"(stop_a), "+s"(stop_b));
-    S.atol = __longlong_as_double(atol_bits);
+          "+s"(th_bits), "+s"(tj_bits), "+s"(ngroups), "+s"(split), "+s"(seq_base), "+s"(stop_a), "+s"(stop_b));
+    S.thr_h_p = __longlong_as_double(th_bits);
+    S.thr_J_p = __longlong_as_double(tj_bits);
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int site = blockIdx.y;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
               info = eliminate2<P, 0>(f, a, b, act, col, mant, expo, quad);
               PGBP_ST(3);
               if (info == 0) {
-                const double logdet = log(mant) + (double)expo * PGBP_LN2;
+                const double logdet = log_by_table(S.logtab, mant) + (double)expo * PGBP_LN2;
                 gmsg += 0.5 * ((double)PR * PGBP_LOG2PI - logdet + quad);  // :81
               }
             }
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         // iscalibrated_residnorm! (src/beliefs.jl:994-1003); an empty message is calibrated
         // x -> fl(x / c) is monotone, so "max over the wave, divide, compare" equals "every lane divides and
         // compares its own maximum": one ballot instead of two 6-step wave reductions on the critical path
-        const bool lane_ok = maxh / sqrt((double)PR) <= S.atol && maxJ / sqrt((double)PR * (double)PR) <= S.atol;
+        const bool lane_ok = maxh <= S.thr_h_p && maxJ <= S.thr_J_p;   // (DevState::thr: no division here)
         const bool all_ok = __all(lane_ok);
         if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en.msg] = (!has_block || all_ok) ? 1 : 0;
       }

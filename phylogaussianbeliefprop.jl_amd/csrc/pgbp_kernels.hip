@@ -34,6 +34,15 @@ __device__ __forceinline__ int pow2_at_least(int n) {  // n in [1, 64] -> smalle
 
 extern __shared__ double lds[];
 
+#ifdef PGBP_GSTAMP  // experiment builds only (tools/stamp_generic.py): clock stamps of the phases of a message
+constexpr int kGStampSlots = 1 << 16, kGStampN = 8;
+__device__ unsigned int g_gstamp[kGStampSlots][kGStampN + 4];
+__device__ unsigned int g_gstamp_n;
+#define PGBP_GST(i) do { gst[i] = (unsigned int)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PGBP_GST(i) do { } while (0)
+#endif
+
 size_t generic_lds_bytes(int max_mf);
 
 // lane -> (lane & (L - 1), lane >> lg) grids with L = 2^lg >= n: index arithmetic without integer division
@@ -60,7 +69,7 @@ __device__ __forceinline__ void task_sync() {
 
 template <bool WAVE = false>
 __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int ni, int lane, double& logdet,
-                                                 double& quad) {
+                                                 double& quad, const double2* __restrict__ logtab = nullptr) {
   logdet = 0.0;
   quad = 0.0;
   double mant = 1.0;
@@ -91,7 +100,7 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
     }
     task_sync<WAVE>();
   }
-  logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
+  logdet = (logtab ? log_by_table(logtab, mant) : log(mant)) + (double)expo * 0.69314718055994530941723212145818;
   return 0;
 }
 
@@ -116,6 +125,199 @@ __device__ __forceinline__ int64_t grec_i64(unsigned int rv, int k) {
   return (int64_t)(((unsigned long long)(unsigned int)grec_dw(rv, k + 1) << 32) | (unsigned int)grec_dw(rv, k));
 }
 
+// ---- SMALL messages in registers: at most kSmallI integrated and kSmallK kept variables (a level-3 network's cluster
+// graphs: clusters of up to three nodes, sepsets of one or two; a handful of traits).  The augmented sender sits in a
+// fixed 16 x 17 frame, one ROW PER LANE: integrated variable k in lane k / column k, kept variable a in lane 8 + a /
+// column 8 + a, h in column 16 (unused rows and columns are zero).  Every operand of the message -- the sender's rows,
+// the sepset's and the receiver's entries this lane will update, the failure mark of the sender -- is requested in one
+// batch at the top; the elimination is straight-line code (the pivot row travels by v_readlane, no LDS, no
+// synchronisation); divide! and mult! are done by the kept lanes on their own rows.  Arithmetic and its order are those
+// of the LDS path below (eliminate_leading): W[i][j] -= (W[i][k] / d_k) * W[k][j], log det as a mantissa product.
+constexpr int kSmallI = 8, kSmallK = 8;
+struct SmallFrame {
+  double row[kSmallI + kSmallK + 1];
+};
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, l);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// returns 0: message applied; 1: the task ends here (the sender is downstream of a failure, or J_I is not positive definite)
+template <bool WAVE>
+__device__ __forceinline__ int small_message(const DevState& S, const GRec* __restrict__ recs, const GLoad& cur, const int site,
+                                             const int lane, unsigned long long seq_base, double* __restrict__ pool,
+                                             double* __restrict__ rpool, SmallFrame& F, double& gmsg_io
+#ifdef PGBP_GSTAMP
+                                             , unsigned int* gst
+#endif
+) {
+  const unsigned int rv = cur.rv;
+  const int next = grec_dw(rv, 15);
+  const int en_msg = grec_dw(rv, 8), en_seq = grec_dw(rv, 9), from_b = grec_dw(rv, 10);
+  const int dims = grec_dw(rv, 16), fl = grec_dw(rv, 17);
+  const int mf = dims & 255, mt = (dims >> 8) & 255, s = (dims >> 16) & 255, ni = (dims >> 24) & 255;
+  const int k0 = (fl & 255) == 255 ? -1 : (fl & 255), u0 = ((fl >> 8) & 255) == 255 ? -1 : ((fl >> 8) & 255);
+  const bool en_reuse = ((fl >> 16) & 255) != 0;
+  int pz = 0;
+  asm volatile("" : "+v"(pz));   // (vector loads of wave-uniform words: see generic_task)
+  const int poisoned = S.poison[(int64_t)site * S.n_clusters + from_b + pz];
+  double* __restrict__ sep = pool + grec_i64(rv, 4);
+  double* __restrict__ to = pool + grec_i64(rv, 2);
+  double* __restrict__ res = rpool + grec_i64(rv, 6);
+  const bool is_int = lane < kSmallI;
+  const int fi = lane & 7;
+  const bool kept_live = lane >= kSmallI && lane < kSmallI + kSmallK && fi < s;
+  const bool row_live = is_int ? fi < ni : kept_live;
+  // ---- receiver / sepset operands of the kept lanes (row a = fi of the message): requested first
+  const int up_lane = __shfl(cur.ub, fi);   // (inline map: lane l holds up[l & 15])
+  const int ua = u0 >= 0 ? u0 + fi : up_lane;
+  double psep[kSmallK], pto[kSmallK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
+  int ubv[kSmallK];
+#pragma unroll
+  for (int b = 0; b < kSmallK; ++b) {
+    psep[b] = 0.0;
+    pto[b] = 0.0;
+    ubv[b] = u0 >= 0 ? u0 + b : __builtin_amdgcn_readlane(cur.ub, b);
+    if (b < s && kept_live) {
+      psep[b] = sep[fi + b * s];
+      pto[b] = to[ua + ubv[b] * mt];
+    }
+  }
+  if (kept_live) {
+    pseph = sep[s * s + fi];
+    ptoh = to[mt * mt + ua];
+  }
+  if (lane == 0) {
+    pre_sepg = sep[s * s + s];
+    pre_tog = to[mt * mt + mt];
+  }
+  const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];   // (here: behind the stores they could not be moved up)
+  double gmsg = gmsg_io;
+  bool fake = false;
+  if (!en_reuse) {
+    const double* __restrict__ from = pool + grec_i64(rv, 0);
+    // position of this lane's variable in the sender, and of every column's (wave-uniform)
+    const int q = is_int ? fi : ni + fi;                       // place in the order "integrated first, kept last"
+    const int pq = __shfl(cur.pb, q < kGInlPerm ? q : 0);      // (inline map: lane l holds perm[l])
+    const int pi = k0 >= 0 ? (q < ni ? (q < k0 ? q : q + s) : k0 + (q - ni)) : pq;
+    double X[kSmallI], Y[kSmallI], Z[kSmallK], hv = 0.0;
+#pragma unroll
+    for (int j = 0; j < kSmallI; ++j) {
+      X[j] = 0.0;
+      Y[j] = 0.0;
+      const int cj = k0 >= 0 ? (j < k0 ? j : j + s) : __builtin_amdgcn_readlane(cur.pb, j);
+      if (j < ni && row_live) {
+        X[j] = from[pi + cj * mf];                             // J[this row, integrated column j]
+        if (is_int) Y[j] = from[cj + pi * mf];                 // J[integrated row j, this column]: the upper triangle of J_I
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < kSmallK; ++b) {
+      Z[b] = 0.0;
+      const int cb = k0 >= 0 ? k0 + b : __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
+      if (b < s && row_live) Z[b] = is_int ? from[cb + pi * mf] : from[pi + cb * mf];   // J_SI' for a pivot row, J_S for a kept one
+    }
+    if (row_live) hv = from[mf * mf + pi];
+    gmsg = from[mf * mf + mf + pz];
+    // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66), on the entries as stored
+    bool nz = is_int && fabs(hv) > PGBP_EPS;
+#pragma unroll
+    for (int j = 0; j < kSmallI; ++j) nz |= fabs(X[j]) > PGBP_EPS;
+    fake = ni == 0 || !__any(nz);
+    // Symmetric(J_I): its upper triangle only (:68)
+#pragma unroll
+    for (int j = 0; j < kSmallI; ++j) F.row[j] = (is_int && j < fi) ? Y[j] : X[j];
+#pragma unroll
+    for (int b = 0; b < kSmallK; ++b) F.row[kSmallI + b] = Z[b];
+    F.row[kSmallI + kSmallK] = hv;
+  }
+  PGBP_GST(2);
+  if (__builtin_amdgcn_readfirstlane(poisoned)) {
+    if (lane == 0) {
+      S.poison[(int64_t)site * S.n_clusters + grec_dw(rv, 11)] = 1;
+      for (int qn = next; qn >= 0; qn = recs[qn].next) S.poison[(int64_t)site * S.n_clusters + recs[qn].to_b] = 1;
+    }
+    return 1;
+  }
+  if (!en_reuse && !fake) {
+    double mant = 1.0, quad = 0.0;
+    int expo = 0, info = 0;
+#pragma unroll
+    for (int k = 0; k < kSmallI; ++k) {
+      if (k < ni && info == 0) {
+        const double d = readlane_f64(F.row[k], k);
+        const double hk = readlane_f64(F.row[kSmallI + kSmallK], k);
+        if (!(d > 0.0)) {
+          info = k + 1;
+        } else {
+          double rd = __builtin_amdgcn_rcp(d);
+          rd = fma(fma(-d, rd, 1.0), rd, rd);
+          rd = fma(fma(-d, rd, 1.0), rd, rd);
+          int ex;
+          mant *= frexp(d, &ex);
+          expo += ex;
+          quad += hk * hk * rd;
+          const double f = F.row[k] * rd;
+#pragma unroll
+          for (int j = k + 1; j <= kSmallI + kSmallK; ++j) {
+            const double pkj = readlane_f64(F.row[j], k);
+            F.row[j] -= f * pkj;   // (rows <= k are dead from here on: no guard)
+          }
+        }
+      }
+    }
+    if (info != 0) {
+      if (lane == 0) {
+        S.status[(int64_t)site * S.n_msgs + en_msg] = info;
+        S.poison[(int64_t)site * S.n_clusters + grec_dw(rv, 11)] = 1;
+        for (int qn = next; qn >= 0; qn = recs[qn].next) S.poison[(int64_t)site * S.n_clusters + recs[qn].to_b] = 1;
+        atomicMin(&S.fail[site], ((seq_base + (unsigned long long)(unsigned int)en_seq) << kInfoBits) |
+                                     (unsigned long long)(unsigned int)info);
+      }
+      return 1;
+    }
+    const double logdet = log_by_table(S.logtab, mant) + (double)expo * 0.69314718055994530941723212145818;
+    gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);  // :81
+  }
+  gmsg_io = gmsg;
+  PGBP_GST(5);
+  // ---- divide! and mult!: kept lane 8 + a owns row a of the message
+  double maxJ = 0.0, maxh = 0.0;
+  if (kept_live) {
+#pragma unroll
+    for (int b = 0; b < kSmallK; ++b) {
+      if (b < s) {
+        const double msg = F.row[kSmallI + b];
+        const double dJ = msg - psep[b];
+        sep[fi + b * s] = msg;
+        res[fi + b * s] = dJ;
+        to[ua + ubv[b] * mt] = pto[b] + dJ;
+        maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+      }
+    }
+    const double msgh = F.row[kSmallI + kSmallK];
+    const double dh = msgh - pseph;
+    sep[s * s + fi] = msgh;
+    res[s * s + fi] = dh;
+    to[mt * mt + ua] = ptoh + dh;
+    maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
+  }
+  if (lane == 0) {
+    const double dg = gmsg - pre_sepg;
+    sep[s * s + s] = gmsg;
+    to[mt * mt + mt] = pre_tog + dg;
+    S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
+  }
+  if (S.update_resnorm) {
+    const bool lane_ok = maxh <= thr_h && maxJ <= thr_J;
+    const bool ok = __all(lane_ok);
+    if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en_msg] = ok ? 1 : 0;
+  }
+  return 0;
+}
+
 // One task (its messages in order) by ONE wavefront, from the task's first record; perm / W: that wavefront's scratch in
 // LDS.  WAVE: other wavefronts of the workgroup run other tasks beside it (the loop mode below), so every
 // synchronisation in here is wave-local and nothing in here may be a workgroup barrier; a `return` ends the task (not
@@ -127,7 +329,13 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   int mf = 0, ni = 0, ld = 1;
   double gmsg = 0.0;
+  SmallFrame frame;
+  bool small_prev = false;   // the previous message of the task went through small_message (its marginal is in `frame`)
   for (;;) {
+#ifdef PGBP_GSTAMP
+    unsigned int gst[kGStampN] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PGBP_GST(0);
     const unsigned int rv = cur.rv;
     const int next = grec_dw(rv, 15);
     GLoad nxt = cur;
@@ -138,6 +346,37 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
     const int k0 = (fl & 255) == 255 ? -1 : (fl & 255), u0 = ((fl >> 8) & 255) == 255 ? -1 : ((fl >> 8) & 255);
     const bool en_reuse = ((fl >> 16) & 255) != 0;
     const int inl = (fl >> 24) & 255;
+    if (((dims >> 24) & 255) <= kSmallI && s <= kSmallK && !(en_reuse && !small_prev)) {
+      // the register-resident path (small_message); a reused marginal stays in the path that computed it
+      small_prev = true;
+#ifdef PGBP_GSTAMP
+      const int done = small_message<WAVE>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, gst);
+#else
+      const int done = small_message<WAVE>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg);
+#endif
+      if (done) return;
+      mf = dims & 255;
+      ni = (dims >> 24) & 255;
+      PGBP_GST(6);
+#ifdef PGBP_GSTAMP
+      __builtin_amdgcn_s_waitcnt(0);
+      PGBP_GST(7);
+      if (lane == 0 && gridDim.x <= 512) {
+        const unsigned int slot = atomicAdd(&g_gstamp_n, 1u);
+        if (slot < kGStampSlots) {
+          for (int i = 0; i < kGStampN; ++i) g_gstamp[slot][i] = gst[i];
+          g_gstamp[slot][kGStampN] = blockIdx.x; g_gstamp[slot][kGStampN + 1] = threadIdx.x >> 6;
+          g_gstamp[slot][kGStampN + 2] = (unsigned int)(mf | (ni << 8) | (s << 16) | ((WAVE ? 1 : 0) << 24) | (1u << 25));
+          g_gstamp[slot][kGStampN + 3] = gridDim.x;
+        }
+      }
+#endif
+      if (next < 0) return;
+      __threadfence_block();
+      cur = nxt;
+      continue;
+    }
+    small_prev = false;
     // the sender sits downstream of a failed message?  Requested with the operands (a vector load: in the loop mode the
     // mark may have been stored by another wavefront of this workgroup one level ago, which the scalar cache does not
     // see), looked at before anything of this message is recorded or stored
@@ -218,8 +457,10 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
         asm volatile("" : "+v"(z));
         gmsg = from[(int64_t)mf * mf + mf + z];
       }
+      PGBP_GST(1);
       task_sync<WAVE>();
     }
+    PGBP_GST(2);
     if (__builtin_amdgcn_readfirstlane(poisoned)) {
       // nothing downstream of a failed message runs: every receiver the rest of this task would have reached is marked
       if (lane == 0) {
@@ -252,7 +493,9 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
         }
         task_sync<WAVE>();
         double logdet, quad;
-        const int info = eliminate_leading<WAVE>(W, ld, mf, ni, lane, logdet, quad);
+        PGBP_GST(3);
+        const int info = eliminate_leading<WAVE>(W, ld, mf, ni, lane, logdet, quad, S.logtab);
+        PGBP_GST(4);
         if (info != 0) {
           if (lane == 0) {
             S.status[(int64_t)site * S.n_msgs + en_msg] = info;
@@ -267,6 +510,7 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
       }
     }
     // ---- divide! and mult!
+    PGBP_GST(5);
     double maxJ = 0.0, maxh = 0.0;
     if (s > 0 && a < s) {
       if (pre) {
@@ -311,12 +555,26 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
       S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
     }
     if (S.update_resnorm) {
-      // iscalibrated_residnorm!: max|dh|/sqrt(s) <= atol && max|dJ|/s <= atol (src/beliefs.jl:994-1003)
-      // x -> fl(x / c) is monotone: every lane tests its own maximum, one ballot instead of two wave reductions
-      const bool lane_ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+      // iscalibrated_residnorm!: max|dh|/sqrt(s) <= atol && max|dJ|/s <= atol (src/beliefs.jl:994-1003), as a comparison
+      // with the host's thresholds (DevState::thr); every lane tests its own maximum, one ballot instead of two reductions
+      const bool lane_ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
       const bool ok = __all(lane_ok);
       if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en_msg] = ok ? 1 : 0;
     }
+    PGBP_GST(6);
+#ifdef PGBP_GSTAMP
+    __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
+    PGBP_GST(7);
+    if (lane == 0 && gridDim.x <= 512) {   // the narrow launches
+      const unsigned int slot = atomicAdd(&g_gstamp_n, 1u);
+      if (slot < kGStampSlots) {
+        for (int i = 0; i < kGStampN; ++i) g_gstamp[slot][i] = gst[i];
+        g_gstamp[slot][kGStampN] = blockIdx.x; g_gstamp[slot][kGStampN + 1] = threadIdx.x >> 6;
+        g_gstamp[slot][kGStampN + 2] = (unsigned int)(mf | (ni << 8) | (s << 16) | ((WAVE ? 1 : 0) << 24));
+        g_gstamp[slot][kGStampN + 3] = gridDim.x;
+      }
+    }
+#endif
     if (next < 0) return;
     __threadfence_block();  // the next message of the task may read or read-modify-write what this one wrote
     cur = nxt;
@@ -518,7 +776,7 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
     }
     if (S.update_resnorm) {
       // iscalibrated_residnorm! (src/beliefs.jl:994-1003): x -> fl(x / c) is monotone, every thread tests its own maximum
-      const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+      const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
       s_red[tid] = ok ? 1.0 : 0.0;
       __syncthreads();
       if (tid == 0) {
@@ -681,7 +939,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     to(mt * mt + mt) += dg;
     *mword(S.status, en.msg) = 0;
     if (S.update_resnorm) {
-      const bool ok = (s == 0) || ((maxh / sqrt((double)s) <= S.atol) && (maxJ / sqrt((double)s * (double)s) <= S.atol));
+      const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
       *mword(S.flags, en.msg) = ok ? 1 : 0;
     }
   }
@@ -1606,3 +1864,15 @@ void launch_transpose_words_f64(const double* src, double* dst, int n, int n_sit
 }
 
 }  // namespace pgbp
+
+#ifdef PGBP_GSTAMP
+extern "C" int pgbp_debug_gstamps(unsigned int* out, unsigned int cap, unsigned int* n) {
+  if (hipDeviceSynchronize() != hipSuccess) return 4;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(pgbp::g_gstamp_n), sizeof(unsigned int)) != hipSuccess) return 1;
+  const unsigned int k = *n < cap ? *n : cap;
+  if (k && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgbp::g_gstamp), sizeof(unsigned int) * (size_t)k * 12) != hipSuccess) return 2;
+  unsigned int z = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pgbp::g_gstamp_n), &z, sizeof(z)) != hipSuccess) return 3;
+  return 0;
+}
+#endif

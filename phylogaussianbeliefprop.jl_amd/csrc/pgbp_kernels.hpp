@@ -25,6 +25,15 @@ struct DevState {
   int32_t n_msgs;
   int32_t update_resnorm;
   double atol;
+  // iscalibrated_residnorm! without a division on the device: thr[s] = the largest x with fl(x / fl(sqrt(s))) <= atol,
+  // thr[PGBP_MAX_DIM + 1 + s] = the largest x with fl(x / s) <= atol (x -> fl(x / c) is monotone, so max|dh| <= thr[s] is
+  // the reference's test bit for bit; s = 0: +inf); thr_h_p / thr_J_p: the two entries of the fast kernel's sepset dimension
+  const double* thr;
+  double thr_h_p, thr_J_p;
+  // log of the pivots' mantissa product without the library routine (about a hundred dependent double-double
+  // operations on the critical path of every message): logtab[i] = {1 / c_i rounded, -log(that)} for the 128 intervals
+  // [0.5 + i / 256, 0.5 + (i + 1) / 256) of a mantissa with centre c_i (the host fills it in extended precision)
+  const double2* logtab;
   int32_t bs16;    // beliefs of dimension P / 2P and residuals of P-dim sepsets are in the packed layout
   int32_t fast_p;  // P: sepset dimension of the register-resident kernel (2 .. 16, the real dimension; 0: none)
   // site-minor layout (univariate batches, every dimension <= 2): element t of belief b of site s lives at
@@ -39,6 +48,27 @@ struct DevState {
 };
 
 size_t generic_lds_bytes(int max_mf);
+
+#if defined(__HIPCC__)
+// log(x) for a positive, normal x (the mantissa product of up to 16 pivots, a single pivot): x = m 2^e with m in
+// [0.5, 1); r = m / c' - 1 with c' = the tabulated centre's reciprocal, |r| <= 2^-8; log x = e ln 2 + log c' + log1p(r),
+// the series of log1p to r^7 (the next term is below 2^-66).  Absolute error about one unit in the last place of the
+// result's leading term (1e-16); the table word is fetched through the scalar cache (the index is wave-uniform wherever
+// this is used: every lane holds the same product).
+__device__ __forceinline__ double log_by_table(const double2* __restrict__ tab, double x) {
+  int e;
+  const double m = frexp(x, &e);
+  const int i = __builtin_amdgcn_readfirstlane((__double2hiint(m) >> 13) & 127);
+  const double2 t = tab[i];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+  p = fma(p, r, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  return fma((double)e, 0.69314718055994530941723212145818, t.y) + fma(p * r, r, r);
+}
+#endif
 
 // wave-per-task kernel: block b of the launch runs the task whose first record is d_recs[rec0 + b] (GRec, pgbp_internal.hpp)
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,

@@ -1408,3 +1408,61 @@ def test_regularization_and_schedule_doctests_on_the_lipson_network_device(P, ca
     with caplog.at_level(logging.INFO):
         assert P.calibrate_(p0, sched, 100, auto=True, info=True) == (True, True)
     assert g["info_line_without_factors"] in caplog.text
+
+
+@pytest.mark.parametrize("kind,p", [("tree", 4), ("tree", 3), ("tree", 16), ("bethe", 2), ("tree1", 1)])
+def test_residual_norm_flags_at_the_tolerance_boundary(P, kind, p):
+    """iscalibrated_residnorm! (src/beliefs.jl:994-1003) on the device is a comparison with thresholds the host derives
+    from atol (no division in the kernels): with atol set to a quotient max|dh|/sqrt(s) (or max|dJ|/s) that some message
+    attains exactly, and to its floating-point neighbour below, every message's flag equals the reference's expression
+    evaluated in numpy on the device's own residuals -- register-resident, wave-per-task and (many sites) univariate
+    kernels."""
+    import ctypes as C
+    from pgbp_amd import _lib as L
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(50 + p)
+    ns = 9 if kind == "tree1" else 1
+    tr = S.random_tree(40, rng)
+    R = S.random_rate_matrix(p, rng)
+    prob = S.bethe_of_tree(tr, p) if kind == "bethe" else S.cliquetree_of_tree(tr, p)
+    packs = []
+    for _ in range(ns):
+        X = S.simulate_bm(tr, R, np.zeros(p), rng)
+        packs.append(S.bm_factors_bethe(tr, prob, R, np.zeros(p), X) if kind == "bethe" else
+                     S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X))
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx,
+                                           np.stack(packs) if ns > 1 else packs[0], n_sites=ns)
+    lib = P.load()
+    cgb.set_schedule(prob.schedule)
+    res = (L.Result * ns)()
+    nm = 2 * cgb.nsepsets
+    sdim = np.repeat(np.asarray(prob.dims[cgb.nclusters:], dtype=np.int64), 2)
+
+    def run(atol):
+        cgb.init_beliefs_reset_fromfactors_()
+        cgb.init_messagecalibrationflags_reset_()
+        o = cgb._opts(atol=atol)
+        assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o), res) == 0
+        cgb.pull()
+        qh, qJ = np.zeros((ns, nm)), np.zeros((ns, nm))
+        for site in range(ns):
+            for d in range(nm):
+                s = int(sdim[d])
+                if s == 0:
+                    continue
+                rec = cgb._res[site, cgb._roff[d]: cgb._roff[d + 1]]
+                qJ[site, d] = np.abs(rec[:s * s]).max() / np.sqrt(float(s * s))
+                qh[site, d] = np.abs(rec[s * s: s * s + s]).max() / np.sqrt(float(s))
+        return qh, qJ, cgb._flg.copy()
+    qh, qJ, flg = run(1e-5)
+    want = (qh <= 1e-5) & (qJ <= 1e-5)
+    assert np.array_equal(flg != 0, want)
+    cand = np.unique(np.concatenate([qh[qh > 0], qJ[qJ > 0]]))
+    assert len(cand) > 10
+    for q in cand[[0, len(cand) // 3, len(cand) // 2, -2]]:
+        for atol in (q, np.nextafter(q, 0.0), np.nextafter(q, np.inf)):
+            qh2, qJ2, flg2 = run(float(atol))
+            assert np.array_equal(qh2, qh) and np.array_equal(qJ2, qJ)            # same messages, same residuals
+            assert np.array_equal(flg2 != 0, (qh <= atol) & (qJ <= atol)), atol
+    qh0, qJ0, flg0 = run(0.0)
+    assert np.array_equal(flg0 != 0, (qh == 0) & (qJ == 0))

@@ -73,11 +73,14 @@ def parse(d, out=None):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)))
     rows.sort()
-    msg = [r for r in rows if r[2].startswith("void pgbp::bp_") or "bp_level" in r[2] or "bp_tail" in r[2] or "bp_stream" in r[2]]
-    # the run does 8 identical calibrates: the last one = the last len/8 message-kernel dispatches
+    msg = [r for r in rows if "pgbp::bp_" in r[2]]
+    # the run sleeps 3 ms between its calibrates: the last one = the dispatches after the last idle gap of over 1 ms
+    cut = 0
+    for i in range(1, len(msg)):
+        if msg[i][0] - msg[i - 1][1] > 1_000_000:
+            cut = i
     groups = [msg]
-    per = len(msg) // 8
-    g = msg[-per:]
+    g = msg[cut:]
     t_first, t_last = g[0][0], g[-1][1]
     res = []
     prev_end = None
