@@ -314,10 +314,12 @@ int  pgbp_sync(pgbp_engine* e);
  * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik, 2 = loglik_bm, 3 = loglik_lg (2, 3: with the device factor fill). */
 int  pgbp_time_enqueued(pgbp_engine* e, int32_t kind, int32_t reps, int32_t reset_each,
                         const pgbp_opts* opts, float* ms_total);
-/* pgbp_enqueue_calibrate with one HIP event pair on the engine's stream around the message launches of every schedule
- * tree (they run back to back), so that a caller who times the whole region on the host gets the message kernels' share
- * of exactly those repetitions: pgbp_fetch_kernel_time waits for the stream and returns the sum of the event intervals
- * (*ms_kernels) and the number of message launches inside them. */
+/* pgbp_enqueue_calibrate with HIP events on the engine's stream around the message launches, so that a caller who times
+ * the whole region on the host gets the message kernels' share of exactly those repetitions: with reset_each = 0 ONE
+ * event pair around all `reps` repetitions (they run back to back; an event record is a barrier packet, a pair per
+ * repetition costs a few percent of a short calibrate), with reset_each != 0 a pair around the message launches of every
+ * schedule tree.  pgbp_fetch_kernel_time waits for the stream and returns the sum of the event intervals (*ms_kernels)
+ * and the number of message launches inside them. */
 int  pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_each, const pgbp_opts* opts);
 int  pgbp_fetch_kernel_time(pgbp_engine* e, float* ms_kernels, int32_t* n_launches);
 /* Time only the message-kernel launches of `reps` calibrate iterations (reset from factors before each):

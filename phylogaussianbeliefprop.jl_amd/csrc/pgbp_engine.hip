@@ -1505,8 +1505,22 @@ int pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_eac
   drop_kernel_events(e);
   DevState S = dev_state(e, opts);
   int launches = 0;
-  for (int r = 0; r < reps; ++r)
-    if ((rc = enqueue_calibrate_once(e, S, reset_each, &e->kernel_events, &launches))) return rc;
+  if (reset_each) {
+    // resets between the repetitions: an event pair around the message launches of every schedule tree
+    for (int r = 0; r < reps; ++r)
+      if ((rc = enqueue_calibrate_once(e, S, reset_each, &e->kernel_events, &launches))) return rc;
+  } else {
+    // nothing but message launches (and the flag reduction behind each tree) in the region: ONE pair around all of it
+    // -- an event record is a barrier packet on the stream, and two of them per repetition cost 4 % of a cfg3 calibrate
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(e, hipEventCreate(&a));
+    HIPCHK(e, hipEventCreate(&b));
+    e->kernel_events.push_back({a, b});
+    HIPCHK(e, hipEventRecord(a, e->st));
+    for (int r = 0; r < reps; ++r)
+      if ((rc = enqueue_calibrate_once(e, S, 0, nullptr, &launches))) return rc;
+    HIPCHK(e, hipEventRecord(b, e->st));
+  }
   e->kernel_launches = launches;
   return PGBP_OK;
 }
