@@ -132,6 +132,16 @@ int  pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* le
  * chunk. */
 int  pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_chunks, int32_t* info, int32_t* wg_off,
                       int32_t* records);
+/* The self-contained message records of the wave-per-task kernels (one 128-byte record per message of a generic-class
+ * task; layout: struct GRec in csrc/pgbp_internal.hpp -- offsets of sender / receiver / sepset / residual inside a
+ * site's pools, message id, sequence number, beliefs, index-pool offsets of the three maps, `next` = the record of the
+ * task's next message or -1, dimensions {mf, mt, s, ni}, first kept / updated index when contiguous (255: not), reuse
+ * flag, inline bits, perm[40] = the sender's variables, integrated first, kept last (bit 0), up[16] = the receiver's
+ * positions (bit 1)).  *n_records; then (any may be NULL) level_first[n_levels] = the record of the level's first
+ * generic-class task (its tasks follow in task order), task_first[n_tasks] = the first record of every task (-1: a
+ * fast-class task), records[128 * n_records]. */
+int  pgbp_plan_records(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_records, int32_t* level_first,
+                       int32_t* task_first, uint8_t* records);
 const char* pgbp_plan_last_error(const pgbp_plan* p);
 
 /* ---- engine lifetime ------------------------------------------------------------------ */

@@ -83,6 +83,7 @@ SYMBOLS = {
     "pgbp_plan_level_nfast": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P]),
     "pgbp_plan_groups": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P]),
     "pgbp_plan_chunks": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P]),
+    "pgbp_plan_records": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, C.c_void_p]),
     "pgbp_plan_last_error": (C.c_char_p, [_P]),
     "pgbp_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_P)]),
     "pgbp_destroy": (None, [_P]),

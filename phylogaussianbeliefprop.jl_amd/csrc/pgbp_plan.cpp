@@ -957,6 +957,17 @@ int pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_c
   return PGBP_OK;
 }
 
+int pgbp_plan_records(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_records, int32_t* level_first,
+                      int32_t* task_first, uint8_t* records) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr || !n_records) return PGBP_ERR_INVALID;
+  *n_records = (int32_t)tr->grecs.size();
+  if (level_first) std::copy(tr->level_gbase.begin(), tr->level_gbase.end(), level_first);
+  if (task_first) std::copy(tr->task_grec.begin(), tr->task_grec.end(), task_first);
+  if (records && !tr->grecs.empty()) std::memcpy(records, tr->grecs.data(), tr->grecs.size() * sizeof(pgbp::GRec));
+  return PGBP_OK;
+}
+
 const char* pgbp_plan_last_error(const pgbp_plan* p) { return p ? p->p.err.c_str() : "null plan"; }
 
 }  // extern "C"

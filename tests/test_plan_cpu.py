@@ -1136,3 +1136,100 @@ def test_level3_networks_have_moral_cliques_of_at_most_4_nodes():
         if 4 in sizes:
             assert len(ed3) > len(cn3) - 1                   # loopy
     assert seen4 >= 10
+
+
+@pytest.mark.parametrize("ntips,p,kind,graph", [(300, 4, "network", "joingraph"), (200, 3, "network", "bethe"),
+                                                (90, 5, "poly7", "cliquetree"), (40, 24, "random", "cliquetree"),
+                                                (25, 30, "poly4", "cliquetree")])
+def test_message_records_of_the_wave_per_task_kernels(ntips, p, kind, graph):
+    """The self-contained 128-byte records (pgbp_plan_records; struct GRec): for every generic-class task the chain
+    first record -> next -> ... -1 lists the task's messages in order; a level's first records are consecutive in task
+    order; dimensions and index maps are those of the message (sender / receiver / sepset dimensions from the problem,
+    kept and updated positions from the scope maps, integrated variables = the rest, ascending); contiguous maps are
+    flagged as such; generic PREORDER tasks hold one message each (one sender, k children = k independent messages)."""
+    rng = np.random.default_rng(7 * ntips + p)
+    if kind == "network":
+        import pgbp_amd as P
+
+        class Prob:
+            pass
+        net = P.random_level3_network_varied(ntips, ntips // 4, rng, n_colors=2)
+        cn, ed, sn = P.joingraph(net.node2family, 3) if graph == "joingraph" else P.bethe(net.node2family)
+        st = P.allocate_scopes(cn, ed, sn, net, p)
+        prob = Prob()
+        prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx = st.dims, st.sepset_clusters, st.scope_off, st.scope_idx
+        prob.schedule = [(np.asarray(t[2]), np.asarray(t[3])) for t in P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)][:1]
+    else:
+        tr = S.random_tree(ntips, rng) if kind == "random" else S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
+        prob = S.cliquetree_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0, lib.pgbp_plan_last_error(pl)
+    assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
+    dims = np.asarray(prob.dims, dtype=np.int64)
+    sc = np.asarray(prob.sepset_clusters).reshape(-1, 2)
+    nc = len(dims) - len(sc)
+    soff, sidx = np.asarray(prob.scope_off), np.asarray(prob.scope_idx)
+    rec_t = np.dtype([("from_off", "<i8"), ("to_off", "<i8"), ("sep_off", "<i8"), ("res_off", "<i8"),
+                      ("msg", "<i4"), ("seq", "<i4"), ("from_b", "<i4"), ("to_b", "<i4"),
+                      ("keep_map", "<i4"), ("up_map", "<i4"), ("int_map", "<i4"), ("next", "<i4"),
+                      ("mf", "u1"), ("mt", "u1"), ("s", "u1"), ("ni", "u1"), ("keep0", "u1"), ("up0", "u1"),
+                      ("reuse", "u1"), ("inl", "u1"), ("perm", "u1", 40), ("up", "u1", 16)])
+    assert rec_t.itemsize == 128
+    seen_generic = 0
+    for d in (0, 1):
+        lo, to, em, ee, er = _traversal(lib, pl, 0, d)
+        nlev, ntask = len(lo) - 1, len(to) - 1
+        n = C.c_int32()
+        assert lib.pgbp_plan_records(pl, 0, d, C.byref(n), None, None, None) == 0
+        lf, tf = np.zeros(max(1, nlev), np.int32), np.zeros(max(1, ntask), np.int32)
+        raw = np.zeros(max(1, n.value) * 128, np.uint8)
+        assert lib.pgbp_plan_records(pl, 0, d, C.byref(n), L.i32p(lf), L.i32p(tf), raw.ctypes.data) == 0
+        recs = raw.view(rec_t)[:n.value]
+        used = np.zeros(n.value, bool)
+        for Lv in range(nlev):
+            firsts = [int(tf[t]) for t in range(lo[Lv], lo[Lv + 1]) if tf[t] >= 0]
+            if firsts:
+                assert firsts == list(range(int(lf[Lv]), int(lf[Lv]) + len(firsts))), "a level's first records: consecutive"
+            for t in range(lo[Lv], lo[Lv + 1]):
+                if tf[t] < 0:
+                    continue
+                seen_generic += 1
+                msgs = [int(m) for m in em[to[t]:to[t + 1]]]
+                if d == 1 and int(dims.max()) > 2:
+                    senders = {int(sc[m // 2][1 - m % 2]) for m in msgs}
+                    assert len(msgs) == 1 or len(senders) > 1, "a generic preorder task = one message (unless chain-fused)"
+                q, chain = int(tf[t]), []
+                while q >= 0:
+                    assert not used[q]
+                    used[q] = True
+                    chain.append(q)
+                    q = int(recs[q]["next"])
+                assert [int(recs[q]["msg"]) for q in chain] == msgs
+                for q, m in zip(chain, msgs):
+                    r = recs[q]
+                    k, side = divmod(m, 2)
+                    receiver, sender = int(sc[k][side]), int(sc[k][1 - side])
+                    s_, mf, mt = int(dims[nc + k]), int(dims[sender]), int(dims[receiver])
+                    assert (int(r["from_b"]), int(r["to_b"])) == (sender, receiver)
+                    assert (int(r["mf"]), int(r["mt"]), int(r["s"]), int(r["ni"])) == (mf, mt, s_, mf - s_)
+                    # scope maps of the sepset: side 0 = its position in cluster sc[k][0], side 1 = in sc[k][1]
+                    keep = sidx[soff[2 * k + (1 - side)]: soff[2 * k + (1 - side) + 1]].tolist()
+                    upd = sidx[soff[2 * k + side]: soff[2 * k + side + 1]].tolist()
+                    assert len(keep) == len(upd) == s_
+                    integ = [v for v in range(mf) if v not in set(keep)]
+                    contiguous = lambda v: len(v) > 0 and v == list(range(v[0], v[0] + len(v)))
+                    if contiguous(keep) or s_ == 0:
+                        assert s_ == 0 or int(r["keep0"]) == keep[0]
+                    else:
+                        assert int(r["keep0"]) == 255
+                        if mf <= 40:
+                            assert int(r["inl"]) & 1 and r["perm"][:mf].tolist() == integ + keep
+                    if contiguous(upd) or s_ == 0:
+                        assert s_ == 0 or int(r["up0"]) == upd[0]
+                    else:
+                        assert int(r["up0"]) == 255
+                        if s_ <= 16:
+                            assert int(r["inl"]) & 2 and r["up"][:s_].tolist() == upd
+        assert used.all(), "every record belongs to exactly one task"
+    assert seen_generic > 0
+    lib.pgbp_plan_destroy(pl)
