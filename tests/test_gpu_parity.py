@@ -1466,3 +1466,67 @@ def test_residual_norm_flags_at_the_tolerance_boundary(P, kind, p):
             assert np.array_equal(flg2 != 0, (qh <= atol) & (qJ <= atol)), atol
     qh0, qJ0, flg0 = run(0.0)
     assert np.array_equal(flg0 != 0, (qh == 0) & (qJ == 0))
+
+
+@pytest.mark.parametrize("p,where", [(4, "root_end"), (4, "both"), (3, "both"), (20, "both")])
+def test_first_failure_in_the_wave_per_task_kernels(P, p, where):
+    """A clique tree of a network (generic-class tasks: the register-resident small-message body for p = 3, 4, the in-LDS
+    body for p = 20; level launches at the leaf end, chunks of fused levels at the root end): clusters whose J is made
+    negative definite fail at their first pivot.  The engine reports the failure the reference's sequential postorder
+    meets first (the largest edge index, src/calibration.jl:121) with its PosDefException.info, from whichever launch
+    mode ran the message; without the damage the same engine calibrates."""
+    import ctypes as C
+    from pgbp_amd import _lib as L
+    rng = np.random.default_rng(300 + p)
+    net = P.random_level3_network_varied(260 if p < 10 else 60, 60 if p < 10 else 12, rng, n_colors=2)
+    cn, ed, sn = P.cliquetree(net.node2family)
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    base = P.synth.random_rate_matrix(p, rng)
+    base = (base + base.T) / 2
+    rates = np.stack([base, 2.0 * base])
+    X = P.simulate_bm_network(net, rates, np.zeros(p), rng)
+    parent_edges = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, parent_edges,
+                        list(range(net.nnodes)), p, n_rates=2)
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    assert len(sched) == 1
+    pa, ch = np.asarray(sched[0][2]), np.asarray(sched[0][3])
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    cgb.lg_setup(fam, X)
+    cgb.assignfactors_lg_(rates, np.zeros(p))
+    cgb.pull()
+    good = cgb._packed[0].copy()
+    cgb.set_schedule(sched)
+    assert P.calibrate_(cgb, sched, 2) == (True, True)
+    # heights in the schedule tree; senders that integrate something (their cluster is larger than the sepset above it)
+    nc = len(cn)
+    h = np.zeros(nc, np.int64)
+    for a, c in zip(pa[::-1].tolist(), ch[::-1].tolist()):
+        h[a] = max(h[a], h[c] + 1)
+    dims = np.asarray(st.dims)
+    sep_of = {}
+    for k, (a, b) in enumerate(np.asarray(st.sepset_clusters).reshape(-1, 2).tolist()):
+        sep_of[(a, b)] = sep_of[(b, a)] = k
+    cand = [i for i in range(len(pa)) if dims[ch[i]] > dims[nc + sep_of[(int(pa[i]), int(ch[i]))]] > 0]
+    near_root = max(cand, key=lambda i: (h[ch[i]], -i))
+    hmin = min(h[ch[i]] for i in cand)
+    leaf_end = max(i for i in cand if h[ch[i]] == hmin)
+    bad = [near_root] if where == "root_end" else [near_root, leaf_end]
+    assert p >= 10 or h[ch[near_root]] >= 6, "the damaged cluster near the root sits in the narrow levels"
+    poff = cgb._poff
+    packed = good.copy()
+    for i in bad:
+        c = int(ch[i]); m = int(dims[c])
+        J = packed[poff[c]: poff[c] + m * m].reshape(m, m)
+        J[np.arange(m), np.arange(m)] = -1.0e6           # every pivot candidate negative: info = 1 whatever is integrated
+    cgb._packed[0][:] = packed
+    cgb._upload(True)                                   # (also the factors: calibrate resets nothing here, but keep both alike)
+    cgb.init_messagecalibrationflags_reset_()
+    assert P.calibrate_(cgb, sched, 1, verbose=False) == (False, False)
+    r = cgb.last_results[0]
+    assert (r.fail_dir, r.fail_info, r.fail_edge) == (0, 1, max(bad))
+    # and the engine recovers: the undamaged beliefs calibrate again
+    cgb._packed[0][:] = good
+    cgb._upload(True)
+    cgb.init_messagecalibrationflags_reset_()
+    assert P.calibrate_(cgb, sched, 2) == (True, True)
