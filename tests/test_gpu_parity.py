@@ -1246,6 +1246,21 @@ def test_launch_modes_differential_fuzz(P, env):
     assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
+@pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}], ids=["default", "level_launches_only"])
+def test_network_differential_fuzz(P, env):
+    """tests/fuzz_gpu_vs_c_oracle_networks.py: random level-3 networks, clique tree / Bethe / join graphs, every spanning
+    tree of the schedule, 1 - 9 traits (and 18 - 22), damaged clusters: the wave-per-task kernels (both message bodies,
+    level and chunk launches, the large-belief kernel) against the plain-C sequential engine -- beliefs, flags, (succ,
+    iscal) and the first failure of the reference's order; once more with every level as its own launch."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle_networks.py"), "60", "17"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "60 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 @pytest.mark.parametrize("argv", [
     ["--ntips", "400", "--traits", "16", "--steps", "2", "--warmup", "1", "--cpu-budget", "0.5"],
     ["--ntips", "300", "--traits", "8", "--graph", "bethe", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
