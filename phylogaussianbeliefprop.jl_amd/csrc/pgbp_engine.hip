@@ -404,7 +404,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
                   e->st, tuning().stream_grid);
     const int nbig = tr.level_nbig[L];
     if (uni)
-      launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->st);
+      launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->max_s, e->st);
     else {
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, e->st);

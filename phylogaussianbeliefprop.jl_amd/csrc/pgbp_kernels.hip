@@ -813,6 +813,12 @@ void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry*
 // batch-of-independent-sites case (cfg4: thousands of univariate problems on one tree), where a wavefront per
 // message would leave 63 of 64 lanes idle.  Same semantics as bp_level_generic (src/beliefupdates.jl:55-83,
 // 483-488, 579-587, src/beliefs.jl:994-1003), closed forms for m_f <= 2.
+// (element picks from 2- and 4-element register arrays by a wave-uniform index: a dynamically indexed local array would
+// live in scratch memory)
+__device__ __forceinline__ double pick4(const double (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+__device__ __forceinline__ double pick2(const double (&v)[2], int i) { return i == 0 ? v[0] : v[1]; }
+__device__ __forceinline__ int pick2i(const int (&v)[2], int i) { return i == 0 ? v[0] : v[1]; }
+
 template <bool SM>
 __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* __restrict__ task_off,
                                                     const Entry* __restrict__ entries, int task0, int n_sites,
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     else return rpool + plain_off + t;
   };
   const int e0 = task_off[task], e1 = task_off[task + 1];
-  double mJ[4] = {0, 0, 0, 0}, mh[2] = {0, 0}, gmsg = 0.0;  // message (s <= 2), column-major
+  double mJs[2][2] = {{0, 0}, {0, 0}}, mh[2] = {0, 0}, gmsg = 0.0;  // message (s <= 2): mJs[a][b]
   for (int e = e0; e < e1; ++e) {
     const Entry en = entries[e];
     const MsgDesc m = S.msgs[en.msg];
@@ -856,33 +862,49 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     const int mf = m.mf, s = m.s, mt = m.mt, ni = m.ni;
     if (!en.reuse) {
       double J[4] = {0, 0, 0, 0}, h[2] = {0, 0};
-      for (int t = 0; t < mf * mf; ++t) J[t] = *bel(m.from_b, m.from_off, t);
-      for (int t = 0; t < mf; ++t) h[t] = *bel(m.from_b, m.from_off, mf * mf + t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < mf * mf) J[t] = *bel(m.from_b, m.from_off, t);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (t < mf) h[t] = *bel(m.from_b, m.from_off, mf * mf + t);
       gmsg = *bel(m.from_b, m.from_off, mf * mf + mf);
       int keep[2] = {0, 0}, integ[2] = {0, 0};
-      for (int t = 0; t < s; ++t) keep[t] = S.idx[m.keep_map + t];
-      for (int t = 0; t < ni; ++t) integ[t] = S.idx[m.int_map + t];
-      for (int b = 0; b < s; ++b) {
-        mh[b] = h[keep[b]];
-        for (int a = 0; a < s; ++a) mJ[a + b * s] = J[keep[a] + keep[b] * mf];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t < s) keep[t] = S.idx[m.keep_map + t];
+        if (t < ni) integ[t] = S.idx[m.int_map + t];
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (b < s) mh[b] = pick2(h, keep[b]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          if (a < s && b < s) mJs[a][b] = pick4(J, keep[a] + keep[b] * mf);
       }
       if (ni > 0) {
         // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
         bool nz = false;
-        for (int b = 0; b < ni; ++b) {
-          nz |= fabs(h[integ[b]]) > PGBP_EPS;
-          for (int a = 0; a < ni; ++a) nz |= fabs(J[integ[a] + integ[b] * mf]) > PGBP_EPS;
-          for (int a = 0; a < s; ++a) nz |= fabs(J[keep[a] + integ[b] * mf]) > PGBP_EPS;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (b < ni) {
+            nz |= fabs(pick2(h, integ[b])) > PGBP_EPS;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              if (a < ni) nz |= fabs(pick4(J, integ[a] + integ[b] * mf)) > PGBP_EPS;
+              if (a < s) nz |= fabs(pick4(J, keep[a] + integ[b] * mf)) > PGBP_EPS;
+            }
+          }
         }
         if (nz) {
           int info = 0;
           // Cholesky of Symmetric(J_I) (upper triangle), ni <= 2
-          const double d0 = J[integ[0] + integ[0] * mf];
+          const double d0 = pick4(J, integ[0] + integ[0] * mf);
           double u01 = 0.0, d1 = 1.0;
           if (!(d0 > 0.0)) info = 1;
           if (!info && ni == 2) {
-            u01 = J[integ[0] + integ[1] * mf];              // upper entry (row integ[0] < integ[1])
-            d1 = J[integ[1] + integ[1] * mf] - u01 * u01 / d0;
+            u01 = pick4(J, integ[0] + integ[1] * mf);       // upper entry (row integ[0] < integ[1])
+            d1 = pick4(J, integ[1] + integ[1] * mf) - u01 * u01 / d0;
             if (!(d1 > 0.0)) info = 2;
           }
           if (info) {
@@ -892,19 +914,27 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
             return;
           }
           // forward substitution with L = U': y = L^-1 [h_I | J_IS columns]
-          const double y0 = h[integ[0]];
-          const double y1 = ni == 2 ? h[integ[1]] - u01 / d0 * y0 : 0.0;
+          const double y0 = pick2(h, integ[0]);
+          const double y1 = ni == 2 ? pick2(h, integ[1]) - u01 / d0 * y0 : 0.0;
           double quad = y0 * y0 / d0 + (ni == 2 ? y1 * y1 / d1 : 0.0);
           const double logdet = log(d0) + (ni == 2 ? log(d1) : 0.0);
           // z_a = L^-1 J_SI[a, :]' (per kept variable a); message J -= z_a . z_b (D^-1 weighted), h -= z_a . y
           double z0[2] = {0, 0}, z1[2] = {0, 0};
-          for (int a = 0; a < s; ++a) {
-            z0[a] = J[keep[a] + integ[0] * mf];
-            z1[a] = ni == 2 ? J[keep[a] + integ[1] * mf] - u01 / d0 * z0[a] : 0.0;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            if (a < s) {
+              z0[a] = pick4(J, keep[a] + integ[0] * mf);
+              z1[a] = ni == 2 ? pick4(J, keep[a] + integ[1] * mf) - u01 / d0 * z0[a] : 0.0;
+            }
           }
-          for (int b = 0; b < s; ++b) {
-            mh[b] -= z0[b] * y0 / d0 + (ni == 2 ? z1[b] * y1 / d1 : 0.0);
-            for (int a = 0; a < s; ++a) mJ[a + b * s] -= z0[a] * z0[b] / d0 + (ni == 2 ? z1[a] * z1[b] / d1 : 0.0);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if (b < s) {
+              mh[b] -= z0[b] * y0 / d0 + (ni == 2 ? z1[b] * y1 / d1 : 0.0);
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+                if (a < s) mJs[a][b] -= z0[a] * z0[b] / d0 + (ni == 2 ? z1[a] * z1[b] / d1 : 0.0);
+            }
           }
           gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
         }
@@ -915,22 +945,159 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     auto to = [&](int t) -> double& { return *bel(m.to_b, m.to_off, t); };
     auto res = [&](int t) -> double& { return *rsd(en.msg, m.res_off, t); };
     int up[2] = {0, 0};
-    for (int t = 0; t < s; ++t) up[t] = S.idx[m.up_map + t];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < s) up[t] = S.idx[m.up_map + t];
     double maxJ = 0.0, maxh = 0.0;
-    for (int b = 0; b < s; ++b) {
-      for (int a = 0; a < s; ++a) {
-        const int o = a + b * s;
-        const double dJ = mJ[o] - sep(o);
-        sep(o) = mJ[o];
-        res(o) = dJ;
-        to(up[a] + up[b] * mt) += dJ;
-        maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (b < s) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if (a < s) {
+            const int o = a + b * s;
+            const double dJ = mJs[a][b] - sep(o);
+            sep(o) = mJs[a][b];
+            res(o) = dJ;
+            to(up[a] + up[b] * mt) += dJ;
+            maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+          }
+        }
+        const int o = s * s + b;
+        const double dh = mh[b] - sep(o);
+        sep(o) = mh[b];
+        res(o) = dh;
+        to(mt * mt + up[b]) += dh;
+        maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
       }
-      const int o = s * s + b;
-      const double dh = mh[b] - sep(o);
-      sep(o) = mh[b];
-      res(o) = dh;
-      to(mt * mt + up[b]) += dh;
+    }
+    const int og = s * s + s;
+    const double dg = gmsg - sep(og);
+    sep(og) = gmsg;
+    to(mt * mt + mt) += dg;
+    *mword(S.status, en.msg) = 0;
+    if (S.update_resnorm) {
+      const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
+      *mword(S.flags, en.msg) = ok ? 1 : 0;
+    }
+  }
+}
+
+// The same for engines whose sepsets hold at most ONE variable (univariate traits: clusters {child, parent} of at most
+// two variables -- cfg4): every element a message needs is loaded by its ROLE (the kept diagonal entry, the pivot, the
+// coupling ...), its index computed on the scalar unit, instead of loading the record and picking elements by runtime
+// indices; one thread = one site, lanes = consecutive sites.  Expressions and their order are those of bp_level_uni.
+template <bool SM>
+__global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* __restrict__ task_off,
+                                                     const Entry* __restrict__ entries, int task0, int n_sites,
+                                                     unsigned long long seq_base, unsigned long long stop_below) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  const int task = task0 + blockIdx.x;
+  double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
+  double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  const int64_t ns = S.n_sites;
+  auto bel = [&](int b, int64_t plain_off, int t) -> double* {
+    if constexpr (SM) return S.pool + (S.packed_off[b] + t) * ns + site;
+    else return pool + plain_off + t;
+  };
+  auto mword = [&](int32_t* base, int msg) -> int32_t* {
+    if constexpr (SM) return base + (int64_t)msg * ns + site;
+    else return base + (int64_t)site * S.n_msgs + msg;
+  };
+  auto cword = [&](int32_t* base, int c) -> int32_t* {
+    if constexpr (SM) return base + (int64_t)c * ns + site;
+    else return base + (int64_t)site * S.n_clusters + c;
+  };
+  auto rsd = [&](int msg, int64_t plain_off, int t) -> double* {
+    if constexpr (SM) return S.rpool + (S.rpacked_off[msg] + t) * ns + site;
+    else return rpool + plain_off + t;
+  };
+  const int e0 = task_off[task], e1 = task_off[task + 1];
+  double mJ = 0.0, mh = 0.0, gmsg = 0.0;   // the message (s = 1)
+  for (int e = e0; e < e1; ++e) {
+    const Entry en = entries[e];
+    const MsgDesc m = S.msgs[en.msg];
+    if (*cword(S.poison, m.from_b)) {
+      *cword(S.poison, m.to_b) = 1;
+      return;
+    }
+    const int mf = m.mf, s = m.s, mt = m.mt, ni = m.ni;
+    auto from = [&](int t) -> double { return *bel(m.from_b, m.from_off, t); };
+    if (!en.reuse) {
+      gmsg = from(mf * mf + mf);
+      int info = 0;
+      if (s == 1) {
+        const int k = S.idx[m.keep_map];
+        mJ = from(k + k * mf);
+        mh = from(mf * mf + k);
+        if (ni == 1) {
+          const int i = S.idx[m.int_map];
+          const double Jii = from(i + i * mf), Jki = from(k + i * mf), hi = from(mf * mf + i);
+          // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
+          if (fabs(hi) > PGBP_EPS || fabs(Jii) > PGBP_EPS || fabs(Jki) > PGBP_EPS) {
+            const double d0 = Jii;
+            if (!(d0 > 0.0)) {
+              info = 1;
+            } else {
+              const double y0 = hi;
+              const double quad = y0 * y0 / d0 + 0.0;
+              const double logdet = log(d0) + 0.0;
+              const double z0 = Jki;
+              mh -= z0 * y0 / d0 + 0.0;
+              mJ -= z0 * z0 / d0 + 0.0;
+              gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
+            }
+          }
+        }
+      } else if (ni > 0) {
+        // an empty sepset: every variable of the sender (one or two) is integrated, the message is its constant
+        const int i0 = S.idx[m.int_map];
+        const int i1 = ni == 2 ? S.idx[m.int_map + 1] : 0;
+        const double d0 = from(i0 + i0 * mf), y0 = from(mf * mf + i0);
+        const double u01 = ni == 2 ? from(i0 + i1 * mf) : 0.0;          // upper entry (row i0 < i1)
+        const double J10 = ni == 2 ? from(i1 + i0 * mf) : 0.0, J11 = ni == 2 ? from(i1 + i1 * mf) : 0.0;
+        const double h1 = ni == 2 ? from(mf * mf + i1) : 0.0;
+        bool nz = fabs(y0) > PGBP_EPS || fabs(d0) > PGBP_EPS;
+        if (ni == 2) nz = nz || fabs(h1) > PGBP_EPS || fabs(u01) > PGBP_EPS || fabs(J10) > PGBP_EPS || fabs(J11) > PGBP_EPS;
+        if (nz) {
+          double d1 = 1.0;
+          if (!(d0 > 0.0)) info = 1;
+          if (!info && ni == 2) {
+            d1 = J11 - u01 * u01 / d0;
+            if (!(d1 > 0.0)) info = 2;
+          }
+          if (!info) {
+            const double y1 = ni == 2 ? h1 - u01 / d0 * y0 : 0.0;
+            const double quad = y0 * y0 / d0 + (ni == 2 ? y1 * y1 / d1 : 0.0);
+            const double logdet = log(d0) + (ni == 2 ? log(d1) : 0.0);
+            gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
+          }
+        }
+      }
+      if (info) {
+        *mword(S.status, en.msg) = info;
+        *cword(S.poison, m.to_b) = 1;
+        atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
+        return;
+      }
+    }
+    // ---- divide! and mult!
+    auto sep = [&](int t) -> double& { return *bel(m.sep_b, m.sep_off, t); };
+    auto to = [&](int t) -> double& { return *bel(m.to_b, m.to_off, t); };
+    double maxJ = 0.0, maxh = 0.0;
+    if (s == 1) {
+      const int u = S.idx[m.up_map];
+      const double dJ = mJ - sep(0);
+      sep(0) = mJ;
+      *rsd(en.msg, m.res_off, 0) = dJ;
+      to(u + u * mt) += dJ;
+      maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+      const double dh = mh - sep(1);
+      sep(1) = mh;
+      *rsd(en.msg, m.res_off, 1) = dh;
+      to(mt * mt + u) += dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
     const int og = s * s + s;
@@ -946,15 +1113,17 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
 }
 
 void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
-                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st) {
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s, hipStream_t st) {
   if (ntasks <= 0) return;
   const int bs = n_sites >= 256 ? 256 : 64;
-  if (S.sm)
-    hipLaunchKernelGGL(bp_level_uni<true>, dim3(ntasks, (n_sites + bs - 1) / bs), dim3(bs), 0, st, S, d_task_off,
-                       d_entries, task0, n_sites, seq_base, stop_below);
-  else
-    hipLaunchKernelGGL(bp_level_uni<false>, dim3(ntasks, (n_sites + bs - 1) / bs), dim3(bs), 0, st, S, d_task_off,
-                       d_entries, task0, n_sites, seq_base, stop_below);
+  const dim3 grid(ntasks, (n_sites + bs - 1) / bs);
+  if (max_s <= 1) {   // every sepset of the engine holds at most one variable
+    if (S.sm) hipLaunchKernelGGL(bp_level_uni1<true>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
+    else hipLaunchKernelGGL(bp_level_uni1<false>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
+  } else {
+    if (S.sm) hipLaunchKernelGGL(bp_level_uni<true>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
+    else hipLaunchKernelGGL(bp_level_uni<false>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
+  }
 }
 
 size_t generic_lds_bytes(int max_mf) {

@@ -87,7 +87,8 @@ void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry*
 
 // thread-per-(site, task) kernel for graphs whose beliefs all have dimension <= 2 (univariate batches)
 void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
-                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s, hipStream_t st);
+// (max_s: the engine's largest sepset dimension; <= 1 selects the instance that loads a message's elements by role)
 
 // register-resident message kernel (pgbp_fast.hip): `ngroups` groups of records (FEntry) of a traversal.
 // mode 0 (level): one group of kFastMaxWaves records per workgroup; 1 (stream): persistent grid over the groups with the
