@@ -13,7 +13,7 @@ re-validated inside the same run on the reset-from-factors copy kernel, whose by
 usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel [kernel [calibrates]]]
   copy_kernel: calibration kernel with a known byte count each way (default copy_strided_kernel; a name without "pgbp::" is
                looked up as given, e.g. __amd_rocclr_copyBuffer for the site-minor reset of the sites workload)
-  kernel:      the message kernel to reduce (default bp_fast16: every launch mode of it; bp_level_uni for the sites workload)
+  kernel:      the message kernel to reduce (default bp_fast16: every launch mode of it; bp_level_uni1 for the sites workload)
   calibrates:  how many calibrate!() iterations the profiled program ran and nothing else on that kernel (e.g.
                `tools/level_times.py run` = 8): adds launches_per_calibrate and hbm_bytes_per_calibrate
 """
