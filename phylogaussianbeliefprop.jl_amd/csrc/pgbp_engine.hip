@@ -388,7 +388,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
         const Traversal::Chunk& ch = tr.chunks[next_chunk];
         if (ch.generic)
           launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
-                               e->plan.n_sites, seq_base, stop_below, ch.max_mf, e->st);
+                               e->plan.n_sites, seq_base, stop_below, ch.max_mf, ch.small_only != 0, e->st);
         else
           launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base,
                         stop_below, stop_below, e->st, 0, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
@@ -407,7 +407,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
       launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->max_s, e->st);
     else {
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
-                           tr.max_mf, e->st);
+                           tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st);
       launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
                        tr.max_mf_big, e->st);
     }
@@ -859,7 +859,7 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   } else {
     const GRec rec = make_grec(p, en, -1);
     HIPCHK(e, hipMemcpyAsync(e->d_one_rec, &rec, sizeof(rec), hipMemcpyHostToDevice, e->st));
-    launch_level_generic(S, e->d_one_rec, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+    launch_level_generic(S, e->d_one_rec, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, false, e->st);
   }
   std::vector<unsigned long long> keys(p.n_sites);
   HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * p.n_sites, hipMemcpyDeviceToHost, e->st));

@@ -44,6 +44,7 @@ constexpr int kTLoad = 1, kTStore = 2;
 // Records of one traversal: per level the FIRST record of each of its generic-class tasks, in task order
 // (Traversal::level_gbase), then the later records of those tasks, chained through `next`.
 constexpr int kGInlPerm = 40, kGInlUp = 16;
+constexpr int kSmallI = 8, kSmallK = 8;   // the register-resident small-message body: at most 8 integrated and 8 kept variables
 struct GRec {
   int64_t from_off, to_off, sep_off, res_off;  // dwords 0 .. 7: doubles, inside one site's pools
   int32_t msg, seq, from_b, to_b;              // 8 .. 11
@@ -115,6 +116,7 @@ struct Traversal {
     int32_t n_groups = 0;
     int32_t generic = 0;              // 1: its groups are kTailWaves task ids each (cgroups), run by bp_chunk_generic
     int32_t max_mf = 0;               // largest sender among its tasks (LDS scratch per wavefront of bp_chunk_generic)
+    int32_t small_only = 0;           // generic chunk: every message fits the small-message body (no LDS scratch at all)
   };
   std::vector<Chunk> chunks;
   std::vector<int32_t> chunk_wg_off;
@@ -123,6 +125,7 @@ struct Traversal {
   std::vector<GRec> grecs;           // records of the generic-class tasks (see GRec)
   std::vector<int32_t> level_gbase;  // [n_levels] record of the level's first generic-class task (its tasks follow in order)
   std::vector<int32_t> task_grec;    // [n_tasks] first record of the task (-1: a fast-class task)
+  std::vector<uint8_t> level_small;  // [n_levels] every message of the level's generic-class tasks fits the register-resident small-message body
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;

@@ -133,7 +133,7 @@ __device__ __forceinline__ int64_t grec_i64(unsigned int rv, int k) {
 // batch at the top; the elimination is straight-line code (the pivot row travels by v_readlane, no LDS, no
 // synchronisation); divide! and mult! are done by the kept lanes on their own rows.  Arithmetic and its order are those
 // of the LDS path below (eliminate_leading): W[i][j] -= (W[i][k] / d_k) * W[k][j], log det as a mantissa product.
-constexpr int kSmallI = 8, kSmallK = 8;
+// (kSmallI = kSmallK = 8: pgbp_internal.hpp -- the planner tells the launches whose messages all fit)
 struct SmallFrame {
   double row[kSmallI + kSmallK + 1];
 };
@@ -322,7 +322,9 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
 // LDS.  WAVE: other wavefronts of the workgroup run other tasks beside it (the loop mode below), so every
 // synchronisation in here is wave-local and nothing in here may be a workgroup barrier; a `return` ends the task (not
 // the kernel).  Dependent loads of a message: record (fetched ahead) -> operands.
-template <bool WAVE>
+// SMALL_ONLY: every message of the launch fits the register-resident body (the planner's promise: Traversal::level_small,
+// Chunk::small_only) -- the in-LDS body is not compiled in, which leaves the wide levels more wavefronts per SIMD.
+template <bool WAVE, bool SMALL_ONLY = false>
 __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __restrict__ recs, GLoad cur, const int site,
                                              const int lane, unsigned long long seq_base, int32_t* perm, double* W) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
@@ -346,7 +348,7 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
     const int k0 = (fl & 255) == 255 ? -1 : (fl & 255), u0 = ((fl >> 8) & 255) == 255 ? -1 : ((fl >> 8) & 255);
     const bool en_reuse = ((fl >> 16) & 255) != 0;
     const int inl = (fl >> 24) & 255;
-    if (((dims >> 24) & 255) <= kSmallI && s <= kSmallK && !(en_reuse && !small_prev)) {
+    if (SMALL_ONLY || (((dims >> 24) & 255) <= kSmallI && s <= kSmallK && !(en_reuse && !small_prev))) {
       // the register-resident path (small_message); a reused marginal stays in the path that computed it
       small_prev = true;
 #ifdef PGBP_GSTAMP
@@ -376,6 +378,7 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
       cur = nxt;
       continue;
     }
+    if constexpr (SMALL_ONLY) __builtin_unreachable();
     small_prev = false;
     // the sender sits downstream of a failed message?  Requested with the operands (a vector load: in the loop mode the
     // mark may have been stored by another wavefront of this workgroup one level ago, which the scalar cache does not
@@ -581,6 +584,7 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
   }
 }
 
+template <bool SMALL_ONLY>
 __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* __restrict__ recs, int rec0,
                                                        unsigned long long seq_base,
                                                        unsigned long long stop_below) {
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* _
   // Failures inside the current traversal only stop what is downstream of them (poison), so that the
   // minimum fail key is the first failure of the reference's sequential order.
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  generic_task<false>(S, recs, load_grec(recs, rec0 + blockIdx.x, threadIdx.x), site, threadIdx.x, seq_base,
+  generic_task<false, SMALL_ONLY>(S, recs, load_grec(recs, rec0 + blockIdx.x, threadIdx.x), site, threadIdx.x, seq_base,
                       reinterpret_cast<int32_t*>(lds), lds + kPermDoubles);
 }
 
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* _
 // of a level are complete (vmcnt) and visible (same CU, same vector L1) before the next level's loads.  No workgroup of
 // a launch depends on another.  per_wave: doubles of LDS scratch per wavefront (perm + the largest working matrix of
 // the chunk).  The record of a wavefront's next task is fetched while it works on the current one.
+template <bool SMALL_ONLY>
 __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, const GRec* __restrict__ recs,
                                                                     const int32_t* __restrict__ grp_recs,
                                                                     const int32_t* __restrict__ wg_off, int per_wave,
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, 
       if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
     }
     if (ri >= 0)
-      generic_task<true>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles);
+      generic_task<true, SMALL_ONLY>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles);
     if (g + 1 < g1) __syncthreads();
     ri = ri_next;
     cur = nxt;
@@ -1133,19 +1138,27 @@ size_t generic_lds_bytes(int max_mf) {
 }
 
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
-                          unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st) {
+                          unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
+                          hipStream_t st) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(bp_level_generic, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S, d_recs, rec0,
-                     seq_base, stop_below);
+  if (small_only)
+    hipLaunchKernelGGL(bp_level_generic<true>, dim3(ntasks, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, seq_base, stop_below);
+  else
+    hipLaunchKernelGGL(bp_level_generic<false>, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S, d_recs, rec0,
+                       seq_base, stop_below);
 }
 
 void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* d_grp_recs, const int32_t* d_wg_off, int n_wg,
                           int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
-                          hipStream_t st) {
+                          bool small_only, hipStream_t st) {
   if (n_wg <= 0) return;
   const size_t per_wave = generic_lds_bytes(max_mf) / sizeof(double);
-  hipLaunchKernelGGL(bp_chunk_generic, dim3(n_wg, n_sites), dim3(kTailWaves * 64), per_wave * sizeof(double) * kTailWaves, st,
-                     S, d_recs, d_grp_recs, d_wg_off, (int)per_wave, seq_base, stop_below);
+  if (small_only)
+    hipLaunchKernelGGL(bp_chunk_generic<true>, dim3(n_wg, n_sites), dim3(kTailWaves * 64), 0, st, S, d_recs, d_grp_recs, d_wg_off,
+                       0, seq_base, stop_below);
+  else
+    hipLaunchKernelGGL(bp_chunk_generic<false>, dim3(n_wg, n_sites), dim3(kTailWaves * 64), per_wave * sizeof(double) * kTailWaves,
+                       st, S, d_recs, d_grp_recs, d_wg_off, (int)per_wave, seq_base, stop_below);
 }
 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2

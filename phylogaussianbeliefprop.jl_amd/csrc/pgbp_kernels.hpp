@@ -71,15 +71,18 @@ __device__ __forceinline__ double log_by_table(const double2* __restrict__ tab, 
 #endif
 
 // wave-per-task kernel: block b of the launch runs the task whose first record is d_recs[rec0 + b] (GRec, pgbp_internal.hpp)
+// small_only: every message of these tasks fits the register-resident body (Traversal::level_small): the instance without the
+// in-LDS body (fewer registers: more wavefronts per SIMD on the wide levels, half the code)
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
-                          unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st);
+                          unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
+                          hipStream_t st);
 
 // loop mode of the generic task body: n_wg workgroups of kTailWaves wavefronts, workgroup b walks the groups
 // [d_wg_off[b], d_wg_off[b + 1]) of kTailWaves first records of tasks (-1: none) with a workgroup barrier in between
 // (a chunk of fused levels)
 void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* d_grp_recs, const int32_t* d_wg_off, int n_wg,
                           int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
-                          hipStream_t st);
+                          bool small_only, hipStream_t st);
 
 // tasks with a belief of dimension 65 .. PGBP_MAX_DIM: one workgroup of 256 threads per task, the sender in up to 132 KB of LDS
 void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,

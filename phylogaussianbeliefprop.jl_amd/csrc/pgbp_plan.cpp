@@ -409,6 +409,7 @@ static void build_grecs(const Plan& p, Traversal& tr) {
   tr.grecs.clear();
   tr.level_gbase.assign(nlev, 0);
   tr.task_grec.assign(ntasks, -1);
+  tr.level_small.assign(nlev, 1);
   for (int L = 0; L < nlev; ++L) {
     const int t0 = tr.level_off[L] + tr.level_nfast[L], t1 = tr.level_off[L + 1];
     tr.level_gbase[L] = (int32_t)tr.grecs.size();
@@ -422,6 +423,11 @@ static void build_grecs(const Plan& p, Traversal& tr) {
     for (int t = t0; t < t1; ++t)
       for (int e = tr.task_off[t] + 1; e < tr.task_off[t + 1]; ++e)
         tr.grecs.push_back(make_grec(p, tr.entries[e], e + 1 < tr.task_off[t + 1] ? (int32_t)tr.grecs.size() + 1 : -1));
+    for (int t = t0; t < t1; ++t)
+      for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e) {
+        const MsgDesc& m = p.msgs[tr.entries[e].msg];
+        if (m.ni > kSmallI || m.s > kSmallK) tr.level_small[L] = 0;
+      }
   }
 }
 
@@ -541,6 +547,8 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     ch.generic = all_fast(L0) ? 0 : 1;
     ch.max_mf = 0;
     for (int L = L0; L < L1; ++L) ch.max_mf = std::max(ch.max_mf, level_mf[L]);
+    ch.small_only = ch.generic;
+    for (int L = L0; L < L1; ++L) ch.small_only = ch.small_only && tr.level_small[L];
     ch.group0 = ch.generic ? (int64_t)(tr.cgroups.size() / kTailWaves) : (int64_t)(tr.centries.size() / kTailWaves);
     int32_t ngroups = 0;
     for (int w : order) {
