@@ -273,18 +273,33 @@ def run_sites(args, torch, dist, rank, world, local_rank):
     default_size = (world == 1 and args.sites == 1000 and args.site_traits == 8 and args.ntips == 20000 and ou
                     and args.seed == 3)
     # the one collective of this configuration: all ranks get every problem's log-likelihood
-    comm = make_comm(dist, torch, rank, world, local_rank)
-    if comm is not None:
-        # behind the C ABI: ONE ncclAllGather carrying every rank's log-likelihoods, info words and (succ, iscal)
-        check(enqueue_ll(eng, 1, C.byref(opts)))
-        slot = -(-nprob // world)
-        g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, slot)
-        full = np.concatenate([g_norm[r, :shard_range(nprob, r, world)[1] - shard_range(nprob, r, world)[0]] for r in range(world)])
-        if g_info.any() or not all_succ:
-            raise SystemExit("sites workload: a rank reported a failed message")
-        comm.close()
-    else:
-        full = gather_sites(norm, nprob, dist, device="cpu" if os.environ.get("PGBP_BENCH_REHEARSAL") == "1" else f"cuda:{local_rank}")
+    rehearsal = os.environ.get("PGBP_BENCH_REHEARSAL") == "1"
+    full, gather_via = None, "single rank"
+    if world > 1 and dist is not None and not rehearsal:
+        # behind the C ABI: ONE ncclAllGather carrying every rank's log-likelihoods, info words and (succ, iscal); outside
+        # the timed region -- should the library's own communicator not come up on this node, every rank falls back to
+        # the launcher's torch.distributed group and the line says so
+        err = None
+        try:
+            comm = make_comm(dist, torch, rank, world, local_rank)
+            check(enqueue_ll(eng, 1, C.byref(opts)))
+            slot = -(-nprob // world)
+            g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, slot)
+            comm.close()
+            if g_info.any() or not all_succ:
+                raise SystemExit("sites workload: a rank reported a failed message")
+            full = np.concatenate([g_norm[r, :shard_range(nprob, r, world)[1] - shard_range(nprob, r, world)[0]] for r in range(world)])
+        except Exception as ex:   # noqa: BLE001 (reported in the JSON line)
+            err = f"{type(ex).__name__}: {ex}"
+        okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 1:
+            gather_via = "pgbp_comm (one ncclAllGather behind the C ABI)"
+        else:
+            full = None
+            gather_via = f"torch.distributed all_gather (pgbp_comm did not come up on this rank or another: {err})"
+    if full is None:
+        full = gather_sites(norm, nprob, dist, device="cpu" if rehearsal else f"cuda:{local_rank}")
     total_msgs = msgs_per_cal / max(1, ns) * nprob        # same per-problem count on every rank
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -307,7 +322,7 @@ def run_sites(args, torch, dist, rank, world, local_rank):
                          "kernel": "bp_level_uni1", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate"},
             "ll_evals_per_s": world * ns * 3 / (ms_ll.value * 1e-3),
             "ll_eval_note": "problem log-likelihoods per second: device factor fill + postorder + root integrate (score() body)",
-            "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": rel}))
+            "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": rel, "loglik_gather": gather_via}))
 
 
 def build_network_workload(args, rank):
@@ -591,15 +606,33 @@ def main():
     rel2 = abs(n2[0] - ll_check) / max(1.0, abs(ll_check))
     if not (i2[0] == 0 and rel2 <= 1e-8) and not skip_parity:
         raise SystemExit(f"post-run parity failed: {n2[0]!r} vs {ll_check!r}")
-    comm = make_comm(dist, torch, rank, world, local_rank)
-    ranks_loglik = None
-    if comm is not None:
-        # N > 1 (replicas): every rank's log-likelihood and success flag reach every rank in ONE ncclAllGather (C ABI)
-        g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, 1)
+    ranks_loglik, ranks_gather = None, None
+    if world > 1 and dist is not None and os.environ.get("PGBP_BENCH_REHEARSAL") != "1":
+        # N > 1 (replicas): every rank's log-likelihood and success flag reach every rank in ONE ncclAllGather behind the
+        # C ABI (pgbp_comm).  This check sits outside the timed region: should the library's own communicator not come up
+        # on this node, every rank falls back to the launcher's torch.distributed group and the line says so.
+        err, g_norm, g_info, all_succ = None, None, None, False
+        try:
+            comm = make_comm(dist, torch, rank, world, local_rank)
+            g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, 1)
+            comm.close()
+        except Exception as ex:   # noqa: BLE001 (reported in the JSON line)
+            err = f"{type(ex).__name__}: {ex}"
+        okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 1:
+            ranks_gather = "pgbp_comm (one ncclAllGather behind the C ABI)"
+        else:
+            mine = torch.tensor([float(n2[0]), float(i2[0])], dtype=torch.float64, device=f"cuda:{local_rank}")
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            g_norm = np.array([[float(q[0].item())] for q in parts])
+            g_info = np.array([[int(q[1].item())] for q in parts])
+            all_succ = True
+            ranks_gather = f"torch.distributed all_gather (pgbp_comm did not come up on this rank or another: {err})"
         if g_info.any() or not all_succ:
             raise SystemExit("a rank reported a failed message after the timed region")
         ranks_loglik = [float(v) for v in g_norm[:, 0]]
-        comm.close()
 
     out = None
     if rank == 0:
@@ -640,7 +673,7 @@ def main():
                        "messages_per_step": int(msgs_per_cal), "tree_depth": int(tr.depth().max()),
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
             "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel), "parity_skipped": skip_parity,
-            "ranks_loglik": ranks_loglik,
+            "ranks_loglik": ranks_loglik, "ranks_gather": ranks_gather,
             "ll_evals_per_s": ll_evals, "ll_evals_per_s_without_factor_fill": ll_evals_nofill,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
