@@ -441,6 +441,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
   static const int depth = [] { const char* v = getenv("PGBP_CHUNK_DEPTH"); return v ? std::max(2, atoi(v)) : kChunkDepth; }();
   static const int max_tasks = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkMaxTasks; }();
+  static const int max_tasks_generic = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkGenericMaxTasks; }();
   const int nlev = (int)tr.level_off.size() - 1;
   if (off || nlev <= 0) return;
   const int ntasks = (int)tr.task_off.size() - 1;
@@ -465,7 +466,8 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   auto all_fast = [&](int L) { return tr.level_nfast[L] == tr.level_off[L + 1] - tr.level_off[L]; };
   auto eligible = [&](int L) {
     const int nt = tr.level_off[L + 1] - tr.level_off[L];
-    return nt > 0 && nt <= max_tasks && tr.level_nbig[L] == 0 && (all_fast(L) || level_mf[L] <= kChunkGenericMaxMf);
+    return nt > 0 && nt <= (all_fast(L) ? max_tasks : max_tasks_generic) && tr.level_nbig[L] == 0 &&
+           (all_fast(L) || level_mf[L] <= kChunkGenericMaxMf);
   };
   auto width = [&](int L) { return tr.level_off[L + 1] - tr.level_off[L]; };
   // levels per chunk, counted from the root-most level (width w0): `depth` of them, and beyond that (up to 4 x depth)
