@@ -280,7 +280,8 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
     // A level that needs the generic kernel anyway and has too few fast-class tasks to fill the chip runs entirely on
     // the generic kernel: one launch instead of two (a narrow level costs its slowest task plus a kernel boundary per
     // launch: loopy cluster graphs of networks, where hybrid families sit beside tree-edge clusters in every level).
-    if (!slow.empty() && fast.size() < kMixedLevelFastMin) {
+    static const size_t mixed_min = [] { const char* v = getenv("PGBP_MIXED_FAST_MIN"); return v ? (size_t)atoll(v) : kMixedLevelFastMin; }();
+    if (!slow.empty() && fast.size() < mixed_min) {
       slow.insert(slow.end(), fast.begin(), fast.end());
       std::sort(slow.begin(), slow.end());
       fast.clear();
@@ -467,7 +468,8 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   auto eligible = [&](int L) {
     const int nt = tr.level_off[L + 1] - tr.level_off[L];
     return nt > 0 && nt <= (all_fast(L) ? max_tasks : max_tasks_generic) && tr.level_nbig[L] == 0 &&
-           (all_fast(L) || level_mf[L] <= kChunkGenericMaxMf);
+           (all_fast(L) || (tr.level_nfast[L] == 0 && level_mf[L] <= kChunkGenericMaxMf));   // (a generic chunk walks message
+           // records, which the fast-class tasks of a mixed level do not have)
   };
   auto width = [&](int L) { return tr.level_off[L + 1] - tr.level_off[L]; };
   // levels per chunk, counted from the root-most level (width w0): `depth` of them, and beyond that (up to 4 x depth)

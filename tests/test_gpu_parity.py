@@ -1246,12 +1246,15 @@ def test_launch_modes_differential_fuzz(P, env):
     assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
-@pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}], ids=["default", "level_launches_only"])
+@pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}, {"PGBP_MIXED_FAST_MIN": "0"}],
+                         ids=["default", "level_launches_only", "mixed_levels_always_split"])
 def test_network_differential_fuzz(P, env):
     """tests/fuzz_gpu_vs_c_oracle_networks.py: random level-3 networks, clique tree / Bethe / join graphs, every spanning
     tree of the schedule, 1 - 9 traits (and 18 - 22), damaged clusters: the wave-per-task kernels (both message bodies,
     level and chunk launches, the large-belief kernel) against the plain-C sequential engine -- beliefs, flags, (succ,
-    iscal) and the first failure of the reference's order; once more with every level as its own launch."""
+    iscal) and the first failure of the reference's order; once more with every level as its own launch, and with every
+    mixed level split into a register-resident and a wave-per-task launch however few fast-class tasks it has (such a level
+    must not enter a generic chunk: its fast-class tasks have no message records)."""
     import os
     import subprocess
     import sys
