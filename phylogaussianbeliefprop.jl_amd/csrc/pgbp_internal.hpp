@@ -88,8 +88,9 @@ constexpr int kChunkMaxTasks = 384;   // a level joins a chunk of fused levels i
 constexpr int kChunkGenericMaxTasks = 768;  // ... of generic-class tasks (cfg5: 384 / 768 / 1 536 / 3 072 tasks: 1.559 / 1.541 / 1.552 / 1.690 ms join graph, 1.876 / 1.824 / 1.836 / 1.978 Bethe)
 constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x (perm + mf x (mf + 1)) doubles of LDS per workgroup
 constexpr int kChunkDepth = 4;        // levels per chunk
-constexpr size_t kMixedLevelFastMin = 8192;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
-                                             // (cfg5 Bethe: 2 048 / 8 192 / never split: 1.817 / 1.780 / 1.787 ms per iteration)
+constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
+constexpr size_t kMixedLevelFastMinNarrow = 8192;  // ... where the sepsets have at most 4 variables (cfg5 Bethe: 2 048 / 8 192 / never
+                                                   // split: 1.817 / 1.780 / 1.787 ms per iteration)
 
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first

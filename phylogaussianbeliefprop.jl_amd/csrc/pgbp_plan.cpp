@@ -280,7 +280,10 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
     // A level that needs the generic kernel anyway and has too few fast-class tasks to fill the chip runs entirely on
     // the generic kernel: one launch instead of two (a narrow level costs its slowest task plus a kernel boundary per
     // launch: loopy cluster graphs of networks, where hybrid families sit beside tree-edge clusters in every level).
-    static const size_t mixed_min = [] { const char* v = getenv("PGBP_MIXED_FAST_MIN"); return v ? (size_t)atoll(v) : kMixedLevelFastMin; }();
+    // (measured: polytomy trees with 8 and 16 traits prefer 2 048 to 8 192 by 2 - 5 %; cfg5, 4 traits -- where the fast
+    // kernel's instance works on 4 lanes of 64 -- prefers 8 192 by 2 %)
+    static const long long mixed_env = [] { const char* v = getenv("PGBP_MIXED_FAST_MIN"); return v ? atoll(v) : -1ll; }();
+    const size_t mixed_min = mixed_env >= 0 ? (size_t)mixed_env : (p.fast_p <= 4 ? kMixedLevelFastMinNarrow : kMixedLevelFastMin);
     if (!slow.empty() && fast.size() < mixed_min) {
       slow.insert(slow.end(), fast.begin(), fast.end());
       std::sort(slow.begin(), slow.end());
