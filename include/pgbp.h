@@ -319,6 +319,11 @@ int  pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info);
  * the parameters uploaded by the LAST pgbp_bm_tree_assignfactors call, postorder of tree 0, root integrate. */
 int  pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts);
 int  pgbp_sync(pgbp_engine* e);
+/* The comparison behind the residual-norm flags (iscalibrated_residnorm!, src/beliefs.jl:994-1003): the kernels do not
+ * divide, they compare max|dh| (max|dJ|) with the largest x for which fl(x / divisor) <= atol -- divisor = fl(sqrt(s)) for dh,
+ * s for dJ.  Pure host function (no device needed): returns that x; +inf for divisor 0 or atol = +inf, -1 (nothing passes)
+ * for a NaN or negative atol. */
+double pgbp_residual_threshold(double divisor, double atol);
 /* Time `reps` repetitions of the enqueued work with HIP events on the engine's stream; returns the
  * total milliseconds in *ms_total and, per kernel family, accumulated device time is NOT measured here
  * (use rocprofv3). kind 0 = calibrate (reset_each honoured), 1 = loglik, 2 = loglik_bm, 3 = loglik_lg (2, 3: with the device factor fill). */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGBP_LIB", os.path.join(_HERE, "csrc", "libpgbp.so"))
 
 PGBP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_TREE, ERR_TOO_LARGE, ERR_NO_DEVICE, ERR_STATE = range(7)
-PGBP_MAX_DIM = 64
+PGBP_MAX_DIM = 128
 
 
 class PgbpError(RuntimeError):
@@ -84,6 +84,7 @@ SYMBOLS = {
     "pgbp_plan_groups": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P]),
     "pgbp_plan_chunks": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, _I32P]),
     "pgbp_plan_records": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, C.c_void_p]),
+    "pgbp_residual_threshold": (C.c_double, [C.c_double, C.c_double]),
     "pgbp_plan_last_error": (C.c_char_p, [_P]),
     "pgbp_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_P)]),
     "pgbp_destroy": (None, [_P]),

@@ -646,6 +646,8 @@ int32_t pgbp_belief_dim(const pgbp_engine* e, int32_t belief) {
   return (e && belief >= 0 && belief < e->plan.n_beliefs()) ? e->plan.dims[belief] : -1;
 }
 
+double pgbp_residual_threshold(double divisor, double atol) { return quotient_threshold(divisor, atol); }
+
 int pgbp_sync(pgbp_engine* e) {
   DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;

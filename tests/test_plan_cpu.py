@@ -1233,3 +1233,28 @@ def test_message_records_of_the_wave_per_task_kernels(ntips, p, kind, graph):
         assert used.all(), "every record belongs to exactly one task"
     assert seen_generic > 0
     lib.pgbp_plan_destroy(pl)
+
+
+def test_residual_norm_thresholds_are_exact():
+    """pgbp_residual_threshold(c, atol) (host): the largest x with fl(x / c) <= atol -- what the kernels compare the
+    residual maxima with instead of dividing (iscalibrated_residnorm!, src/beliefs.jl:994-1003).  For divisors sqrt(s)
+    and s, tolerances over 300 orders of magnitude (subnormal ones included): x passes, its upper neighbour does not; the
+    special cases of the header."""
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    f = lib.pgbp_residual_threshold
+    for s in list(range(1, 130)) + [1000, 4096]:
+        for c in (float(np.sqrt(float(s))), float(s)):
+            tols = np.concatenate([10.0 ** rng.uniform(-300, 300, 40), [1e-5, 1.0, 5e-324, 2.2250738585072014e-308, 1e308, 0.0],
+                                   rng.random(10)])
+            for atol in tols.tolist():
+                x = f(c, float(atol))
+                if np.isinf(x):
+                    assert atol * c > 1.7e308          # everything finite passes
+                    continue
+                assert x >= 0.0 and np.float64(x) / np.float64(c) <= atol, (s, c, atol, x)
+                with np.errstate(over="ignore"):
+                    up = np.nextafter(x, np.inf)
+                assert np.isinf(up) or np.float64(up) / np.float64(c) > atol, (s, c, atol, x)
+    assert f(0.0, 1e-5) == np.inf and f(3.0, np.inf) == np.inf
+    assert f(3.0, -1.0) == -1.0 and f(3.0, float("nan")) == -1.0
