@@ -25,159 +25,14 @@
 #include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
 
+#include "pgbp_fast_dev.hpp"
+
 namespace pgbp {
-
-#define PGBP_LOG2PI 1.8378770664093454835606594728112
-#define PGBP_LN2 0.69314718055994530941723212145818
-#define PGBP_EPS 2.220446049250313e-16
-
-namespace {
-
-
-struct Frag {
-  double w[4][4];  // w[i][j] = W[R(i)][C(j)]; w[0..1][2..3] (integrated rows x kept cols) is never used
-  double h[4];     // h[i] = h[R(i)], replicated over b
-};
-
-// Wave-synchronous exchange through LDS: the hardware executes a wave's DS instructions in order, but the
-// compiler reasons per thread; this fence pair + wave barrier stops it from forwarding a lane's own stale
-// store to its later load or moving loads across the other lanes' stores.  Emits no instruction.
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Blocked elimination of the 16 integrated variables, two pivots per round (8 rounds).
-// Round R: the 8 lanes with b == R own columns 2R, 2R+1 of W; they publish them (rows R_a) in the wave's
-// private LDS strip; every lane reads back the entries of the rows R_a (xr) and C_b (xc) plus the 2 x 2 pivot
-// block D and h_2R, h_2R+1, and applies  W <- W - X D^-1 X',  h <- h - X D^-1 h_K.  Mathematically identical
-// to two successive rank-1 eliminations (src/beliefupdates.jl:68-81); D^-1 by v_rcp_f64 + 2 Newton steps.
-// Returns 0, or the 1-based index of the first non-positive pivot (LAPACK potrf info).
-constexpr int kColStride = 10;                       // doubles per owner-lane slot (80 B: conflict-free b128 reads)
-constexpr int kColDoubles = 8 * kColStride + 4;      // + h_2R, h_2R+1
-
-template <int P, int R>
-__device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, const bool act, double* __restrict__ col,
-                                          double& mant, int& expo, double& quad) {
-  if constexpr (R == P / 2) {
-    return 0;
-  } else {
-    if (act && b == R) {
-      double* dst = col + a * kColStride;
-      *reinterpret_cast<double4*>(dst) = make_double4(f.w[0][0], f.w[1][0], f.w[2][0], f.w[3][0]);
-      *reinterpret_cast<double4*>(dst + 4) = make_double4(f.w[0][1], f.w[1][1], f.w[2][1], f.w[3][1]);
-      if (a == R) *reinterpret_cast<double2*>(col + 8 * kColStride) = make_double2(f.h[0], f.h[1]);
-    }
-    wave_sync_lds();  // other LANES wrote what this lane reads: not visible to per-thread alias analysis
-    const double4 xr0 = *reinterpret_cast<const double4*>(col + a * kColStride);
-    const double4 xr1 = *reinterpret_cast<const double4*>(col + a * kColStride + 4);
-    const double4 xc0 = *reinterpret_cast<const double4*>(col + b * kColStride);
-    const double4 xc1 = *reinterpret_cast<const double4*>(col + b * kColStride + 4);
-    const double2 p0 = *reinterpret_cast<const double2*>(col + R * kColStride);      // W[2R][2R], W[2R+1][2R]
-    const double2 p1 = *reinterpret_cast<const double2*>(col + R * kColStride + 4);  // W[2R][2R+1], W[2R+1][2R+1]
-    const double2 hk = *reinterpret_cast<const double2*>(col + 8 * kColStride);
-    wave_sync_lds();  // the next round overwrites the strip
-    const double d00 = p0.x, d01 = p1.x, d11 = p1.y;  // upper triangle of the pivot block
-    const double det = fma(d00, d11, -(d01 * d01));
-    const int bad = __builtin_amdgcn_readfirstlane(!(d00 > 0.0) ? 2 * R + 1 : (!(det > 0.0) ? 2 * R + 2 : 0));
-    if (bad) return bad;
-    double rdet = __builtin_amdgcn_rcp(det);
-    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
-    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
-    const double e00 = d11 * rdet, e01 = -(d01 * rdet), e11 = d00 * rdet;
-    int e;
-    mant *= frexp(det, &e);
-    expo += e;
-    // y = D^-1 x_c for my 4 columns; g = D^-1 h_K
-    const double xc0v[4] = {xc0.x, xc0.y, xc0.z, xc0.w}, xc1v[4] = {xc1.x, xc1.y, xc1.z, xc1.w};
-    const double xr0v[4] = {xr0.x, xr0.y, xr0.z, xr0.w}, xr1v[4] = {xr1.x, xr1.y, xr1.z, xr1.w};
-    const double g0 = fma(e00, hk.x, e01 * hk.y), g1 = fma(e01, hk.x, e11 * hk.y);
-    quad = fma(hk.x, g0, fma(hk.y, g1, quad));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double y0 = fma(e00, xc0v[j], e01 * xc1v[j]);
-      const double y1 = fma(e01, xc0v[j], e11 * xc1v[j]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (!(i < 2 && j >= 2)) f.w[i][j] = fma(-xr0v[i], y0, fma(-xr1v[i], y1, f.w[i][j]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
-    return eliminate2<P, R + 1>(f, a, b, act, col, mant, expo, quad);
-  }
-}
-
-}  // namespace
 
 // LDS hand-over slot of one wave: 2 x 2 block per lane (256 doubles, lane-major), h (16), g, status
 constexpr int kSlotJ = 0, kSlotH = 256, kSlotG = 272, kSlotStatus = 273, kSlotDoubles = 288;
 
 extern __shared__ double fast_lds[];
-
-// 2 x 2 block of a lane as (x, y, z, w) = (T(2a,2b), T(2a+1,2b), T(2a,2b+1), T(2a+1,2b+1))
-struct Blk { double x, y, z, w; };
-
-// Load / store the lane's block of a 16 x 16 symmetric quantity (sepset J, residual dJ, receiver sub-block,
-// a 16-dim sender).  Plain layout: column-major with leading dimension ld, all 64 lanes (two double2).
-// BS16: packed upper blocks, lanes a <= b only (one double4), pgbp_bs16.hpp.
-// ODD (plain layout only): the quantity really is n x n with n = P - 1 odd; the lane grid is the one of P, index n is
-// a phantom (reads 0, is never stored), and the accesses are element-wise because rows no longer pair up on 16 bytes.
-template <bool BS, bool ODD = false>
-__device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld, int a, int b, bool up, int kidx,
-                                        int n = 0) {
-  Blk r{0.0, 0.0, 0.0, 0.0};
-  if constexpr (BS) {
-    if (up) {
-      const double4 v = *reinterpret_cast<const double4*>(base + kidx);
-      r = Blk{v.x, v.y, v.z, v.w};
-    }
-  } else if constexpr (ODD) {
-    const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
-    if (r0 < n && c0 < n) r.x = base[r0 + (int64_t)ld * c0];
-    if (r1 < n && c0 < n) r.y = base[r1 + (int64_t)ld * c0];
-    if (r0 < n && c1 < n) r.z = base[r0 + (int64_t)ld * c1];
-    if (r1 < n && c1 < n) r.w = base[r1 + (int64_t)ld * c1];
-  } else {
-    const double2 c0 = *reinterpret_cast<const double2*>(base + 2 * a + (int64_t)ld * (2 * b));
-    const double2 c1 = *reinterpret_cast<const double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1));
-    r = Blk{c0.x, c0.y, c1.x, c1.y};
-  }
-  return r;
-}
-template <bool BS, bool ODD = false>
-__device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int a, int b, bool up, bool act, int kidx,
-                                          const Blk& v, int n = 0) {
-  if constexpr (BS) {
-    if (up) *reinterpret_cast<double4*>(base + kidx) = make_double4(v.x, v.y, v.z, v.w);
-  } else if constexpr (ODD) {
-    if (act) {
-      const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
-      if (r0 < n && c0 < n) base[r0 + (int64_t)ld * c0] = v.x;
-      if (r1 < n && c0 < n) base[r1 + (int64_t)ld * c0] = v.y;
-      if (r0 < n && c1 < n) base[r0 + (int64_t)ld * c1] = v.z;
-      if (r1 < n && c1 < n) base[r1 + (int64_t)ld * c1] = v.w;
-    }
-  } else if (act) {
-    *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b)) = make_double2(v.x, v.y);
-    *reinterpret_cast<double2*>(base + 2 * a + (int64_t)ld * (2 * b + 1)) = make_double2(v.z, v.w);
-  }
-}
-// entries 2a, 2a+1 of a vector (h, dh)
-template <bool ODD>
-__device__ __forceinline__ double2 load_pair(const double* __restrict__ v, int a, int n) {
-  if constexpr (ODD) return make_double2(2 * a < n ? v[2 * a] : 0.0, 2 * a + 1 < n ? v[2 * a + 1] : 0.0);
-  else return *reinterpret_cast<const double2*>(v + 2 * a);
-}
-template <bool ODD>
-__device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double x, double y, int n) {
-  if constexpr (ODD) {
-    if (2 * a < n) v[2 * a] = x;
-    if (2 * a + 1 < n) v[2 * a + 1] = y;
-  } else {
-    *reinterpret_cast<double2*>(v + 2 * a) = make_double2(x, y);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The message kernel.  A launch walks GROUPS of W records (FEntry, pgbp_internal.hpp): wave w of the workgroup runs
@@ -231,20 +86,6 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // workgroup -- same CU, same vector L1 -- load them after the barrier: the workgroup-scope release / acquire of
 // __syncthreads()
 __device__ __forceinline__ void wg_barrier_global() { __syncthreads(); }
-
-// One 64-byte record by scalar loads, pinned in SGPRs: left to itself the compiler sinks the field loads into the
-// branches that use them, and the wave then pays a dependent memory round trip per field group.
-__device__ __forceinline__ FEntry load_record(const FEntry* __restrict__ r) {
-  const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(r);
-  uint4 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
-  asm("; record resident"
-      : "+s"(q0.x), "+s"(q0.y), "+s"(q0.z), "+s"(q0.w), "+s"(q1.x), "+s"(q1.y), "+s"(q1.z), "+s"(q1.w), "+s"(q2.x),
-        "+s"(q2.y), "+s"(q2.z), "+s"(q2.w), "+s"(q3.x), "+s"(q3.y), "+s"(q3.z), "+s"(q3.w));
-  const uint4 q[4] = {q0, q1, q2, q3};
-  FEntry en;
-  __builtin_memcpy(&en, q, sizeof(FEntry));
-  return en;
-}
 
 // What a wave must know of a record to prefetch its sender: the first 8 bytes (from_off) and bytes 48..55 (the byte-sized
 // fields), two scalar loads instead of the whole 64-byte record.

@@ -645,6 +645,17 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
       hp = std::max(hp, chained ? h : h + 1);
       nlev = std::max(nlev, h + 1);
     }
+    // PGBP_POSTORDER_ALAP=1 (opt-in, measured 1 % slower on cfg3: 0.889 - 0.899 against 0.886 ms): every message into a
+    // cluster X goes out in the level just below X's own (height(X) - 1) instead of the level of its sender's height.
+    // All of X's children then form ONE task: X's block is loaded and stored once however different the heights of its
+    // children and their deltas are added in exactly the reference's order (src/calibration.jl:121) -- but a leaf
+    // clique's streaming message then shares a workgroup with eliminations, and a workgroup lives as long as its slowest
+    // wavefront: the mixed levels take as many workgroup lifetimes as before for fewer eliminations each.
+    // (A receiver with more children than a fast-class task has wavefronts keeps the height order.)
+    static const bool post_alap_env = getenv("PGBP_POSTORDER_ALAP") != nullptr;
+    if (!fuse && post_alap_env)
+      for (int i = 0; i < n; ++i)
+        if (nchild[t.pa[i]] <= kFastMaxWaves) lvl[i] = hnode[t.pa[i]] - 1;
     // tasks: group by (level, target parent); entries in reference order (decreasing i)
     std::vector<std::vector<int>> bylevel(nlev);
     for (int i = n - 1; i >= 0; --i) {

@@ -3,7 +3,8 @@
 
   step 1 (under the profiler; the program itself after `--`):
      rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lt -- python3 tools/level_times.py run [ntips] [traits]
-     (or `run-network [joingraph|bethe] [ntips]`: the cfg5 network workload of bench.py)
+     (or `run-network [joingraph|bethe] [ntips]`: the cfg5 network workload of bench.py;
+      `run-bethe [ntips] [traits]`: cfg2, the Bethe cluster graph of a tree)
   step 2 (plain): python3 tools/level_times.py parse gpurun_out/lt [out.json]
 
 `run` builds the workload, does 3 warm-up calibrates and 5 more, each bracketed by a device sync so that the
@@ -18,16 +19,20 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(ntips, p):
+def run(ntips, p, bethe=False):
     import numpy as np
     import pgbp_amd as P
     from pgbp_amd import synth as S
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(2 if bethe else 3)
     tr = S.random_tree(ntips, rng)
     R = S.random_rate_matrix(p, rng)
     X = S.simulate_bm(tr, R, np.zeros(p), rng)
-    prob = S.cliquetree_of_tree(tr, p)
-    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    if bethe:   # cfg2: Bethe cluster graph of the tree (a tree itself: one spanning tree, exact in one iteration)
+        prob = S.bethe_of_tree(tr, p)
+        packed = S.bm_factors_bethe(tr, prob, R, np.zeros(p), X)
+    else:
+        prob = S.cliquetree_of_tree(tr, p)
+        packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
     cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
     import time
     for _ in range(8):
@@ -104,6 +109,8 @@ def parse(d, out=None):
 if __name__ == "__main__":
     if sys.argv[1] == "run-network":
         run_network(sys.argv[2] if len(sys.argv) > 2 else "joingraph", int(sys.argv[3]) if len(sys.argv) > 3 else 20000)
+    elif sys.argv[1] == "run-bethe":   # cfg2: 10 000 tips, 8 traits
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 10000, int(sys.argv[3]) if len(sys.argv) > 3 else 8, bethe=True)
     elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 50000, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
     else:
