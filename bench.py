@@ -13,6 +13,9 @@ directed canonical messages, src/calibration.jl:72-84) on factors already reside
 N > 1: one process per GPU, each calibrating its own replica of the workload (one big tree does
 not shard -- "replicas only"); no data-path collective; timing = barrier +
 synchronize on both sides, MAX over ranks; value = all ranks' messages / that time.
+The same line carries, for every N, the block `site_sharded_cfg4`: BASELINE.json configs[3] (8000
+independent univariate OU problems on a 20k-tip tree) sharded over the N ranks -- the configuration
+that does shard (strong scaling), its one all-gather (RCCL, behind the C ABI) inside the timed region.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -147,19 +150,25 @@ def timed_region(enqueue_and_wait, dist, device_sync, reduce_device=None):
 
 def make_comm(dist, torch, rank, world, local_rank):
     """pgbp_comm (C ABI, RCCL bound inside libpgbp.so) for the one exchange of the sharded paths; rank 0's unique id
-    travels over the launcher's torch.distributed group.  None for a single rank or the one-GPU gloo rehearsal
-    (two RCCL ranks cannot share a device)."""
+    travels over the launcher's torch.distributed group, as does the agreement that every rank can open its communicator.
+    None for a single rank or the one-GPU gloo rehearsal (two RCCL ranks cannot share a device).  A communicator that does
+    not come up is an ERROR on every rank (the run exits non-zero): there is no fallback to another collective."""
     if world == 1 or dist is None or os.environ.get("PGBP_BENCH_REHEARSAL") == "1":
         return None
     from pgbp_amd.sharding import Comm
 
     def bcast(raw):
-        t = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        t = torch.zeros(1 + Comm.ID_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}")
         if raw is not None:
             t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
         dist.broadcast(t, src=0)
         return bytes(t.cpu().numpy().tobytes())
-    return Comm(world, rank, local_rank, bcast)
+
+    def allmin(v):
+        t = torch.tensor([int(v)], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+    return Comm(world, rank, local_rank, bcast, allmin)
 
 
 def whole_job_rate(units_per_rank_step, steps, world, dt):
@@ -189,25 +198,49 @@ def measured_copy_bandwidth(torch, local_rank):
         return None
 
 
+def csrc_sha16():
+    """Stamp of the kernel sources of the running tree: sha256 over csrc/*.{hip,hpp,cpp} in name order, first 16 hex digits.
+    tools/pmc_traffic.py writes the same stamp into the PMC reduction it produces."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "phylogaussianbeliefprop.jl_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc_traffic(name="pmc_traffic_latest.json"):
     """HBM bytes per launch of the message kernel from the committed rocprofv3 PMC passes
     (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json; the sites workload: pmc_traffic_sites_latest.json);
-    None if absent."""
+    None if absent.  `stale` is set when the file's source stamp is not the running tree's (or it has none): the figure
+    then belongs to other kernels than the ones being timed."""
     path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
-            return json.load(f)
+            d = json.load(f)
     except Exception:
         return None
+    d["stale"] = d.get("csrc_sha16") != csrc_sha16()
+    return d
 
 
-def run_sites(args, torch, dist, rank, world, local_rank):
+def run_sites(args, torch, dist, rank, world, local_rank, emit=True):
     """cfg4 (BASELINE.json configs[3]: "OU model, 8 traits x 1000 independent sites, 20k-tip tree, sites sharded"):
     the reference's only OU is UnivariateOrnsteinUhlenbeck, so 8 traits x 1000 sites = 8000 independent univariate OU
     problems (one sigma2, alpha, theta, mu and one data column each) on one tree.  Problems are
-    sharded contiguously across ranks, no communication during calibration, ONE all-gather (RCCL) of the per-problem
-    log-likelihoods at the end.  Factors are assigned on the device (pgbp_lg_assignfactors, OU), so only the four
-    parameters per problem and the tip data cross the bus.  --site-model bm: univariate BM instead."""
+    sharded contiguously across ranks (STRONG scaling: the 8000 problems are fixed), no communication during calibration,
+    ONE all-gather (RCCL, behind the C ABI: pgbp_comm) of the per-problem log-likelihoods per step.  Factors are
+    assigned on the device (pgbp_lg_assignfactors, OU), so only the four parameters per problem and the tip data cross the
+    bus.  --site-model bm: univariate BM instead.
+
+    Two timed regions, both under the timing contract (barrier + sync on both sides, MAX over ranks):
+      * the sharded step -- calibrate!() of every local problem, then the score() body (device factor fill + postorder +
+        root integratebelief!) and THE ALL-GATHER that puts every problem's log-likelihood on every rank, K times:
+        `value` and `sharded_step` (the collective is inside the timed region);
+      * calibrate!() alone, K times back to back (`calibrate_only`: the hot path without its exchange step).
+    Returns the result dict on rank 0 (None elsewhere); emit: print it as the JSON line."""
     import pgbp_amd
     from pgbp_amd import _lib as L
     from pgbp_amd import synth as S
@@ -256,12 +289,53 @@ def run_sites(args, torch, dist, rank, world, local_rank):
     if info.any() or rel > 1e-8:
         raise SystemExit(f"parity gate failed (sites): max rel err {rel:.3e}, failures {int(info.astype(bool).sum())}")
     bytes_per_cal, msgs_per_cal = cgb.traffic_model()     # all local problems, one calibrate
+
+    # the one collective of this configuration: all ranks get every problem's log-likelihood.  Behind the C ABI: ONE
+    # ncclAllGather carrying every rank's log-likelihoods, info words and (succ, iscal).  A communicator that does not come
+    # up raises on every rank (exit code != 0): no silent fallback.
+    rehearsal = os.environ.get("PGBP_BENCH_REHEARSAL") == "1"
+    comm = make_comm(dist, torch, rank, world, local_rank)
+    slot = -(-nprob // world)
+    gather_via = ("single rank (pgbp_fetch_loglik)" if world == 1 else
+                  "torch.distributed all_gather over gloo (one-GPU rehearsal)" if comm is None else
+                  "pgbp_comm (one ncclAllGather behind the C ABI), inside the timed region")
+
+    def gather_all():
+        if comm is not None:
+            g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, slot)
+            if g_info.any() or not all_succ:
+                raise SystemExit("sites workload: a rank reported a failed message")
+            return np.concatenate([g_norm[r, :shard_range(nprob, r, world)[1] - shard_range(nprob, r, world)[0]] for r in range(world)])
+        check(lib.pgbp_fetch_loglik(eng, L.f64p(norm), L.i32p(info)))
+        if info.any():
+            raise SystemExit("sites workload: a failed message")
+        return gather_sites(norm, nprob, dist if world > 1 else None, device="cpu")
+    full = None
+
+    def one_sharded_step():
+        nonlocal full
+        check(lib.pgbp_enqueue_calibrate(eng, 1, 0, C.byref(opts)))
+        check(enqueue_ll(eng, 1, C.byref(opts)))
+        full = gather_all()
+    for _ in range(max(1, args.warmup)):
+        one_sharded_step()
+
+    def k_sharded_steps():
+        for _ in range(args.steps):
+            one_sharded_step()
+    dt_sh = timed_region(k_sharded_steps, dist, torch.cuda.synchronize)
+    rel_all = float(np.max(np.abs(full[lo:hi] - ll_check) / np.maximum(1.0, np.abs(ll_check))))
+    if rel_all > 1e-8:
+        raise SystemExit(f"parity gate failed (sites, gathered): max rel err {rel_all:.3e}")
+    # calibrate!() alone
     check(lib.pgbp_enqueue_calibrate(eng, args.warmup, 0, C.byref(opts)))
 
     def k_steps():
         check(lib.pgbp_enqueue_calibrate(eng, args.steps, 0, C.byref(opts)))
         check(lib.pgbp_sync(eng))
     dt = timed_region(k_steps, dist, torch.cuda.synchronize)
+    if comm is not None:
+        comm.close()
     # log-likelihood evaluations (device factor fill + postorder + root integrate) of all local problems per second
     ms_ll = C.c_float()
     check(lib.pgbp_time_enqueued(eng, ll_kind, 3, 0, C.byref(opts), C.byref(ms_ll)))
@@ -270,59 +344,41 @@ def run_sites(args, torch, dist, rank, world, local_rank):
     check(lib.pgbp_time_message_kernels(eng, 1, C.byref(opts), C.byref(ms_k), C.byref(nl_k)))
     n_launches_per_cal = int(nl_k.value)
     sites_traffic = load_pmc_traffic("pmc_traffic_sites_latest.json")
-    default_size = (world == 1 and args.sites == 1000 and args.site_traits == 8 and args.ntips == 20000 and ou
-                    and args.seed == 3)
-    # the one collective of this configuration: all ranks get every problem's log-likelihood
-    rehearsal = os.environ.get("PGBP_BENCH_REHEARSAL") == "1"
-    full, gather_via = None, "single rank"
-    if world > 1 and dist is not None and not rehearsal:
-        # behind the C ABI: ONE ncclAllGather carrying every rank's log-likelihoods, info words and (succ, iscal); outside
-        # the timed region -- should the library's own communicator not come up on this node, every rank falls back to
-        # the launcher's torch.distributed group and the line says so
-        err = None
-        try:
-            comm = make_comm(dist, torch, rank, world, local_rank)
-            check(enqueue_ll(eng, 1, C.byref(opts)))
-            slot = -(-nprob // world)
-            g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, slot)
-            comm.close()
-            if g_info.any() or not all_succ:
-                raise SystemExit("sites workload: a rank reported a failed message")
-            full = np.concatenate([g_norm[r, :shard_range(nprob, r, world)[1] - shard_range(nprob, r, world)[0]] for r in range(world)])
-        except Exception as ex:   # noqa: BLE001 (reported in the JSON line)
-            err = f"{type(ex).__name__}: {ex}"
-        okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
-        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-        if int(okf.item()) == 1:
-            gather_via = "pgbp_comm (one ncclAllGather behind the C ABI)"
-        else:
-            full = None
-            gather_via = f"torch.distributed all_gather (pgbp_comm did not come up on this rank or another: {err})"
-    if full is None:
-        full = gather_sites(norm, nprob, dist, device="cpu" if rehearsal else f"cuda:{local_rank}")
+    default_size = (args.sites == 1000 and args.site_traits == 8 and args.ntips == 20000 and ou and args.seed == 4)
     total_msgs = msgs_per_cal / max(1, ns) * nprob        # same per-problem count on every rank
-    if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        print(json.dumps({
-            "metric": "clique-tree messages/sec (calibrate!), independent univariate sites sharded across GPUs",
-            "value": total_msgs * args.steps / dt, "unit": "messages/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg4: {args.sites} sites x {args.site_traits} traits = {nprob} independent univariate "
-                                   f"{'OU' if ou else 'BM'} problems, {args.ntips}-tip tree, clique tree, sharded over "
-                                   f"{world} rank(s); one all-gather of per-problem log-likelihoods",
-                       "problems_per_rank": ns, "messages_per_problem_per_step": int(msgs_per_cal // max(1, ns))},
-            "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / 8000.0,
-                         # PMC passes of the default-size run (8000 problems, 20 000 tips); not valid for other sizes
-                         "traffic": (sites_traffic or {}).get("hbm_bytes_per_launch") if default_size else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
-                                         "profiles/pmc_traffic_sites_latest.json)",
-                         "algorithmic_bytes_per_launch": bytes_per_cal / max(1, n_launches_per_cal),
-                         "kernel": "bp_level_uni1", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate"},
-            "ll_evals_per_s": world * ns * 3 / (ms_ll.value * 1e-3),
-            "ll_eval_note": "problem log-likelihoods per second: device factor fill + postorder + root integrate (score() body)",
-            "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": rel, "loglik_gather": gather_via}))
+    if rank != 0:
+        return None
+    ms_step, ms_cal = dt_sh / args.steps * 1e3, dt / args.steps * 1e3
+    out = {
+        "metric": "clique-tree messages/sec (calibrate!), independent univariate sites sharded across GPUs",
+        "value": total_msgs * args.steps / dt_sh, "unit": "messages/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg4: {args.sites} sites x {args.site_traits} traits = {nprob} independent univariate "
+                               f"{'OU' if ou else 'BM'} problems, {args.ntips}-tip tree (seed {args.seed}), clique tree, sharded over "
+                               f"{world} rank(s); step = calibrate! + score() body (device factor fill, postorder, root "
+                               f"integrate) + one all-gather of the per-problem log-likelihoods",
+                   "problems_per_rank": ns, "messages_per_problem_per_step": int(msgs_per_cal // max(1, ns))},
+        "sharded_step": {"ms_per_step": ms_step, "problem_logliks_per_s": nprob * args.steps / dt_sh,
+                         "calibrate_messages_per_s": total_msgs * args.steps / dt_sh, "collective_in_timed_region": world > 1,
+                         "loglik_gather": gather_via},
+        "calibrate_only": {"ms_per_step": ms_cal, "messages_per_s": total_msgs * args.steps / dt,
+                           "note": "calibrate!() alone, K times back to back: the hot path without its exchange step"},
+        "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_cal * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": bytes_per_cal / (ms_cal * 1e-3) / 1e9 / 8000.0,
+                     # PMC passes of the default-size run on ONE rank (8000 problems, 20 000 tips); not valid for other sizes
+                     "traffic": (sites_traffic or {}).get("hbm_bytes_per_launch") if (default_size and world == 1) else None,
+                     "traffic_stale": (sites_traffic or {}).get("stale") if (default_size and world == 1) else None,
+                     "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                                     "profiles/pmc_traffic_sites_latest.json)",
+                     "algorithmic_bytes_per_launch": bytes_per_cal / max(1, n_launches_per_cal),
+                     "kernel": "bp_level_uni1", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate (calibrate_only)"},
+        "ll_evals_per_s": world * ns * 3 / (ms_ll.value * 1e-3),
+        "ll_eval_note": "problem log-likelihoods per second: device factor fill + postorder + root integrate (score() body)",
+        "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": max(rel, rel_all), "loglik_gather": gather_via}
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 def build_network_workload(args, rank):
@@ -490,7 +546,11 @@ def main():
                     "moral graph has cliques of at most 4 nodes: 3 is the largest bound under which the join graph is loopy)")
     ap.add_argument("--blob-style", default="varied", choices=["varied", "template"], help="network workload: random blobs "
                     "of level <= 3 (default) or copies of the reference's level-3 test blob")
-    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--seed", type=int, default=None, help="default: SURVEY.md section 8(d)'s recorded seeds -- 3 (tree workload: cfg3), "
+                    "4 (sites workload: cfg4), 5 (network workload: cfg5)")
+    ap.add_argument("--no-sites-block", action="store_true",
+                    help="tree workload at the cfg3 size: skip the site_sharded_cfg4 block (the site-sharded configuration, strong scaling, "
+                         "with its all-gather inside the timed region) that the default line carries for every --gpus N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-reading", action="store_true",
                     help="skip the 25001-tip (50k-clique) side measurement: profiler runs want one workload per kernel name")
@@ -511,6 +571,8 @@ def main():
         args.graph = "joingraph" if args.workload == "network" else "cliquetree"
     if args.blobs is None:
         args.blobs = (args.ntips + 11) // 12
+    if args.seed is None:
+        args.seed = {"tree": 3, "sites": 4, "network": 5}[args.workload]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the launcher as a CHILD process (this process has not
@@ -601,7 +663,6 @@ def main():
     check(lib.pgbp_fetch_kernel_time(eng, C.byref(ms_k), C.byref(nl_k)))
 
     # after the timed region: no message failed, and the calibrated beliefs still integrate to the right log-likelihood
-    res = (L.Result * 1)()
     mu_, n2, i2 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
     rel2 = abs(n2[0] - ll_check) / max(1.0, abs(ll_check))
     if not (i2[0] == 0 and rel2 <= 1e-8) and not skip_parity:
@@ -609,27 +670,11 @@ def main():
     ranks_loglik, ranks_gather = None, None
     if world > 1 and dist is not None and os.environ.get("PGBP_BENCH_REHEARSAL") != "1":
         # N > 1 (replicas): every rank's log-likelihood and success flag reach every rank in ONE ncclAllGather behind the
-        # C ABI (pgbp_comm).  This check sits outside the timed region: should the library's own communicator not come up
-        # on this node, every rank falls back to the launcher's torch.distributed group and the line says so.
-        err, g_norm, g_info, all_succ = None, None, None, False
-        try:
-            comm = make_comm(dist, torch, rank, world, local_rank)
-            g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, 1)
-            comm.close()
-        except Exception as ex:   # noqa: BLE001 (reported in the JSON line)
-            err = f"{type(ex).__name__}: {ex}"
-        okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
-        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-        if int(okf.item()) == 1:
-            ranks_gather = "pgbp_comm (one ncclAllGather behind the C ABI)"
-        else:
-            mine = torch.tensor([float(n2[0]), float(i2[0])], dtype=torch.float64, device=f"cuda:{local_rank}")
-            parts = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            g_norm = np.array([[float(q[0].item())] for q in parts])
-            g_info = np.array([[int(q[1].item())] for q in parts])
-            all_succ = True
-            ranks_gather = f"torch.distributed all_gather (pgbp_comm did not come up on this rank or another: {err})"
+        # C ABI (pgbp_comm).  A communicator that does not come up raises on every rank: the run exits non-zero.
+        comm = make_comm(dist, torch, rank, world, local_rank)
+        g_norm, g_info, all_succ, _ = comm.gather_loglik(eng, 1)
+        comm.close()
+        ranks_gather = "pgbp_comm (one ncclAllGather behind the C ABI)"
         if g_info.any() or not all_succ:
             raise SystemExit("a rank reported a failed message after the timed region")
         ranks_loglik = [float(v) for v in g_norm[:, 0]]
@@ -681,6 +726,8 @@ def main():
                          # algorithmic bytes): what fraction of the peak the chip actually streamed
                          "frac_physical": (traffic * launches_pmc * reps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic": traffic,
+                         # true: profiles/pmc_traffic_latest.json was reduced from another state of csrc/ than the one running
+                         "traffic_stale": (pmc or {}).get("stale"),
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
                                          "profiles/pmc_traffic_latest.json)",
                          "algorithmic_bytes_per_launch": bytes_per_cal / max(1, nl.value // reps),
@@ -765,6 +812,19 @@ def main():
             if out["cpu_baseline"].get("value"):
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     barrier()
+    if not args.no_sites_block and (args.traits, args.ntips, args.graph) == (16, 50000, "cliquetree"):
+        # BASELINE.json configs[3] (cfg4), the configuration north_star's ">= 6x at 8 GPUs" is quoted on, beside the
+        # headline for EVERY N: 8000 univariate OU problems sharded over the N ranks (strong scaling), step = calibrate! +
+        # score() body + the all-gather, the collective inside the timed region (run_sites)
+        cgb = None
+        sargs = argparse.Namespace(**vars(args))
+        sargs.sites, sargs.site_traits, sargs.ntips, sargs.seed, sargs.site_model = 1000, 8, 20000, 4, "ou"
+        blk = run_sites(sargs, torch, dist, rank, world, local_rank, emit=False)
+        if rank == 0:
+            out["site_sharded_cfg4"] = {k: blk[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config",
+                                                            "sharded_step", "calibrate_only", "roofline",
+                                                            "loglik_max_rel_err_vs_pruning")}
+        barrier()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

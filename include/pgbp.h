@@ -163,6 +163,9 @@ int  pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_fac
 int  pgbp_get_beliefs(pgbp_engine* e, double* packed);
 int  pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* rec); /* J,h,g of one belief */
 int  pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec);
+/* all beliefs of ONE site (packed: pgbp_packed_size doubles): what a host reads back into the arrays of one
+ * ClusterGraphBelief of a batch without downloading the other sites */
+int  pgbp_get_site_beliefs(pgbp_engine* e, int32_t site, double* packed);
 /* init_factors_frombeliefs! (src/beliefs.jl:746-761) */
 int  pgbp_init_factors_frombeliefs(pgbp_engine* e);
 /* init_beliefs_reset_fromfactors! (src/clustergraphbeliefs.jl:126-139) */
@@ -382,7 +385,8 @@ int  pgbp_group_sync(pgbp_group* g);
 
 /* (2) ONE PROCESS PER GPU (torchrun / MPI / Distributed.jl).  Every rank owns an ordinary engine over its own sites;
  * the only exchange is ONE ncclAllGather (RCCL over xGMI) per pgbp_comm_gather_loglik call.  RCCL is bound at run time
- * (dlopen of librccl.so.1); without it the calls return PGBP_ERR_NO_DEVICE.
+ * (dlopen of librccl.so.1, or of the one path in the environment variable PGBP_RCCL_LIB); without it the calls return
+ * PGBP_ERR_NO_DEVICE.
  * Rank 0 calls pgbp_comm_unique_id and hands the PGBP_COMM_ID_BYTES to the other ranks by whatever channel launched
  * them; every rank then calls pgbp_comm_create (ncclCommInitRank: collective, blocks until all ranks arrived). */
 #define PGBP_COMM_ID_BYTES 128
@@ -400,6 +404,15 @@ const char* pgbp_comm_last_error(const pgbp_comm* c);
  * stream behind the kernels that produce the values; returns after the result reached the host. */
 int  pgbp_comm_gather_loglik(pgbp_comm* c, pgbp_engine* e, int32_t slot_sites, double* norm_all, int32_t* info_all,
                              int32_t* all_succ, int32_t* all_iscal);
+/* What can fail on THIS rank before the collective pgbp_comm_create (RCCL not loadable, no such device), without
+ * touching the other ranks: a launcher takes the minimum of (status == 0) over its ranks and only then lets every rank
+ * enter pgbp_comm_create -- a rank that fails there alone would leave its peers blocked inside ncclCommInitRank. */
+int  pgbp_comm_precheck(int32_t device);
+/* The host-side half of pgbp_comm_gather_loglik on its own (no GPU, no RCCL): recv = the gathered buffer, n_ranks slots
+ * of 2 * slot_sites + 2 doubles each, a slot = [norm (slot_sites) | info (slot_sites) | succ | iscal] as a rank packs it;
+ * outputs as for pgbp_comm_gather_loglik. */
+int  pgbp_comm_unpack_slots(const double* recv, int32_t n_ranks, int32_t slot_sites, double* norm_all, int32_t* info_all,
+                            int32_t* all_succ, int32_t* all_iscal);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,7 @@ SYMBOLS = {
     "pgbp_belief_dim": (C.c_int32, [_P, C.c_int32]),
     "pgbp_set_beliefs": (C.c_int, [_P, _F64P, C.c_int32]),
     "pgbp_get_beliefs": (C.c_int, [_P, _F64P]),
+    "pgbp_get_site_beliefs": (C.c_int, [_P, C.c_int32, _F64P]),
     "pgbp_set_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
     "pgbp_get_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
     "pgbp_init_factors_frombeliefs": (C.c_int, [_P]),
@@ -149,6 +150,8 @@ SYMBOLS = {
     "pgbp_comm_destroy": (None, [_P]),
     "pgbp_comm_last_error": (C.c_char_p, [_P]),
     "pgbp_comm_gather_loglik": (C.c_int, [_P, _P, C.c_int32, _F64P, _I32P, _I32P, _I32P]),
+    "pgbp_comm_precheck": (C.c_int, [C.c_int32]),
+    "pgbp_comm_unpack_slots": (C.c_int, [_F64P, C.c_int32, C.c_int32, _F64P, _I32P, _I32P, _I32P]),
 }
 
 _lib = None

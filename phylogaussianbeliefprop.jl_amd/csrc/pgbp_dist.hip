@@ -247,13 +247,25 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    // by soname: the copy already mapped into the process (PyTorch ships one) is returned if there is one
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    // by soname: the copy already mapped into the process (PyTorch ships one) is returned if there is one.
+    // PGBP_RCCL_LIB=<path> names the one library to try instead (a site with its own build; the test of this very path)
+    std::string last;
+    auto try_open = [&](const char* name) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.lib) break;
+      if (!r.lib) {
+        const char* m = dlerror();   // (read ONCE: glibc clears the message on the first call)
+        last = m ? m : "";
+      }
+      return r.lib != nullptr;
+    };
+    if (const char* forced = getenv("PGBP_RCCL_LIB")) {
+      (void)try_open(forced);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if (try_open(name)) break;
     }
     if (!r.lib) {
-      r.err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "");
+      r.err = std::string("RCCL not found (dlopen librccl.so.1): ") + last;
       return;
     }
     r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.lib, "ncclGetUniqueId");
@@ -299,6 +311,39 @@ int pgbp_comm_unique_id(uint8_t* id128) {
     return PGBP_ERR_HIP;
   }
   std::memcpy(id128, &id, sizeof(id));
+  return PGBP_OK;
+}
+
+int pgbp_comm_precheck(int32_t device) {
+  Rccl& r = rccl();
+  if (!r.err.empty()) {
+    g_comm_create_error = r.err;
+    return PGBP_ERR_NO_DEVICE;
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    g_comm_create_error = "pgbp_comm_precheck: no device " + std::to_string(device) + " (" + std::to_string(n) + " visible)";
+    return PGBP_ERR_NO_DEVICE;
+  }
+  return PGBP_OK;
+}
+
+int pgbp_comm_unpack_slots(const double* recv, int32_t n_ranks, int32_t slot_sites, double* norm_all, int32_t* info_all,
+                           int32_t* all_succ, int32_t* all_iscal) {
+  if (!recv || n_ranks < 1 || slot_sites < 1 || !norm_all) return PGBP_ERR_INVALID;
+  const int64_t slot = 2 * (int64_t)slot_sites + 2;
+  int succ = 1, iscal = 1;
+  for (int r = 0; r < n_ranks; ++r) {
+    const double* s = recv + (size_t)r * slot;
+    for (int i = 0; i < slot_sites; ++i) {
+      norm_all[(size_t)r * slot_sites + i] = s[i];
+      if (info_all) info_all[(size_t)r * slot_sites + i] = (int32_t)s[slot_sites + i];
+    }
+    succ = std::min(succ, (int)s[2 * slot_sites]);
+    iscal = std::min(iscal, (int)s[2 * slot_sites + 1]);
+  }
+  if (all_succ) *all_succ = succ;
+  if (all_iscal) *all_iscal = iscal;
   return PGBP_OK;
 }
 
@@ -380,18 +425,8 @@ int pgbp_comm_gather_loglik(pgbp_comm* c, pgbp_engine* e, int32_t slot_sites, do
     c->err = "copy of the gathered log-likelihoods failed";
     return PGBP_ERR_HIP;
   }
-  int succ = 1, iscal = 1;
-  for (int r = 0; r < c->n_ranks; ++r) {
-    const double* s = c->h_recv.data() + (size_t)r * slot;
-    for (int i = 0; i < slot_sites; ++i) {
-      norm_all[(size_t)r * slot_sites + i] = s[i];
-      if (info_all) info_all[(size_t)r * slot_sites + i] = (int32_t)s[slot_sites + i];
-    }
-    succ = std::min(succ, (int)s[2 * slot_sites]);
-    iscal = std::min(iscal, (int)s[2 * slot_sites + 1]);
-  }
-  if (all_succ) *all_succ = succ;
-  if (all_iscal) *all_iscal = iscal;
+  const int urc = pgbp_comm_unpack_slots(c->h_recv.data(), c->n_ranks, slot_sites, norm_all, info_all, all_succ, all_iscal);
+  if (urc) return urc;
   return PGBP_OK;
 }
 

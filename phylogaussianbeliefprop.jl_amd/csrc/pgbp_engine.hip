@@ -195,9 +195,7 @@ DevState dev_state(pgbp_engine* e, const pgbp_opts* o) {
   S.n_msgs = e->plan.n_msgs();
   S.update_resnorm = o ? o->update_residualnorm : 1;
   S.atol = o ? o->atol : 1e-5;
-  if (ensure_thresholds(e, S.atol) != PGBP_OK) {  // (the error text is set; the launch that follows reports it through hipGetLastError)
-    e->thr_valid = false;
-  }
+  // (DevState::thr belongs to this tolerance: every entry point went through check_opts -> ensure_thresholds first)
   S.thr = e->d_thr;
   S.logtab = reinterpret_cast<const double2*>(e->d_logtab);
   const int sp = e->plan.fast_p > 0 ? e->plan.fast_p : 0;
@@ -331,12 +329,19 @@ void free_traversals(pgbp_engine* e) {
   e->d_tail.clear();
 }
 
+constexpr int kKlMaxS = 96;  // residual_kldiv_kernel: [J0 | dJ | h0] of one sepset in a CU's LDS
+
+// Every entry point that launches a message kernel comes through here BEFORE its first launch: the options are sane and
+// the threshold table of DevState::thr is the one of this tolerance (a failed upload is this call's error, not a launch
+// with whatever the table held).
 int check_opts(pgbp_engine* e, const pgbp_opts* o) {
   if (o && !(o->atol >= 0.0)) return e->fail(PGBP_ERR_INVALID, "pgbp_opts.atol must be >= 0");
-  if (o && o->update_residualkldiv && e->max_s > 96)
-    return e->fail(PGBP_ERR_TOO_LARGE, "update_residualkldiv needs sepsets of dimension <= 96 (this graph: " +
-                                           std::to_string(e->max_s) + ")");
-  return PGBP_OK;
+  if (o && o->update_residualkldiv && e->max_s > kKlMaxS)
+    return e->fail(PGBP_ERR_TOO_LARGE, "update_residualkldiv needs sepsets of dimension <= " + std::to_string(kKlMaxS) +
+                                           " (this graph: " + std::to_string(e->max_s) + ")");
+  const int rc = ensure_thresholds(e, o ? o->atol : 1e-5);
+  if (rc != PGBP_OK) e->thr_valid = false;
+  return rc;
 }
 
 unsigned long long seq_stride(const pgbp_engine* e) {
@@ -414,7 +419,9 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
     if (launches) *launches += (nf > 0) + (nt - nf - nbig > 0) + (nbig > 0);
     if (kl) {  // residual_kldiv! right after the messages of the level (src/calibration.jl:128,154)
       const int e0 = tr.task_off[t0], e1 = tr.task_off[t0 + nt];
-      launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, e->max_s, e->d_kldiv, e->d_klflags, e->plan.n_sites,
+      int level_s = 0;   // the largest sepset of THIS level's messages sizes the launch's LDS, not the graph's largest
+      for (int q = e0; q < e1; ++q) level_s = std::max(level_s, (int)e->plan.msgs[tr.entries[q].msg].s);
+      launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, level_s, e->d_kldiv, e->d_klflags, e->plan.n_sites,
                             stop_below, e->st);
     }
   }
@@ -714,6 +721,27 @@ int pgbp_get_beliefs(pgbp_engine* e, double* packed) {
   return PGBP_OK;
 }
 
+int pgbp_get_site_beliefs(pgbp_engine* e, int32_t site, double* packed) {
+  DeviceScope device_scope(e);
+  if (!e || !packed) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  if (site < 0 || site >= p.n_sites) return e->fail(PGBP_ERR_INVALID, "site index out of range");
+  {
+    int rc0 = ensure_layout(e, false);
+    if (rc0) return rc0;
+  }
+  const int64_t psz = p.packed_off.back();
+  double* stage = nullptr;
+  HIPCHK(e, hipMalloc((void**)&stage, sizeof(double) * (size_t)std::max<int64_t>(1, psz)));
+  launch_records(e->d_pool + (int64_t)site * p.pool_stride(), p.pool_stride(), e->d_boff, stage, psz, e->d_packed_off,
+                 e->d_packed_off, p.n_beliefs(), 1, e->st);
+  hipError_t rc = hipMemcpyAsync(packed, stage, sizeof(double) * (size_t)psz, hipMemcpyDeviceToHost, e->st);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(e->st);
+  (void)hipFree(stage);
+  if (rc != hipSuccess) return e->fail(PGBP_ERR_HIP, std::string("pgbp_get_site_beliefs: ") + hipGetErrorString(rc));
+  return PGBP_OK;
+}
+
 static int belief_rec(pgbp_engine* e, int32_t site, int32_t b, double** dptr, int64_t* len) {
   const Plan& p = e->plan;
   if (site < 0 || site >= p.n_sites || b < 0 || b >= p.n_beliefs())
@@ -891,11 +919,15 @@ int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int3
   else
     return e->fail(PGBP_ERR_INVALID, "pgbp_residual_kldiv: the sepset does not connect these two clusters");
   Entry en{2 * k + dir, 0, 0, 0};
+  const int s_msg = p.msgs[en.msg].s;
+  if (s_msg > kKlMaxS)   // whatever opts says: the kernel holds this sepset's [J0 | dJ | h0] in LDS
+    return e->fail(PGBP_ERR_TOO_LARGE, "pgbp_residual_kldiv needs a sepset of dimension <= " + std::to_string(kKlMaxS) +
+                                           " (this one: " + std::to_string(s_msg) + ")");
   HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
   if (e->layout_sm && (rc = ensure_site_minor(e, false))) return rc;
   DevState S = dev_state(e, opts);
   // a standalone call always computes (stop_below = 0; the status of the last attempt of this message still gates)
-  launch_residual_kldiv(S, e->d_one_entry, 0, 1, e->max_s, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st);
+  launch_residual_kldiv(S, e->d_one_entry, 0, 1, s_msg, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st);
   if (iscalibrated_kl) {
     std::vector<int32_t> all((size_t)p.n_sites * std::max(1, p.n_msgs()));
     HIPCHK(e, hipMemcpyAsync(all.data(), e->d_klflags, sizeof(int32_t) * (size_t)p.n_sites * p.n_msgs(),

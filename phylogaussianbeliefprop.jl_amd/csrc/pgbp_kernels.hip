@@ -797,10 +797,9 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
 static void allow_large_lds(const void* kernel, size_t bytes) {
   // more than 64 KB of dynamic LDS is asked for explicitly (what the launch needs, not the device maximum: a kernel
   // with static LDS of its own would be refused the full 160 KB, and a refused attribute call is a sticky HIP error)
-  if (bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    (void)hipGetLastError();
-  }
+  // (only the call's own status is looked at: the thread's last-error word may hold an earlier launch's failure, which
+  // the entry point still has to report)
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,

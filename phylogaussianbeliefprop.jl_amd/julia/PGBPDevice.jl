@@ -93,6 +93,13 @@ function pull!(o::DeviceClusterGraphBelief)
     end
 end
 
+"all beliefs of one site of a batched engine (several sites sharing topology and scopes), packed like `o.packed`"
+function site_beliefs(o::DeviceClusterGraphBelief, site::Integer)
+    out = zeros(o.offsets[end])
+    check(o.handle, @ccall LIB.pgbp_get_site_beliefs(o.handle::Ptr{Cvoid}, Int32(site - 1)::Int32, out::Ptr{Float64})::Cint)
+    return out
+end
+
 function set_schedule!(o::DeviceClusterGraphBelief, schedule)
     o.schedule_set === schedule && return
     off = Int32[0]; pa = Int32[]; ch = Int32[]
@@ -389,6 +396,9 @@ function comm_unique_id()
     rc == 0 || error(unsafe_string(@ccall LIB.pgbp_comm_last_error(C_NULL::Ptr{Cvoid})::Cstring))
     return id
 end
+"0 if this rank can open its communicator (RCCL loadable, the device exists): agree on the minimum over the ranks
+BEFORE the collective `comm_create` -- a rank that failed there alone would leave its peers inside ncclCommInitRank"
+comm_precheck(device::Integer) = @ccall LIB.pgbp_comm_precheck(device::Int32)::Cint
 function comm_create(id::Vector{UInt8}, n_ranks::Integer, rank::Integer, device::Integer)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = @ccall LIB.pgbp_comm_create(id::Ptr{UInt8}, n_ranks::Int32, rank::Int32, device::Int32, h::Ref{Ptr{Cvoid}})::Cint

@@ -137,24 +137,45 @@ class EngineGroup:
 
 
 class Comm:
-    """pgbp_comm: one process per GPU; ONE ncclAllGather (RCCL) per gather_loglik call.  `bcast(bytes_or_None) -> bytes`
-    carries rank 0's unique id to the other ranks (e.g. a torch.distributed / MPI broadcast); unused for n_ranks == 1."""
+    """pgbp_comm: one process per GPU; ONE ncclAllGather (RCCL) per gather_loglik call.
+    `bcast(bytes_or_None) -> bytes` carries rank 0's message (a status byte + the unique id) to the other ranks and
+    `allmin(int) -> int` the minimum of an integer over the ranks (e.g. torch.distributed / MPI collectives of the group
+    that launched the ranks); both unused for n_ranks == 1.  Every rank takes part in BOTH collectives whatever happened
+    to it locally and all ranks raise together: a rank that gave up alone would leave its peers inside a collective
+    (the launcher's broadcast, or ncclCommInitRank, which blocks until every rank has arrived)."""
 
-    def __init__(self, n_ranks, rank, device, bcast=None):
+    ID_BYTES = 128
+
+    def __init__(self, n_ranks, rank, device, bcast=None, allmin=None):
         import ctypes as C
         from . import _lib as L
         self._C, self._L = C, L
         self.lib = L.load()
         self.n_ranks, self.rank = int(n_ranks), int(rank)
-        ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            code = self.lib.pgbp_comm_unique_id(ident)
-            if code != 0:
-                raise L.PgbpError(code, self.lib.pgbp_comm_last_error(None).decode())
-        if n_ranks > 1:
-            raw = bcast(bytes(ident) if rank == 0 else None)
-            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         self._c = C.c_void_p()
+        # 1. what can fail on this rank alone (RCCL not loadable, no such device), agreed on by all ranks
+        code = self.lib.pgbp_comm_precheck(int(device))
+        why = self.lib.pgbp_comm_last_error(None).decode() if code != 0 else ""
+        if n_ranks > 1 and allmin is not None:
+            if allmin(1 if code == 0 else 0) == 0:
+                raise L.PgbpError(code or L.ERR_NO_DEVICE, why or "pgbp_comm: another rank cannot open its communicator")
+        elif code != 0:
+            raise L.PgbpError(code, why)
+        # 2. rank 0's unique id: the broadcast always runs; a failure travels in the status byte
+        ident = (C.c_uint8 * self.ID_BYTES)()
+        status, msg = 0, ""
+        if rank == 0:
+            status = self.lib.pgbp_comm_unique_id(ident)
+            if status != 0:
+                msg = self.lib.pgbp_comm_last_error(None).decode()
+                ident = (C.c_uint8 * self.ID_BYTES)()
+        if n_ranks > 1:
+            raw = bcast((bytes([min(255, abs(int(status)))]) + bytes(ident)) if rank == 0 else None)
+            status = raw[0]
+            ident = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(raw[1:1 + self.ID_BYTES])
+        if status != 0:
+            raise L.PgbpError(int(status), msg or "pgbp_comm_unique_id failed on rank 0")
+        # 3. the collective create
         code = self.lib.pgbp_comm_create(ident, self.n_ranks, self.rank, int(device), C.byref(self._c))
         if code != 0:
             raise L.PgbpError(code, self.lib.pgbp_comm_last_error(None).decode())
@@ -175,3 +196,21 @@ class Comm:
         if code != 0:
             raise L.PgbpError(code, self.lib.pgbp_comm_last_error(self._c).decode())
         return norm, info, bool(succ.value), bool(iscal.value)
+
+
+def unpack_slots(recv, n_ranks, slot_sites):
+    """pgbp_comm_unpack_slots: the host half of pgbp_comm_gather_loglik on a gathered buffer
+    -> (norm [n_ranks, slot_sites], info, all_succ, all_iscal)"""
+    import ctypes as C
+    from . import _lib as L
+    lib = L.load()
+    recv = np.ascontiguousarray(recv, dtype=np.float64)
+    assert recv.size == n_ranks * (2 * slot_sites + 2)
+    norm = np.zeros((n_ranks, slot_sites))
+    info = np.zeros((n_ranks, slot_sites), np.int32)
+    succ, iscal = C.c_int32(), C.c_int32()
+    code = lib.pgbp_comm_unpack_slots(L.f64p(recv), int(n_ranks), int(slot_sites), L.f64p(norm), L.i32p(info),
+                                      C.byref(succ), C.byref(iscal))
+    if code != 0:
+        raise L.PgbpError(code, "pgbp_comm_unpack_slots")
+    return norm, info, bool(succ.value), bool(iscal.value)

@@ -110,3 +110,99 @@ def test_gpus_flag_never_prints_a_figure_for_another_world_size():
     assert out.returncode != 0
     assert "--gpus 2 but WORLD_SIZE=1" in (out.stderr + out.stdout)
     assert '"metric"' not in out.stdout
+
+
+def test_unpack_of_two_fabricated_rank_slots():
+    """The host half of pgbp_comm_gather_loglik (pgbp_comm_unpack_slots, no GPU / RCCL needed) on the buffer two ranks
+    would have gathered: 11 sites split 6 + 5 in slots of 6, a failed site on rank 1 (info word, succ = 0)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import pgbp_amd  # noqa: F401
+    from pgbp_amd.sharding import shard_range, unpack_slots
+    n_total, world = 11, 2
+    slot = -(-n_total // world)
+    ll = np.arange(n_total) * -2.5 - 100.0
+    recv = np.zeros((world, 2 * slot + 2))
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        recv[r, : hi - lo] = ll[lo:hi]
+        recv[r, 2 * slot] = 1.0          # succ
+        recv[r, 2 * slot + 1] = 1.0      # iscal
+    recv[1, slot + 3] = 7.0              # rank 1, its 4th site: PosDefException.info = 7
+    recv[1, 2 * slot] = 0.0              # ... so that rank's calibration did not succeed
+    recv[0, 2 * slot + 1] = 0.0          # rank 0 not calibrated
+    norm, info, succ, iscal = unpack_slots(recv.reshape(-1), world, slot)
+    full = np.concatenate([norm[r, : shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0]] for r in range(world)])
+    assert full.tolist() == ll.tolist()
+    assert norm[1, 5] == 0.0                        # the unused tail of the shorter rank's slot
+    assert info[1, 3] == 7 and int(np.count_nonzero(info)) == 1
+    assert succ is False and iscal is False
+    recv[1, 2 * slot] = 1.0
+    recv[0, 2 * slot + 1] = 1.0
+    _, _, succ, iscal = unpack_slots(recv.reshape(-1), world, slot)
+    assert succ is True and iscal is True
+
+
+def test_rccl_not_found_is_an_error_code_not_a_crash():
+    """the RCCL-not-found path read dlerror() twice (the second call returns NULL: a segfault).  A child
+    process points the loader at a library that does not exist and must get PGBP_ERR_NO_DEVICE plus a message."""
+    import subprocess
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); import pgbp_amd; from pgbp_amd import _lib as L; lib = L.load();"
+            "ident = (C.c_uint8 * 128)(); rc = lib.pgbp_comm_unique_id(ident); msg = lib.pgbp_comm_last_error(None).decode();"
+            "h = C.c_void_p(); rc2 = lib.pgbp_comm_create(ident, 1, 0, 0, C.byref(h)); rc3 = lib.pgbp_comm_precheck(0);"
+            "print(rc, rc2, rc3, msg)") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PGBP_RCCL_LIB="/nonexistent/librccl.so.1"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr[-800:])
+    rc, rc2, rc3, msg = out.stdout.strip().split(" ", 3)
+    assert (rc, rc2, rc3) == ("5", "5", "5")          # PGBP_ERR_NO_DEVICE
+    assert "RCCL not found" in msg and "/nonexistent/librccl.so.1" in msg
+
+
+def _comm_fail_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    if rank == 1:
+        os.environ["PGBP_RCCL_LIB"] = "/nonexistent/librccl.so.1"   # only this rank cannot open its communicator
+    import pgbp_amd  # noqa: F401
+    from pgbp_amd import _lib as L
+    from pgbp_amd.sharding import Comm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def bcast(raw):
+        t = torch.zeros(1 + Comm.ID_BYTES, dtype=torch.uint8)
+        if raw is not None:
+            t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.numpy().tobytes())
+
+    def allmin(v):
+        t = torch.tensor([int(v)], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+    try:
+        Comm(world, rank, 0, bcast, allmin)
+        q.put((rank, "created"))
+    except L.PgbpError as ex:
+        q.put((rank, f"PgbpError {ex.code}"))
+    dist.barrier()   # every rank is still in step with the launcher's group
+    dist.destroy_process_group()
+
+
+def test_comm_failure_on_one_rank_is_raised_by_every_rank():
+    """a rank that fails before the launcher's broadcast (or inside ncclCommInitRank) must not leave its
+    peers in a collective.  Rank 1 cannot load RCCL: both ranks raise the same error after the agreed minimum and go on
+    to the next collective of the launcher's group together (here, without a GPU, rank 0's own precheck fails as well;
+    what is tested is that nobody hangs and nobody proceeds alone)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1].startswith("PgbpError") and out[1][1].startswith("PgbpError")

@@ -953,8 +953,9 @@ def test_full_size_config_against_c_oracle(P, ntips, p, graph):
 def test_full_size_cfg4_sites_against_pruning_and_c_oracle(P):
     """BASELINE.json configs[3] at full size: 1000 sites x 8 traits = 8 000 independent univariate OU problems on a
     20 000-tip tree (site-minor layout, thread-per-site kernel, OU factors assigned on the device).  Every problem's
-    log-likelihood against the independent pruning recursion (1e-8 relative); 4 sampled problems belief by belief,
-    flag by flag against the plain-C sequential engine on factors pulled from the device; size-independent properties:
+    log-likelihood against the independent pruning recursion (1e-8 relative); 32 sampled problems belief by belief,
+    flag by flag against the plain-C sequential engine on factors pulled from the device, and 64 sampled (problem, cluster)
+    factors of the device fill against the oracle's assignfactors! formulas (1e-10); size-independent properties:
     a second calibration leaves the beliefs where they are, every flag is set, no message failed."""
     from oracle import cengine
     from pgbp_amd import synth as S
@@ -981,21 +982,39 @@ def test_full_size_cfg4_sites_against_pruning_and_c_oracle(P):
     assert lib.pgbp_fetch_loglik(cgb._eng, L.f64p(norm), L.i32p(info)) == 0
     assert not info.any()
     assert float(np.max(np.abs(norm - ll_ref) / np.maximum(1.0, np.abs(ll_ref)))) <= 1e-8
-    # factors of a sample of problems -> the sequential C engine
-    sample = np.random.default_rng(0).choice(nprob, size=4, replace=False)
+    # factors of a sample of 32 problems -> the sequential C engine (one download of the whole state, sliced on the host)
+    sample = np.random.default_rng(0).choice(nprob, size=32, replace=False)
     assert lib.pgbp_reset_from_factors(cgb._eng) == 0
     psz = int(lib.pgbp_packed_size(cgb._eng))
-    factors = {}
-    rec = np.zeros(psz)
     nb = len(prob.dims)
+    factors = {}
     for s_ in sample:
         buf = np.zeros(psz)
-        for b in range(nb):
-            ln = int(prob.packed_off[b + 1] - prob.packed_off[b])
-            if ln:
-                assert lib.pgbp_get_belief(cgb._eng, int(s_), b, L.f64p(rec)) == 0
-                buf[prob.packed_off[b]:prob.packed_off[b + 1]] = rec[:ln]
+        assert lib.pgbp_get_site_beliefs(cgb._eng, int(s_), L.f64p(buf)) == 0    # one site of the batch, packed
         factors[int(s_)] = buf
+    # the device factor fill at full size against the ORACLE's assignfactors! formulas (oracle/models.py: the OU
+    # factor_treeedge, absorbleaf, absorbevidence at the fixed root): 64 sampled (problem, cluster) pairs
+    import types
+    from oracle import beliefupdates as OBU
+    from oracle import models as OM
+    frng = np.random.default_rng(1)
+    for _ in range(64):
+        s_ = int(sample[frng.integers(len(sample))])
+        c = int(frng.integers(1, tr.nnodes))                      # cluster c - 1 = {node c, its parent}
+        model = OM.UnivariateOrnsteinUhlenbeck(sigma2[s_], alpha[s_], theta[s_], mu[s_], 0.0)
+        phi = model.factor_treeedge(types.SimpleNamespace(length=float(tr.length[c]), gamma=1.0, number=c))
+        if tr.is_leaf[c]:
+            phi = OBU.absorbleaf(*phi, [float(X[s_, c])], rowlabel=c)
+        if tr.parent[c] == 0:
+            n = phi[0].shape[0]
+            phi, _ = OBU.absorbevidence(*phi, range(n - 1, n), [float(mu[s_])])
+        h_o, J_o, g_o = np.asarray(phi[0], float), np.asarray(phi[1], float), float(phi[2])
+        m = int(prob.dims[c - 1])
+        assert h_o.shape == (m,)
+        rec_ = factors[s_][prob.packed_off[c - 1]:prob.packed_off[c]]
+        ref_ = np.concatenate([J_o.reshape(-1, order="F"), h_o, [g_o]])
+        assert float(np.max(np.abs(rec_ - ref_))) <= 1e-10 * max(1.0, float(np.max(np.abs(ref_)))), (s_, c, rec_, ref_)
+    rec = np.zeros(psz)
     res = (L.Result * nprob)()
     assert lib.pgbp_calibrate(cgb._eng, 2, C.byref(opts), res) == 0
     assert all(res[i].succ == 1 and res[i].iscal == 1 for i in range(nprob))
@@ -1005,11 +1024,13 @@ def test_full_size_cfg4_sites_against_pruning_and_c_oracle(P):
         assert eng.calibrate(pa, ch, 2, return_iscal=True) == (True, True)
         ref = eng.packed()
         got = np.zeros(psz)
-        for b in range(nb):
-            ln = int(prob.packed_off[b + 1] - prob.packed_off[b])
-            if ln:
-                assert lib.pgbp_get_belief(cgb._eng, int(s_), b, L.f64p(rec)) == 0
-                got[prob.packed_off[b]:prob.packed_off[b + 1]] = rec[:ln]
+        assert lib.pgbp_get_site_beliefs(cgb._eng, int(s_), L.f64p(got)) == 0
+        if s_ == sample[0]:     # the single-belief read-back agrees with the per-site one
+            for b in np.random.default_rng(2).choice(nb, size=50, replace=False):
+                ln = int(prob.packed_off[b + 1] - prob.packed_off[b])
+                if ln:
+                    assert lib.pgbp_get_belief(cgb._eng, int(s_), int(b), L.f64p(rec)) == 0
+                    assert np.array_equal(got[prob.packed_off[b]:prob.packed_off[b + 1]], rec[:ln])
         err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
         assert float(err.max()) <= 1e-8, (int(s_), float(err.max()))
         assert rel_close(eng.integrate(prob.root_cluster)[1], ll_ref[s_])
@@ -1028,11 +1049,13 @@ def test_full_size_cfg5_network_against_c_oracle(P, graph):
     20 000 tips and 5 000 reticulations in varied blobs (networks.py:random_level3_network_varied), loopy cluster graph
     (join-graph structuring with maxclustersize 3 -- the largest bound under which a level-3 network's join graph is
     loopy: its moral graph has cliques of at most 4 nodes -- or Bethe), regularised, calibrate!(beliefs, schedule, 100;
-    auto=true) over the spanningtrees_clusterlist schedule.  Against the plain-C sequential engine from the same start:
-    the same (iteration, schedule tree) at which calibration is detected and EVERY belief to 1e-8 * max|.|."""
+    auto=true) over the spanningtrees_clusterlist schedule.  The factors come from the device fill (checked at this size
+    on 96 sampled clusters, 32 of them holding a hybrid family, against the oracle's assignfactors! restatement to 1e-10).
+    Against the plain-C sequential engine from the same start: the same (iteration, schedule tree) at which calibration is
+    detected and EVERY belief to 1e-8 * max|.|."""
     from oracle import cengine
     from pgbp_amd.regularization import regularizebeliefs_onschedule_
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(5)                           # SURVEY.md section 8(d): the recorded seed of cfg5
     p = 4
     net = P.random_level3_network_varied(20000, 5001, rng, n_colors=3)
     assert net.nhybrids >= 4900
@@ -1050,6 +1073,28 @@ def test_full_size_cfg5_network_against_c_oracle(P, graph):
     cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
     cgb.lg_setup(fam, X)
     cgb.assignfactors_lg_(rates, mu)
+    # the device factor fill at this size (50 003 node families) against the ORACLE's assignfactors! restatement, cluster by
+    # cluster on a random sample of 96 clusters (helpers.oracle_cluster_factor: the oracle's factor_treeedge /
+    # factor_hybridnode, absorbleaf, absorbevidence and mult! replayed for the families of one cluster)
+    from helpers import oracle_cluster_factor
+    from oracle import models as OM
+    cgb.pull()
+    filled = cgb._packed[0].copy()
+    colors = {(ni, k): int(c) + 1 for ni in range(net.nnodes) for k, c in enumerate(net.color[ni])}
+    omodel = OM.HeterogeneousBrownianMotion([rates[0], rates[1], rates[2]], colors, mu)
+    fam_of = {}
+    for ni, c in enumerate(st.node2cluster):
+        fam_of.setdefault(c, []).append(ni)
+    srng = np.random.default_rng(11)
+    with_hybrid = [c for c, nis in fam_of.items() if any(len(net.node2family[ni]) > 2 for ni in nis)]
+    sample_c = list(srng.choice(len(cn), size=64, replace=False)) + list(srng.choice(with_hybrid, size=32, replace=False))
+    for c in sample_c:
+        c = int(c)
+        h_o, J_o, g_o = oracle_cluster_factor(omodel, net, st, X, c, fam_of.get(c, []))
+        ref_ = np.concatenate([J_o.reshape(-1, order="F"), h_o, [g_o]])
+        got_ = filled[cgb._poff[c]:cgb._poff[c + 1]]
+        assert got_.shape == ref_.shape
+        assert float(np.max(np.abs(got_ - ref_))) <= 1e-10 * max(1.0, float(np.max(np.abs(ref_)))), (c, cn[c])
     if graph == "joingraph":
         regularizebeliefs_onschedule_(cgb)
     else:

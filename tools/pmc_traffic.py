@@ -59,6 +59,19 @@ def main():
                                     "WRITE_SIZE = bytes written, to three digits, for 8-B-per-lane and 16-B-per-lane accesses"),
         "note": "average over every %s launch of one bench.py run (postorder and preorder levels)" % kname,
     }
+    # stamp: which kernels these counters belong to (bench.py prints roofline.traffic_stale when the stamp is not the running
+    # tree's); the git head is informative only (the profile is usually taken on an uncommitted tree)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    res["csrc_sha16"] = bench.csrc_sha16()
+    try:
+        res["git_head"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                         timeout=20).stdout.strip() or None
+    except Exception:
+        res["git_head"] = None
     if ncal > 0:
         res["calibrates"] = ncal
         res["launches_per_calibrate"] = n / ncal
