@@ -106,7 +106,8 @@ int32_t pgbp_plan_n_messages(const pgbp_plan* p);     /* 2 * n_sepsets */
  * tasks and message entries; then the arrays (caller-allocated):
  * level_off[n_levels+1] -> tasks, task_off[n_tasks+1] -> entries,
  * entry_msg[n_entries] directed message id, entry_edge[n_entries] position in the tree's edge list,
- * entry_reuse[n_entries] 1 if the marginal of the previous entry of the task is reused. */
+ * entry_reuse[n_entries] 1 if the marginal of the previous entry of the task is reused; 2: the entry is the PROLOGUE of
+ * the next entry of its task (pgbp_plan_prologues). */
 int  pgbp_plan_traversal_sizes(const pgbp_plan* p, int32_t tree, int32_t dir,
                                int32_t* n_levels, int32_t* n_tasks, int32_t* n_entries);
 int  pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_off,
@@ -119,8 +120,9 @@ int  pgbp_plan_level_nfast(const pgbp_plan* p, int32_t tree, int32_t dir, int32_
  * *tail_levels: how many levels at the root end of the schedule tree (the last ones of a postorder, the first of a
  *   preorder) are walked by the single-workgroup tail launch (8 records per level);
  * records[6 * 4 * sum(level_ngroups)], tail_records[6 * 8 * tail_levels]: per record {valid, message id, first record of
- *   its task inside the group, messages of the task, record that computes its marginal, mode bits (1 own receiver
- *   block, 2 accumulate task)}. */
+ *   its task inside the group, records of the task, record that computes its marginal, mode bits (1 own receiver
+ *   block, 2 accumulate task, 4 the accumulate task only touches the receiver's g, 8 the record has a prologue:
+ *   pgbp_plan_prologues)}. */
 int  pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_ngroups, int32_t* tail_levels,
                       int32_t* records, int32_t* tail_records);
 /* Chunks of fused levels of one traversal: runs of narrow levels below the tail that go out as ONE launch each, one
@@ -132,6 +134,13 @@ int  pgbp_plan_groups(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* le
  * chunk. */
 int  pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_chunks, int32_t* info, int32_t* wg_off,
                       int32_t* records);
+/* PROLOGUES of the records above (any may be NULL): one word per record of pgbp_plan_groups' records / tail_records and
+ * of pgbp_plan_chunks' records, in the same order: the directed message X -> F the record's wavefront sends first -- F the
+ * sender of the record's own message, the message lands on the block that one integrates out and integrates nothing
+ * itself (a variable cluster of a Bethe graph into a factor cluster) -- or -1.  In pgbp_plan_traversal such a message is
+ * the entry in front of the record's own, in the same task. */
+int  pgbp_plan_prologues(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_pro, int32_t* tail_pro,
+                         int32_t* chunk_pro);
 /* The self-contained message records of the wave-per-task kernels (one 128-byte record per message of a generic-class
  * task; layout: struct GRec in csrc/pgbp_internal.hpp -- offsets of sender / receiver / sepset / residual inside a
  * site's pools, message id, sequence number, beliefs, index-pool offsets of the three maps, `next` = the record of the

@@ -34,6 +34,8 @@ struct DevTraversal {
   int32_t* d_task_off = nullptr;
   Entry* d_entries = nullptr;
   FEntry* d_fentries = nullptr;
+  FPro* d_fpros = nullptr;           // Traversal::fpros / cpros (null: no record of the traversal has a prologue)
+  FPro* d_cpros = nullptr;
   FEntry* d_centries = nullptr;      // Traversal::centries: the groups of the chunks of fused levels
   int32_t* d_chunk_wg_off = nullptr; // Traversal::chunk_wg_off
   int32_t* d_cgroups = nullptr;      // Traversal::cgroups as first records of the tasks (Traversal::task_grec)
@@ -93,6 +95,7 @@ struct pgbp_engine {
   GRec* d_one_rec = nullptr;
   std::vector<DevTraversal> dpost, dpre;
   std::vector<FEntry*> d_tail;   // per tree: the tail groups of its postorder followed by those of its preorder
+  std::vector<FPro*> d_tail_pros;  // ... and their prologues (null: none)
   // HIP events of the last pgbp_enqueue_calibrate_timed call (resolved by pgbp_fetch_kernel_time)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
   int32_t kernel_launches = 0;
@@ -317,6 +320,8 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_task_off) (void)hipFree(d.d_task_off);
       if (d.d_entries) (void)hipFree(d.d_entries);
       if (d.d_fentries) (void)hipFree(d.d_fentries);
+      if (d.d_fpros) (void)hipFree(d.d_fpros);
+      if (d.d_cpros) (void)hipFree(d.d_cpros);
       if (d.d_centries) (void)hipFree(d.d_centries);
       if (d.d_chunk_wg_off) (void)hipFree(d.d_chunk_wg_off);
       if (d.d_cgroups) (void)hipFree(d.d_cgroups);
@@ -327,6 +332,9 @@ void free_traversals(pgbp_engine* e) {
   for (FEntry* t : e->d_tail)
     if (t) (void)hipFree(t);
   e->d_tail.clear();
+  for (FPro* t : e->d_tail_pros)
+    if (t) (void)hipFree(t);
+  e->d_tail_pros.clear();
 }
 
 constexpr int kKlMaxS = 96;  // residual_kldiv_kernel: [J0 | dJ | h0] of one sepset in a CU's LDS
@@ -352,18 +360,10 @@ unsigned long long seq_stride(const pgbp_engine* e) {
 
 // Launch tuning read once from the environment (A/B runs and debugging; the defaults are what was measured best):
 //   PGBP_NO_TAIL=1     no single-workgroup tail launch: every level gets its own launch
-//   PGBP_STREAM=1      persistent streaming launch for wide levels (measured slower than one workgroup per group on the
-//                      50 000-tip tree: 1.00 against 0.94 ms per calibrate)
-//   PGBP_STREAM_MIN=n  a level streams when it has at least n groups of 4 messages (default 1536)
-//   PGBP_STREAM_GRID=n at most n workgroups per streaming launch (tests: many passes per workgroup on small inputs)
 struct LaunchTuning {
-  bool tail = true, stream = false;
-  int stream_min = 1536, stream_grid = 0;
+  bool tail = true;
   LaunchTuning() {
     if (getenv("PGBP_NO_TAIL")) tail = false;
-    if (getenv("PGBP_STREAM")) stream = true;
-    if (const char* v = getenv("PGBP_STREAM_MIN")) stream_min = std::max(1, atoi(v));
-    if (const char* v = getenv("PGBP_STREAM_GRID")) stream_grid = std::max(1, atoi(v));
   }
 };
 const LaunchTuning& tuning() {
@@ -395,8 +395,9 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
           launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
                                e->plan.n_sites, seq_base, stop_below, ch.max_mf, ch.small_only != 0, e->st);
         else
-          launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base,
-                        stop_below, stop_below, e->st, 0, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
+          launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, d.d_cpros ? d.d_cpros + ch.group0 * kTailWaves : nullptr,
+                        kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base, stop_below, stop_below, e->st,
+                        d.d_chunk_wg_off + ch.wg0, ch.n_wg);
         if (launches) *launches += 1;
         L = ch.level1 - 1;
         continue;
@@ -404,9 +405,8 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
     }
     const int t0 = tr.level_off[L], nt = tr.level_off[L + 1] - t0;
     const int nf = tr.level_nfast[L], ng = tr.level_ngroups[L];
-    const int mode = (tuning().stream && !kl && ng >= tuning().stream_min) ? kFastStream : kFastLevel;
-    launch_fast16(S, d.d_fentries + tr.level_fbase[L], mode, ng, ng, e->plan.n_sites, seq_base, stop_below, stop_below,
-                  e->st, tuning().stream_grid);
+    launch_fast16(S, d.d_fentries + tr.level_fbase[L], d.d_fpros ? d.d_fpros + tr.level_fbase[L] : nullptr, kFastLevel, ng, ng,
+                  e->plan.n_sites, seq_base, stop_below, stop_below, e->st);
     const int nbig = tr.level_nbig[L];
     if (uni)
       launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->max_s, e->st);
@@ -444,8 +444,9 @@ void enqueue_tree(pgbp_engine* e, const DevState& S, int tree, int dirs, unsigne
   if (dirs & 1) enqueue_levels(e, S, T.post, e->dpost[tree], 0, nlev_post - np, seq_base, stop_post, kl, n_launches);
   if (np + nq > 0) {
     // d_tail = the postorder's tail groups followed by the preorder's
-    const FEntry* recs = e->d_tail[tree] + (size_t)(np > 0 ? 0 : T.post.tail_levels) * kTailWaves;
-    launch_fast16(S, recs, kFastTail, np + nq, np, e->plan.n_sites, seq_base, stop_post, stop_pre, e->st);
+    const size_t first = (size_t)(np > 0 ? 0 : T.post.tail_levels) * kTailWaves;
+    launch_fast16(S, e->d_tail[tree] + first, e->d_tail_pros[tree] ? e->d_tail_pros[tree] + first : nullptr, kFastTail, np + nq,
+                  np, e->plan.n_sites, seq_base, stop_post, stop_pre, e->st);
     if (n_launches) *n_launches += 1;
   }
   if (dirs & 2) enqueue_levels(e, S, T.pre, e->dpre[tree], nq, nlev_pre, seq_base, stop_pre, kl, n_launches);
@@ -837,6 +838,10 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_task_off, tr.task_off))) break;
       if ((rc = upload(e, &d.d_entries, tr.entries))) break;
       if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
+      if (tr.has_pro) {
+        if ((rc = upload(e, &d.d_fpros, tr.fpros))) break;
+        if ((rc = upload(e, &d.d_cpros, tr.cpros))) break;
+      }
       if ((rc = upload(e, &d.d_centries, tr.centries))) break;
       if ((rc = upload(e, &d.d_chunk_wg_off, tr.chunk_wg_off))) break;
       std::vector<int32_t> grp_recs(tr.cgroups);
@@ -850,6 +855,13 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       tail.insert(tail.end(), e->plan.trees[t].pre.tentries.begin(), e->plan.trees[t].pre.tentries.end());
       FEntry* dt = nullptr;
       if ((rc = upload(e, &dt, tail)) == PGBP_OK) e->d_tail.push_back(dt);
+      FPro* dp = nullptr;   // (null unless a traversal of this tree has prologues: then both halves, zero-filled where none)
+      if (rc == PGBP_OK && (e->plan.trees[t].post.has_pro || e->plan.trees[t].pre.has_pro)) {
+        std::vector<FPro> tp(e->plan.trees[t].post.tpros);
+        tp.insert(tp.end(), e->plan.trees[t].pre.tpros.begin(), e->plan.trees[t].pre.tpros.end());
+        rc = upload(e, &dp, tp);
+      }
+      if (rc == PGBP_OK) e->d_tail_pros.push_back(dp);
     }
   }
   if (rc) {  // out of device memory half way: leave the engine without a schedule rather than with half of one

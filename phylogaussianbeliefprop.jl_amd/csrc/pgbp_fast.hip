@@ -46,19 +46,15 @@ extern __shared__ double fast_lds[];
 // Every wave of the workgroup executes the same two workgroup barriers per group whatever its record holds (an invalid
 // record = a wave with nothing to do: it skips the work, not the barriers).
 //
-// Three launch modes of the same body:
+// Two launch modes of the same body:
 //   kLevel  one group per workgroup, W = 4: one launch per level of the schedule (pgbp_plan.cpp);
-//   kStream wide levels: a PERSISTENT grid (as many workgroups as the chip holds) strides over the level's groups, and
-//           while a wave eliminates message i the packed record of the sender of its message i + 1 is already on its way
-//           into the wave's LDS image by LDS-DMA (global_load_lds_dwordx4: no registers, 1 KiB per instruction), so the
-//           HBM stream no longer stops while the waves compute; BS16 layout only (a packed 2P record is 4.6 KB);
 //   kTail   the narrow levels at the root end of the schedule tree: ONE workgroup of 8 waves walks them, one group per
 //           level, a workgroup barrier between levels instead of a kernel boundary (what a level hands to the next one
 //           never leaves this CU's L2 slice); a postorder's tail and the following preorder's head go out as one launch.
 // BS: beliefs / residuals are in the BS16 symmetric block-packed layout (pgbp_bs16.hpp).
 // ODD: the sepsets really have PR = P - 1 variables (an odd trait count): same lane grid, one phantom variable per
 // block, unit precision where it is integrated so that its pivot is 1 (log det and quadratic term unchanged).
-constexpr int kLevel = 0, kStream = 1, kTail = 2;
+constexpr int kLevel = 0, kTail = 2;   // (1 was the streaming launch of rounds 1 - 2, built and measured slower: DESIGN.md section 4.2)
 
 #ifdef PGBP_STAMP  // experiment builds only (tools/stamp_passes.py): clock stamps of the phases of a pass
 constexpr int kStampSlots = 1 << 16, kStampN = 12;
@@ -68,10 +64,6 @@ __device__ unsigned int g_stamp_n;
 #else
 #define PGBP_ST(i) do { } while (0)
 #endif
-// kStream, per wave: LDS image of a packed sender record (5 LDS-DMA pieces of 128 doubles; lanes past the record's end
-// stay idle, so 584 doubles hold the 577 of a 2P record) + the sepset tile + the receiver tile (144 doubles each)
-constexpr int kImgSender = 584, kImgTile = 144, kImgDoubles = kImgSender + 2 * kImgTile;
-
 // LDS exchange between the waves of a workgroup: release / acquire fences restricted to the LDS address space around the
 // barrier, i.e. s_waitcnt lgkmcnt(0) + s_barrier.  Unlike __syncthreads() this does NOT wait for outstanding global
 // loads / stores / LDS-DMA (vmcnt): the prefetch of the next sender stays in flight across it.  (The barrier has to be
@@ -87,63 +79,22 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // __syncthreads()
 __device__ __forceinline__ void wg_barrier_global() { __syncthreads(); }
 
-// What a wave must know of a record to prefetch its sender: the first 8 bytes (from_off) and bytes 48..55 (the byte-sized
-// fields), two scalar loads instead of the whole 64-byte record.
-struct FHead {
-  int64_t from_off;
-  uint8_t valid, mf, mt, s, keep0, up0, src_wave, mode;
-};
-__device__ __forceinline__ FHead load_head(const FEntry* __restrict__ r) {
-  const uint2* __restrict__ rq = reinterpret_cast<const uint2*>(r);
-  uint2 q0 = rq[0], q6 = rq[6];
-  asm("; record head resident" : "+s"(q0.x), "+s"(q0.y), "+s"(q6.x), "+s"(q6.y));
-  const uint2 q[2] = {q0, q6};
-  FHead h;
-  __builtin_memcpy(&h, q, sizeof(FHead));
-  return h;
-}
-static_assert(sizeof(FHead) == 16 && offsetof(FEntry, valid) == 48, "FHead mirrors FEntry");
-
-// kStream: start the LDS-DMA of the packed sender record of `en` (if this wave computes a marginal from one) into `img`
-template <int P>
-__device__ __forceinline__ void prefetch_sender(const FHead& en, int wave, const double* __restrict__ pool, double* img,
-                                                int lane) {
-  if (!en.valid || en.src_wave != wave || en.mf == 0) return;
-  const int len = en.mf == P ? bs16::len1(P) : bs16::len2(P);  // doubles in use of the packed record
-  const double* __restrict__ g = pool + en.from_off;
-#pragma unroll
-  for (int piece = 0; piece * 128 < bs16::len2(P); ++piece) {
-    const int d = piece * 128 + lane * 2;  // this lane's 16 bytes
-    if (piece * 128 < len && d < len)      // (wave-uniform && lane mask: lanes past the record's end stay idle)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + d),
-                                       (__attribute__((address_space(3))) void*)(img + piece * 128), 16, 0, 0);
-  }
-}
-
-// kStream: one packed symmetric tile (sepset precision, receiver block) by LDS-DMA instead of into registers: the
-// 2 x 2 blocks wait in LDS while the elimination needs every register the instance has at four waves per SIMD
-template <int P>
-__device__ __forceinline__ void dma_tile(const double* __restrict__ g, double* timg, int lane) {
-  constexpr int len = bs16::sym_len(P);
-#pragma unroll
-  for (int piece = 0; piece * 128 < len; ++piece) {
-    const int d = piece * 128 + lane * 2;
-    if (d < len)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + d),
-                                       (__attribute__((address_space(3))) void*)(timg + piece * 128), 16, 0, 0);
-  }
-}
-
-template <int P, bool BS, bool ODD, int MODE>
+// PRO: records may carry a PROLOGUE (kFPro; FPro, pgbp_internal.hpp): a message X -> F that integrates nothing (X's whole
+// belief, e.g. a variable cluster of a Bethe graph) and lands exactly on the block of F that this record's own message
+// F -> Y integrates out.  The wavefront first sends it -- divide! by the sepset (X, F), store sepset and residual, add the
+// delta to F's block in registers and in memory (mult!) -- and goes straight on with F's elimination: the level in which
+// X -> F would have run alone (a launch or a loop pass, with its memory round trips) no longer exists.  Same arithmetic,
+// same order as the two messages one after the other (src/beliefupdates.jl:650-665 twice).
+template <int P, bool BS, bool ODD, int MODE, bool PRO>
 #ifdef PGBP_FORCE4
 __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 64) void bp_fast16(
-    DevState S_arg, const FEntry* __restrict__ recs_arg, int ngroups_arg, int split_arg, unsigned long long seq_base_arg,
-    unsigned long long stop_a_arg, unsigned long long stop_b_arg, const int32_t* __restrict__ wg_off) {
+    DevState S_arg, const FEntry* __restrict__ recs_arg, const FPro* __restrict__ pros, int ngroups_arg, int split_arg,
+    unsigned long long seq_base_arg, unsigned long long stop_a_arg, unsigned long long stop_b_arg,
+    const int32_t* __restrict__ wg_off) {
   constexpr int W = MODE == kTail ? kTailWaves : kFastMaxWaves;
   static_assert(!(ODD && BS), "odd dimensions run in the plain layout");
-  static_assert(MODE != kStream || BS, "the streaming launch prefetches packed records");
   // The kernarg segment spans three cache lines and the compiler fetches arguments one group at a time, each a
   // dependent round trip on the critical path of a narrow level.  Pinning the plain scalars of all three lines in SGPRs
   // here makes ONE batch of scalar loads touch every line; the pointer arguments are left alone (an asm operand would
@@ -168,10 +119,6 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   double* const slot = fast_lds + wave * kSlotDoubles;
   double* const col = fast_lds + W * kSlotDoubles + wave * kColDoubles;  // private strip of this wave
-  // kStream only: this wave's images of the sender record, the sepset tile and the receiver tile
-  double* const img = fast_lds + W * (kSlotDoubles + kColDoubles) + wave * kImgDoubles;
-  double* const simg = img + kImgSender;
-  double* const timg = simg + kImgTile;
 
   // kTail with wg_off: workgroup b walks the groups [wg_off[b], wg_off[b + 1]) -- its own dependency-closed piece of a
   // run of fused levels (pgbp_plan.cpp: build_chunks); without: the one workgroup walks all of them
@@ -179,10 +126,11 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     if (wg_off) ngroups = wg_off[blockIdx.x + 1];
   }
   int g = MODE == kTail ? (wg_off ? wg_off[blockIdx.x] : 0) : blockIdx.x;
-  const int gstride = MODE == kStream ? gridDim.x : 1;
+  constexpr int gstride = 1;
   FEntry en = load_record(recs + ((int64_t)g * W + wave));
+  FPro pr{};
+  if constexpr (PRO) pr = load_pro(pros + ((int64_t)g * W + wave));
   unsigned long long failkey = S.fail[site];
-  if constexpr (MODE == kStream) prefetch_sender<P>(load_head(recs + ((int64_t)g * W + wave)), wave, pool, img, threadIdx.x & 63);
 
   for (;;) {
 #ifdef PGBP_STAMP
@@ -198,17 +146,17 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     const bool up = act && a <= b;               // this lane's block is stored in the packed layout
     const int kidx = (b * (b + 1) / 2 + a) * 4;  // its offset inside a packed symmetric tile
 
-    // the next pass's record: its head now (kStream: what the prefetch of its sender needs), the rest at the end of
-    // this pass
     const bool has_next = MODE != kLevel && g + gstride < ngroups;
-    FHead nh{};
-    if (MODE == kStream && has_next) nh = load_head(recs + ((int64_t)(g + gstride) * W + wave));
     // kTail: the whole next record is requested here as a VECTOR load (lanes 0 .. 3 fetch 16 bytes each): the compiler
     // tracks it like any other load and waits for it where it is used, at the end of the pass -- a scalar load pinned in
     // SGPRs would be waited for on the spot, a dependent round trip (about 900 clocks) in every level of the tail
     uint4 nxv = make_uint4(0, 0, 0, 0);
-    if (MODE == kTail && has_next)
-      nxv = reinterpret_cast<const uint4*>(recs + ((int64_t)(g + gstride) * W + wave))[lane & 3];
+    if (MODE == kTail && has_next) {
+      if (PRO && (lane & 4))   // (PRO: lanes 4, 5 fetch the 32 bytes of the next record's prologue)
+        nxv = reinterpret_cast<const uint4*>(pros + ((int64_t)(g + gstride) * W + wave))[lane & 1];
+      else
+        nxv = reinterpret_cast<const uint4*>(recs + ((int64_t)(g + gstride) * W + wave))[lane & 3];
+    }
     if constexpr (MODE == kTail) {
       // a failure in the postorder part of this launch must stop its preorder part: at the first preorder level the fail
       // word is read again, coherently (every other level keeps the value read at the start: a dependent memory round
@@ -227,6 +175,8 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     const bool has_block = en.s > 0;                // the message has a J/h part
     const bool own = (en.mode & kFOwn) != 0;        // this wave loads/stores the receiver block
     const bool accum = (en.mode & kFAccum) != 0;
+    // the receiver has a J / h block to load and store (an accumulate task of constants only touches its g)
+    const bool recv_blk = has_block || (accum && !(en.mode & kFNoBlock));
     const bool provider = en.src_wave == wave;      // computes the marginal itself
     const int first_wave = en.grp_base;             // first wave of this record's task
 
@@ -246,10 +196,6 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     double2 sh = make_double2(0.0, 0.0);
     double sg = 0.0;
     int info = 0;
-    if constexpr (MODE == kStream) {
-      // the image of this pass's sender has landed (this also drains the previous pass's stores)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     PGBP_ST(1);
     if (state == 1) {
       // (kTail: the mark may have been set by an earlier level of this very launch -- by a wave of this workgroup, i.e.
@@ -259,22 +205,22 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
       // level of the tail; like this it is waited for where it is used, behind the elimination.
       int zero_v = 0;
       if constexpr (MODE != kLevel) asm volatile("" : "+v"(zero_v));
-      const int poison_v = S.poison[(int64_t)site * S.n_clusters + en.from_b + zero_v];
+      int poison_v = S.poison[(int64_t)site * S.n_clusters + en.from_b + zero_v];
+      const bool pro = PRO && (en.mode & kFPro) != 0;
+      if (pro) poison_v |= S.poison[(int64_t)site * S.n_clusters + pr.from_b + zero_v];   // X poisoned: so is F
       // ---- every load of this message is issued before any arithmetic; the sender (the largest operand and
       // the one the elimination waits for) goes first, the sepset and the receiver block right behind it
       auto load_sep_to = [&]() {
         if (!S.sep_zero) {
           if (has_block) {
-            if constexpr (MODE == kStream) dma_tile<P>(sep, simg, lane);  // read back before divide!
-            else sJ = load_blk<BS, ODD>(sep, PR, a, b, up, kidx, PR);
+            sJ = load_blk<BS, ODD>(sep, PR, a, b, up, kidx, PR);
             if (b == 0) sh = load_pair<ODD>(sep + sepH, a, PR);
           }
           sg = sep[sepG];
         }
         if (own) {
-          if (accum || has_block) {
-            if constexpr (MODE == kStream) dma_tile<P>(to + tJ0, timg, lane);  // read back before mult!
-            else tJ = load_blk<BS, ODD>(to + tJ0, mt, a, b, up, kidx, PR);
+          if (recv_blk) {
+            tJ = load_blk<BS, ODD>(to + tJ0, mt, a, b, up, kidx, PR);
             if (b == 0) {
               const double2 t2 = load_pair<ODD>(to + tH0, a, PR);
               th[0] = t2.x; th[1] = t2.y;
@@ -286,8 +232,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
       if (!provider) load_sep_to();
       if (provider) {
         const double* __restrict__ gfrom = pool + en.from_off;
-        // kStream: the packed record was brought into this wave's LDS image one pass ahead
-        const double* __restrict__ from = MODE == kStream ? img : gfrom;
+        const double* __restrict__ from = gfrom;
         if (en.mf == 0) {
           gmsg = gfrom[0];  // a constant factor
           load_sep_to();
@@ -372,11 +317,63 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
             gmsg = from[4 * P * P + 2 * P];
           }
           load_sep_to();
-          if constexpr (MODE == kStream) {
-            // the image has been read into registers (lgkmcnt): the next pass's sender may now overwrite it.  Issued
-            // here, behind this message's own loads (the memory pipe returns in order), in flight during the elimination.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (has_next) prefetch_sender<P>(nh, wave, pool, img, lane);
+          if (pro) {
+            // ---- PROLOGUE: the message X -> F (nothing to integrate: X's belief), then mult! onto F's integrated block
+            const double* __restrict__ xfrom = pool + pr.from_off;
+            double* __restrict__ sep2 = pool + pr.sep_off;
+            double* __restrict__ res2 = rpool + pr.res_off;
+            constexpr int xH = BS ? bs16::h1(P) : PR * PR, xG = BS ? bs16::g1(P) : PR * PR + PR;
+            const Blk xJ = load_blk<BS, ODD>(xfrom, PR, a, b, up, kidx, PR);
+            const double2 xh = load_pair<ODD>(xfrom + xH, a, PR);
+            const double xg = xfrom[xG];
+            Blk s2{0, 0, 0, 0};
+            double2 s2h = make_double2(0.0, 0.0);
+            double s2g = 0.0;
+            if (!S.sep_zero) {
+              s2 = load_blk<BS, ODD>(sep2, PR, a, b, up, kidx, PR);
+              s2h = load_pair<ODD>(sep2 + xH, a, PR);
+              s2g = sep2[xG];
+            }
+            // nothing of the prologue is applied from a poisoned X (or F): the whole record is then skipped below
+            if (!__builtin_amdgcn_readfirstlane(poison_v)) {
+              // divide! (src/beliefupdates.jl:579-587)
+              const Blk d2{xJ.x - s2.x, xJ.y - s2.y, xJ.z - s2.z, xJ.w - s2.w};
+              const double d2h0 = xh.x - s2h.x, d2h1 = xh.y - s2h.y, d2g = xg - s2g;
+              store_blk<BS, ODD>(sep2, PR, a, b, up, act, kidx, xJ, PR);
+              store_blk<BS, ODD>(res2, PR, a, b, up, act, kidx, d2, PR);
+              double maxJ2 = 0.0, maxh2 = 0.0;
+              if (BS ? up : act) {
+                maxJ2 = fmax(fmax(fabs(d2.x), fabs(d2.y)), fmax(fabs(d2.z), fabs(d2.w)));
+                if (d2.x != d2.x || d2.y != d2.y || d2.z != d2.z || d2.w != d2.w) maxJ2 = INFINITY;
+              }
+              if (act && b == 0) {
+                store_pair<ODD>(sep2 + xH, a, xh.x, xh.y, PR);
+                store_pair<ODD>(res2 + xH, a, d2h0, d2h1, PR);
+                maxh2 = (d2h0 != d2h0 || d2h1 != d2h1) ? INFINITY : fmax(fabs(d2h0), fabs(d2h1));
+              }
+              if (lane == 0) {
+                sep2[xG] = xg;
+                S.status[(int64_t)site * S.n_msgs + pr.msg] = 0;
+              }
+              if (S.update_resnorm) {   // iscalibrated_residnorm! (src/beliefs.jl:994-1003)
+                const bool all_ok2 = __all(maxh2 <= S.thr_h_p && maxJ2 <= S.thr_J_p);
+                if (lane == 0) S.flags[(int64_t)site * S.n_msgs + pr.msg] = all_ok2 ? 1 : 0;
+              }
+              // mult! (src/beliefupdates.jl:483-488): F's integrated block, in the registers of the elimination ...
+              f.w[0][0] += d2.x; f.w[1][0] += d2.y; f.w[0][1] += d2.z; f.w[1][1] += d2.w;
+              f.h[0] += d2h0; f.h[1] += d2h1;
+              gmsg += d2g;
+              // ... and in F's record: F's belief holds the message it received, as after the two-level schedule
+              double* __restrict__ fw = pool + en.from_off;
+              const int i0 = (en.keep0 == 0) ? PR : 0;   // first integrated variable of F (plain layouts)
+              double* __restrict__ iJ = BS ? fw + (en.keep0 == 0 ? bs16::t11(P) : 0) : fw + i0 + (int64_t)(2 * PR) * i0;
+              double* __restrict__ iH = BS ? fw + bs16::h2(P) + (en.keep0 == 0 ? P : 0) : fw + 4 * PR * PR + i0;
+              double* __restrict__ iG = BS ? fw + bs16::g2(P) : fw + 4 * PR * PR + 2 * PR;
+              // (ODD: the phantom corner holds the unit pivot in registers only: store_blk skips indices >= PR)
+              store_blk<BS, ODD>(iJ, 2 * PR, a, b, up, act, kidx, Blk{f.w[0][0], f.w[1][0], f.w[0][1], f.w[1][1]}, PR);
+              if (act && b == 0) store_pair<ODD>(iH, a, f.h[0], f.h[1], PR);
+              if (lane == 0) iG[0] = gmsg;
+            }
           }
           // Symmetric(J_I): entries below the diagonal take the value of their transpose (:68)
           // (in BS16 the lanes a > b hold nothing yet: all four of their entries come from lane (b, a))
@@ -417,16 +414,6 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
       if (__builtin_amdgcn_readfirstlane(poison_v)) state = 3;
       else if (info != 0) state = 2;
     }
-    if constexpr (MODE == kStream) {
-      // waves that did not come through the elimination path above (no sender of their own this pass, a light message,
-      // a stopped or invalid record) start the next pass's prefetch here; the image is theirs alone, its last reader was
-      // this wave, and those reads have returned
-      const bool through_elim = state >= 1 && provider && en.mf != 0 && !(en.mf == PR && has_block);
-      if (!through_elim) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (has_next) prefetch_sender<P>(nh, wave, pool, img, lane);
-      }
-    }
     // ---- hand the marginal over to the waves that reuse it
     if (provider && en.valid && !accum && en.grp_len > 1) {
       if (state == 1) {
@@ -459,13 +446,6 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     // ---- divide! (src/beliefupdates.jl:579-587): every wave for its own sepset
     Blk dJ{0, 0, 0, 0};
     double dh0 = 0.0, dh1 = 0.0, dg = 0.0;
-    if constexpr (MODE == kStream) {
-      // the tiles brought in by LDS-DMA (and, as it happens, the next sender) have landed; take them into registers
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PGBP_ST(6);
-      if (state == 1 && has_block && !S.sep_zero) sJ = load_blk<true>(simg, P, a, b, up, kidx);
-      if (state == 1 && own && (accum || has_block)) tJ = load_blk<true>(timg, P, a, b, up, kidx);
-    }
     if (state == 1) {
       double maxJ = 0.0, maxh = 0.0;
       if (has_block) {
@@ -520,7 +500,6 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     wg_barrier_lds();
     PGBP_ST(8);
     FEntry nx{};
-    if (MODE == kStream && has_next) nx = load_record(recs + ((int64_t)(g + gstride) * W + wave));
     if (MODE == kTail && has_next) {
       unsigned int q[16];
 #pragma unroll
@@ -531,6 +510,17 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         q[4 * i + 3] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.w, i);
       }
       __builtin_memcpy(&nx, q, sizeof(FEntry));
+      if constexpr (PRO) {
+        unsigned int w8[8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          w8[4 * i + 0] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.x, 4 + i);
+          w8[4 * i + 1] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.y, 4 + i);
+          w8[4 * i + 2] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.z, 4 + i);
+          w8[4 * i + 3] = (unsigned int)__builtin_amdgcn_readlane((int)nxv.w, 4 + i);
+        }
+        __builtin_memcpy(&pr, w8, sizeof(FPro));
+      }
     }
     PGBP_ST(9);
     if (state == 1) {
@@ -551,7 +541,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         }
       }
       if (own) {
-        if (accum || has_block) {
+        if (recv_blk) {
           store_blk<BS, ODD>(to + tJ0, mt, a, b, up, act, kidx, tJ, PR);
           if (act && b == 0) store_pair<ODD>(to + tH0, a, th[0], th[1], PR);
         }
@@ -576,8 +566,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
     if (g >= ngroups) break;
     // the hand-over slots are reused by the next pass: every wave has finished reading them (kTail: and every global
     // store of this level is complete before the next level's loads)
-    if constexpr (MODE == kTail) wg_barrier_global();
-    else wg_barrier_lds();
+    wg_barrier_global();
     en = nx;
   }
 }
@@ -586,52 +575,34 @@ namespace {
 
 size_t fast_lds_bytes(int mode) {
   const int W = mode == kTail ? kTailWaves : kFastMaxWaves;
-  return sizeof(double) * (size_t)W * (size_t)(kSlotDoubles + kColDoubles + (mode == kStream ? kImgDoubles : 0));
+  return sizeof(double) * (size_t)W * (size_t)(kSlotDoubles + kColDoubles);
 }
 
-int g_stream_grid = 0;  // workgroups of a persistent streaming launch: what the device holds at once
-
 template <int P, bool ODD>
-void launch_fast_p(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
+void launch_fast_p(const DevState& S, const FEntry* d_recs, const FPro* d_pros, int mode, int ngroups, int split, int n_sites,
                    unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
-                   int max_grid, const int32_t* d_wg_off, int n_wg) {
-  const int32_t* no_wg = nullptr;
-  const int tail_grid = d_wg_off ? n_wg : 1;
+                   const int32_t* d_wg_off, int n_wg) {
+  const bool tail = mode == kTail;
+  const dim3 grid(tail ? (d_wg_off ? n_wg : 1) : ngroups, n_sites), block((tail ? kTailWaves : kFastMaxWaves) * 64);
   const size_t lds = fast_lds_bytes(mode);
+  const int sp = tail ? split : ngroups;
+  const int32_t* wg = tail ? d_wg_off : nullptr;
+#define PGBP_GO(BSV, ODV, MD, PROV) \
+  hipLaunchKernelGGL((bp_fast16<P, BSV, ODV, MD, PROV>), grid, block, lds, st, S, d_recs, d_pros, ngroups, sp, seq_base, stop_a, stop_b, wg)
+#define PGBP_GO2(BSV, ODV)                                  \
+  do {                                                      \
+    if (tail) { if (d_pros) PGBP_GO(BSV, ODV, kTail, true); else PGBP_GO(BSV, ODV, kTail, false); } \
+    else { if (d_pros) PGBP_GO(BSV, ODV, kLevel, true); else PGBP_GO(BSV, ODV, kLevel, false); }    \
+  } while (0)
   if constexpr (!ODD) {
     if (S.bs16) {
-      if (mode == kStream) {
-        if (g_stream_grid == 0) {
-          int dev = 0, cus = 256, per_cu = 0;
-          (void)hipGetDevice(&dev);
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp_fast16<P, true, false, kStream>, kFastMaxWaves * 64,
-                                                           lds) != hipSuccess || per_cu <= 0)
-            per_cu = 4;
-          g_stream_grid = cus * per_cu;
-        }
-        // as many workgroups as stay resident, shrunk so that every one walks the same number of groups
-        const int cap = max_grid > 0 ? std::min(max_grid, g_stream_grid) : g_stream_grid;
-        const int passes = (ngroups + cap - 1) / cap;
-        const int grid = (ngroups + passes - 1) / passes;
-        hipLaunchKernelGGL((bp_fast16<P, true, false, kStream>), dim3(grid, n_sites), dim3(kFastMaxWaves * 64), lds, st, S,
-                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b, no_wg);
-      } else if (mode == kTail) {
-        hipLaunchKernelGGL((bp_fast16<P, true, false, kTail>), dim3(tail_grid, n_sites), dim3(kTailWaves * 64), lds, st, S,
-                           d_recs, ngroups, split, seq_base, stop_a, stop_b, d_wg_off);
-      } else {
-        hipLaunchKernelGGL((bp_fast16<P, true, false, kLevel>), dim3(ngroups, n_sites), dim3(kFastMaxWaves * 64), lds, st, S,
-                           d_recs, ngroups, ngroups, seq_base, stop_a, stop_b, no_wg);
-      }
+      PGBP_GO2(true, false);
       return;
     }
   }
-  if (mode == kTail)
-    hipLaunchKernelGGL((bp_fast16<P, false, ODD, kTail>), dim3(tail_grid, n_sites), dim3(kTailWaves * 64), lds, st, S, d_recs,
-                       ngroups, split, seq_base, stop_a, stop_b, d_wg_off);
-  else  // plain layout: no streaming instance (a plain 2P record is 8.5 KB)
-    hipLaunchKernelGGL((bp_fast16<P, false, ODD, kLevel>), dim3(ngroups, n_sites), dim3(kFastMaxWaves * 64),
-                       fast_lds_bytes(kLevel), st, S, d_recs, ngroups, ngroups, seq_base, stop_a, stop_b, no_wg);
+  PGBP_GO2(false, ODD);
+#undef PGBP_GO2
+#undef PGBP_GO
 }
 
 }  // namespace
@@ -787,19 +758,18 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
 // The kernel is instantiated for every even sepset dimension P <= 16 ((P/2)^2 lanes: all 64 for P = 16, 16 for P = 8,
 // 1 for P = 2), and each instance once more for the odd dimension P - 1 (plain layout, a phantom variable per block);
 // the small-P instances trade lane utilisation for the same per-level latency (one wave per message).
-// mode: kLevel (0) one group of kFastMaxWaves records per workgroup; kStream (1) persistent grid with LDS-DMA prefetch
-// (packed layout only: falls back to kLevel otherwise); kTail (2) one workgroup walks `ngroups` groups of kTailWaves
-// records, groups >= split stop below stop_b instead of stop_a (a postorder's tail followed by a preorder's head);
-// with d_wg_off (n_wg + 1 group offsets) n_wg workgroups each walk their own range of groups (a chunk of fused levels).
-void launch_fast16(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
+// mode: kLevel (0) one group of kFastMaxWaves records per workgroup; kTail (2) one workgroup walks `ngroups` groups of
+// kTailWaves records, groups >= split stop below stop_b instead of stop_a (a postorder's tail followed by a preorder's
+// head); with d_wg_off (n_wg + 1 group offsets) n_wg workgroups each walk their own range of groups (a chunk of fused
+// levels).  d_pros: the prologues of the records (same indexing), or null if none of them has one.
+void launch_fast16(const DevState& S, const FEntry* d_recs, const FPro* d_pros, int mode, int ngroups, int split, int n_sites,
                    unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
-                   int max_grid, const int32_t* d_wg_off, int n_wg) {
+                   const int32_t* d_wg_off, int n_wg) {
   if (ngroups <= 0) return;
-  if (mode == kStream && !(S.bs16 && S.fast_p % 2 == 0)) mode = kLevel;
 #ifdef PGBP_ONLY_P16  // experiment builds: one instance, seconds to compile
-  if (S.fast_p == 16) launch_fast_p<16, false>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid, d_wg_off, n_wg);
+  if (S.fast_p == 16) launch_fast_p<16, false>(S, d_recs, d_pros, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, d_wg_off, n_wg);
 #else
-#define PGBP_FAST(PP, OD) launch_fast_p<PP, OD>(S, d_recs, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, max_grid, d_wg_off, n_wg); break
+#define PGBP_FAST(PP, OD) launch_fast_p<PP, OD>(S, d_recs, d_pros, mode, ngroups, split, n_sites, seq_base, stop_a, stop_b, st, d_wg_off, n_wg); break
   switch (S.fast_p) {  // the real sepset dimension; odd ones run on the next even instance with a phantom variable
     case 16: PGBP_FAST(16, false);
     case 15: PGBP_FAST(16, true);

@@ -169,4 +169,15 @@ __device__ __forceinline__ FEntry load_record(const FEntry* __restrict__ r) {
   return en;
 }
 
+// the 32-byte prologue of a record (FPro), likewise
+__device__ __forceinline__ FPro load_pro(const FPro* __restrict__ r) {
+  const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(r);
+  uint4 q0 = rq[0], q1 = rq[1];
+  asm("; prologue resident" : "+s"(q0.x), "+s"(q0.y), "+s"(q0.z), "+s"(q0.w), "+s"(q1.x), "+s"(q1.y), "+s"(q1.z), "+s"(q1.w));
+  const uint4 q[2] = {q0, q1};
+  FPro pr;
+  __builtin_memcpy(&pr, q, sizeof(FPro));
+  return pr;
+}
+
 }  // namespace pgbp

@@ -32,7 +32,9 @@ struct Entry {
   int32_t reuse;  // 1: same sender and same keep indices as the previous entry of the task
   int32_t seq;    // position in the reference's sequential order of one (post, pre) pair
   int32_t tflags; // fast kernels: bit 0 = load the receiver's block before this entry, bit 1 = store it after
-  int32_t pad[3];
+  int32_t pro;    // 1: this entry is the PROLOGUE of the next one (a message X -> F that integrates nothing, sent by the
+                  // wavefront that then sends F's own message: build_traversals, bp_fast16)
+  int32_t pad[2];
 };
 constexpr int kTLoad = 1, kTStore = 2;
 
@@ -73,14 +75,24 @@ struct FEntry {
   uint8_t keep0;         // first kept index in the sender (0 or P)
   uint8_t up0;           // first index of the receiver's block
   uint8_t src_wave;      // wave of the workgroup that computes this record's marginal (== own index unless reused)
-  uint8_t mode;          // bit 0: this wave loads+stores the receiver block itself; bit 1: accumulate task
+  uint8_t mode;          // bit 0: this wave loads+stores the receiver block itself; bit 1: accumulate task; bit 2: kFNoBlock; bit 3: kFPro
                          // (its first wave owns the receiver block, the other waves hand their delta over through LDS)
   uint8_t grp_base;      // wave (record index inside the group) of the first message of this record's task
   uint8_t grp_len;       // number of messages of the task
   uint8_t pad[6];
 };
 static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
+// Prologue of a record (kFPro): the message X -> F, F = the record's sender, that integrates nothing and lands on the block
+// of F the record's own message integrates out (a variable cluster's message into a factor cluster of a Bethe graph).
+// What is not here comes from the record: F's record (from_off), the block (keep0), F's belief index (from_b).
+struct FPro {
+  int64_t from_off, sep_off, res_off;  // X's record, the sepset (X, F), the residual of X -> F; doubles, inside one site's pools
+  int32_t msg, from_b;                 // directed message id of X -> F, belief index of X
+};
+static_assert(sizeof(FPro) == 32, "FPro is half a 64-byte line");
 constexpr int kFOwn = 1, kFAccum = 2;
+constexpr int kFPro = 8;           // the record has a PROLOGUE (FPro, same index in the parallel array): see bp_fast16
+constexpr int kFNoBlock = 4;       // accumulate task whose messages are all constants (dimension-0 sepsets): only the receiver's g
 constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = records per group of a level launch
 constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
 constexpr int kGenericMaxDim = 64;    // largest sender the wave-per-task generic kernel's lane grids handle
@@ -98,6 +110,9 @@ struct Traversal {
   std::vector<int32_t> level_nbig;   // [n_levels] how many of its LAST tasks hold a sender of dimension > 64 (bp_level_big)
   int32_t max_mf_big = 0;            // largest sender dimension among those
   std::vector<FEntry> fentries;      // packed groups of the fast tasks (kFastMaxWaves records each), level after level
+  // prologues of the records (kFPro), same indexing as fentries / tentries / centries; has_pro: some record has one
+  std::vector<FPro> fpros, tpros, cpros;
+  bool has_pro = false;
   std::vector<int64_t> level_fbase;  // [n_levels] first record of the level in fentries
   std::vector<int32_t> level_ngroups;  // [n_levels] groups of the level
   std::vector<int32_t> level_nrecs;    // [n_levels] messages (valid records) of the level's fast tasks

@@ -94,15 +94,14 @@ void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry*
 // (max_s: the engine's largest sepset dimension; <= 1 selects the instance that loads a message's elements by role)
 
 // register-resident message kernel (pgbp_fast.hip): `ngroups` groups of records (FEntry) of a traversal.
-// mode 0 (level): one group of kFastMaxWaves records per workgroup; 1 (stream): persistent grid over the groups with the
-// next sender prefetched by LDS-DMA (packed layout; other layouts run as mode 0); 2 (tail): ONE workgroup walks the groups
-// (kTailWaves records each) with a workgroup barrier between them; groups >= split stop below stop_b instead of stop_a.
-constexpr int kFastLevel = 0, kFastStream = 1, kFastTail = 2;
-// max_grid > 0: cap on the workgroups of a streaming launch (tests).  mode 2 with d_wg_off (n_wg + 1 offsets into the
-// groups): n_wg workgroups, workgroup b walks the groups [d_wg_off[b], d_wg_off[b + 1]) -- a chunk of fused levels.
-void launch_fast16(const DevState& S, const FEntry* d_recs, int mode, int ngroups, int split, int n_sites,
+// mode 0 (level): one group of kFastMaxWaves records per workgroup; 2 (tail): ONE workgroup walks the groups (kTailWaves
+// records each) with a workgroup barrier between them; groups >= split stop below stop_b instead of stop_a; with d_wg_off
+// (n_wg + 1 offsets into the groups): n_wg workgroups, workgroup b walks the groups [d_wg_off[b], d_wg_off[b + 1]) -- a
+// chunk of fused levels.  d_pros: the records' prologues (FPro, same indexing) or null when none has one.
+constexpr int kFastLevel = 0, kFastTail = 2;
+void launch_fast16(const DevState& S, const FEntry* d_recs, const FPro* d_pros, int mode, int ngroups, int split, int n_sites,
                    unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
-                   int max_grid = 0, const int32_t* d_wg_off = nullptr, int n_wg = 0);
+                   const int32_t* d_wg_off = nullptr, int n_wg = 0);
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
                       double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);

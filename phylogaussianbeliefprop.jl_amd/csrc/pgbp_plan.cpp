@@ -175,16 +175,36 @@ static bool fast_msg(const MsgDesc& m, int P) {
   return snd && rcv;
 }
 
+// wavefronts a task takes on the register-resident kernel: its messages less the prologues, which ride with the next one
+static int task_waves(const Traversal& tr, int t) {
+  int n = 0;
+  for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e) n += tr.entries[e].pro ? 0 : 1;
+  return n;
+}
+
+// A PROLOGUE pair (bp_fast16, FPro): `light` = X -> F sends X's whole belief (nothing integrated) and lands exactly on
+// the block of F that `heavy` = F -> Y integrates out.
+static bool prologue_pair(const MsgDesc& light, const MsgDesc& heavy, int P) {
+  return P > 0 && fast_msg(light, P) && fast_msg(heavy, P) && light.to_b == heavy.from_b && light.mf == P && light.s == P &&
+         light.ni == 0 && light.mt == 2 * P && heavy.mf == 2 * P && heavy.ni == P && heavy.s == P &&
+         light.up0 == (heavy.keep0 == 0 ? P : 0);
+}
+
 // Can the whole task run as ONE workgroup of the register-resident kernel, one wave per message?
 static bool fast_task(const Plan& p, const Traversal& tr, int t, bool postorder, int* block_up0, int* block_mt) {
   const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1];
-  if (e1 - e0 > kFastMaxWaves) return false;
-  int up0 = -1, mt = -1;
+  int up0 = -1, mt = -1, first_main = -1, mains = 0;
   for (int e = e0; e < e1; ++e) {
     const MsgDesc& m = p.msgs[tr.entries[e].msg];
     if (!fast_msg(m, p.fast_p)) return false;
+    if (tr.entries[e].pro) {  // the prologue of the next entry
+      if (e + 1 >= e1 || tr.entries[e + 1].pro || !prologue_pair(m, p.msgs[tr.entries[e + 1].msg], p.fast_p)) return false;
+      continue;
+    }
+    if (first_main < 0) first_main = e;
+    if (++mains > kFastMaxWaves) return false;
     // a fused chain (build_traversals) passes through several receivers / senders: generic kernel
-    const MsgDesc& m0 = p.msgs[tr.entries[e0].msg];
+    const MsgDesc& m0 = p.msgs[tr.entries[first_main].msg];
     if (postorder ? m.to_b != m0.to_b : m.from_b != m0.from_b) return false;
     if (postorder && m.s > 0) {  // all deltas must land on the same receiver block
       if (up0 >= 0 && (m.up0 != up0 || m.mt != mt)) return false;
@@ -192,27 +212,36 @@ static bool fast_task(const Plan& p, const Traversal& tr, int t, bool postorder,
       mt = m.mt;
     }
   }
-  if (postorder && e1 - e0 > 1 && up0 < 0) return false;  // several g-only messages: leave to the generic kernel
+  if (mains == 0) return false;
+  // (several constant messages into one receiver -- the two root-child factors of a Bethe graph under a fixed root --
+  // accumulate into its g alone: block_mt = -1 marks "no block", kFNoBlock in the records)
   *block_up0 = up0 < 0 ? 0 : up0;
   *block_mt = mt;
   return true;
 }
 
-// The W-record group of fast-class tasks `members` (sum of their lengths <= W): one record per message, a task's
-// records consecutive, invalid records behind the last task.
+// The W-record group of fast-class tasks `members` (sum of their wavefronts <= W): one record per message, a task's
+// records consecutive, invalid records behind the last task; a prologue entry goes into the record of the entry behind
+// it (kFPro + the parallel array out_pro).
 static void append_group(const Plan& p, const Traversal& tr, const std::vector<int>& members,
                          const std::vector<std::pair<int, int>>& blk_of_task, int t_first, bool postorder, int W,
-                         std::vector<FEntry>& out) {
+                         std::vector<FEntry>& out, std::vector<FPro>& out_pro, bool* any_pro) {
   int fill = 0;
   for (int t : members) {
-    const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1], len = e1 - e0;
+    const int e0 = tr.task_off[t], e1 = tr.task_off[t + 1], len = task_waves(tr, t);
     const bool accum = postorder && len > 1;
     const std::pair<int, int>& blk = blk_of_task[t - t_first];
-    int provider = fill;
-    for (int w = 0; w < len; ++w) {
-      const Entry& en = tr.entries[e0 + w];
+    int provider = fill, w = 0;
+    const Entry* pending = nullptr;
+    for (int e = e0; e < e1; ++e) {
+      const Entry& en = tr.entries[e];
+      if (en.pro) {
+        pending = &en;
+        continue;
+      }
       const MsgDesc& m = p.msgs[en.msg];
       FEntry f{};
+      FPro fp{};
       f.from_off = m.from_off; f.to_off = m.to_off; f.sep_off = m.sep_off; f.res_off = m.res_off;
       f.msg = en.msg; f.seq = en.seq; f.from_b = m.from_b; f.to_b = m.to_b;
       f.valid = 1;
@@ -225,7 +254,7 @@ static void append_group(const Plan& p, const Traversal& tr, const std::vector<i
       f.grp_len = (uint8_t)len;
       if (accum) {
         // the task's first wave owns the shared receiver block (even if its own message is g-only)
-        f.mode = (uint8_t)(kFAccum | (w == 0 ? kFOwn : 0));
+        f.mode = (uint8_t)(kFAccum | (w == 0 ? kFOwn : 0) | (blk.second < 0 ? kFNoBlock : 0));
         if (w == 0 && m.s == 0) {
           f.up0 = (uint8_t)blk.first;
           f.mt = (uint8_t)(blk.second >= 0 ? blk.second : m.mt);
@@ -233,11 +262,24 @@ static void append_group(const Plan& p, const Traversal& tr, const std::vector<i
       } else {
         f.mode = kFOwn;
       }
+      if (pending) {
+        const MsgDesc& x = p.msgs[pending->msg];
+        f.mode |= kFPro;
+        fp.from_off = x.from_off; fp.sep_off = x.sep_off; fp.res_off = x.res_off;
+        fp.msg = pending->msg; fp.from_b = x.from_b;
+        pending = nullptr;
+        if (any_pro) *any_pro = true;
+      }
       out.push_back(f);
+      out_pro.push_back(fp);
+      ++w;
     }
     fill += len;
   }
-  for (; fill < W; ++fill) out.push_back(FEntry{});
+  for (; fill < W; ++fill) {
+    out.push_back(FEntry{});
+    out_pro.push_back(FPro{});
+  }
 }
 
 static void build_chunks(const Plan& p, Traversal& tr, bool postorder);
@@ -259,6 +301,9 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   tr.level_nrecs.assign(nlev, 0);
   tr.fentries.clear();
   tr.tentries.clear();
+  tr.fpros.clear();
+  tr.tpros.clear();
+  tr.has_pro = false;
   tr.tail_levels = 0;
   tr.max_mf = 0;
   std::vector<std::vector<int>> level_fast(nlev);               // fast tasks of each level (old task ids)
@@ -305,7 +350,7 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
     // first-fit-decreasing into groups of kFastMaxWaves wave slots; tasks of one size keep their order
     {
       std::vector<std::vector<int>> by_len(kFastMaxWaves + 1);
-      for (int t : fast) by_len[tr.task_off[t + 1] - tr.task_off[t]].push_back(t);
+      for (int t : fast) by_len[task_waves(tr, t)].push_back(t);
       std::vector<size_t> next(kFastMaxWaves + 1, 0);
       size_t left = fast.size();
       std::vector<int> members;
@@ -321,10 +366,10 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
             --len;
           }
         }
-        append_group(p, tr, members, blk, t_first, postorder, kFastMaxWaves, tr.fentries);
+        append_group(p, tr, members, blk, t_first, postorder, kFastMaxWaves, tr.fentries, tr.fpros, &tr.has_pro);
         ++tr.level_ngroups[L];
       }
-      for (int t : fast) tr.level_nrecs[L] += tr.task_off[t + 1] - tr.task_off[t];
+      for (int t : fast) tr.level_nrecs[L] += task_waves(tr, t);
     }
     level_fast[L] = fast;
     for (const auto* grp : {&fast, &slow})
@@ -373,7 +418,7 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   }
   for (int q = 0; q < tr.tail_levels; ++q) {
     const int L = postorder ? nlev - tr.tail_levels + q : q;
-    append_group(p, tr, level_fast[L], level_blk[L], tr.level_off[L], postorder, kTailWaves, tr.tentries);
+    append_group(p, tr, level_fast[L], level_blk[L], tr.level_off[L], postorder, kTailWaves, tr.tentries, tr.tpros, &tr.has_pro);
   }
   tr.task_off.swap(new_task_off);
   tr.entries.swap(new_entries);
@@ -440,6 +485,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   tr.chunks.clear();
   tr.chunk_wg_off.clear();
   tr.centries.clear();
+  tr.cpros.clear();
   tr.cgroups.clear();
   // (chain fusion makes tasks that pass through several receivers: the forest below assumes one receiver / sender per task)
   static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
@@ -511,7 +557,9 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     // workgroup of every task: the tree of the chunk's forest it belongs to (roots first)
     int n_wg = 0;
     auto parent_task = [&](int t) -> int {
-      const MsgDesc& m = p.msgs[tr.entries[tr.task_off[t]].msg];
+      // (a task's LAST entry is never a prologue: its receiver is the task's; its FIRST entry's sender is the cluster the
+      // task waits for -- the prologue's X where there is one)
+      const MsgDesc& m = p.msgs[tr.entries[postorder ? tr.task_off[t + 1] - 1 : tr.task_off[t]].msg];
       const int c = postorder ? m.to_b : m.from_b;  // the cluster whose own message (post) / receipt (pre) is the parent
       const int q = task_of[c];
       if (q < 0) return -1;
@@ -528,7 +576,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
           if (q >= 0) {
             wg_of[t] = wg_of[q];
           } else {
-            const int R = p.msgs[tr.entries[tr.task_off[t]].msg].to_b;
+            const int R = p.msgs[tr.entries[tr.task_off[t + 1] - 1].msg].to_b;
             auto it = wg_of_receiver.find(R);
             if (it == wg_of_receiver.end()) it = wg_of_receiver.emplace(R, n_wg++).first;
             wg_of[t] = it->second;
@@ -575,7 +623,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
         std::vector<int> members;
         int fill = 0;
         while (i < ts.size() && task_level[ts[i]] == L) {
-          const int len = tr.task_off[ts[i] + 1] - tr.task_off[ts[i]];
+          const int len = task_waves(tr, ts[i]);
           if (fill + len > kTailWaves) break;
           members.push_back(ts[i]);
           fill += len;
@@ -593,7 +641,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
           (void)fast_task(p, tr, t, postorder, &up0, &mt);
           blk_by_task[t - tmin] = {up0, mt};
         }
-        append_group(p, tr, members, blk_by_task, tmin, postorder, kTailWaves, tr.centries);
+        append_group(p, tr, members, blk_by_task, tmin, postorder, kTailWaves, tr.centries, tr.cpros, &tr.has_pro);
         ++ngroups;
       }
     }
@@ -604,14 +652,20 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
 }
 
 // Level-synchronous schedules of one spanning tree.
-// fuse: CHAIN FUSION.  A cluster with exactly one child in the schedule tree receives one message and can send at
-// once: the wave that delivered the message goes on with the cluster's own message(s) instead of leaving them to the
+// fuse = 1: CHAIN FUSION (opt-in).  A cluster with exactly one child in the schedule tree receives one message and can send
+// at once: the wave that delivered the message goes on with the cluster's own message(s) instead of leaving them to the
 // next level (= the next kernel launch).  Postorder: the single message into a unary cluster X is prepended to the
 // entry X -> parent(X) of the task of parent(X); preorder: the task of a cluster S whose parent has no other child is
 // appended to the parent's task.  Message order into every receiver, sequence numbers and arithmetic are unchanged;
 // only the grouping into waves and levels is: Bethe graphs (factor clusters are unary) lose half of their levels.
 // Fused tasks run on the generic kernel (entries of a task are executed in order by one wavefront).
-static void build_traversals(const Plan& p, Tree& t, bool fuse) {
+// fuse = 2: PROLOGUE FUSION (default where it applies).  Only the pairs the register-resident kernel runs as one record
+// (prologue_pair): F has one child C and a parent Y; its one incoming message of a traversal (postorder: C -> F,
+// preorder: Y -> F) integrates nothing and lands on the block its own message (F -> Y / F -> C) integrates out: the
+// incoming message becomes the PROLOGUE entry (Entry::pro) in front of F's own.  Every factor cluster of a tree's Bethe
+// graph is such an F: half of the levels go, and the tasks stay on the register-resident kernel.
+static bool tree_all_fast(const Tree& t);
+static void build_traversals(const Plan& p, Tree& t, int fuse) {
   const int n = (int)t.pa.size();
   // message id of edge i in each direction: sepset k = (a, b); dir 0 is received by a
   auto msg_to = [&](int i, int receiver) {
@@ -626,13 +680,27 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
   }
   auto unary = [&](int cluster) {
     auto it = nchild.find(cluster);
-    return fuse && it != nchild.end() && it->second == 1;
+    return fuse == 1 && it != nchild.end() && it->second == 1;
+  };
+  // fuse = 2: is F's one incoming message of the postorder / preorder the prologue of its own?
+  auto pro_cluster = [&](int F, bool post) {
+    if (fuse != 2) return false;
+    auto ic = nchild.find(F);
+    auto ip = parent_edge.find(F);
+    if (ic == nchild.end() || ic->second != 1 || ip == parent_edge.end()) return false;
+    const int ec = only_child_edge[F], ep = ip->second;
+    const int light = post ? msg_to(ec, F) : msg_to(ep, F);
+    const int heavy = post ? msg_to(ep, t.pa[ep]) : msg_to(ec, t.ch[ec]);
+    return prologue_pair(p.msgs[light], p.msgs[heavy], p.fast_p);
   };
   // ---- postorder: level = height of the child in the schedule tree (chains collapsed)
   std::unordered_map<int, int> hnode;  // cluster -> level at which it can send (its height; leaves are absent: 0)
   int post_levels = 0;
   {
     std::vector<int> lvl(n);
+    std::vector<uint8_t> chained_edge(n, 0);  // the message of edge i rides in front of the edge above its receiver
+    for (int i = 0; i < n; ++i)
+      chained_edge[i] = (unary(t.pa[i]) && parent_edge.count(t.pa[i])) || pro_cluster(t.pa[i], true);
     int nlev = 0;
     for (int i = n - 1; i >= 0; --i) {
       int h = 0;
@@ -641,8 +709,7 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
       lvl[i] = h;
       int& hp = hnode[t.pa[i]];
       // a unary parent that has an edge above it sends in the same level, right after this message
-      const bool chained = unary(t.pa[i]) && parent_edge.count(t.pa[i]);
-      hp = std::max(hp, chained ? h : h + 1);
+      hp = std::max(hp, chained_edge[i] ? h : h + 1);
       nlev = std::max(nlev, h + 1);
     }
     // PGBP_POSTORDER_ALAP=1 (opt-in, measured 1 % slower on cfg3: 0.889 - 0.899 against 0.886 ms): every message into a
@@ -658,10 +725,8 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
         if (nchild[t.pa[i]] <= kFastMaxWaves) lvl[i] = hnode[t.pa[i]] - 1;
     // tasks: group by (level, target parent); entries in reference order (decreasing i)
     std::vector<std::vector<int>> bylevel(nlev);
-    for (int i = n - 1; i >= 0; --i) {
-      const bool chained = unary(t.pa[i]) && parent_edge.count(t.pa[i]);
-      if (!chained) bylevel[lvl[i]].push_back(i);  // chained edges ride in front of the edge above their receiver
-    }
+    for (int i = n - 1; i >= 0; --i)
+      if (!chained_edge[i]) bylevel[lvl[i]].push_back(i);  // chained edges ride in front of the edge above their receiver
     Traversal& tr = t.post;
     tr = Traversal{};
     tr.level_off.push_back(0);
@@ -681,9 +746,10 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
       }
       for (auto& tk : tasks) {
         for (int top : tk) {
-          // the chain below `top`: single child edges of unary clusters, deepest first
+          // the chain below `top`: single child edges of unary / prologue clusters, deepest first
           chain.assign(1, top);
-          while (unary(t.ch[chain.back()])) chain.push_back(only_child_edge[t.ch[chain.back()]]);
+          while (unary(t.ch[chain.back()]) || pro_cluster(t.ch[chain.back()], true))
+            chain.push_back(only_child_edge[t.ch[chain.back()]]);
           for (int q = (int)chain.size() - 1; q >= 0; --q) {
             const int i = chain[q];
             Entry e{};
@@ -691,6 +757,7 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
             e.edge = i;
             e.reuse = 0;
             e.seq = n - 1 - i;
+            e.pro = (fuse == 2 && q > 0) ? 1 : 0;
             tr.entries.push_back(e);
             tr.max_mf = std::max(tr.max_mf, p.msgs[e.msg].mf);
           }
@@ -706,12 +773,11 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
   // its depth: as soon as possible) and no later than its height allows (level = tree height - its height: as late as
   // possible); both take as many levels as the tree is deep.  Default: AS LATE AS POSSIBLE, the mirror image of the
   // postorder -- the levels near the root are then as narrow as the postorder's last ones (they join the single-workgroup
-  // tail launch), and the bulk of the messages sits in a few very wide levels at the leaf end (streamed by the
-  // persistent launch), instead of a bell of mid-sized levels that each pay a full launch latency.
-  // PGBP_PREORDER_ASAP=1 (or chain fusion) keeps the depth order.
+  // tail launch), and the bulk of the messages sits in a few very wide levels at the leaf end, instead of a bell of
+  // mid-sized levels that each pay a full launch latency.  PGBP_PREORDER_ASAP=1 (or chain fusion) keeps the depth order.
   {
     static const bool asap_env = getenv("PGBP_PREORDER_ASAP") != nullptr;
-    const bool alap = !fuse && !asap_env;
+    const bool alap = fuse != 1 && !asap_env;
     auto height = [&](int cluster) {
       auto it = hnode.find(cluster);
       return it == hnode.end() ? 0 : it->second;
@@ -719,22 +785,63 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
     std::unordered_map<int, int> dnode;   // cluster -> level at which it sends
     std::unordered_map<int, int> head;    // cluster -> the cluster whose task carries its messages
     std::vector<int> lvl(n);
+    std::vector<uint8_t> pro_edge(n, 0);  // fuse = 2: the message of edge i is the prologue of its receiver's own task
     int nlev = 0;
-    for (int i = 0; i < n; ++i) {
-      int dpt = 0;
-      auto it = dnode.find(t.pa[i]);
-      if (it != dnode.end()) dpt = it->second;
-      if (alap) dpt = post_levels - height(t.pa[i]);
-      lvl[i] = dpt;
-      const bool chained = unary(t.pa[i]);   // the child's task follows this message in the same wave
-      dnode[t.ch[i]] = chained ? dpt : dpt + 1;
-      auto ih = head.find(t.pa[i]);
-      const int hp = ih == head.end() ? t.pa[i] : ih->second;
-      head[t.ch[i]] = chained ? hp : t.ch[i];
-      nlev = std::max(nlev, dpt + 1);
+    if (fuse == 2) {
+      // Levels from the dependencies themselves (the postorder's heights do not carry over: there a prologue shortens the
+      // path through F, here it moves X -> F from X's task into F's).  The task of a sender S waits for the task that
+      // delivered into S -- its parent's -- or, where parent(S) -> S is S's prologue, for the one that delivered into
+      // parent(S): its grandparent's.  depth = the longest chain of such waits above, ph = below; as late as possible:
+      // level = (largest depth) - ph.
+      for (int i = 0; i < n; ++i) pro_edge[i] = pro_cluster(t.ch[i], false);
+      std::unordered_map<int, int> depth, ph;
+      auto dep_of = [&](int S) -> int {   // the cluster whose task S's task waits for (-1: none)
+        auto ip = parent_edge.find(S);
+        if (ip == parent_edge.end()) return -1;
+        const int X = t.pa[ip->second];
+        if (!pro_edge[ip->second]) return X;
+        auto ix = parent_edge.find(X);
+        return ix == parent_edge.end() ? -1 : t.pa[ix->second];
+      };
+      int maxdepth = 0;
+      for (int i = 0; i < n; ++i) {   // senders in preorder: a sender's ancestors come before it
+        const int S = t.pa[i];
+        if (depth.count(S)) continue;
+        const int d = dep_of(S);
+        depth[S] = d < 0 ? 0 : depth[d] + 1;
+        maxdepth = std::max(maxdepth, depth[S]);
+      }
+      // (a cluster all of whose child edges are prologue edges has no task of its own: its depth is only a relay)
+      for (int i = n - 1; i >= 0; --i) {
+        const int S = t.pa[i];
+        const int d = dep_of(S);
+        if (!ph.count(S)) ph[S] = 0;
+        if (d >= 0) ph[d] = std::max(ph.count(d) ? ph[d] : 0, ph[S] + 1);
+      }
+      for (int i = 0; i < n; ++i) {
+        const int S = t.pa[i];
+        lvl[i] = alap ? maxdepth - ph[S] : depth[S];
+      }
+      // (levels of prologue edges are not used: they follow their receiver's task)
+      nlev = maxdepth + 1;
+    } else {
+      for (int i = 0; i < n; ++i) {
+        int dpt = 0;
+        auto it = dnode.find(t.pa[i]);
+        if (it != dnode.end()) dpt = it->second;
+        if (alap) dpt = post_levels - height(t.pa[i]);
+        lvl[i] = dpt;
+        const bool chained = unary(t.pa[i]);   // the child's task follows this message in the same wave
+        dnode[t.ch[i]] = chained ? dpt : dpt + 1;
+        auto ih = head.find(t.pa[i]);
+        const int hp = ih == head.end() ? t.pa[i] : ih->second;
+        head[t.ch[i]] = chained ? hp : t.ch[i];
+        nlev = std::max(nlev, dpt + 1);
+      }
     }
     std::vector<std::vector<int>> bylevel(nlev);
-    for (int i = 0; i < n; ++i) bylevel[lvl[i]].push_back(i);
+    for (int i = 0; i < n; ++i)
+      if (!pro_edge[i]) bylevel[lvl[i]].push_back(i);
     Traversal& tr = t.pre;
     tr = Traversal{};
     tr.level_off.push_back(0);
@@ -755,6 +862,21 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
       }
       for (auto& tk : tasks) {
         int prev_msg = -1;
+        if (fuse == 2) {
+          // the prologue of this sender's task: the message its parent sends into it
+          auto ip = parent_edge.find(t.pa[tk[0]]);
+          if (ip != parent_edge.end() && pro_edge[ip->second]) {
+            const int i = ip->second;
+            Entry e{};
+            e.msg = msg_to(i, t.ch[i]);
+            e.edge = i;
+            e.seq = n + i;
+            e.reuse = 0;
+            e.pro = 1;
+            tr.entries.push_back(e);
+            tr.max_mf = std::max(tr.max_mf, p.msgs[e.msg].mf);
+          }
+        }
         for (int i : tk) {
           Entry e{};
           e.msg = msg_to(i, t.ch[i]);
@@ -775,7 +897,7 @@ static void build_traversals(const Plan& p, Tree& t, bool fuse) {
         }
         tr.task_off.push_back((int)tr.entries.size());
       }
-      tr.level_off.push_back((int)tr.task_off.size() - 1);
+      if (!tasks.empty() || !fuse) tr.level_off.push_back((int)tr.task_off.size() - 1);
     }
     finalize_traversal(p, tr, false);
   }
@@ -832,7 +954,41 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
       }
       T.sep[i] = it->second;
     }
-    build_traversals(p, T, false);
+    build_traversals(p, T, 0);
+    // Prologue fusion (fuse = 2) where some cluster qualifies (every factor cluster of a tree's Bethe graph) AND the
+    // register-resident kernel runs the whole tree: on a mixed schedule (cfg5's Bethe graph: hybrid families beside
+    // tree edges in every level) the levels go to the wave-per-task kernel whole, where a prologue is one more message
+    // for the same wavefront -- half the levels at twice the time each (measured: 1.86 against 1.78 ms per iteration).
+    // The univariate site batches run on the thread-per-site kernel and keep the plain levels.  PGBP_NO_PROLOGUE=1: A/B.
+    if (tree_all_fast(T)) {
+      static const bool no_pro = getenv("PGBP_NO_PROLOGUE") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
+      const bool uni = p.max_dim <= 2 && p.n_sites >= 8;
+      if (!no_pro && !uni && p.fast_p > 0) {
+        std::unordered_map<int, int> nch, par, only;
+        for (int i = 0; i < n; ++i) {
+          if (++nch[T.pa[i]] == 1) only[T.pa[i]] = i;
+          par[T.ch[i]] = i;
+        }
+        auto msg_to = [&](int i, int receiver) {
+          const int k = T.sep[i];
+          return 2 * k + (p.sepset_clusters[2 * k] == receiver ? 0 : 1);
+        };
+        bool any = false;
+        for (const auto& kv : nch) {
+          if (kv.second != 1 || !par.count(kv.first)) continue;
+          const int F = kv.first, ec = only[F], ep = par[F];
+          if (prologue_pair(p.msgs[msg_to(ec, F)], p.msgs[msg_to(ep, T.pa[ep])], p.fast_p) ||
+              prologue_pair(p.msgs[msg_to(ep, F)], p.msgs[msg_to(ec, T.ch[ec])], p.fast_p)) {
+            any = true;
+            break;
+          }
+        }
+        if (any) {
+          build_traversals(p, T, 2);
+          if (!tree_all_fast(T)) build_traversals(p, T, 0);
+        }
+      }
+    }
     // Chain fusion is OPT-IN (PGBP_CHAIN_FUSION=1): measured on the cfg5 network (Bethe graph, 20 000 tips) it trades
     // 398 launches for 152 but a fused level lasts as long as its longest chain (about 5 us per message inside a wave
     // against about 10 us per launch): 4.8 ms per iteration against 3.9 ms.  It pays on path-like
@@ -840,7 +996,7 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
     // the thread-per-site kernel of univariate batches always keep the plain levels.
     static const bool fuse_on = getenv("PGBP_CHAIN_FUSION") != nullptr;
     const bool uni_batch = p.max_dim <= 2 && p.n_sites >= 8;
-    if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, true);
+    if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, 1);
   }
   p.trees.swap(trees);
   p.all_fast = !p.trees.empty();
@@ -927,7 +1083,7 @@ int pgbp_plan_traversal(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* 
   for (size_t i = 0; i < tr->entries.size(); ++i) {
     if (entry_msg) entry_msg[i] = tr->entries[i].msg;
     if (entry_edge) entry_edge[i] = tr->entries[i].edge;
-    if (entry_reuse) entry_reuse[i] = tr->entries[i].reuse;
+    if (entry_reuse) entry_reuse[i] = tr->entries[i].pro ? 2 : tr->entries[i].reuse;
   }
   return PGBP_OK;
 }
@@ -979,6 +1135,29 @@ int pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_c
             r[0] = f.valid; r[1] = f.msg; r[2] = f.grp_base; r[3] = f.grp_len; r[4] = f.src_wave; r[5] = f.mode;
           }
         }
+  }
+  return PGBP_OK;
+}
+
+int pgbp_plan_prologues(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_pro, int32_t* tail_pro,
+                        int32_t* chunk_pro) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr) return PGBP_ERR_INVALID;
+  auto dump = [](const std::vector<pgbp::FEntry>& v, const std::vector<pgbp::FPro>& q, size_t i0, size_t i1, int32_t* out) {
+    for (size_t i = i0; i < i1; ++i) out[i - i0] = (v[i].mode & pgbp::kFPro) ? q[i].msg : -1;
+  };
+  if (level_pro) dump(tr->fentries, tr->fpros, 0, tr->fentries.size(), level_pro);
+  if (tail_pro) dump(tr->tentries, tr->tpros, 0, tr->tentries.size(), tail_pro);
+  if (chunk_pro) {
+    size_t o = 0;
+    for (const auto& ch : tr->chunks) {
+      const size_t nrec = (size_t)ch.n_groups * pgbp::kTailWaves;
+      if (ch.generic)
+        std::fill(chunk_pro + o, chunk_pro + o + nrec, -1);
+      else
+        dump(tr->centries, tr->cpros, (size_t)ch.group0 * pgbp::kTailWaves, (size_t)ch.group0 * pgbp::kTailWaves + nrec, chunk_pro + o);
+      o += nrec;
+    }
   }
   return PGBP_OK;
 }

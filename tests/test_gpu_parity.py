@@ -1268,20 +1268,23 @@ def test_chain_fusion_opt_in_differential_fuzz(P):
 
 
 @pytest.mark.parametrize("env", [
-    {"PGBP_STREAM": "1", "PGBP_STREAM_MIN": "1", "PGBP_STREAM_GRID": "3"},
-    {"PGBP_STREAM": "1", "PGBP_STREAM_MIN": "1", "PGBP_STREAM_GRID": "2", "PGBP_NO_TAIL": "1"},
     {"PGBP_NO_TAIL": "1"},
-    {"PGBP_PREORDER_ASAP": "1", "PGBP_STREAM": "1", "PGBP_STREAM_MIN": "2", "PGBP_STREAM_GRID": "1"},
-], ids=["stream_everywhere_3wg", "stream_2wg_no_tail", "levels_only", "asap_stream_1wg"])
+    {"PGBP_PREORDER_ASAP": "1"},
+    {"PGBP_NO_PROLOGUE": "1"},
+    {"PGBP_NO_PROLOGUE": "1", "PGBP_NO_TAIL": "1"},
+    {"PGBP_POSTORDER_ALAP": "1"},
+    {"PGBP_NO_CHUNKS": "1"},
+], ids=["levels_only", "asap_preorder", "no_prologues", "no_prologues_levels_only", "alap_postorder", "no_chunks"])
 def test_launch_modes_differential_fuzz(P, env):
-    """The three launch modes of the register-resident kernel (pgbp_fast.hip: one group per workgroup; persistent grid
-    with the next sender prefetched by LDS-DMA; single-workgroup tail) run the same message body.  The tuning variables
-    are read once per process, hence child processes: the streaming launch forced onto every level with a grid of 1-3
-    workgroups (so that every workgroup walks many groups: prefetch, slot reuse, a group's invalid records), with and
-    without the tail, the level launches alone, and the depth-ordered preorder.  Same differential fuzz against the
+    """The launch modes of the register-resident kernel (pgbp_fast.hip: one group per workgroup; chunks of fused levels;
+    the single-workgroup tail) run the same message body, with or without PROLOGUES (a Bethe graph's variable-to-factor
+    messages riding in the record of the factor's own message).  The tuning variables are read once per process, hence
+    child processes: the level launches alone (no tail, no chunks), without the chunks, the depth-ordered preorder, the
+    as-late-as-possible postorder, and the two-level schedule without prologues.  Same differential fuzz against the
     plain-C sequential engine as for the defaults: random trees (polytomies: tasks of 3 and 4 messages beside tasks of 1
-    and 2 in one group; caterpillars: the whole traversal in the tail), 1-16 traits (packed and plain layouts, odd
-    instances), 1-3 sites, injected non-positive-definite blocks (first failure of the reference's order)."""
+    and 2 in one group; caterpillars: the whole traversal in the tail), clique trees and Bethe graphs, 1-16 traits (packed
+    and plain layouts, odd instances), 1-3 sites, injected non-positive-definite blocks (first failure of the reference's
+    order)."""
     import os
     import subprocess
     import sys

@@ -721,7 +721,19 @@ def _groups(lib, pl, tree, d, nlev):
     rec = np.zeros((max(1, int(ng.sum())), 4, 6), np.int32)
     trec = np.zeros((max(1, tl.value), 8, 6), np.int32)
     assert lib.pgbp_plan_groups(pl, tree, d, None, None, L.i32p(rec), L.i32p(trec)) == 0
+    # the records' prologues (pgbp_plan_prologues) ride along as a 7th word: message id or -1
+    pro = np.full((max(1, int(ng.sum())), 4), -1, np.int32)
+    tpro = np.full((max(1, tl.value), 8), -1, np.int32)
+    assert lib.pgbp_plan_prologues(pl, tree, d, L.i32p(pro), L.i32p(tpro), None) == 0
+    rec = np.concatenate([rec, pro[:, :, None]], axis=2)
+    trec = np.concatenate([trec, tpro[:, :, None]], axis=2)
+    assert np.array_equal(rec[:, :, 6] >= 0, (rec[:, :, 5] & 8) != 0) and np.array_equal(trec[:, :, 6] >= 0, (trec[:, :, 5] & 8) != 0)
     return ng, tl.value, rec[:int(ng.sum())], trec[:tl.value]
+
+
+def _record_msgs(r):
+    """messages a record's wavefront sends, in order: its prologue (if any), then its own"""
+    return ([int(r[6])] if r[6] >= 0 else []) + [int(r[1])]
 
 
 @pytest.mark.parametrize("ntips,p,kind", [(2, 3, "random"), (3, 2, "random"), (40, 4, "random"), (500, 16, "random"),
@@ -750,14 +762,15 @@ def test_group_packing_and_tail_invariants(ntips, p, kind):
         while w < W and grp[w, 0]:
             base, ln = int(grp[w, 2]), int(grp[w, 3])
             assert base == w and 1 <= ln <= 4 and w + ln <= W
-            msgs = tuple(int(grp[w + i, 1]) for i in range(ln))
+            msgs = tuple(m for i in range(ln) for m in _record_msgs(grp[w + i]))
             assert level_tasks.pop(msgs, None) is not None, "a group's task is a task of its level, once"
             for i in range(ln):
-                valid, msg, gb, gl, src, mode = (int(x) for x in grp[w + i])
+                valid, msg, gb, gl, src, mode, pro = (int(x) for x in grp[w + i])
                 assert valid == 1 and gb == base and gl == ln
                 assert base <= src <= w + i, "the marginal comes from an earlier (or the same) wave of the task"
+                mode &= ~8                                                  # (bit 3: the record has a prologue)
                 if d == 0 and ln > 1:
-                    assert mode == (3 if i == 0 else 2) and src == w + i   # accumulate: first wave owns the block
+                    assert mode & ~4 == (3 if i == 0 else 2) and src == w + i   # accumulate: first wave owns the block
                 else:
                     assert mode == 1
                     assert src == w + i or er_of[msg] == 1                 # reuse only where the planner said so
@@ -776,8 +789,8 @@ def test_group_packing_and_tail_invariants(ntips, p, kind):
         level_msgs = []
         for lv in range(nlev):
             tasks = {tuple(int(m) for m in em[to[t]:to[t + 1]]): True for t in range(lo[lv], lo[lv] + nf[lv])}
-            n_msgs = sum(len(k) for k in tasks)
-            level_msgs.append(n_msgs)
+            n_msgs = sum(len(k) for k in tasks) - sum(int(er[e] == 2) for t in range(lo[lv], lo[lv] + nf[lv]) for e in range(to[t], to[t + 1]))
+            level_msgs.append(n_msgs)     # wavefront records: a prologue rides in the record of the message behind it
             used = 0
             for g in range(g0, g0 + ng[lv]):
                 used += check_group(rec[g], 4, tasks)
@@ -962,6 +975,9 @@ def _chunks(lib, pl, tree, d):
     wg = np.zeros(max(1, int((info[:, 2] + 1).sum())), np.int32)
     rec = np.zeros((max(1, int(np.abs(info[:, 3]).sum())), 8, 6), np.int32)
     assert lib.pgbp_plan_chunks(pl, tree, d, C.byref(n), None, L.i32p(wg), L.i32p(rec)) == 0
+    cpro = np.full((rec.shape[0], 8), -1, np.int32)          # the records' prologues as a 7th word
+    assert lib.pgbp_plan_prologues(pl, tree, d, None, None, L.i32p(cpro)) == 0
+    rec = np.concatenate([rec, cpro[:, :, None]], axis=2)
     out, w0, g0 = [], 0, 0
     for (l0, l1, nwg, ng) in info:
         generic = ng < 0          # groups of 8 task ids instead of 8 message records
@@ -1024,7 +1040,7 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
         w, tasks = 0, []
         while w < grp.shape[0] and grp[w, 0]:
             ln = int(grp[w, 3])
-            tasks.append([int(grp[w + i, 1]) for i in range(ln)])
+            tasks.append([m for i in range(ln) for m in _record_msgs(grp[w + i])])
             w += ln
         assert not grp[w:, 0].any()
         return tasks
@@ -1068,8 +1084,9 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                 for wi, wg in enumerate(wg_order):
                     local = set()
                     for step in wg:
-                        readers, writers = set(), {}
+                        readers, writers = {}, {}
                         for ti, tk in enumerate(step):
+                            mine = set()      # delivered earlier in this very task (a prologue in front of its record's own message)
                             for m in tk:
                                 s_, r_, k_ = ends(m)
                                 pre = [(c, s_) for c in children.get(s_, []) if c != r_]
@@ -1078,8 +1095,9 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                                     if s_ in parent:
                                         pre.append((parent[s_], s_))
                                 for q in pre:
-                                    assert q in done or q in local, (d, m, q)
-                                readers.add(s_)
+                                    assert q in done or q in local or q in mine, (d, m, q)
+                                mine.add((s_, r_))
+                                readers.setdefault(s_, set()).add(ti)
                                 assert writers.setdefault(r_, ti) == ti
                                 # what a workgroup WRITES (the receiver, the sepset) no other workgroup of the launch
                                 # touches; a sender that nobody writes may be read by several (preorder: one task
@@ -1089,7 +1107,8 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                                     assert read_by.get(obj, {wi}) == {wi}, "a workgroup writes what another one reads"
                                 assert touched.get(("c", s_), wi) == wi, "a workgroup reads what another one writes"
                                 read_by.setdefault(("c", s_), set()).add(wi)
-                        assert not (readers & set(writers))
+                        # a cluster written in a step is read in it only by the task that writes it (a prologue's F)
+                        assert all(readers.get(c, {ti}) == {ti} for c, ti in writers.items())
                         for tk in step:
                             for m in tk:
                                 local.add(ends(m)[:2])
@@ -1258,3 +1277,64 @@ def test_residual_norm_thresholds_are_exact():
                 assert np.isinf(up) or np.float64(up) / np.float64(c) > atol, (s, c, atol, x)
     assert f(0.0, 1e-5) == np.inf and f(3.0, np.inf) == np.inf
     assert f(3.0, -1.0) == -1.0 and f(3.0, float("nan")) == -1.0
+
+
+@pytest.mark.parametrize("ntips,p", [(300, 8), (57, 5), (200, 16)])
+def test_bethe_graph_of_a_tree_is_scheduled_with_prologues(ntips, p):
+    """Prologue fusion (build_traversals, fuse = 2): in the Bethe graph of a tree every factor cluster F = {v, pa(v)} has
+    one child and one parent in the schedule tree, and the one message it receives in a traversal (from a variable
+    cluster: nothing integrated) lands on the block its own message integrates out.  That message is planned as the
+    PROLOGUE of F's own -- the entry in front of it in the same task (entry_reuse = 2), the 7th word of its record -- in
+    both traversals; no variable-to-factor message is left as a record of its own, so the levels are those of the
+    factor-to-variable messages alone; a clique tree has no such pair and keeps its schedule."""
+    rng = np.random.default_rng(ntips)
+    tr = S.random_tree(ntips, rng)
+    prob = S.bethe_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0 and _set_sched(lib, pl, prob.schedule) == 0
+    pa, ch = (np.asarray(x) for x in prob.schedule[0])
+    sc = np.asarray(prob.sepset_clusters).reshape(-1, 2)
+    nchild = {}
+    for a in pa:
+        nchild[int(a)] = nchild.get(int(a), 0) + 1
+    has_parent = {int(c) for c in ch}
+    dims = np.asarray(prob.dims)
+
+    def ends(m):
+        k, side = divmod(int(m), 2)
+        return int(sc[k][1 - side]), int(sc[k][side])     # sender, receiver
+    fusable = {c for c in nchild if nchild[c] == 1 and c in has_parent and dims[c] == 2 * p}
+    assert len(fusable) >= ntips // 2                       # the factor clusters of the internal edges
+    for d in (0, 1):
+        lo, to, em, ee, er = _traversal(lib, pl, 0, d)
+        n_pro = 0
+        for t in range(len(to) - 1):
+            for e in range(to[t], to[t + 1]):
+                s_, r_ = ends(em[e])
+                if er[e] == 2:
+                    n_pro += 1
+                    assert e + 1 < to[t + 1] and er[e + 1] != 2
+                    s2, r2 = ends(em[e + 1])
+                    assert r_ == s2 and r_ in fusable and dims[s_] == p    # X -> F in front of F -> Y, X a variable cluster
+                else:
+                    # a message that is not a prologue never goes INTO a cluster that could have taken it as one
+                    assert not (r_ in fusable and dims[s_] == p and (s_, r_) in {(int(c), int(a)) for a, c in zip(pa, ch)} and d == 0)
+        assert n_pro == len(fusable)
+        nlev = len(lo) - 1
+        ng, tl, rec, trec = _groups(lib, pl, 0, d, nlev)
+        assert int((rec[:, :, 6] >= 0).sum()) + int((trec[:, :, 6] >= 0).sum()) > 0
+    # height of the schedule tree in clusters ~ 2 x (levels of factor-to-variable messages): the fused schedule has
+    # about half as many levels as the tree is high
+    depth = {int(pa[0]): 0}
+    for a, c in zip(pa, ch):
+        depth[int(c)] = depth[int(a)] + 1
+    lo0 = _traversal(lib, pl, 0, 0)[0]
+    assert len(lo0) - 1 <= max(depth.values()) // 2 + 2
+    lib.pgbp_plan_destroy(pl)
+    # a clique tree: no prologues
+    prob = S.cliquetree_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0 and _set_sched(lib, pl, prob.schedule) == 0
+    for d in (0, 1):
+        assert not (_traversal(lib, pl, 0, d)[4] == 2).any()
+    lib.pgbp_plan_destroy(pl)
