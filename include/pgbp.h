@@ -141,6 +141,13 @@ int  pgbp_plan_chunks(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_
  * the entry in front of the record's own, in the same task. */
 int  pgbp_plan_prologues(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* level_pro, int32_t* tail_pro,
                          int32_t* chunk_pro);
+/* CHAINS of the loop launches in the packed layout (csrc/pgbp_loop.hip), one word per record of the tail and of the chunks
+ * (order as above; either may be NULL): kind | source record of the previous group << 8 | late << 16.  A workgroup loads
+ * the operands of a group while the group before it still runs: kind 1 / 3 = the integrated block of the record's 2P-dim
+ * sender / its P-dim sender's whole belief, 2 = the X of its prologue, was stored by that source record in the group
+ * before and reaches this one through the workgroup's LDS; late = the group reads from memory something else the group
+ * before it writes, or is the first of its walk: the workgroup waits for every store and loads at the group's top. */
+int  pgbp_plan_chains(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* tail_chain, int32_t* chunk_chain);
 /* The self-contained message records of the wave-per-task kernels (one 128-byte record per message of a generic-class
  * task; layout: struct GRec in csrc/pgbp_internal.hpp -- offsets of sender / receiver / sepset / residual inside a
  * site's pools, message id, sequence number, beliefs, index-pool offsets of the three maps, `next` = the record of the

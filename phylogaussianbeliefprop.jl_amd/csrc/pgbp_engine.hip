@@ -360,9 +360,14 @@ unsigned long long seq_stride(const pgbp_engine* e) {
 
 // Launch tuning read once from the environment (A/B runs and debugging; the defaults are what was measured best):
 //   PGBP_NO_TAIL=1     no single-workgroup tail launch: every level gets its own launch
+//   PGBP_LOOP=1        the loop launches (tail, chunks) of the packed layout on pgbp_loop.hip (sender operands requested
+//                      half a pass early, what a pass hands to the next one through LDS chain slots) instead of
+//                      pgbp_fast.hip's loop mode: built, bit-identical, measured 2.5 % slower on cfg3 (0.886 - 0.910
+//                      against 0.858 - 0.887 ms) and 8 % on cfg2: DESIGN.md section 4.2
 struct LaunchTuning {
-  bool tail = true;
+  bool tail = true, loop = false;
   LaunchTuning() {
+    if (getenv("PGBP_LOOP")) loop = true;
     if (getenv("PGBP_NO_TAIL")) tail = false;
   }
 };
@@ -376,6 +381,16 @@ int tail_levels(const pgbp_engine* e, const Traversal& tr, bool kl) {
   // residual_kldiv! runs between levels; the site-minor layout belongs to the thread-per-site kernel
   if (kl || e->layout_sm || !tuning().tail) return 0;
   return tr.tail_levels;
+}
+
+// a loop launch (the tail, a chunk of fused levels): pgbp_loop.hip in the packed layout, pgbp_fast.hip's loop mode otherwise
+void launch_loop_or_tail(pgbp_engine* e, const DevState& S, const FEntry* recs, const FPro* pros, int ngroups, int split,
+                         unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b,
+                         const int32_t* d_wg_off, int n_wg) {
+  if (tuning().loop && S.bs16 && e->plan.fast_p % 2 == 0)
+    launch_loop16(S, recs, pros, ngroups, split, e->plan.n_sites, seq_base, stop_a, stop_b, e->st, d_wg_off, n_wg);
+  else
+    launch_fast16(S, recs, pros, kFastTail, ngroups, split, e->plan.n_sites, seq_base, stop_a, stop_b, e->st, d_wg_off, n_wg);
 }
 
 // levels [L0, L1) of one traversal: one launch per level (two where a level mixes fast-class and generic tasks)
@@ -395,9 +410,8 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
           launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
                                e->plan.n_sites, seq_base, stop_below, ch.max_mf, ch.small_only != 0, e->st);
         else
-          launch_fast16(S, d.d_centries + ch.group0 * kTailWaves, d.d_cpros ? d.d_cpros + ch.group0 * kTailWaves : nullptr,
-                        kFastTail, ch.n_groups, INT32_MAX, e->plan.n_sites, seq_base, stop_below, stop_below, e->st,
-                        d.d_chunk_wg_off + ch.wg0, ch.n_wg);
+          launch_loop_or_tail(e, S, d.d_centries + ch.group0 * kTailWaves, d.d_cpros ? d.d_cpros + ch.group0 * kTailWaves : nullptr,
+                              ch.n_groups, INT32_MAX, seq_base, stop_below, stop_below, d.d_chunk_wg_off + ch.wg0, ch.n_wg);
         if (launches) *launches += 1;
         L = ch.level1 - 1;
         continue;
@@ -445,8 +459,8 @@ void enqueue_tree(pgbp_engine* e, const DevState& S, int tree, int dirs, unsigne
   if (np + nq > 0) {
     // d_tail = the postorder's tail groups followed by the preorder's
     const size_t first = (size_t)(np > 0 ? 0 : T.post.tail_levels) * kTailWaves;
-    launch_fast16(S, e->d_tail[tree] + first, e->d_tail_pros[tree] ? e->d_tail_pros[tree] + first : nullptr, kFastTail, np + nq,
-                  np, e->plan.n_sites, seq_base, stop_post, stop_pre, e->st);
+    launch_loop_or_tail(e, S, e->d_tail[tree] + first, e->d_tail_pros[tree] ? e->d_tail_pros[tree] + first : nullptr, np + nq,
+                        np, seq_base, stop_post, stop_pre, nullptr, 0);
     if (n_launches) *n_launches += 1;
   }
   if (dirs & 2) enqueue_levels(e, S, T.pre, e->dpre[tree], nq, nlev_pre, seq_base, stop_pre, kl, n_launches);
@@ -851,16 +865,11 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_grecs, tr.grecs))) break;
     }
     if (rc == PGBP_OK) {
-      std::vector<FEntry> tail(e->plan.trees[t].post.tentries);
-      tail.insert(tail.end(), e->plan.trees[t].pre.tentries.begin(), e->plan.trees[t].pre.tentries.end());
+      const Tree& T = e->plan.trees[t];
       FEntry* dt = nullptr;
-      if ((rc = upload(e, &dt, tail)) == PGBP_OK) e->d_tail.push_back(dt);
-      FPro* dp = nullptr;   // (null unless a traversal of this tree has prologues: then both halves, zero-filled where none)
-      if (rc == PGBP_OK && (e->plan.trees[t].post.has_pro || e->plan.trees[t].pre.has_pro)) {
-        std::vector<FPro> tp(e->plan.trees[t].post.tpros);
-        tp.insert(tp.end(), e->plan.trees[t].pre.tpros.begin(), e->plan.trees[t].pre.tpros.end());
-        rc = upload(e, &dp, tp);
-      }
+      if ((rc = upload(e, &dt, T.tail)) == PGBP_OK) e->d_tail.push_back(dt);
+      FPro* dp = nullptr;   // (null unless a traversal of this tree has prologues)
+      if (rc == PGBP_OK && (T.post.has_pro || T.pre.has_pro)) rc = upload(e, &dp, T.tail_pros);
       if (rc == PGBP_OK) e->d_tail_pros.push_back(dp);
     }
   }

@@ -79,9 +79,16 @@ struct FEntry {
                          // (its first wave owns the receiver block, the other waves hand their delta over through LDS)
   uint8_t grp_base;      // wave (record index inside the group) of the first message of this record's task
   uint8_t grp_len;       // number of messages of the task
+  // loop launches in the packed layout (pgbp_loop.hip; set by link_chains): pad[0] = CHAIN kind -- what this record's
+  // sender (1: the integrated block of a 2P sender, 3: a P-dim sender's whole belief) or its prologue's X (2) received
+  // in the previous pass of the walk is taken from the LDS chain slot of wave pad[1] instead of memory; pad[2] != 0: the
+  // record's group is LATE (it reads from memory something else the previous pass wrote: full barrier, loads at its top)
   uint8_t pad[6];
 };
 static_assert(sizeof(FEntry) == 64, "FEntry must be one 64-byte record");
+// walks: ranges [first group, one past the last) of groups of kTailWaves records that ONE workgroup walks pass after pass
+void link_chains(std::vector<FEntry>& recs, const std::vector<struct FPro>& pros, const std::vector<std::pair<int64_t, int64_t>>& walks,
+                 int P);
 // Prologue of a record (kFPro): the message X -> F, F = the record's sender, that integrates nothing and lands on the block
 // of F the record's own message integrates out (a variable cluster's message into a factor cluster of a Bethe graph).
 // What is not here comes from the record: F's record (from_off), the block (keep0), F's belief index (from_b).
@@ -152,6 +159,10 @@ struct Traversal {
 struct Tree {
   std::vector<int32_t> pa, ch, sep;  // per edge: parent cluster, child cluster, sepset (0-based among sepsets)
   Traversal post, pre;
+  // the tail launch's records: the postorder's tail groups followed by the preorder's (one walk: link_chains), and their
+  // prologues (same indexing; all zero where no record has one)
+  std::vector<FEntry> tail;
+  std::vector<FPro> tail_pros;
 };
 
 struct Plan {

@@ -103,6 +103,11 @@ void launch_fast16(const DevState& S, const FEntry* d_recs, const FPro* d_pros, 
                    unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
                    const int32_t* d_wg_off = nullptr, int n_wg = 0);
 
+// the loop launches in the packed layout, even P (pgbp_loop.hip): arguments as for launch_fast16's mode kFastTail
+void launch_loop16(const DevState& S, const FEntry* d_recs, const FPro* d_pros, int ngroups, int split, int n_sites,
+                   unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b, hipStream_t st,
+                   const int32_t* d_wg_off = nullptr, int n_wg = 0);
+
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
                       double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
 

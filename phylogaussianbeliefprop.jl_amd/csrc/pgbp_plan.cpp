@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <unordered_map>
 
 #include "pgbp_internal.hpp"
@@ -279,6 +280,88 @@ static void append_group(const Plan& p, const Traversal& tr, const std::vector<i
   for (; fill < W; ++fill) {
     out.push_back(FEntry{});
     out_pro.push_back(FPro{});
+  }
+}
+
+// CHAINS and LATE groups of the loop launches (pgbp_loop.hip).  A workgroup walks its groups pass after pass; the operands
+// of pass g + 1 are loaded while pass g still runs, so nothing pass g + 1 reads from memory may be written by pass g:
+//   * the block a wavefront of pass g accumulates into a cluster that SENDS in pass g + 1 -- the integrated block of a 2P
+//     sender (kind 1), a P-dim sender's whole belief (3), the X of a prologue (2) -- travels through that wavefront's LDS
+//     chain slot;
+//   * any other overlap (a receiver block or a receiver's g, a sepset, the kept block of a sender) makes group g + 1 LATE:
+//     the workgroup waits for every store of pass g and loads at the top of pass g + 1;
+//   * the first group of a walk is always late.
+void link_chains(std::vector<FEntry>& recs, const std::vector<FPro>& pros, const std::vector<std::pair<int64_t, int64_t>>& walks,
+                 int P) {
+  constexpr int W = kTailWaves;
+  struct Wr { int wave; bool block; int mt, up0; };
+  for (const auto& wk : walks) {
+    for (int64_t g = wk.first; g < wk.second; ++g) {
+      FEntry* B = &recs[(size_t)g * W];
+      for (int w = 0; w < W; ++w) B[w].pad[0] = B[w].pad[1] = B[w].pad[2] = 0;
+      bool late = g == wk.first;
+      if (!late) {
+        const FEntry* A = &recs[(size_t)(g - 1) * W];
+        std::unordered_map<int, Wr> wrote;          // cluster -> the (one) record of pass g - 1 that stores into it
+        std::unordered_map<int, int> wrote_n;
+        std::set<int64_t> seps;                     // sepsets pass g - 1 stores
+        for (int w = 0; w < W; ++w) {
+          const FEntry& r = A[w];
+          if (!r.valid) continue;
+          seps.insert(r.sep_off);
+          if (r.mode & kFPro) {
+            seps.insert(pros[(size_t)(g - 1) * W + w].sep_off);
+            wrote[r.from_b] = Wr{w, false, 0, 0};   // the prologue's F: not chainable
+            wrote_n[r.from_b] += 2;
+          }
+          if (r.mode & kFOwn) {
+            const bool blk = r.s > 0 || ((r.mode & kFAccum) && !(r.mode & kFNoBlock));
+            wrote[r.to_b] = Wr{w, blk, r.mt, r.up0};
+            wrote_n[r.to_b] += 1;
+          }
+        }
+        for (int w = 0; w < W && !late; ++w) {
+          FEntry& r = B[w];
+          if (!r.valid) continue;
+          const bool has_pro = (r.mode & kFPro) != 0;
+          const FPro* q = has_pro ? &pros[(size_t)g * W + w] : nullptr;
+          if (seps.count(r.sep_off) || (q && seps.count(q->sep_off))) late = true;
+          if ((r.mode & kFOwn) && wrote.count(r.to_b)) late = true;
+          if (r.src_wave == w) {   // it reads its sender
+            auto it = wrote.find(r.from_b);
+            if (it != wrote.end()) {
+              const Wr& x = it->second;
+              const bool one = wrote_n[r.from_b] == 1 && x.block;
+              if (one && r.mf == 2 * P && x.mt == 2 * P && x.up0 == (r.keep0 == 0 ? P : 0) && !has_pro) {
+                r.pad[0] = 1; r.pad[1] = (uint8_t)x.wave;
+              } else if (one && r.mf == P && x.mt == P) {
+                r.pad[0] = 3; r.pad[1] = (uint8_t)x.wave;
+              } else {
+                late = true;
+              }
+            }
+            if (q) {
+              auto ix = wrote.find(q->from_b);
+              if (ix != wrote.end()) {
+                const Wr& x = ix->second;
+                if (wrote_n[q->from_b] == 1 && x.block && x.mt == P && r.pad[0] == 0) {
+                  r.pad[0] = 2; r.pad[1] = (uint8_t)x.wave;
+                } else {
+                  late = true;
+                }
+              }
+            }
+          }
+          // (a record that reuses a sibling's marginal reads nothing of the sender: what the previous pass did to it,
+          // a failure included, reaches it through the providing record's state)
+        }
+      }
+      if (late)
+        for (int w = 0; w < W; ++w) {
+          B[w].pad[0] = B[w].pad[1] = 0;
+          B[w].pad[2] = 1;
+        }
+    }
   }
 }
 
@@ -649,6 +732,17 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     ch.n_groups = ngroups;
     tr.chunks.push_back(ch);
   }
+  // chains / late groups of the register-resident chunks: one walk per workgroup
+  {
+    std::vector<std::pair<int64_t, int64_t>> walks;
+    for (const Traversal::Chunk& ch : tr.chunks) {
+      if (ch.generic) continue;
+      for (int b = 0; b < ch.n_wg; ++b)
+        walks.push_back({ch.group0 + tr.chunk_wg_off[ch.wg0 + b], ch.group0 + tr.chunk_wg_off[ch.wg0 + b + 1]});
+    }
+    if (tr.cpros.size() < tr.centries.size()) tr.cpros.resize(tr.centries.size());
+    link_chains(tr.centries, tr.cpros, walks, p.fast_p);
+  }
 }
 
 // Level-synchronous schedules of one spanning tree.
@@ -997,6 +1091,13 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
     static const bool fuse_on = getenv("PGBP_CHAIN_FUSION") != nullptr;
     const bool uni_batch = p.max_dim <= 2 && p.n_sites >= 8;
     if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, 1);
+    // the tail launch walks the postorder's last levels and the preorder's first ones as ONE sequence of passes
+    T.tail = T.post.tentries;
+    T.tail.insert(T.tail.end(), T.pre.tentries.begin(), T.pre.tentries.end());
+    T.tail_pros = T.post.tpros;
+    T.tail_pros.insert(T.tail_pros.end(), T.pre.tpros.begin(), T.pre.tpros.end());
+    T.tail_pros.resize(T.tail.size());
+    link_chains(T.tail, T.tail_pros, {{0, (int64_t)(T.tail.size() / kTailWaves)}}, p.fast_p);
   }
   p.trees.swap(trees);
   p.all_fast = !p.trees.empty();
@@ -1156,6 +1257,27 @@ int pgbp_plan_prologues(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* 
         std::fill(chunk_pro + o, chunk_pro + o + nrec, -1);
       else
         dump(tr->centries, tr->cpros, (size_t)ch.group0 * pgbp::kTailWaves, (size_t)ch.group0 * pgbp::kTailWaves + nrec, chunk_pro + o);
+      o += nrec;
+    }
+  }
+  return PGBP_OK;
+}
+
+int pgbp_plan_chains(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* tail_chain, int32_t* chunk_chain) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr) return PGBP_ERR_INVALID;
+  auto word = [](const pgbp::FEntry& f) { return (int32_t)f.pad[0] | ((int32_t)f.pad[1] << 8) | ((int32_t)f.pad[2] << 16); };
+  if (tail_chain) {
+    const pgbp::Tree& T = p->p.trees[tree];
+    const size_t first = dir == 0 ? 0 : T.post.tentries.size();
+    for (size_t i = 0; i < tr->tentries.size(); ++i) tail_chain[i] = word(T.tail[first + i]);
+  }
+  if (chunk_chain) {
+    size_t o = 0;
+    for (const auto& ch : tr->chunks) {
+      const size_t nrec = (size_t)ch.n_groups * pgbp::kTailWaves;
+      for (size_t i = 0; i < nrec; ++i)
+        chunk_chain[o + i] = ch.generic ? 0 : word(tr->centries[(size_t)ch.group0 * pgbp::kTailWaves + i]);
       o += nrec;
     }
   }

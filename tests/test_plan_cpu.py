@@ -1338,3 +1338,110 @@ def test_bethe_graph_of_a_tree_is_scheduled_with_prologues(ntips, p):
     for d in (0, 1):
         assert not (_traversal(lib, pl, 0, d)[4] == 2).any()
     lib.pgbp_plan_destroy(pl)
+
+
+@pytest.mark.parametrize("ntips,p,kind,graph", [(3000, 16, "random", "cliquetree"), (900, 8, "random", "bethe"),
+                                                (60, 16, "caterpillar", "cliquetree"), (400, 4, "poly4", "cliquetree"),
+                                                (300, 6, "random", "bethe")])
+def test_loop_launches_read_nothing_the_pass_before_wrote_except_through_a_chain(ntips, p, kind, graph):
+    """Chains and late groups of the loop launches (link_chains in pgbp_plan.cpp, pgbp_loop.hip): the workgroup of a tail or
+    chunk loads a group's operands while the group before it is still being stored.  Replaying every walk group by group:
+    whatever a record of a group that is not `late` reads -- its sender, its prologue's X, its sepset(s), its receiver --
+    was not written by the group before it, EXCEPT the one block a chain names: then the chain's source record of the
+    group before is the owner of that very cluster, and the chain covers exactly what was written (the integrated block
+    of a 2P sender, a P-dim cluster whole).  The first group of a walk is late; on a tree the tail has late groups only
+    at its start and where the postorder turns into the preorder, so that the chains are what the tail runs on."""
+    rng = np.random.default_rng(ntips + p)
+    if kind == "random":
+        tr = S.random_tree(ntips, rng)
+    elif kind == "caterpillar":
+        tr = S.caterpillar_tree(ntips, rng)
+    else:
+        tr = S.random_multifurcating_tree(ntips, int(kind[4:]), rng)
+    prob = S.cliquetree_of_tree(tr, p) if graph == "cliquetree" else S.bethe_of_tree(tr, p)
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0 and _set_sched(lib, pl, prob.schedule) == 0
+    sc = np.asarray(prob.sepset_clusters).reshape(-1, 2)
+    dims = np.asarray(prob.dims)
+
+    def ends(m):
+        k, side = divmod(int(m), 2)
+        return int(sc[k][1 - side]), int(sc[k][side]), k     # sender, receiver, sepset
+
+    def check_walk(groups, chains):
+        """groups: [n][8][7] records (+ prologue word); chains: [n][8] words"""
+        n_chain = n_late = 0
+        for gi in range(len(groups)):
+            late = [int(c) >> 16 & 1 for c in chains[gi]]
+            assert len(set(late)) == 1, "late is a property of the group"
+            if gi == 0:
+                assert late[0] == 1
+            if late[0]:
+                n_late += 1
+                assert not any(int(c) & 0xff for c in chains[gi])
+                continue
+            prev = groups[gi - 1]
+            wrote_cl, wrote_sep, owner = set(), set(), {}
+            for w in range(8):
+                if not prev[w, 0]:
+                    continue
+                for m in _record_msgs(prev[w]):
+                    s_, r_, k_ = ends(m)
+                    wrote_sep.add(k_)
+                    if m != int(prev[w, 1]):
+                        wrote_cl.add(r_)                      # a prologue stores into F
+                if prev[w, 5] & 1:                            # kFOwn: this record stores the receiver
+                    r_ = ends(prev[w, 1])[1]
+                    wrote_cl.add(r_)
+                    owner[r_] = w
+            for w in range(8):
+                rec = groups[gi][w]
+                if not rec[0]:
+                    continue
+                kind, src = int(chains[gi][w]) & 0xff, int(chains[gi][w]) >> 8 & 0xff
+                s_, r_, k_ = ends(rec[1])
+                assert k_ not in wrote_sep
+                if rec[5] & 1:
+                    assert r_ not in wrote_cl, "a receiver written in the pass before: the group must be late"
+                provider = int(rec[4]) == w
+                x_ = ends(rec[6])[0] if rec[6] >= 0 else None
+                if rec[6] >= 0:
+                    assert ends(rec[6])[2] not in wrote_sep
+                if provider and s_ in wrote_cl:
+                    assert kind in (1, 3) and owner.get(s_) == src
+                    assert (kind == 1) == (dims[s_] == 2 * p)
+                elif kind in (1, 3):
+                    assert False, "a chain without a write to carry"
+                if x_ is not None and x_ in wrote_cl:
+                    assert kind == 2 and owner.get(x_) == src and dims[x_] == p
+                elif kind == 2:
+                    assert False, "a chain without a write to carry"
+                n_chain += kind != 0
+        return n_chain, n_late
+
+    for d in (0, 1):
+        lo = _traversal(lib, pl, 0, d)[0]
+        nlev = len(lo) - 1
+        ng, tl, rec, trec = _groups(lib, pl, 0, d, nlev)
+        ch = _chunks(lib, pl, 0, d)
+        n_rec_chunks = sum(len(g) for c in ch for w in c[2] for g in [w]) if ch else 0
+        tail_chain = np.zeros((max(1, tl), 8), np.int32)
+        chunk_chain = np.zeros((max(1, sum(len(w) for c in ch for w in c[2])), 8), np.int32)
+        assert lib.pgbp_plan_chains(pl, 0, d, L.i32p(tail_chain), L.i32p(chunk_chain)) == 0
+        if d == 0:
+            post_tail = (trec, tail_chain[:tl].copy())
+        else:
+            # the tail launch walks the postorder's tail, then the preorder's, as one sequence
+            groups = np.concatenate([post_tail[0], trec]) if tl + len(post_tail[0]) else trec
+            chains = np.concatenate([post_tail[1], tail_chain[:tl]])
+            if len(groups):
+                n_chain, n_late = check_walk(groups, chains)
+                if ntips >= 300 and graph == "cliquetree" and kind == "random":
+                    assert n_late <= len(groups) // 2 and n_chain >= len(groups) // 2
+        o = 0
+        for (l0, l1, wgs, generic) in ch:
+            for w in wgs:
+                if not generic and len(w):
+                    check_walk(w, chunk_chain[o:o + len(w)])
+                o += len(w)
+    lib.pgbp_plan_destroy(pl)
