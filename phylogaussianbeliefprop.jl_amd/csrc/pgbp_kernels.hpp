@@ -59,7 +59,13 @@ __device__ __forceinline__ double log_by_table(const double2* __restrict__ tab, 
   int e;
   const double m = frexp(x, &e);
   const int i = __builtin_amdgcn_readfirstlane((__double2hiint(m) >> 13) & 127);
-  const double2 t = tab[i];
+  // (through the CONSTANT address space: with a wave-uniform index the compiler then issues a scalar load -- a hundred
+  // clocks out of the scalar cache on the critical path of a message instead of a vector load's trip to L2)
+  typedef double pgbp_cdouble2 __attribute__((ext_vector_type(2)));
+  const __attribute__((address_space(4))) pgbp_cdouble2* ctab =
+      reinterpret_cast<const __attribute__((address_space(4))) pgbp_cdouble2*>(reinterpret_cast<unsigned long long>(tab));
+  const pgbp_cdouble2 tv = ctab[i];
+  const double2 t = make_double2(tv.x, tv.y);
   const double r = fma(m, t.x, -1.0);
   double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
   p = fma(p, r, 0.2);
