@@ -399,6 +399,30 @@ int  pgbp_group_enqueue_loglik_lg(pgbp_group* g, int32_t reps, const pgbp_opts* 
 int  pgbp_group_fetch_loglik(pgbp_group* g, double* norm, int32_t* info); /* [n_sites_total] */
 int  pgbp_group_sync(pgbp_group* g);
 
+/* ---- several scope patterns behind one handle (src/beliefs.jl:551-559) ------------------------------------------------
+ * A site whose data miss other traits at other tips than another site's has other scopes: an internal node has a trait in
+ * scope iff some tip below it has a value for it, so belief dimensions and index maps -- the pgbp_desc -- differ.  One
+ * engine per PATTERN, the sites that share it batched inside (descs[k]->n_sites of them), on the device descs[k] names;
+ * every pattern describes the same cluster graph (clusters, sepsets, their order), so one schedule serves all.
+ * sites[sum n_sites]: the caller's (global) index of every site, pattern after pattern: per-site results come back in the
+ * caller's order.  Beliefs, factors and family tables have pattern-specific sizes: use pgbp_patterns_engine(k) with the
+ * single-engine calls (pgbp_set_beliefs, pgbp_lg_setup, pgbp_lg_assignfactors, ...). */
+typedef struct pgbp_patterns pgbp_patterns;
+int  pgbp_patterns_create(int32_t n_patterns, const pgbp_desc* const* descs, const int32_t* sites, pgbp_patterns** out);
+void pgbp_patterns_destroy(pgbp_patterns* g);
+const char* pgbp_patterns_last_error(const pgbp_patterns* g);
+int32_t pgbp_patterns_size(const pgbp_patterns* g);
+pgbp_engine* pgbp_patterns_engine(pgbp_patterns* g, int32_t pattern);
+int  pgbp_patterns_set_schedule(pgbp_patterns* g, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
+                                const int32_t* ch_j);
+int  pgbp_patterns_calibrate(pgbp_patterns* g, int32_t niter, const pgbp_opts* opts, pgbp_result* results); /* [n_sites] */
+int  pgbp_patterns_enqueue_calibrate(pgbp_patterns* g, int32_t reps, int32_t reset_each, const pgbp_opts* opts);
+int  pgbp_patterns_enqueue_loglik(pgbp_patterns* g, int32_t reps, const pgbp_opts* opts);
+int  pgbp_patterns_enqueue_loglik_lg(pgbp_patterns* g, int32_t reps, const pgbp_opts* opts);
+int  pgbp_patterns_fetch_loglik(pgbp_patterns* g, double* norm, int32_t* info);            /* [n_sites], caller's order */
+int  pgbp_patterns_integrate(pgbp_patterns* g, int32_t belief, double* norm, int32_t* info); /* [n_sites], caller's order */
+int  pgbp_patterns_sync(pgbp_patterns* g);
+
 /* (2) ONE PROCESS PER GPU (torchrun / MPI / Distributed.jl).  Every rank owns an ordinary engine over its own sites;
  * the only exchange is ONE ncclAllGather (RCCL over xGMI) per pgbp_comm_gather_loglik call.  RCCL is bound at run time
  * (dlopen of librccl.so.1, or of the one path in the environment variable PGBP_RCCL_LIB); without it the calls return

@@ -147,6 +147,19 @@ SYMBOLS = {
     "pgbp_group_enqueue_loglik_lg": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
     "pgbp_group_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),
     "pgbp_group_sync": (C.c_int, [_P]),
+    "pgbp_patterns_create": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(Desc)), _I32P, C.POINTER(_P)]),
+    "pgbp_patterns_destroy": (None, [_P]),
+    "pgbp_patterns_last_error": (C.c_char_p, [_P]),
+    "pgbp_patterns_size": (C.c_int32, [_P]),
+    "pgbp_patterns_engine": (_P, [_P, C.c_int32]),
+    "pgbp_patterns_set_schedule": (C.c_int, [_P, C.c_int32, _I32P, _I32P, _I32P]),
+    "pgbp_patterns_calibrate": (C.c_int, [_P, C.c_int32, C.POINTER(Opts), C.POINTER(Result)]),
+    "pgbp_patterns_enqueue_calibrate": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_patterns_enqueue_loglik": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_patterns_enqueue_loglik_lg": (C.c_int, [_P, C.c_int32, C.POINTER(Opts)]),
+    "pgbp_patterns_fetch_loglik": (C.c_int, [_P, _F64P, _I32P]),
+    "pgbp_patterns_integrate": (C.c_int, [_P, C.c_int32, _F64P, _I32P]),
+    "pgbp_patterns_sync": (C.c_int, [_P]),
     "pgbp_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "pgbp_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "pgbp_comm_destroy": (None, [_P]),

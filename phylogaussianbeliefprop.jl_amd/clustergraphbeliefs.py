@@ -81,13 +81,13 @@ class ClusterGraphBelief:
 
     @classmethod
     def from_arrays(cls, dims, sepset_clusters, scope_off, scope_idx, packed, n_sites=1, device=0,
-                    labels=None):
+                    labels=None, engine=None):
         """Bulk constructor: description arrays of include/pgbp.h + packed (J,h,g) beliefs
         [n_sites, packed_size]; the cluster part is snapshot as the factors.  packed=None: nothing is uploaded and no
         host mirror is kept (large site batches whose factors are assigned on the device)."""
         self = cls.__new__(cls)
         self._init_common(np.asarray(dims, np.int32), np.asarray(sepset_clusters, np.int32).reshape(-1),
-                          np.asarray(scope_off, np.int64), np.asarray(scope_idx, np.int32), n_sites, device)
+                          np.asarray(scope_off, np.int64), np.asarray(scope_idx, np.int32), n_sites, device, engine=engine)
         self._objs = None
         self._labels = labels
         self.cdict = self.sdict = None
@@ -97,9 +97,12 @@ class ClusterGraphBelief:
         return self
 
     # ------------------------------------------------------------------ internals
-    def _init_common(self, dims, sepcl, scope_off, scope_idx, n_sites, device):
+    def _init_common(self, dims, sepcl, scope_off, scope_idx, n_sites, device, engine=None):
+        """engine: an engine created elsewhere for the same description (PatternGroup: pgbp_patterns_engine); it is
+        borrowed, not destroyed with this object."""
         self._lib = L.load()
         self._eng = None
+        self._borrowed = engine is not None
         self.n_sites = int(n_sites)
         self._dims = dims
         self.nsepsets = (len(scope_off) - 1) // 2
@@ -109,9 +112,12 @@ class ClusterGraphBelief:
         self._scope_off, self._scope_idx = scope_off, scope_idx
         desc, self._keep = L.make_desc(dims, sepcl, scope_off, scope_idx, n_sites, device)
         eng = C.c_void_p()
-        code = self._lib.pgbp_create(C.byref(desc), C.byref(eng))
-        if code != L.PGBP_OK:
-            raise L.PgbpError(code, self._lib.pgbp_last_error(None).decode())
+        if engine is not None:
+            eng = engine if isinstance(engine, C.c_void_p) else C.c_void_p(engine)
+        else:
+            code = self._lib.pgbp_create(C.byref(desc), C.byref(eng))
+            if code != L.PGBP_OK:
+                raise L.PgbpError(code, self._lib.pgbp_last_error(None).decode())
         self._eng = eng
         m = dims.astype(np.int64)
         self._poff = np.concatenate([[0], np.cumsum(m * m + m + 1)])
@@ -139,7 +145,8 @@ class ClusterGraphBelief:
     def __del__(self):
         try:
             if getattr(self, "_eng", None):
-                self._lib.pgbp_destroy(self._eng)
+                if not getattr(self, "_borrowed", False):
+                    self._lib.pgbp_destroy(self._eng)
                 self._eng = None
         except Exception:
             pass

@@ -230,6 +230,168 @@ int pgbp_group_sync(pgbp_group* g) {
 
 }  // extern "C"
 
+// ------------------------------------------------------------------------------------------------ several scope patterns
+// Sites whose data miss different traits at different tips have different scopes (allocatebeliefs, src/beliefs.jl:551-559:
+// an internal node has a trait in scope iff some tip below it has a value for it): different belief dimensions, different
+// index maps -- a different pgbp_desc.  One engine per PATTERN, the sites of a pattern batched inside it, every call fanned
+// out over the engines (their streams run side by side on the device) and the per-site results scattered back into the
+// caller's site order.
+struct pgbp_patterns {
+  std::vector<pgbp_engine*> eng;
+  std::vector<int32_t> first, count;  // position of each pattern's sites in `sites`
+  std::vector<int32_t> sites;         // global site index of every site, pattern after pattern
+  int32_t n_sites = 0;
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_patterns_create_error;
+
+template <class F>
+int for_patterns(pgbp_patterns* g, F fn) {
+  const int k = (int)g->eng.size();
+  std::vector<int> rc(k, PGBP_OK);
+  if (k == 1) {
+    rc[0] = fn(0);
+  } else {
+    std::vector<std::thread> th;
+    th.reserve(k);
+    for (int i = 0; i < k; ++i) th.emplace_back([&, i] { rc[i] = fn(i); });
+    for (auto& t : th) t.join();
+  }
+  for (int i = 0; i < k; ++i)
+    if (rc[i] != PGBP_OK) {
+      g->err = "pattern " + std::to_string(i) + ": " + pgbp_last_error(g->eng[i]);
+      return rc[i];
+    }
+  return PGBP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pgbp_patterns_last_error(const pgbp_patterns* g) { return g ? g->err.c_str() : g_patterns_create_error.c_str(); }
+
+void pgbp_patterns_destroy(pgbp_patterns* g) {
+  if (!g) return;
+  for (pgbp_engine* e : g->eng) pgbp_destroy(e);
+  delete g;
+}
+
+int pgbp_patterns_create(int32_t n_patterns, const pgbp_desc* const* descs, const int32_t* sites, pgbp_patterns** out) {
+  if (!out) return PGBP_ERR_INVALID;
+  *out = nullptr;
+  if (n_patterns < 1 || !descs || !sites) {
+    g_patterns_create_error = "pgbp_patterns_create: need at least one pattern, its descriptions and the site list";
+    return PGBP_ERR_INVALID;
+  }
+  std::unique_ptr<pgbp_patterns> g(new pgbp_patterns());
+  for (int k = 0; k < n_patterns; ++k) {
+    if (!descs[k] || descs[k]->n_sites < 1 || descs[k]->n_clusters != descs[0]->n_clusters ||
+        descs[k]->n_sepsets != descs[0]->n_sepsets) {
+      g_patterns_create_error = "pgbp_patterns_create: pattern " + std::to_string(k) +
+                                " is not the same cluster graph (clusters, sepsets) as pattern 0, or has no site";
+      return PGBP_ERR_INVALID;
+    }
+    g->first.push_back(g->n_sites);
+    g->count.push_back(descs[k]->n_sites);
+    g->n_sites += descs[k]->n_sites;
+  }
+  g->sites.assign(sites, sites + g->n_sites);
+  {  // a permutation of 0 .. n_sites - 1
+    std::vector<char> seen(g->n_sites, 0);
+    for (int32_t v : g->sites)
+      if (v < 0 || v >= g->n_sites || seen[v]++) {
+        g_patterns_create_error = "pgbp_patterns_create: `sites` is not a permutation of 0 .. n_sites - 1";
+        return PGBP_ERR_INVALID;
+      }
+  }
+  g->eng.assign(n_patterns, nullptr);
+  for (int k = 0; k < n_patterns; ++k) {
+    const int rc = pgbp_create(descs[k], &g->eng[k]);
+    if (rc) {
+      g_patterns_create_error = "pattern " + std::to_string(k) + ": " + pgbp_last_error(nullptr);
+      pgbp_patterns_destroy(g.release());
+      return rc;
+    }
+  }
+  *out = g.release();
+  return PGBP_OK;
+}
+
+int32_t pgbp_patterns_size(const pgbp_patterns* g) { return g ? (int32_t)g->eng.size() : -1; }
+
+pgbp_engine* pgbp_patterns_engine(pgbp_patterns* g, int32_t pattern) {
+  return (g && pattern >= 0 && pattern < (int)g->eng.size()) ? g->eng[pattern] : nullptr;
+}
+
+int pgbp_patterns_set_schedule(pgbp_patterns* g, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
+                               const int32_t* ch_j) {
+  if (!g) return PGBP_ERR_INVALID;
+  return for_patterns(g, [&](int i) { return pgbp_set_schedule(g->eng[i], n_trees, tree_off, pa_j, ch_j); });
+}
+
+int pgbp_patterns_calibrate(pgbp_patterns* g, int32_t niter, const pgbp_opts* opts, pgbp_result* results) {
+  if (!g || !results) return PGBP_ERR_INVALID;
+  std::vector<pgbp_result> tmp(g->n_sites);
+  const int rc = for_patterns(g, [&](int i) { return pgbp_calibrate(g->eng[i], niter, opts, tmp.data() + g->first[i]); });
+  if (rc) return rc;
+  for (int q = 0; q < g->n_sites; ++q) results[g->sites[q]] = tmp[q];
+  return PGBP_OK;
+}
+
+int pgbp_patterns_enqueue_calibrate(pgbp_patterns* g, int32_t reps, int32_t reset_each, const pgbp_opts* opts) {
+  if (!g) return PGBP_ERR_INVALID;
+  return for_patterns(g, [&](int i) { return pgbp_enqueue_calibrate(g->eng[i], reps, reset_each, opts); });
+}
+
+int pgbp_patterns_enqueue_loglik(pgbp_patterns* g, int32_t reps, const pgbp_opts* opts) {
+  if (!g) return PGBP_ERR_INVALID;
+  return for_patterns(g, [&](int i) { return pgbp_enqueue_loglik(g->eng[i], reps, opts); });
+}
+
+int pgbp_patterns_enqueue_loglik_lg(pgbp_patterns* g, int32_t reps, const pgbp_opts* opts) {
+  if (!g) return PGBP_ERR_INVALID;
+  return for_patterns(g, [&](int i) { return pgbp_enqueue_loglik_lg(g->eng[i], reps, opts); });
+}
+
+int pgbp_patterns_fetch_loglik(pgbp_patterns* g, double* norm, int32_t* info) {
+  if (!g || !norm) return PGBP_ERR_INVALID;
+  std::vector<double> tn(g->n_sites);
+  std::vector<int32_t> ti(g->n_sites);
+  const int rc = for_patterns(g, [&](int i) { return pgbp_fetch_loglik(g->eng[i], tn.data() + g->first[i], ti.data() + g->first[i]); });
+  if (rc) return rc;
+  for (int q = 0; q < g->n_sites; ++q) {
+    norm[g->sites[q]] = tn[q];
+    if (info) info[g->sites[q]] = ti[q];
+  }
+  return PGBP_OK;
+}
+
+int pgbp_patterns_integrate(pgbp_patterns* g, int32_t belief, double* norm, int32_t* info) {
+  if (!g || !norm) return PGBP_ERR_INVALID;
+  std::vector<double> tn(g->n_sites);
+  std::vector<int32_t> ti(g->n_sites);
+  const int rc = for_patterns(g, [&](int i) {
+    return pgbp_integrate(g->eng[i], belief, nullptr, tn.data() + g->first[i], ti.data() + g->first[i]);
+  });
+  if (rc) return rc;
+  for (int q = 0; q < g->n_sites; ++q) {
+    norm[g->sites[q]] = tn[q];
+    if (info) info[g->sites[q]] = ti[q];
+  }
+  return PGBP_OK;
+}
+
+int pgbp_patterns_sync(pgbp_patterns* g) {
+  if (!g) return PGBP_ERR_INVALID;
+  return for_patterns(g, [&](int i) { return pgbp_sync(g->eng[i]); });
+}
+
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------------------ one process per GPU: RCCL
 namespace {
 

@@ -136,6 +136,89 @@ class EngineGroup:
         self._check(self.lib.pgbp_group_sync(self._g))
 
 
+class PatternGroup:
+    """pgbp_patterns: sites with different missing-data patterns -- different scopes, hence different belief dimensions
+    (allocatebeliefs, src/beliefs.jl:551-559) -- behind one handle: one engine per pattern, the sites of a pattern batched
+    inside it, per-site results in the caller's site order.
+    patterns: list of (dims, sepset_clusters, scope_off, scope_idx, sites) -- the description arrays of include/pgbp.h for
+    the pattern's scopes and the (global) indices of the sites that have it.  self.beliefs[k]: a ClusterGraphBelief over
+    pattern k's engine (pgbp_patterns_engine) for everything pattern-specific: beliefs, lg_setup, assignfactors_lg_."""
+
+    def __init__(self, patterns, device=0):
+        import ctypes as C
+        from . import _lib as L
+        from .clustergraphbeliefs import ClusterGraphBelief
+        self._C, self._L = C, L
+        self.lib = L.load()
+        descs, self._keep = [], []
+        sites = []
+        for dims, sc, so, si, st in patterns:
+            d, k = L.make_desc(dims, sc, so, si, len(st), device)
+            descs.append(d)
+            self._keep.append(k)
+            sites.extend(int(x) for x in st)
+        self.n_sites = len(sites)
+        self.sites = np.ascontiguousarray(sites, dtype=np.int32)
+        arr = (C.POINTER(L.Desc) * len(descs))(*[C.pointer(d) for d in descs])
+        self._descs = descs
+        self._g = C.c_void_p()
+        code = self.lib.pgbp_patterns_create(len(descs), arr, L.i32p(self.sites), C.byref(self._g))
+        if code != 0:
+            raise L.PgbpError(code, self.lib.pgbp_patterns_last_error(None).decode())
+        self.beliefs = [ClusterGraphBelief.from_arrays(dims, sc, so, si, None, n_sites=len(st), device=device,
+                                                       engine=self.lib.pgbp_patterns_engine(self._g, k))
+                        for k, (dims, sc, so, si, st) in enumerate(patterns)]
+
+    def _check(self, code):
+        if code != 0:
+            raise self._L.PgbpError(code, self.lib.pgbp_patterns_last_error(self._g).decode())
+
+    def close(self):
+        if self._g:
+            for b in self.beliefs:
+                b._eng = None
+            self.lib.pgbp_patterns_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_schedule(self, schedule):
+        L = self._L
+        trees = [(np.asarray(t[-2], np.int32), np.asarray(t[-1], np.int32)) for t in schedule]
+        off = np.zeros(len(trees) + 1, np.int32)
+        for i, (pa, _) in enumerate(trees):
+            off[i + 1] = off[i] + len(pa)
+        pa = np.ascontiguousarray(np.concatenate([t[0] for t in trees]))
+        ch = np.ascontiguousarray(np.concatenate([t[1] for t in trees]))
+        self._check(self.lib.pgbp_patterns_set_schedule(self._g, len(trees), L.i32p(off), L.i32p(pa), L.i32p(ch)))
+
+    def calibrate(self, niter=1, opts=None):
+        """-> pgbp_result per site, in the caller's site order"""
+        L = self._L
+        res = (L.Result * self.n_sites)()
+        o = opts if opts is not None else L.Opts(0, 1, 0, 0, 1e-5)
+        self._check(self.lib.pgbp_patterns_calibrate(self._g, int(niter), self._C.byref(o), res))
+        return res
+
+    def loglik_lg(self, reps=1, opts=None):
+        """device factor fill + postorder + root integrate of every site (score() body) -> (loglik, info) in site order"""
+        L = self._L
+        o = opts if opts is not None else L.Opts(0, 1, 0, 0, 1e-5)
+        self._check(self.lib.pgbp_patterns_enqueue_loglik_lg(self._g, int(reps), self._C.byref(o)))
+        norm, info = np.zeros(self.n_sites), np.zeros(self.n_sites, np.int32)
+        self._check(self.lib.pgbp_patterns_fetch_loglik(self._g, L.f64p(norm), L.i32p(info)))
+        return norm, info
+
+    def integrate(self, belief):
+        norm, info = np.zeros(self.n_sites), np.zeros(self.n_sites, np.int32)
+        self._check(self.lib.pgbp_patterns_integrate(self._g, int(belief), self._L.f64p(norm), self._L.i32p(info)))
+        return norm, info
+
+
 class Comm:
     """pgbp_comm: one process per GPU; ONE ncclAllGather (RCCL) per gather_loglik call.
     `bcast(bytes_or_None) -> bytes` carries rank 0's message (a status byte + the unique id) to the other ranks and

@@ -46,6 +46,29 @@ def test_group_needs_a_device_and_valid_arguments():
         assert b"no CPU path" in lib.pgbp_group_last_error(None)
 
 
+def test_patterns_handle_checks_its_arguments():
+    """pgbp_patterns_create: the site list must be a permutation of the caller's site indices, every pattern the same
+    cluster graph; no CPU fallback behind this handle either."""
+    lib = pgbp_amd.load()
+    tr, prob, packs, _ = _problem(6, 2, 3, 0)
+    d0, k0 = L.make_desc(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, 2, 0)
+    d1, k1 = L.make_desc(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, 1, 0)
+    arr = (C.POINTER(L.Desc) * 2)(C.pointer(d0), C.pointer(d1))
+    h = C.c_void_p()
+    bad = np.array([0, 1, 1], np.int32)
+    assert lib.pgbp_patterns_create(2, arr, L.i32p(bad), C.byref(h)) == 1 and not h.value
+    assert b"permutation" in lib.pgbp_patterns_last_error(None)
+    tr2, prob2, _, _ = _problem(7, 2, 1, 1)                       # another cluster graph
+    d2, k2 = L.make_desc(prob2.dims, prob2.sepset_clusters, prob2.scope_off, prob2.scope_idx, 1, 0)
+    arr2 = (C.POINTER(L.Desc) * 2)(C.pointer(d0), C.pointer(d2))
+    assert lib.pgbp_patterns_create(2, arr2, L.i32p(np.array([2, 0, 1], np.int32)), C.byref(h)) == 1
+    assert b"same cluster graph" in lib.pgbp_patterns_last_error(None)
+    import torch
+    if not torch.cuda.is_available():
+        code = lib.pgbp_patterns_create(2, arr, L.i32p(np.array([2, 0, 1], np.int32)), C.byref(h))
+        assert code == 5 and not h.value                                                # PGBP_ERR_NO_DEVICE
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ntips,p,ns,nshards", [(40, 16, 5, 2), (25, 3, 7, 3), (60, 1, 70, 2)])
 def test_group_equals_single_engine(ntips, p, ns, nshards):
@@ -235,3 +258,100 @@ def test_muller_clique_tree_with_beliefs_beyond_64_dimensions(p):
     for i in (to, len(cn) + k):
         x, y = cgb._packed[0][off[i]:off[i + 1]], r2[off[i]:off[i + 1]]
         assert float(np.max(np.abs(x - y))) <= 1e-8 * max(1.0, float(np.max(np.abs(y))))
+
+
+@pytest.mark.gpu
+def test_three_missing_data_patterns_twelve_sites_behind_one_handle():
+    """pgbp_patterns (include/pgbp.h): sites whose tips miss different traits have different scopes (allocatebeliefs,
+    src/beliefs.jl:551-559) -- one engine per pattern behind one handle, results in the caller's site order.  A network
+    with hybrid nodes, one trait (test/test_exactBM.jl:228-251 is the reference's own case of this kind; with several
+    correlated traits the reference's assignfactors! itself fails its Cholesky on the numerically-zero precision a fully
+    missing subtree leaves, src/beliefs.jl:842 "fixit"), 12 sites in 3 missing-data patterns -- complete; missing at three
+    scattered tips; missing at both tips of a cherry, so that their parent drops out of scope -- interleaved.  Every
+    site against the ORACLE run on that site alone (allocatebeliefs + assignfactors! + calibrate! on its own scopes): the
+    postorder log-likelihood (device factor fill with scope masks, 1e-8), the dense multivariate-normal likelihood, and
+    after calibrate!() the integral of the root cluster; the per-site (succ, iscal)."""
+    import zlib
+    import pgbp_amd as P
+    from helpers import lg_inputs_from_oracle, oracle_setup, product_beliefs_from_oracle
+    from oracle import calibration as OC
+    from oracle import clustergraph as OCG
+    from oracle import densemvn as OD
+    from oracle import models as OM
+    from oracle import network as ON
+    from pgbp_amd.sharding import PatternGroup
+    rng = np.random.default_rng(zlib.crc32(b"patterns"))
+    p, ntips = 1, 12
+    net = ON.random_network(ntips, 3, rng)
+    taxa = net.tip_names
+    model = OM.UnivariateBrownianMotion(1.7, 0.4)
+    ct = OCG.cliquetree(net)
+    spt = OCG.spanningtree_clusterlist(ct, OCG.default_rootcluster(ct, net))
+    # a cherry (two tips with the same parent) for pattern 2
+    par = {}
+    for e in net.edges:
+        if e.child.leaf and not e.child.hybrid:
+            par.setdefault(id(e.parent), []).append(taxa.index(e.child.name))
+    cherry = next((v for v in par.values() if len(v) == 2), [0, 1])
+    others = [i for i in range(ntips) if i not in cherry]
+
+    def mask_of(k):
+        m = np.zeros((ntips, p), bool)         # True = missing
+        if k == 1:
+            m[others[0], 0] = m[others[1], 0] = m[others[2], 0] = True
+        elif k == 2:
+            m[cherry[0], :] = True
+            m[cherry[1], :] = True
+        return m
+    n_sites = 12
+    pattern_of = [0, 1, 2, 2, 1, 0, 1, 1, 2, 0, 2, 0]        # interleaved
+    X = rng.normal(size=(n_sites, ntips, p))
+    tbls = []
+    for s in range(n_sites):
+        m = mask_of(pattern_of[s])
+        tbls.append([[None if m[r, t] else float(X[s, r, t]) for r in range(ntips)] for t in range(p)])
+    # the oracle, site by site
+    want_ll, want_root = [], []
+    ocgbs = {}
+    for s in range(n_sites):
+        ocgb = oracle_setup(net, ct, model, tbls[s], taxa)
+        ocgbs.setdefault(pattern_of[s], (s, ocgb))
+        import copy
+        o2 = copy.deepcopy(ocgb)
+        assert OC.propagate_1traversal_postorder(o2, *spt)
+        ll = o2.integratebelief(spt[2][0])[1]
+        dense = OD.loglik(net, model, tbls[s], taxa)
+        assert abs(ll - dense) <= 1e-8 * max(1.0, abs(dense))
+        want_ll.append(ll)
+    # the product: one description per pattern, from the oracle's scopes of one of its sites
+    patterns, fams = [], []
+    for k in range(3):
+        s0, ocgb = ocgbs[k]
+        pb = product_beliefs_from_oracle(ocgb.belief)
+        host = P.ClusterGraphBelief(pb, ocgb.node2cluster, ocgb.node2family, ocgb.node2fixed, ocgb.cluster2nodes)
+        sites = [s for s in range(n_sites) if pattern_of[s] == k]
+        patterns.append((host._dims.copy(), host._sepcl.reshape(-1).copy(), host._scope_off.copy(), host._scope_idx.copy(), sites))
+        fam, _, kw = lg_inputs_from_oracle(P, net, ocgb, model, tbls[s0], taxa)
+        data = np.stack([np.where(mask_of(k), np.nan, X[s]) for s in sites])
+        fams.append((fam, data, kw))
+        del host
+    dims_by_pattern = [tuple(int(x) for x in pt[0]) for pt in patterns]
+    assert len(set(dims_by_pattern)) >= 2                     # the cherry pattern has other scopes than the complete one
+    grp = PatternGroup(patterns)
+    grp.set_schedule([spt])
+    for k in range(3):
+        fam, data, kw = fams[k]
+        grp.beliefs[k].lg_setup(fam, data)
+        grp.beliefs[k].assignfactors_lg_(**kw)
+    ll, info = grp.loglik_lg()
+    assert not info.any()
+    assert np.max(np.abs(ll - np.array(want_ll)) / np.maximum(1.0, np.abs(want_ll))) <= 1e-8
+    # calibrate!() of every site from its factors: (succ, iscal) per site, the root cluster integrates to the likelihood
+    for k in range(3):
+        assert grp.lib.pgbp_reset_from_factors(grp.beliefs[k]._eng) == 0
+    res = grp.calibrate(2)
+    assert all(res[s].succ == 1 and res[s].iscal == 1 for s in range(n_sites))
+    norm, info = grp.integrate(spt[2][0])
+    assert not info.any()
+    assert np.max(np.abs(norm - np.array(want_ll)) / np.maximum(1.0, np.abs(want_ll))) <= 1e-8
+    grp.close()
