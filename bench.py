@@ -475,6 +475,9 @@ def run_network(args, torch, dist, rank, world, local_rank):
     if rank != 0:
         return
     ms_step = dt / args.steps * 1e3
+    net_traffic = load_pmc_traffic(f"pmc_traffic_network_{args.graph}_latest.json")
+    default_net = (args.ntips == 20000 and args.traits == 4 and args.seed == 5 and args.blob_style == "varied"
+                   and args.graph in ("joingraph", "bethe") and args.maxclustersize == 3 and args.blobs == (20000 + 11) // 12)
     out = {
         "metric": "cluster-graph messages/sec (calibrate!: every schedule tree, postorder+preorder), loopy BP on a level-3 network",
         "value": whole_job_rate(msgs_per_cal, args.steps, world, dt), "unit": "messages/s", "n_gpus": world,
@@ -494,8 +497,14 @@ def run_network(args, torch, dist, rank, world, local_rank):
                            "ms": 1e3 * t_auto, "messages_per_s": nmsg_auto / t_auto,
                            "note": "calibrate!(beliefs, sched, 100; auto=true) end to end: the device halts itself at the first calibrated tree, one host round trip per 4 schedule trees"},
         "roofline": {"bound": "hbm", "achieved": bytes_per_cal / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "bp_level_generic + bp_fast16<4>", "algorithmic_bytes_per_step": bytes_per_cal,
+                     "frac": bytes_per_cal / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     # HBM bytes of ONE step (calibrate iteration: every launch of it) from the committed PMC passes of the
+                     # default-size run (tools/pmc_network.sh); None for other sizes / graphs
+                     "traffic": (net_traffic or {}).get("hbm_bytes_per_calibrate") if default_net else None,
+                     "traffic_stale": (net_traffic or {}).get("stale") if default_net else None,
+                     "traffic_unit": "bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, every message-kernel "
+                                     f"launch of one calibrate iteration; profiles/pmc_traffic_network_{args.graph}_latest.json)",
+                     "kernel": "bp_level_generic + bp_chunk_generic + bp_fast16<4>", "algorithmic_bytes_per_step": bytes_per_cal,
                      "note": "algorithmic bytes of one calibrate iteration / its wall time; launch-latency-bound (levels per tree >> width)"},
         "host_setup_s": t_host,
     }

@@ -48,7 +48,7 @@ def run_network(graph, ntips):
     import time
     import pgbp_amd as P
     import bench as B
-    args = argparse.Namespace(seed=0, traits=4, blob_style="varied", ntips=ntips, blobs=ntips // 12, graph=graph, maxclustersize=3)
+    args = argparse.Namespace(seed=5, traits=4, blob_style="varied", ntips=ntips, blobs=(ntips + 11) // 12, graph=graph, maxclustersize=3)   # bench.py's defaults
     net, (cn, ed, sn), st, fam, X, rates, mu, sched = B.build_network_workload(args, 0)
     cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
     cgb.lg_setup(fam, X)

@@ -13,7 +13,8 @@ re-validated inside the same run on the reset-from-factors copy kernel, whose by
 usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv copy_bytes out.json [copy_kernel [kernel [calibrates]]]
   copy_kernel: calibration kernel with a known byte count each way (default copy_strided_kernel; a name without "pgbp::" is
                looked up as given, e.g. __amd_rocclr_copyBuffer for the site-minor reset of the sites workload)
-  kernel:      the message kernel to reduce (default bp_fast16: every launch mode of it; bp_level_uni1 for the sites workload)
+  kernel:      the message kernel to reduce (default bp_fast16: every launch mode of it; bp_level_uni1 for the sites workload;
+               several kernels joined by '+': bp_level_generic+bp_chunk_generic+bp_fast16 for the network workload)
   calibrates:  how many calibrate!() iterations the profiled program ran and nothing else on that kernel (e.g.
                `tools/level_times.py run` = 8): adds launches_per_calibrate and hbm_bytes_per_calibrate
 """
@@ -44,14 +45,18 @@ def main():
     have_cal = copy_bytes > 0 and ck in F and ck in W   # copy_bytes 0: calibrated elsewhere (tools/copy8_microbench.hip)
     cal_f = 2.0 * 1024 * sum(F[ck]) / len(F[ck]) if have_cal else 0.0
     cal_w = 1024 * sum(W[ck]) / len(W[ck]) if have_cal else 0.0
-    k = "pgbp::" + kname
-    n = len(F[k])
-    fetch = 2.0 * 1024 * sum(F[k])
-    write = 1024 * sum(W[k])
+    # kernel: one name or several joined by '+' (the network workload runs bp_level_generic + bp_chunk_generic + bp_fast16)
+    ks = ["pgbp::" + x for x in kname.split("+")]
+    missing = [k for k in ks if k not in F or k not in W]
+    ks = [k for k in ks if k not in missing]
+    n = sum(len(F[k]) for k in ks)
+    nw = sum(len(W[k]) for k in ks)
+    fetch = 2.0 * 1024 * sum(sum(F[k]) for k in ks)
+    write = 1024 * sum(sum(W[k]) for k in ks)
     res = {
         "kernel": kname, "launches": n,
-        "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / len(W[k]),
-        "hbm_bytes_per_launch": fetch / n + write / len(W[k]),
+        "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / nw,
+        "hbm_bytes_per_launch": fetch / n + write / nw,
         "corrections": "KiB units; FETCH_SIZE x2 (16-B/lane reads on gfx950); WRITE_SIZE exact",
         "calibration_copy_kernel": ({"kernel": ck, "known_bytes_each_way": copy_bytes, "fetch_corrected": cal_f, "write": cal_w,
                                      "fetch_ratio": cal_f / copy_bytes, "write_ratio": cal_w / copy_bytes} if have_cal else
