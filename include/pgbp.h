@@ -34,9 +34,12 @@ extern "C" {
 #endif
 
 #define PGBP_VERSION 1
-#define PGBP_MAX_DIM 128 /* largest belief dimension the kernels accept (refused above): a 128 x 129 working matrix is
-                            132 KB of a CU's 160 KB of LDS; update_residualkldiv / pgbp_residual_kldiv need sepsets of
-                            dimension <= 96 (two systems side by side) */
+#define PGBP_MAX_DIM 240 /* largest belief dimension the kernels accept (refused above).  Up to 128 variables the working
+                            matrix of a message ([J | h]: 128 x 129 doubles = 132 KB) lives in a CU's 160 KB of LDS; above,
+                            in a workspace in global memory that stays in the L2 (the 54-node clique of the reference's
+                            documented clique tree, docs/src/man/clustergraphs.md:40-89, has 162 / 216 variables with 3 / 4
+                            traits).  update_residualkldiv / pgbp_residual_kldiv need sepsets of dimension <= 96 (two
+                            systems side by side in LDS), pgbp_free_energy beliefs of dimension <= 139. */
 
 enum pgbp_status {
   PGBP_OK = 0,

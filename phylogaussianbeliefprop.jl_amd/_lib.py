@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGBP_LIB", os.path.join(_HERE, "csrc", "libpgbp.so"))
 
 PGBP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_TREE, ERR_TOO_LARGE, ERR_NO_DEVICE, ERR_STATE = range(7)
-PGBP_MAX_DIM = 128
+PGBP_MAX_DIM = 240
 
 
 class PgbpError(RuntimeError):

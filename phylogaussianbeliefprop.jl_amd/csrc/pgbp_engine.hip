@@ -99,6 +99,8 @@ struct pgbp_engine {
   // HIP events of the last pgbp_enqueue_calibrate_timed call (resolved by pgbp_fetch_kernel_time)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
   int32_t kernel_launches = 0;
+  double* d_ws = nullptr;        // workspace of the kernels whose working matrix exceeds the LDS (beliefs above kLdsMaxDim)
+  int64_t ws_cap = 0;
   double* d_gather = nullptr;    // send slot of pgbp_comm_gather_loglik: [norm | info | succ, iscal]
   int64_t gather_cap = 0;
   bool have_factors = false;
@@ -337,6 +339,18 @@ void free_traversals(pgbp_engine* e) {
   e->d_tail_pros.clear();
 }
 
+// at least `doubles` of workspace (grown when a launch needs more: the stream is drained first, kernels in flight use it)
+int ensure_ws(pgbp_engine* e, int64_t doubles) {
+  if (doubles <= e->ws_cap) return PGBP_OK;
+  HIPCHK(e, hipStreamSynchronize(e->st));
+  if (e->d_ws) (void)hipFree(e->d_ws);
+  e->d_ws = nullptr;
+  e->ws_cap = 0;
+  HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_ws), sizeof(double) * (size_t)doubles));
+  e->ws_cap = doubles;
+  return PGBP_OK;
+}
+
 constexpr int kKlMaxS = 96;  // residual_kldiv_kernel: [J0 | dJ | h0] of one sepset in a CU's LDS
 
 // Every entry point that launches a message kernel comes through here BEFORE its first launch: the options are sane and
@@ -427,8 +441,9 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
     else {
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st);
-      launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
-                       tr.max_mf_big, e->st);
+      if (nbig > 0 && ensure_ws(e, (int64_t)nbig * e->plan.n_sites * big_ws_doubles(tr.max_mf_big)) == PGBP_OK)
+        launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
+                         tr.max_mf_big, e->d_ws, e->st);
     }
     if (launches) *launches += (nf > 0) + (nt - nf - nbig > 0) + (nbig > 0);
     if (kl) {  // residual_kldiv! right after the messages of the level (src/calibration.jl:128,154)
@@ -472,9 +487,10 @@ void integrate_async(pgbp_engine* e, int belief, double* d_mu) {
   if (e->layout_sm)
     launch_integrate_sm(e->d_pool_sm, p.packed_off[belief], p.dims[belief], d_mu, std::max(1, p.max_dim), e->d_norm,
                         e->d_info, p.n_sites, e->st);
-  else
+  else if (ensure_ws(e, (int64_t)p.n_sites * big_ws_doubles(p.dims[belief])) == PGBP_OK)   // (a failed allocation: e->err is
+    // set and the caller's status check of the stream reports it)
     launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], p.dims[belief], e->layout_bs16 ? 1 : 0, p.fast_p, d_mu,
-                     std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->st);
+                     std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->d_ws, e->st);
 }
 
 // skip_sepsets: the caller's next traversal overwrites every sepset without reading it (DevState::sep_zero)
@@ -545,6 +561,7 @@ void pgbp_destroy(pgbp_engine* e) {
   for (void* p : {(void*)e->d_lg_R, (void*)e->d_lg_alpha, (void*)e->d_lg_theta, (void*)e->d_lg_mu})
     if (p) (void)hipFree(p);
   if (e->d_gather) (void)hipFree(e->d_gather);
+  if (e->d_ws) (void)hipFree(e->d_ws);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
 }
@@ -906,7 +923,8 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   if ((rc = reset_fail(e))) return rc;
   DevState S = dev_state(e, opts);
   if (p.msgs[en.msg].mf > kGenericMaxDim) {
-    launch_level_big(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->st);
+    if ((rc = ensure_ws(e, (int64_t)p.n_sites * big_ws_doubles(p.msgs[en.msg].mf)))) return rc;
+    launch_level_big(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->d_ws, e->st);
   } else {
     const GRec rec = make_grec(p, en, -1);
     HIPCHK(e, hipMemcpyAsync(e->d_one_rec, &rec, sizeof(rec), hipMemcpyHostToDevice, e->st));
@@ -1152,6 +1170,10 @@ int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
   }
   const Plan& p = e->plan;
   const int ns = p.n_sites;
+  // the kernel keeps [J | one column of J_t | h] of a belief in LDS: 139 variables at most (right-hand sides in blocks)
+  if (p.max_dim > 139)
+    return e->fail(PGBP_ERR_TOO_LARGE, "pgbp_free_energy needs beliefs of dimension <= 139 (this graph: " +
+                                           std::to_string(p.max_dim) + ")");
   double *d_contrib = nullptr, *d_out = nullptr;
   int32_t* d_inf = nullptr;
   int rc;

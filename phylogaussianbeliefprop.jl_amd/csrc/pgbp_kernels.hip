@@ -639,10 +639,15 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, 
 // cliques (the 54-node clique of docs/src/man/clustergraphs.md:40-89); everything about the message itself is as in
 // bp_level_generic: both early exits of marginalize, Symmetric(J_I) = upper triangle, potrf-style info, poison marks,
 // first-failure key, residual-norm flag (src/beliefupdates.jl:55-83, 579-587, 483-488; src/beliefs.jl:994-1003).
+// WS: senders of more than kLdsMaxDim variables (up to PGBP_MAX_DIM): the working matrix does not fit the CU's LDS and lives
+// in a WORKSPACE in global memory, one slab per workgroup (engine: pgbp_engine::d_ws) -- a few hundred KB that stay in the
+// XCD's L2 between the rank-1 updates; the barriers of the elimination order its accesses (same CU, same vector L1).
 constexpr int kBigThreads = 256;
+template <bool WS>
 __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const int32_t* __restrict__ task_off,
                                                             const Entry* __restrict__ entries, int task0,
-                                                            unsigned long long seq_base, unsigned long long stop_below) {
+                                                            unsigned long long seq_base, unsigned long long stop_below,
+                                                            double* __restrict__ ws, int64_t ws_stride) {
   const int tid = threadIdx.x;
   const int site = blockIdx.y;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   int32_t* perm = reinterpret_cast<int32_t*>(lds);
-  double* W = lds + kPermDoubles;
+  double* W = WS ? ws + ((int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y) * ws_stride : lds + kPermDoubles;
   __shared__ int s_info;
   __shared__ double s_red[kBigThreads];
   __shared__ int s_flag;
@@ -802,13 +807,21 @@ static void allow_large_lds(const void* kernel, size_t bytes) {
   if (bytes > 64 * 1024) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+int64_t big_ws_doubles(int max_mf) { return max_mf > kLdsMaxDim ? (int64_t)max_mf * ((max_mf + 1) | 1) : 0; }
+
 void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
-                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st) {
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf, double* d_ws,
+                      hipStream_t st) {
   if (ntasks <= 0) return;
+  if (max_mf > kLdsMaxDim) {   // the working matrix in the workspace (ntasks * n_sites slabs of big_ws_doubles(max_mf))
+    hipLaunchKernelGGL(bp_level_big<true>, dim3(ntasks, n_sites), dim3(kBigThreads), sizeof(double) * kPermDoubles, st, S,
+                       d_task_off, d_entries, task0, seq_base, stop_below, d_ws, big_ws_doubles(max_mf));
+    return;
+  }
   const size_t bytes = generic_lds_bytes(max_mf);
-  allow_large_lds(reinterpret_cast<const void*>(bp_level_big), bytes);
-  hipLaunchKernelGGL(bp_level_big, dim3(ntasks, n_sites), dim3(kBigThreads), bytes, st, S, d_task_off, d_entries, task0,
-                     seq_base, stop_below);
+  allow_large_lds(reinterpret_cast<const void*>(bp_level_big<false>), bytes);
+  hipLaunchKernelGGL(bp_level_big<false>, dim3(ntasks, n_sites), dim3(kBigThreads), bytes, st, S, d_task_off, d_entries, task0,
+                     seq_base, stop_below, (double*)nullptr, (int64_t)0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1161,15 +1174,18 @@ void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* 
 }
 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2
+// WS: a belief of more than kLdsMaxDim variables: [J | h] in a workspace slab in global memory (one per site)
+template <bool WS>
 __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict__ pool_all, int64_t pool_stride,
                                                        int64_t rec_off, int m, int bs, int fp,
                                                        double* __restrict__ mu,
                                                        int mu_stride, double* __restrict__ norm,
-                                                       int32_t* __restrict__ info_out) {
+                                                       int32_t* __restrict__ info_out, double* __restrict__ ws,
+                                                       int64_t ws_stride) {
   const int lane = threadIdx.x;
   const int site = blockIdx.x;
   const double* __restrict__ rec = pool_all + (int64_t)site * pool_stride + rec_off;
-  double* W = lds + kPermDoubles;
+  double* W = WS ? ws + (int64_t)site * ws_stride : lds + kPermDoubles;
   const int ld = (m + 1) | 1;
   const bool packed = bs && bs16::applies(m, fp);
   const double g = packed ? rec[bs16::g_off(m, fp)] : rec[(int64_t)m * m + m];
@@ -1229,10 +1245,15 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
 }
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
-                      double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st) {
-  allow_large_lds(reinterpret_cast<const void*>(integrate_kernel), generic_lds_bytes(m));
-  hipLaunchKernelGGL(integrate_kernel, dim3(n_sites), dim3(kWave), generic_lds_bytes(m), st, pool, pool_stride,
-                     rec_off, m, bs16, fast_p, d_mu, mu_stride, d_norm, d_info);
+                      double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, double* d_ws, hipStream_t st) {
+  if (m > kLdsMaxDim) {   // (n_sites slabs of big_ws_doubles(m))
+    hipLaunchKernelGGL(integrate_kernel<true>, dim3(n_sites), dim3(kWave), 0, st, pool, pool_stride, rec_off, m, bs16, fast_p,
+                       d_mu, mu_stride, d_norm, d_info, d_ws, big_ws_doubles(m));
+    return;
+  }
+  allow_large_lds(reinterpret_cast<const void*>(integrate_kernel<false>), generic_lds_bytes(m));
+  hipLaunchKernelGGL(integrate_kernel<false>, dim3(n_sites), dim3(kWave), generic_lds_bytes(m), st, pool, pool_stride,
+                     rec_off, m, bs16, fast_p, d_mu, mu_stride, d_norm, d_info, (double*)nullptr, (int64_t)0);
 }
 
 // ---- BS16 <-> plain, in place, one workgroup per record (pgbp_bs16.hpp)

@@ -91,8 +91,12 @@ void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* 
                           bool small_only, hipStream_t st);
 
 // tasks with a belief of dimension 65 .. PGBP_MAX_DIM: one workgroup of 256 threads per task, the sender in up to 132 KB of LDS
+// (a sender of more than kLdsMaxDim variables: the working matrix in d_ws, ntasks * n_sites slabs of big_ws_doubles(max_mf))
 void launch_level_big(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
-                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf, hipStream_t st);
+                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf, double* d_ws,
+                      hipStream_t st);
+constexpr int kLdsMaxDim = 128;   // largest working matrix [J | h] that fits a CU's LDS (128 x 129 doubles = 132 KB of 160)
+int64_t big_ws_doubles(int max_mf);   // doubles of one workspace slab for a working matrix of dimension max_mf (0: fits LDS)
 
 // thread-per-(site, task) kernel for graphs whose beliefs all have dimension <= 2 (univariate batches)
 void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
@@ -115,7 +119,7 @@ void launch_loop16(const DevState& S, const FEntry* d_recs, const FPro* d_pros, 
                    const int32_t* d_wg_off = nullptr, int n_wg = 0);
 
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
-                      double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, hipStream_t st);
+                      double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, double* d_ws, hipStream_t st);
 
 // In-place layout conversion of the records listed by (d_off, d_dim): to_bs16 != 0: plain -> BS16, else back.
 // is_residual: records are [dJ | dh] (no g).  One workgroup per record.

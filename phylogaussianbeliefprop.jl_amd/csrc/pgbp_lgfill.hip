@@ -83,7 +83,13 @@ __global__ __launch_bounds__(64) void lg_fill_kernel(LgStatic F, LgParams M, dou
   const int p = F.p, K = F.K;
   const int m = dim[c];
   const int nrec = m * m + m + 1;
-  double* rec = lg_lds;               // [m*m | m | 1] plain column-major accumulator of the cluster
+  double* __restrict__ out = pool + (int64_t)site * pool_stride + boff[c];
+  double* __restrict__ fout = fpool ? fpool + (int64_t)site * fpool_stride + boff[c] : nullptr;
+  // [m*m | m | 1] plain column-major accumulator of the cluster: in LDS, or -- a cluster of more than kLdsMaxDim variables,
+  // whose record exceeds the LDS -- the cluster's own record in the pool (never packed: accumulated in place; only this
+  // wavefront touches it, the barriers between its steps order the accesses)
+  const bool in_place = m > kLdsMaxDim;
+  double* rec = in_place ? out : lg_lds;
   double* W = lg_lds + rec_cap;       // p x ld
   const int ldmax = (2 * p + 1) | 1;
   double* cz = W + p * ldmax;         // c_a (K+1)
@@ -190,13 +196,11 @@ __global__ __launch_bounds__(64) void lg_fill_kernel(LgStatic F, LgParams M, dou
   __syncthreads();
   if (bad && lane == 0) rec[m * m + m] = NAN;  // a variance that is not positive definite: the reference throws here
   __syncthreads();
-  double* __restrict__ out = pool + (int64_t)site * pool_stride + boff[c];
-  double* __restrict__ fout = fpool ? fpool + (int64_t)site * fpool_stride + boff[c] : nullptr;
   const bool packed = bs && bs16::applies(m, fp);
   if (!packed) {
     for (int t = lane; t < nrec; t += kWave) {
       const double v = rec[t];
-      out[t] = v;
+      if (!in_place) out[t] = v;
       if (fout) fout[t] = v;
     }
   } else {
@@ -301,7 +305,7 @@ void launch_lg_fill(const LgStatic& F, const LgParams& M, double* pool, int64_t 
                     int64_t fpool_stride, const int64_t* d_boff, const int32_t* d_dim, int bs16, int fast_p, int max_dim,
                     int n_clusters, int n_sites, hipStream_t st) {
   if (n_clusters <= 0) return;
-  const int mm = max_dim < 1 ? 1 : max_dim;
+  const int mm = max_dim < 1 ? 1 : (max_dim > kLdsMaxDim ? kLdsMaxDim : max_dim);   // (larger clusters accumulate in place)
   const int rec_cap = (mm * mm + mm + 1 + 1) & ~1;
   const int ld = (2 * F.p + 1) | 1;
   const size_t doubles = (size_t)rec_cap + (size_t)F.p * ld + (size_t)(F.K + 1) + (size_t)(F.K + 2 + F.p) / 2 + 2;

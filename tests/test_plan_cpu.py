@@ -165,11 +165,14 @@ def test_plan_rejects_bad_input():
     assert code == L.ERR_INVALID and b"strictly increasing" in lib.pgbp_plan_last_error(pl)
     lib.pgbp_plan_destroy(pl)
     # dimension above PGBP_MAX_DIM is refused, not silently mishandled
-    p3 = S.cliquetree_of_tree(tr, 70)          # internal cliques of dimension 140 > 128
+    p3 = S.cliquetree_of_tree(tr, 125)         # internal cliques of dimension 250 > 240
     lib, pl, code, keep = _plan(p3)
-    assert code == L.ERR_TOO_LARGE and b"PGBP_MAX_DIM=128" in lib.pgbp_plan_last_error(pl)
+    assert code == L.ERR_TOO_LARGE and b"PGBP_MAX_DIM=240" in lib.pgbp_plan_last_error(pl)
     lib.pgbp_plan_destroy(pl)
     lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 40))   # dimension 80: the large-belief kernel's range
+    assert code == 0
+    lib.pgbp_plan_destroy(pl)
+    lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 100))  # dimension 200: its workspace variant's
     assert code == 0
     # more sites than grid.y holds: refused for the wavefront-per-message kernels, fine for univariate batches
     lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 2), n_sites=70000)
