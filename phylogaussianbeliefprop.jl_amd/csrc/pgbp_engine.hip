@@ -374,14 +374,15 @@ unsigned long long seq_stride(const pgbp_engine* e) {
 
 // Launch tuning read once from the environment (A/B runs and debugging; the defaults are what was measured best):
 //   PGBP_NO_TAIL=1     no single-workgroup tail launch: every level gets its own launch
-//   PGBP_LOOP=1        the loop launches (tail, chunks) of the packed layout on pgbp_loop.hip (sender operands requested
-//                      half a pass early, what a pass hands to the next one through LDS chain slots) instead of
-//                      pgbp_fast.hip's loop mode: built, bit-identical, measured 2.5 % slower on cfg3 (0.886 - 0.910
-//                      against 0.858 - 0.887 ms) and 8 % on cfg2: DESIGN.md section 4.2
+//   PGBP_LOOP=0        the loop launches (tail, chunks) of the packed layout on pgbp_fast.hip's loop mode (one wavefront
+//                      per record) instead of pgbp_loop.hip (two wavefronts per record -- one eliminates, one does
+//                      divide!, mult! and the stores --, sender operands requested half a pass early, what a pass hands
+//                      to the next one through LDS chain slots): bit-identical, 4 % slower on cfg3 and cfg2
+//                      
 struct LaunchTuning {
-  bool tail = true, loop = false;
+  bool tail = true, loop = true;
   LaunchTuning() {
-    if (getenv("PGBP_LOOP")) loop = true;
+    if (const char* v = getenv("PGBP_LOOP")) loop = v[0] != '0';
     if (getenv("PGBP_NO_TAIL")) tail = false;
   }
 };

@@ -86,9 +86,8 @@ __device__ __forceinline__ void wg_barrier_global() { __syncthreads(); }
 // X -> F would have run alone (a launch or a loop pass, with its memory round trips) no longer exists.  Same arithmetic,
 // same order as the two messages one after the other (src/beliefupdates.jl:650-665 twice).
 template <int P, bool BS, bool ODD, int MODE, bool PRO>
-#ifdef PGBP_FORCE4
-__attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
+// (the level launches live on four waves per SIMD, 128 registers: left to itself the scheduler trades occupancy for them)
+__attribute__((amdgpu_waves_per_eu(MODE == kTail ? 2 : 4, 4)))
 __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 64) void bp_fast16(
     DevState S_arg, const FEntry* __restrict__ recs_arg, const FPro* __restrict__ pros, int ngroups_arg, int split_arg,
     unsigned long long seq_base_arg, unsigned long long stop_a_arg, unsigned long long stop_b_arg,

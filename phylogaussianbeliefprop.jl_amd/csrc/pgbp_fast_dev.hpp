@@ -29,64 +29,122 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Blocked elimination of the 16 integrated variables, two pivots per round (8 rounds).
-// Round R: the 8 lanes with b == R own columns 2R, 2R+1 of W; they publish them (rows R_a) in the wave's
-// private LDS strip; every lane reads back the entries of the rows R_a (xr) and C_b (xc) plus the 2 x 2 pivot
-// block D and h_2R, h_2R+1, and applies  W <- W - X D^-1 X',  h <- h - X D^-1 h_K.  Mathematically identical
-// to two successive rank-1 eliminations (src/beliefupdates.jl:68-81); D^-1 by v_rcp_f64 + 2 Newton steps.
+// Blocked elimination of the P integrated variables, two pivots per round (P / 2 rounds).
+// Round R: the lanes with b == R own columns 2R, 2R+1 of W; they have published them (rows R_a) in the wave's private LDS
+// strip; every lane reads back the entries of the rows R_a (xr) and C_b (xc) plus the 2 x 2 pivot block D and
+// h_2R, h_2R+1, and applies  W <- W - X D^-1 X',  h <- h - X D^-1 h_K.  Mathematically identical to two successive
+// rank-1 eliminations (src/beliefupdates.jl:68-81); D^-1 by v_rcp_f64 + 2 Newton steps.
+// The chain of dependent latencies of a round is  strip -> D^-1 -> the two columns of the NEXT pivot -> strip, so a round
+//   1. updates the integrated columns (where the next pivot's are) and h_I,
+//   2. publishes the next pivot's columns into the OTHER of two strips and requests its pivot block back at once (the rest
+//      of the columns at the top of the next round: they arrive while D^-1 is worked out),
+//   3. updates the kept columns and h_S while that round trip is in flight;
+// and it never branches: a non-positive pivot is remembered (the first one) and the arithmetic carries on on whatever it
+// has -- the caller discards everything when the result is not 0.
 // Returns 0, or the 1-based index of the first non-positive pivot (LAPACK potrf info).
 constexpr int kColStride = 10;                       // doubles per owner-lane slot (80 B: conflict-free b128 reads)
-constexpr int kColDoubles = 8 * kColStride + 4;      // + h_2R, h_2R+1
+constexpr int kColStrip = 8 * kColStride + 4;        // + h_2R, h_2R+1
+constexpr int kColDoubles = 2 * kColStrip;           // two strips: a round reads one while the next pivot goes into the other
+
+struct PivotOps {   // the pivot block and h_K: what the chain of a round starts from
+  double2 p0, p1, hk;
+};
+
+template <int R>
+__device__ __forceinline__ void publish_pivot(const Frag& f, const int a, const int b, const bool act, double* __restrict__ col) {
+  double* strip = col + (R & 1) * kColStrip;
+  if (act && b == R) {
+    double* dst = strip + a * kColStride;
+    *reinterpret_cast<double4*>(dst) = make_double4(f.w[0][0], f.w[1][0], f.w[2][0], f.w[3][0]);
+    *reinterpret_cast<double4*>(dst + 4) = make_double4(f.w[0][1], f.w[1][1], f.w[2][1], f.w[3][1]);
+    if (a == R) *reinterpret_cast<double2*>(strip + 8 * kColStride) = make_double2(f.h[0], f.h[1]);
+  }
+}
+template <int R>
+__device__ __forceinline__ PivotOps fetch_pivot(const double* __restrict__ col) {
+  const double* strip = col + (R & 1) * kColStrip;
+  PivotOps o;
+  o.p0 = *reinterpret_cast<const double2*>(strip + R * kColStride);      // W[2R][2R], W[2R+1][2R]
+  o.p1 = *reinterpret_cast<const double2*>(strip + R * kColStride + 4);  // W[2R][2R+1], W[2R+1][2R+1]
+  o.hk = *reinterpret_cast<const double2*>(strip + 8 * kColStride);
+  return o;
+}
 
 template <int P, int R>
-__device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, const bool act, double* __restrict__ col,
-                                          double& mant, int& expo, double& quad) {
+__device__ __forceinline__ int eliminate_round(Frag& f, const int a, const int b, const bool act, double* __restrict__ col,
+                                               const PivotOps& o, int bad, double& mant, int& expo, double& quad) {
   if constexpr (R == P / 2) {
-    return 0;
+    return bad;
   } else {
-    if (act && b == R) {
-      double* dst = col + a * kColStride;
-      *reinterpret_cast<double4*>(dst) = make_double4(f.w[0][0], f.w[1][0], f.w[2][0], f.w[3][0]);
-      *reinterpret_cast<double4*>(dst + 4) = make_double4(f.w[0][1], f.w[1][1], f.w[2][1], f.w[3][1]);
-      if (a == R) *reinterpret_cast<double2*>(col + 8 * kColStride) = make_double2(f.h[0], f.h[1]);
-    }
-    wave_sync_lds();  // other LANES wrote what this lane reads: not visible to per-thread alias analysis
-    const double4 xr0 = *reinterpret_cast<const double4*>(col + a * kColStride);
-    const double4 xr1 = *reinterpret_cast<const double4*>(col + a * kColStride + 4);
-    const double4 xc0 = *reinterpret_cast<const double4*>(col + b * kColStride);
-    const double4 xc1 = *reinterpret_cast<const double4*>(col + b * kColStride + 4);
-    const double2 p0 = *reinterpret_cast<const double2*>(col + R * kColStride);      // W[2R][2R], W[2R+1][2R]
-    const double2 p1 = *reinterpret_cast<const double2*>(col + R * kColStride + 4);  // W[2R][2R+1], W[2R+1][2R+1]
-    const double2 hk = *reinterpret_cast<const double2*>(col + 8 * kColStride);
-    wave_sync_lds();  // the next round overwrites the strip
-    const double d00 = p0.x, d01 = p1.x, d11 = p1.y;  // upper triangle of the pivot block
+    // the rows R_a (xr) and C_b (xc) of the pivot's columns: they arrive while D^-1 is worked out
+    const double* strip = col + (R & 1) * kColStrip;
+    const double4 xr0 = *reinterpret_cast<const double4*>(strip + a * kColStride);
+    const double4 xr1 = *reinterpret_cast<const double4*>(strip + a * kColStride + 4);
+    const double4 xc0 = *reinterpret_cast<const double4*>(strip + b * kColStride);
+    const double4 xc1 = *reinterpret_cast<const double4*>(strip + b * kColStride + 4);
+    const double d00 = o.p0.x, d01 = o.p1.x, d11 = o.p1.y;  // upper triangle of the pivot block
     const double det = fma(d00, d11, -(d01 * d01));
-    const int bad = __builtin_amdgcn_readfirstlane(!(d00 > 0.0) ? 2 * R + 1 : (!(det > 0.0) ? 2 * R + 2 : 0));
-    if (bad) return bad;
+    const int bad_here = __builtin_amdgcn_readfirstlane(!(d00 > 0.0) ? 2 * R + 1 : (!(det > 0.0) ? 2 * R + 2 : 0));
+    bad = bad ? bad : bad_here;
     double rdet = __builtin_amdgcn_rcp(det);
     rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
     rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
     const double e00 = d11 * rdet, e01 = -(d01 * rdet), e11 = d00 * rdet;
-    int e;
-    mant *= frexp(det, &e);
-    expo += e;
-    // y = D^-1 x_c for my 4 columns; g = D^-1 h_K
     const double xc0v[4] = {xc0.x, xc0.y, xc0.z, xc0.w}, xc1v[4] = {xc1.x, xc1.y, xc1.z, xc1.w};
     const double xr0v[4] = {xr0.x, xr0.y, xr0.z, xr0.w}, xr1v[4] = {xr1.x, xr1.y, xr1.z, xr1.w};
-    const double g0 = fma(e00, hk.x, e01 * hk.y), g1 = fma(e01, hk.x, e11 * hk.y);
-    quad = fma(hk.x, g0, fma(hk.y, g1, quad));
+    // y = D^-1 x_c for my 4 columns; g = D^-1 h_K
+    const double g0 = fma(e00, o.hk.x, e01 * o.hk.y), g1 = fma(e01, o.hk.x, e11 * o.hk.y);
+    // 1. the integrated columns and h_I
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       const double y0 = fma(e00, xc0v[j], e01 * xc1v[j]);
       const double y1 = fma(e01, xc0v[j], e11 * xc1v[j]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (!(i < 2 && j >= 2)) f.w[i][j] = fma(-xr0v[i], y0, fma(-xr1v[i], y1, f.w[i][j]));
+      for (int i = 0; i < 4; ++i) f.w[i][j] = fma(-xr0v[i], y0, fma(-xr1v[i], y1, f.w[i][j]));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
-    return eliminate2<P, R + 1>(f, a, b, act, col, mant, expo, quad);
+    for (int i = 0; i < 2; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
+    // (what step 3 needs of this round's operands, so that nothing else of them is live beside the next round's)
+    const double ys0[2] = {fma(e00, xc0v[2], e01 * xc1v[2]), fma(e00, xc0v[3], e01 * xc1v[3])};
+    const double ys1[2] = {fma(e01, xc0v[2], e11 * xc1v[2]), fma(e01, xc0v[3], e11 * xc1v[3])};
+    quad = fma(o.hk.x, g0, fma(o.hk.y, g1, quad));
+    int e;
+    mant *= frexp(det, &e);
+    expo += e;
+    // 2. the next pivot on its way
+    PivotOps nx{};
+    if constexpr (R + 1 < P / 2) {
+      publish_pivot<R + 1>(f, a, b, act, col);
+      wave_sync_lds();  // other LANES wrote what this lane reads: not visible to per-thread alias analysis
+      nx = fetch_pivot<R + 1>(col);
+    }
+    // 3. the kept columns and h_S
+#pragma unroll
+    for (int j = 2; j < 4; ++j)
+#pragma unroll
+      for (int i = 2; i < 4; ++i) f.w[i][j] = fma(-xr0v[i], ys0[j - 2], fma(-xr1v[i], ys1[j - 2], f.w[i][j]));
+#pragma unroll
+    for (int i = 2; i < 4; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
+    // (the kept block, the quadratic form and the determinant are chains of their own -- no later pivot needs them -- and
+    // instruction selection would let all of their updates sink to the end of the elimination, every round's operands live
+    // until then: the empty statement below is ordered against the next round's strip accesses and wants them computed)
+    asm volatile("; round done"
+                 : "+v"(f.w[2][2]), "+v"(f.w[3][2]), "+v"(f.w[2][3]), "+v"(f.w[3][3]), "+v"(f.h[2]), "+v"(f.h[3]), "+v"(quad),
+                   "+v"(mant), "+v"(expo));
+    return eliminate_round<P, R + 1>(f, a, b, act, col, nx, bad, mant, expo, quad);
   }
+}
+
+template <int P, int R>
+__device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, const bool act, double* __restrict__ col,
+                                          double& mant, int& expo, double& quad) {
+  static_assert(R == 0, "the elimination starts at the first pivot");
+  publish_pivot<0>(f, a, b, act, col);
+  wave_sync_lds();
+  const PivotOps o = fetch_pivot<0>(col);
+  const int bad = eliminate_round<P, 0>(f, a, b, act, col, o, 0, mant, expo, quad);
+  wave_sync_lds();  // (whatever comes next in this strip)
+  return bad;
 }
 
 }  // namespace

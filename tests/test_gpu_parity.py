@@ -1274,18 +1274,18 @@ def test_chain_fusion_opt_in_differential_fuzz(P):
     {"PGBP_NO_PROLOGUE": "1", "PGBP_NO_TAIL": "1"},
     {"PGBP_POSTORDER_ALAP": "1"},
     {"PGBP_NO_CHUNKS": "1"},
-    {"PGBP_LOOP": "1"},
-    {"PGBP_LOOP": "1", "PGBP_NO_PROLOGUE": "1"},
+    {"PGBP_LOOP": "0"},
+    {"PGBP_LOOP": "0", "PGBP_NO_PROLOGUE": "1"},
 ], ids=["levels_only", "asap_preorder", "no_prologues", "no_prologues_levels_only", "alap_postorder", "no_chunks",
-        "early_loads_and_chains", "early_loads_and_chains_no_prologues"])
+        "one_wave_per_record_loops", "one_wave_per_record_loops_no_prologues"])
 def test_launch_modes_differential_fuzz(P, env):
     """The launch modes of the register-resident kernel (pgbp_fast.hip: one group per workgroup; chunks of fused levels;
     the single-workgroup tail) run the same message body, with or without PROLOGUES (a Bethe graph's variable-to-factor
     messages riding in the record of the factor's own message).  The tuning variables are read once per process, hence
     child processes: the level launches alone (no tail, no chunks), without the chunks, the depth-ordered preorder, the
-    as-late-as-possible postorder, the two-level schedule without prologues, and the tail and chunks on pgbp_loop.hip
-    (sender operands requested half a pass early, chains through LDS: opt-in, PGBP_LOOP=1) instead of pgbp_fast.hip's own
-    loop mode.  Same differential fuzz against the
+    as-late-as-possible postorder, the two-level schedule without prologues, and the tail and chunks on pgbp_fast.hip's own
+    loop mode (one wavefront per record, PGBP_LOOP=0) instead of pgbp_loop.hip (the default: two wavefronts per record,
+    sender operands requested half a pass early, chains through LDS).  Same differential fuzz against the
     plain-C sequential engine as for the defaults: random trees (polytomies: tasks of 3 and 4 messages beside tasks of 1
     and 2 in one group; caterpillars: the whole traversal in the tail), clique trees and Bethe graphs, 1-16 traits (packed
     and plain layouts, odd instances), 1-3 sites, injected non-positive-definite blocks (first failure of the reference's
