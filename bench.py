@@ -740,7 +740,8 @@ def main():
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
                                          "profiles/pmc_traffic_latest.json)",
                          "algorithmic_bytes_per_launch": bytes_per_cal / max(1, nl.value // reps),
-                         "kernel": "bp_fast16", "launches_per_step": nl.value // reps,
+                         "kernel": "bp_fast16 (level launches) + bp_loop16 (tail, chunks of fused levels)",
+                         "launches_per_step": nl.value // reps,
                          "algorithmic_bytes_per_step": bytes_per_cal,
                          "kernel_ms_per_step": kern_ms / reps,
                          # context for `frac`: what a plain device-to-device copy of 1 GiB reaches on this box

@@ -25,7 +25,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p3 -- python3 tools/level
 step "cfg3 pmc write"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p4 -- python3 tools/level_times.py run > $out/pmc_w.txt 2>&1 || exit 1
 F=$(find /tmp/p3 -name "*counter_collection.csv" | head -1); W=$(find /tmp/p4 -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py $F $W 0 $out/cfg3_pmc_traffic.json none bp_fast16 8 > $out/cfg3_pmc_traffic.txt 2>&1; rm -rf /tmp/p3 /tmp/p4
+python3 tools/pmc_traffic.py $F $W 0 $out/cfg3_pmc_traffic.json none bp_fast16+bp_loop16 8 > $out/cfg3_pmc_traffic.txt 2>&1; rm -rf /tmp/p3 /tmp/p4
+step "cfg3 instruction issue (pmc)"
+bash tools/pmc_issue.sh ${tag}_cfg3 > /dev/null 2>&1; cp $PWD/gpurun_out/${tag}_cfg3_pmc_issue.txt $out/cfg3_pmc_issue.txt 2>/dev/null
+step "cfg2 kernel stats + level times"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2b -- python3 tools/level_times.py run-bethe > $out/lt2_run.txt 2>&1 || exit 1
+keep_stats /tmp/p2b cfg2_kernel_stats.csv
+python3 tools/level_times.py parse /tmp/p2b $out/cfg2_level_times.json > $out/cfg2_level_times.txt 2>&1; rm -rf /tmp/p2b
 step "cfg4 kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -- python3 bench.py --workload sites --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_cfg4_under_profiler.json 2>$out/e5.txt || exit 1
 keep_stats /tmp/p5 cfg4_kernel_stats.csv; rm -rf /tmp/p5
@@ -41,6 +47,12 @@ keep_stats /tmp/p8 cfg5_joingraph_kernel_stats.csv; rm -rf /tmp/p8
 step "cfg5 kernel stats (Bethe)"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p9 -- python3 bench.py --workload network --graph bethe --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_cfg5_bethe_under_profiler.json 2>$out/e9.txt || exit 1
 keep_stats /tmp/p9 cfg5_bethe_kernel_stats.csv; rm -rf /tmp/p9
+step "cfg5 pmc traffic"
+bash tools/pmc_network.sh $tag joingraph > /dev/null 2>&1; cp $PWD/gpurun_out/${tag}_pmc_traffic_network_joingraph.json $out/ 2>/dev/null
+bash tools/pmc_network.sh $tag bethe > /dev/null 2>&1; cp $PWD/gpurun_out/${tag}_pmc_traffic_network_bethe.json $out/ 2>/dev/null
+step "cfg5 level times"
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p9b -- python3 tools/level_times.py run-network joingraph > $out/lt5_run.txt 2>&1 || exit 1
+python3 tools/level_times.py parse /tmp/p9b $out/cfg5_joingraph_level_times.json > $out/cfg5_joingraph_level_times.txt 2>&1; rm -rf /tmp/p9b
 step "plain bench lines"
 python3 bench.py > $out/bench_default.json 2>$out/e10.txt || exit 1
 python3 bench.py --workload sites > $out/bench_cfg4.json 2>$out/e11.txt || exit 1
