@@ -182,6 +182,15 @@ int  pgbp_set_beliefs(pgbp_engine* e, const double* packed, int32_t snapshot_fac
 int  pgbp_get_beliefs(pgbp_engine* e, double* packed);
 int  pgbp_set_belief(pgbp_engine* e, int32_t site, int32_t belief, const double* rec); /* J,h,g of one belief */
 int  pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec);
+/* The EXCHANGE BUFFER of a cluster graph cut across devices (the roots of the subtrees a rank owns
+ * before the top of a traversal, the records it owns after one): the records (J, h, g; the plain packing of
+ * pgbp_get_belief) of `n` listed beliefs of one site, back to back in the order of the list -- gathered on the device
+ * into one contiguous buffer and moved across the bus once (pack), or the reverse (unpack: overwrites those beliefs).
+ * pgbp_packed_beliefs_size: doubles in that buffer (-1: a bad index).  This is the calibration loop's only exchange
+ * when the traversals of src/calibration.jl:111-161 are cut by spanning-tree subtrees (sharding.py: NetworkCut). */
+int64_t pgbp_packed_beliefs_size(pgbp_engine* e, int32_t n, const int32_t* beliefs);
+int  pgbp_pack_beliefs(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, double* buf);
+int  pgbp_unpack_beliefs(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, const double* buf);
 /* all beliefs of ONE site (packed: pgbp_packed_size doubles): what a host reads back into the arrays of one
  * ClusterGraphBelief of a batch without downloading the other sites */
 int  pgbp_get_site_beliefs(pgbp_engine* e, int32_t site, double* packed);

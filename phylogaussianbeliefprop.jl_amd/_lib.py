@@ -100,6 +100,9 @@ SYMBOLS = {
     "pgbp_get_site_beliefs": (C.c_int, [_P, C.c_int32, _F64P]),
     "pgbp_set_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
     "pgbp_get_belief": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P]),
+    "pgbp_packed_beliefs_size": (C.c_int64, [_P, C.c_int32, _I32P]),
+    "pgbp_pack_beliefs": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _F64P]),
+    "pgbp_unpack_beliefs": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _F64P]),
     "pgbp_init_factors_frombeliefs": (C.c_int, [_P]),
     "pgbp_reset_from_factors": (C.c_int, [_P]),
     "pgbp_reset_flags": (C.c_int, [_P, C.c_int32]),

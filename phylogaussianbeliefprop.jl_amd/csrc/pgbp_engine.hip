@@ -103,6 +103,10 @@ struct pgbp_engine {
   int64_t ws_cap = 0;
   double* d_gather = nullptr;    // send slot of pgbp_comm_gather_loglik: [norm | info | succ, iscal]
   int64_t gather_cap = 0;
+  double* d_xbuf = nullptr;      // exchange buffer of pgbp_pack_beliefs / pgbp_unpack_beliefs
+  int64_t xbuf_cap = 0;
+  int64_t* d_xoff = nullptr;     // ... its record offsets: [n] in the pool, [n + 1] in the buffer
+  int64_t xoff_cap = 0;
   bool have_factors = false;
   // pgbp_bm_tree: static description + last parameters of the device factor fill
   int32_t bm_p = 0, bm_rows = 0, bm_per_site = 0;
@@ -563,6 +567,8 @@ void pgbp_destroy(pgbp_engine* e) {
     if (p) (void)hipFree(p);
   if (e->d_gather) (void)hipFree(e->d_gather);
   if (e->d_ws) (void)hipFree(e->d_ws);
+  if (e->d_xbuf) (void)hipFree(e->d_xbuf);
+  if (e->d_xoff) (void)hipFree(e->d_xoff);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
 }
@@ -806,6 +812,80 @@ int pgbp_get_belief(pgbp_engine* e, int32_t site, int32_t belief, double* rec) {
   if (rc) return rc;
   if ((rc = ensure_layout(e, false))) return rc;
   HIPCHK(e, hipMemcpyAsync(rec, d, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
+  return pgbp_sync(e);
+}
+
+// The exchange buffer of a cut cluster graph: records gathered on the device into one contiguous buffer (what a
+// collective would carry), one copy across the bus.
+static int xbuf_prepare(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, int64_t* total) {
+  const Plan& p = e->plan;
+  if (site < 0 || site >= p.n_sites || n < 0 || (n > 0 && !beliefs)) return e->fail(PGBP_ERR_INVALID, "site or belief list");
+  std::vector<int64_t> off((size_t)2 * n + 1);
+  int64_t at = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t b = beliefs[i];
+    if (b < 0 || b >= p.n_beliefs()) return e->fail(PGBP_ERR_INVALID, "belief index out of range");
+    off[i] = p.boff[b];
+    off[(size_t)n + i] = at;
+    at += p.packed_off[b + 1] - p.packed_off[b];
+  }
+  off[(size_t)2 * n] = at;
+  *total = at;
+  int rc = ensure_layout(e, false);
+  if (rc) return rc;
+  if ((int64_t)off.size() > e->xoff_cap || at > e->xbuf_cap) HIPCHK(e, hipStreamSynchronize(e->st));
+  if ((int64_t)off.size() > e->xoff_cap) {
+    if (e->d_xoff) (void)hipFree(e->d_xoff);
+    e->d_xoff = nullptr;
+    e->xoff_cap = 0;
+    HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_xoff), sizeof(int64_t) * off.size()));
+    e->xoff_cap = (int64_t)off.size();
+  }
+  if (at > e->xbuf_cap) {
+    if (e->d_xbuf) (void)hipFree(e->d_xbuf);
+    e->d_xbuf = nullptr;
+    e->xbuf_cap = 0;
+    HIPCHK(e, hipMalloc(reinterpret_cast<void**>(&e->d_xbuf), sizeof(double) * (size_t)std::max<int64_t>(at, 1)));
+    e->xbuf_cap = std::max<int64_t>(at, 1);
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_xoff, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));   // (`off` is a local)
+  return PGBP_OK;
+}
+
+int64_t pgbp_packed_beliefs_size(pgbp_engine* e, int32_t n, const int32_t* beliefs) {
+  if (!e || n < 0 || (n > 0 && !beliefs)) return -1;
+  const Plan& p = e->plan;
+  int64_t at = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    if (beliefs[i] < 0 || beliefs[i] >= p.n_beliefs()) return -1;
+    at += p.packed_off[beliefs[i] + 1] - p.packed_off[beliefs[i]];
+  }
+  return at;
+}
+
+int pgbp_pack_beliefs(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, double* buf) {
+  DeviceScope device_scope(e);
+  if (!e || (n > 0 && !buf)) return PGBP_ERR_INVALID;
+  int64_t total = 0;
+  int rc = xbuf_prepare(e, site, n, beliefs, &total);
+  if (rc || n == 0) return rc;
+  launch_pack_records(e->d_pool + (int64_t)site * e->plan.pool_stride(), e->d_xoff, e->d_xoff + n, n, e->d_xbuf, 1, e->st);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(buf, e->d_xbuf, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, e->st));
+  return pgbp_sync(e);
+}
+
+int pgbp_unpack_beliefs(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, const double* buf) {
+  DeviceScope device_scope(e);
+  if (!e || (n > 0 && !buf)) return PGBP_ERR_INVALID;
+  int64_t total = 0;
+  int rc = xbuf_prepare(e, site, n, beliefs, &total);
+  if (rc || n == 0) return rc;
+  e->sym_known = false;
+  HIPCHK(e, hipMemcpyAsync(e->d_xbuf, buf, sizeof(double) * (size_t)total, hipMemcpyHostToDevice, e->st));
+  launch_pack_records(e->d_pool + (int64_t)site * e->plan.pool_stride(), e->d_xoff, e->d_xoff + n, n, e->d_xbuf, 0, e->st);
+  HIPCHK(e, hipGetLastError());
   return pgbp_sync(e);
 }
 

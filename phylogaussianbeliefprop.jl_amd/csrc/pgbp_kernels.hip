@@ -1717,6 +1717,30 @@ void launch_copy_records(const double* src, int64_t src_stride, double* dst, int
                      d_dim, n_records, bs16, fast_p);
 }
 
+// ---- the exchange buffer of a cut cluster graph (pgbp_pack_beliefs / pgbp_unpack_beliefs): the records of a list of
+// beliefs of one site, back to back in the order of the list.  One workgroup per record (grid-stride), 8 bytes per thread
+// and step: the records are a few hundred bytes to a few KB each and the list is a boundary, not the graph.
+__global__ __launch_bounds__(256) void pack_records_kernel(double* __restrict__ pool_site, const int64_t* __restrict__ rec_off,
+                                                           const int64_t* __restrict__ buf_off, int n,
+                                                           double* __restrict__ buf, int to_buf) {
+  for (int r = blockIdx.x; r < n; r += gridDim.x) {
+    double* __restrict__ rec = pool_site + rec_off[r];
+    double* __restrict__ b = buf + buf_off[r];
+    const int64_t len = buf_off[r + 1] - buf_off[r];
+    for (int64_t t = threadIdx.x; t < len; t += blockDim.x) {
+      if (to_buf) b[t] = rec[t];
+      else rec[t] = b[t];
+    }
+  }
+}
+
+void launch_pack_records(double* pool_site, const int64_t* d_rec_off, const int64_t* d_buf_off, int n, double* d_buf, int to_buf,
+                         hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(pack_records_kernel, dim3(std::min(n, 4096)), dim3(256), 0, st, pool_site, d_rec_off, d_buf_off, n, d_buf,
+                     to_buf);
+}
+
 // ---- site-minor layout (univariate batches) ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void site_minor_kernel(double* __restrict__ plain, int64_t plain_stride,
                                                          double* __restrict__ sm, const int64_t* __restrict__ off,

@@ -151,6 +151,9 @@ void launch_bm_tree_fill_uni_sm(double* pool_sm, double* fpool_sm, const int64_t
                                 int n_rows, const double* d_Rinv, const double* d_logdetR, const double* d_mu, int per_site,
                                 int n_clusters, int n_sites, hipStream_t st);
 // record-aware copy: only the part of each record slot that the current layout uses (pgbp_kernels.hip)
+// records of listed beliefs of one site <-> one contiguous buffer (the exchange buffer of a cut cluster graph)
+void launch_pack_records(double* pool_site, const int64_t* d_rec_off, const int64_t* d_buf_off, int n, double* d_buf, int to_buf,
+                         hipStream_t st);
 void launch_copy_records(const double* src, int64_t src_stride, double* dst, int64_t dst_stride, const int64_t* d_boff,
                          const int32_t* d_dim, int n_records, int bs16, int fast_p, int n_sites, hipStream_t st);
 

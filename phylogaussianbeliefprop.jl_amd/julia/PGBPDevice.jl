@@ -100,6 +100,31 @@ function site_beliefs(o::DeviceClusterGraphBelief, site::Integer)
     return out
 end
 
+# The exchange buffer of a cluster graph cut across devices (DESIGN.md section 6): the records of the listed beliefs
+# (1-based, clusters then sepsets as in `o.belief`) of the first site, back to back, gathered on the device.
+function pack_beliefs(o::DeviceClusterGraphBelief, beliefs::Vector{<:Integer})
+    idx = Int32.(beliefs .- 1)
+    n = @ccall LIB.pgbp_packed_beliefs_size(o.handle::Ptr{Cvoid}, Int32(length(idx))::Int32, idx::Ptr{Int32})::Int64
+    n >= 0 || error("belief index out of range")
+    buf = zeros(n)
+    check(o.handle, @ccall LIB.pgbp_pack_beliefs(o.handle::Ptr{Cvoid}, Int32(0)::Int32, Int32(length(idx))::Int32,
+                                                 idx::Ptr{Int32}, buf::Ptr{Float64})::Cint)
+    return buf
+end
+"the reverse: overwrite the listed beliefs of the first site from a buffer another rank packed"
+function unpack_beliefs!(o::DeviceClusterGraphBelief, beliefs::Vector{<:Integer}, buf::Vector{Float64})
+    idx = Int32.(beliefs .- 1)
+    check(o.handle, @ccall LIB.pgbp_unpack_beliefs(o.handle::Ptr{Cvoid}, Int32(0)::Int32, Int32(length(idx))::Int32,
+                                                   idx::Ptr{Int32}, buf::Ptr{Float64})::Cint)
+end
+"propagate_1traversal_postorder! (dir 0) / _preorder! (dir 1) of schedule tree `tree` (1-based): the pieces a cut traversal is made of"
+function traverse!(o::DeviceClusterGraphBelief, tree::Integer, dir::Integer; update_residualnorm=true)
+    r = Ref(Result(ntuple(_ -> Int32(0), 10)...))
+    check(o.handle, @ccall LIB.pgbp_traverse(o.handle::Ptr{Cvoid}, Int32(tree - 1)::Int32, Int32(dir)::Int32,
+        Ref(Opts(0, update_residualnorm, 0, 0, 1e-5))::Ref{Opts}, r::Ref{Result})::Cint)
+    return r[].succ != 0
+end
+
 function set_schedule!(o::DeviceClusterGraphBelief, schedule)
     o.schedule_set === schedule && return
     off = Int32[0]; pa = Int32[]; ch = Int32[]
@@ -385,6 +410,45 @@ function loglik(g::DeviceGroup, j::Integer)
     checkg(g.handle, @ccall LIB.pgbp_group_integrate(g.handle::Ptr{Cvoid}, (j-1)::Int32, C_NULL::Ptr{Float64}, norm::Ptr{Float64}, info::Ptr{Int32})::Cint)
     any(!=(0), info) && throw(PGBP.LA.PosDefException(first(filter(!=(0), info))))
     return norm
+end
+
+# Sites with different missing-data patterns behind one handle: one pgbp_desc per pattern (its own scopes), `sites` = for
+# every pattern in turn the (1-based) global indices of its sites.  Pattern k's engine takes everything pattern-specific.
+mutable struct DevicePatterns
+    handle::Ptr{Cvoid}
+    n_sites::Int
+end
+function DevicePatterns(descs::Vector{Desc}, sites::Vector{<:Integer})
+    refs = [Ref(d) for d in descs]
+    ptrs = [Base.unsafe_convert(Ptr{Desc}, r) for r in refs]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    s0 = Int32.(sites .- 1)
+    rc = GC.@preserve refs @ccall LIB.pgbp_patterns_create(Int32(length(descs))::Int32, ptrs::Ptr{Ptr{Desc}}, s0::Ptr{Int32},
+                                                         h::Ref{Ptr{Cvoid}})::Cint
+    rc == 0 || error(unsafe_string(@ccall LIB.pgbp_patterns_last_error(C_NULL::Ptr{Cvoid})::Cstring))
+    g = DevicePatterns(h[], length(sites))
+    finalizer(x -> @ccall(LIB.pgbp_patterns_destroy(x.handle::Ptr{Cvoid})::Cvoid), g)
+    return g
+end
+checkp(h, rc) = rc == 0 || error(unsafe_string(@ccall LIB.pgbp_patterns_last_error(h::Ptr{Cvoid})::Cstring))
+pattern_engine(g::DevicePatterns, k::Integer) = @ccall LIB.pgbp_patterns_engine(g.handle::Ptr{Cvoid}, Int32(k - 1)::Int32)::Ptr{Cvoid}
+function set_schedule!(g::DevicePatterns, off::Vector{Int32}, pa::Vector{Int32}, ch::Vector{Int32})
+    checkp(g.handle, @ccall LIB.pgbp_patterns_set_schedule(g.handle::Ptr{Cvoid}, Int32(length(off) - 1)::Int32, off::Ptr{Int32},
+                                                           pa::Ptr{Int32}, ch::Ptr{Int32})::Cint)
+end
+function PGBP.calibrate!(g::DevicePatterns, niter::Integer=1; auto=false, update_residualnorm=true)
+    res = Vector{Result}(undef, g.n_sites)
+    checkp(g.handle, @ccall LIB.pgbp_patterns_calibrate(g.handle::Ptr{Cvoid}, Int32(niter)::Int32,
+        Ref(Opts(auto, update_residualnorm, 0, 0, 1e-5))::Ref{Opts}, res::Ptr{Result})::Cint)
+    return [(r.succ != 0, r.iscal != 0) for r in res]
+end
+"score() body of every site (device factor fill + postorder + root integrate), in the caller's site order"
+function loglik_lg(g::DevicePatterns)
+    checkp(g.handle, @ccall LIB.pgbp_patterns_enqueue_loglik_lg(g.handle::Ptr{Cvoid}, Int32(1)::Int32,
+        Ref(Opts(0, 1, 0, 0, 1e-5))::Ref{Opts})::Cint)
+    norm = zeros(g.n_sites); info = zeros(Int32, g.n_sites)
+    checkp(g.handle, @ccall LIB.pgbp_patterns_fetch_loglik(g.handle::Ptr{Cvoid}, norm::Ptr{Float64}, info::Ptr{Int32})::Cint)
+    return norm, info
 end
 
 # One process per GPU (Distributed.jl / MPI.jl workers): ONE ncclAllGather per gather.

@@ -297,3 +297,253 @@ def unpack_slots(recv, n_ranks, slot_sites):
     if code != 0:
         raise L.PgbpError(code, "pgbp_comm_unpack_slots")
     return norm, info, bool(succ.value), bool(iscal.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A cluster graph CUT across devices (third bullet): the loop of
+# src/calibration.jl:35-60 with each traversal (src/calibration.jl:111-161) cut by spanning-tree subtrees.
+
+def cut_spanning_tree(pa, ch, n_ranks, min_subtrees=4):
+    """Cut one spanning tree -- its preorder edge list (pa[i], ch[i]), as spanningtree_clusterlist returns it
+    (src/clustergraph.jl:885-894) -- into a TOP (the clusters less than `depth` edges from the root, every rank runs it)
+    and the SUBTREES hanging below it, dealt to the ranks largest first, each to the rank with the least edges so far.
+    depth: the smallest that leaves at least min_subtrees * n_ranks subtrees with an edge of their own, none of them larger
+    than half a rank's share (or the whole tree in the top when it is too small to cut).
+    -> dict(top=(pa, ch) edge arrays of the top INCLUDING the boundary edges top -> subtree root,
+            sub=[(rank, root cluster, (pa, ch) of the edges inside the subtree)], boundary=[edge index of each boundary edge])"""
+    pa = np.asarray(pa, np.int64)
+    ch = np.asarray(ch, np.int64)
+    n = len(pa)
+    if n == 0:
+        return {"top": (pa.astype(np.int32), ch.astype(np.int32)), "sub": [], "boundary": [], "depth": 0}
+    depth = {int(pa[0]): 0}
+    for a, c in zip(pa, ch):
+        depth[int(c)] = depth[int(a)] + 1
+    dch = np.array([depth[int(c)] for c in ch])           # depth of the child end of edge i
+    dmax = int(dch.max())
+    # size of the subtree below each edge's child (edges strictly inside): children come after parents in preorder
+    below = {int(c): 0 for c in ch}
+    below[int(pa[0])] = 0
+    for a, c in zip(pa[::-1], ch[::-1]):
+        below[int(a)] = below.get(int(a), 0) + below[int(c)] + 1
+    # the smallest depth with enough subtrees AND none larger than half a rank's share (largest-first dealing then balances
+    # the ranks to about a quarter of a share); failing that, the best-balanced depth whose top stays below 5 % of the tree
+    pick, best = None, None
+    for d in range(1, dmax + 1):
+        sizes = [below[int(ch[i])] for i in range(n) if dch[i] == d and below[int(ch[i])] > 0]
+        if len(sizes) < min_subtrees * n_ranks:
+            continue
+        top_size = int((dch <= d).sum())
+        if top_size > max(64, n // 20):
+            break
+        if max(sizes) <= (n - top_size) / (2.0 * n_ranks):
+            pick = d
+            break
+        if best is None or max(sizes) < best[0]:
+            best = (max(sizes), d)
+    if pick is None and best is not None:
+        pick = best[1]
+    if pick is None or n_ranks <= 1:
+        return {"top": (pa.astype(np.int32), ch.astype(np.int32)), "sub": [], "boundary": [], "depth": dmax + 1}
+    top_edges = [i for i in range(n) if dch[i] <= pick]            # edges with the parent in the top (depth < pick)
+    boundary = [i for i in range(n) if dch[i] == pick]
+    # the subtree of each boundary edge's child: a contiguous run of the preorder list?  Not necessarily (the list is A
+    # preorder, children of a node need not be adjacent), so collect by root
+    root_of = {}
+    for i in boundary:
+        root_of[int(ch[i])] = int(ch[i])
+    sub_edges = {int(ch[i]): [] for i in boundary}
+    for i in range(n):
+        if dch[i] > pick:
+            r = root_of[int(pa[i])]
+            root_of[int(ch[i])] = r
+            sub_edges[r].append(i)
+    load = [0] * n_ranks
+    sub = []
+    for r, edges in sorted(sub_edges.items(), key=lambda kv: (-len(kv[1]), kv[0])):
+        k = int(np.argmin(load))
+        load[k] += len(edges)
+        sub.append((k, r, (pa[edges].astype(np.int32), ch[edges].astype(np.int32))))
+    return {"top": (pa[top_edges].astype(np.int32), ch[top_edges].astype(np.int32)), "sub": sub, "boundary": boundary,
+            "depth": pick, "load": load}
+
+
+class NetworkCut:
+    """calibrate!(beliefs, schedule, niter) (src/calibration.jl:35-60) of ONE cluster graph on several engines ("ranks":
+    one per GPU; on a one-GPU box the same device several times), every traversal cut by cut_spanning_tree:
+      1. postorder inside the subtrees a rank owns (propagate_1traversal_postorder!, src/calibration.jl:111-135);
+      2. EXCHANGE A: the root cluster of every subtree (one record each: the boundary buffer) goes to every rank;
+      3. every rank runs the top, postorder then preorder, boundary edges included -- the same arithmetic on the same
+         operands, so the top, the boundary sepsets and the subtree roots stay bit-identical on all ranks;
+      4. preorder inside the owned subtrees (src/calibration.jl:137-161);
+      5. EXCHANGE B: what a rank's subtrees hold now (clusters, sepsets) goes to every rank -- the next spanning tree of a
+         loopy graph is cut elsewhere.  (One spanning tree: nothing to do, the beliefs are read from their owners.)
+    Messages that do not depend on each other run in another order than on one engine, nothing else changes: the beliefs
+    are those of the single-engine run bit for bit.  The exchanges are pgbp_pack_beliefs / pgbp_unpack_beliefs through the
+    host here (one process, engines side by side); between processes the packed buffer is what an all-gather carries.
+    `beliefs`: one ClusterGraphBelief per rank over the same graph, same state.  A subtree is a tree of its rank's schedule
+    of its own (the planner takes trees, not forests): its launches are narrower than the uncut traversal's."""
+
+    def __init__(self, beliefs, schedule, min_subtrees=4):
+        self.ranks = list(beliefs)
+        self.K = len(self.ranks)
+        self.schedule = [(np.asarray(t[-2], np.int32), np.asarray(t[-1], np.int32)) for t in schedule]
+        self.cuts = [cut_spanning_tree(pa, ch, self.K, min_subtrees) for pa, ch in self.schedule]
+        b0 = self.ranks[0]
+        sep_of = {}
+        for k, (a, c) in enumerate(b0._sepcl):
+            sep_of[(min(int(a), int(c)), max(int(a), int(c)))] = b0.nclusters + k
+        self._sep_of = sep_of
+        # per rank: its schedule = for every spanning tree, the top, then its subtrees (those with an edge)
+        self.tree_index = []        # [t] -> dict(top={rank: idx}, sub={rank: [idx, ...]}): indices into the rank's own schedule
+        per_rank = [[] for _ in range(self.K)]
+        for cut in self.cuts:
+            entry = {"sub": {r: [] for r in range(self.K)}, "top": {}}
+            for r in range(self.K):
+                entry["top"][r] = len(per_rank[r])
+                per_rank[r].append(cut["top"])
+            for r in range(self.K):
+                for (k, _root, edges) in cut["sub"]:
+                    if k == r:
+                        entry["sub"][r].append(len(per_rank[r]))
+                        per_rank[r].append(edges)
+            self.tree_index.append(entry)
+        for r, b in enumerate(self.ranks):
+            b.set_schedule(per_rank[r])
+        # exchange lists
+        self.roots = []        # [t][rank] -> belief indices of the roots of its subtrees
+        self.owned = []        # [t][rank] -> belief indices of everything inside its subtrees (clusters incl. roots, sepsets)
+        for cut in self.cuts:
+            roots = [[] for _ in range(self.K)]
+            owned = [[] for _ in range(self.K)]
+            for (k, root, (pa, ch)) in cut["sub"]:
+                roots[k].append(root)
+                owned[k].append(root)
+                for a, c in zip(pa, ch):
+                    owned[k].append(int(c))
+                    owned[k].append(sep_of[(min(int(a), int(c)), max(int(a), int(c)))])
+            self.roots.append([np.asarray(x, np.int32) for x in roots])
+            self.owned.append([np.asarray(x, np.int32) for x in owned])
+        self.last_writer = {}      # (receiver, sender) -> rank that sent the message last
+        self.exchanged_doubles = 0
+
+    # -- the exchange: `idx[r]` from rank r to every other rank
+    def _exchange(self, idx):
+        import ctypes as C
+        from . import _lib as L
+        for r, b in enumerate(self.ranks):
+            if len(idx[r]) == 0:
+                continue
+            lst = np.ascontiguousarray(idx[r], np.int32)
+            n = int(b._lib.pgbp_packed_beliefs_size(b._eng, len(lst), L.i32p(lst)))
+            buf = np.zeros(n)
+            code = b._lib.pgbp_pack_beliefs(b._eng, 0, len(lst), L.i32p(lst), L.f64p(buf))
+            if code != 0:
+                raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
+            self.exchanged_doubles += n
+            for q, o in enumerate(self.ranks):
+                if q == r:
+                    continue
+                code = o._lib.pgbp_unpack_beliefs(o._eng, 0, len(lst), L.i32p(lst), L.f64p(buf))
+                if code != 0:
+                    raise L.PgbpError(code, o._lib.pgbp_last_error(o._eng).decode())
+
+    def _traverse(self, r, tree, direction, opts):
+        import ctypes as C
+        from . import _lib as L
+        b = self.ranks[r]
+        res = (L.Result * b.n_sites)()
+        code = b._lib.pgbp_traverse(b._eng, int(tree), int(direction), C.byref(opts), res)
+        if code != 0:
+            raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
+        return bool(res[0].succ)
+
+    def _note(self, r, edges, direction):
+        pa, ch = edges
+        for a, c in zip(pa, ch):
+            key = (int(a), int(c)) if direction == 0 else (int(c), int(a))   # (receiver, sender)
+            self.last_writer[key] = r
+
+    def traversal(self, t, opts=None):
+        """one spanning tree, postorder then preorder, cut -> True if every message went through"""
+        from . import _lib as L
+        o = opts if opts is not None else L.Opts(0, 1, 0, 0, 1e-5)
+        cut, ix = self.cuts[t], self.tree_index[t]
+        ok = True
+        subs = {r: [e for (k, _root, e) in cut["sub"] if k == r] for r in range(self.K)}
+        for r in range(self.K):                                   # 1
+            for j, tree in enumerate(ix["sub"][r]):
+                ok &= self._traverse(r, tree, 0, o)
+                self._note(r, subs[r][j], 0)
+        self._exchange(self.roots[t])                             # 2
+        for r in range(self.K):                                   # 3 (every rank; rank 0 speaks for the top's flags)
+            ok &= self._traverse(r, ix["top"][r], 0, o)
+            ok &= self._traverse(r, ix["top"][r], 1, o)
+        self._note(0, cut["top"], 0)
+        self._note(0, cut["top"], 1)
+        for r in range(self.K):                                   # 4
+            for j, tree in enumerate(ix["sub"][r]):
+                ok &= self._traverse(r, tree, 1, o)
+                self._note(r, subs[r][j], 1)
+        if len(self.schedule) > 1:                                # 5
+            self._exchange(self.owned[t])
+        return ok
+
+    def iscalibrated_residnorm(self):
+        """iscalibrated_residnorm over every message residual (src/beliefs.jl:994-1003), each read from the rank that
+        sent the message last; a message never sent is not calibrated"""
+        from . import _lib as L
+        b0 = self.ranks[0]
+        nm = 2 * b0.nsepsets
+        flags = []
+        for b in self.ranks:
+            f = np.zeros(b.n_sites * nm, np.int32)
+            code = b._lib.pgbp_get_residuals(b._eng, None, L.i32p(f), None, None)
+            if code != 0:
+                raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
+            flags.append(f[:nm])
+        for k, (a, c) in enumerate(b0._sepcl):
+            for mid, key in ((2 * k, (int(a), int(c))), (2 * k + 1, (int(c), int(a)))):   # (receiver, sender)
+                r = self.last_writer.get(key)
+                if r is None or not flags[r][mid]:
+                    return False
+        return True
+
+    def calibrate(self, niter=1, auto=False, opts=None):
+        """-> (succ, iscal, (iteration, tree) reached if auto stopped there else None)"""
+        for it in range(niter):
+            for t in range(len(self.schedule)):
+                if not self.traversal(t, opts):
+                    return False, False, None
+                if auto and self.iscalibrated_residnorm():
+                    return True, True, (it + 1, t + 1)
+        return True, self.iscalibrated_residnorm(), None
+
+    def gather(self):
+        """the calibrated beliefs [packed_size], every record from the rank that owns it after the last traversal (one
+        spanning tree: exchange B was skipped; several: any rank holds everything)"""
+        b0 = self.ranks[0]
+        from . import _lib as L
+        out = np.zeros(int(b0._lib.pgbp_packed_size(b0._eng)))
+        full = np.zeros((1, len(out)))
+        code = b0._lib.pgbp_get_beliefs(b0._eng, L.f64p(full))
+        if code != 0:
+            raise L.PgbpError(code, b0._lib.pgbp_last_error(b0._eng).decode())
+        out[:] = full[0]
+        if len(self.schedule) == 1:
+            for r in range(1, self.K):
+                lst = self.owned[0][r]
+                if len(lst) == 0:
+                    continue
+                b = self.ranks[r]
+                n = int(b._lib.pgbp_packed_beliefs_size(b._eng, len(lst), L.i32p(lst)))
+                buf = np.zeros(n)
+                code = b._lib.pgbp_pack_beliefs(b._eng, 0, len(lst), L.i32p(lst), L.f64p(buf))
+                if code != 0:
+                    raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
+                at = 0
+                for i in lst:
+                    ln = int(b0._poff[i + 1] - b0._poff[i])
+                    out[b0._poff[i]:b0._poff[i] + ln] = buf[at:at + ln]
+                    at += ln
+        return out

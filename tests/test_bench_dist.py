@@ -206,3 +206,54 @@ def test_comm_failure_on_one_rank_is_raised_by_every_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out[0][1].startswith("PgbpError") and out[1][1].startswith("PgbpError")
+
+
+def test_cut_of_a_spanning_tree_partitions_its_edges():
+    """sharding.cut_spanning_tree (the cfg5-across-GPUs cut): top + subtrees hold every edge exactly
+    once; every subtree edge list is itself a preorder list of a tree whose root is the child end of a boundary edge;
+    boundary edges belong to the top; the loads of the ranks are balanced to within the largest subtree; a tree too small
+    to cut stays whole."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from pgbp_amd.sharding import cut_spanning_tree
+    rng = np.random.default_rng(11)
+    for n_nodes, K in ((2000, 2), (5000, 4), (777, 8)):
+        # a random recursive tree, preorder edge list by DFS
+        parent = np.zeros(n_nodes, np.int64)
+        for v in range(1, n_nodes):
+            parent[v] = rng.integers(0, v)
+        kids = [[] for _ in range(n_nodes)]
+        for v in range(1, n_nodes):
+            kids[parent[v]].append(v)
+        pa, ch, stack = [], [], [0]
+        while stack:
+            u = stack.pop()
+            for v in kids[u]:
+                pa.append(u)
+                ch.append(v)
+                stack.append(v)
+        # (a stack DFS emits all children of u before descending: still parent-before-child, as the planner requires)
+        cut = cut_spanning_tree(pa, ch, K)
+        all_edges = set(zip(pa, ch))
+        top = set(zip(cut["top"][0].tolist(), cut["top"][1].tolist()))
+        seen = set(top)
+        assert len(top) == len(cut["top"][0])
+        roots = {int(ch[i]) for i in cut["boundary"]}
+        assert {(int(pa[i]), int(ch[i])) for i in cut["boundary"]} <= top
+        load = [0] * K
+        for (k, root, (spa, sch)) in cut["sub"]:
+            assert root in roots and 0 <= k < K
+            placed = {root}
+            for a, c in zip(spa.tolist(), sch.tolist()):
+                assert a in placed and c not in placed        # preorder list of a tree rooted at `root`
+                placed.add(c)
+                assert (a, c) not in seen
+                seen.add((a, c))
+            load[k] += len(spa)
+        assert seen == all_edges
+        assert len(cut["sub"]) >= 4 * K or not cut["sub"]
+        if cut["sub"]:
+            biggest = max(len(s[2][0]) for s in cut["sub"])
+            assert max(load) - min(load) <= biggest
+    whole = cut_spanning_tree([0, 1], [1, 2], 2)
+    assert whole["sub"] == [] and len(whole["top"][0]) == 2

@@ -363,3 +363,75 @@ def test_three_missing_data_patterns_twelve_sites_behind_one_handle():
     assert not info.any()
     assert np.max(np.abs(norm - np.array(want_ll)) / np.maximum(1.0, np.abs(want_ll))) <= 1e-8
     grp.close()
+
+
+def _small_network(graph, ntips=600, seed=3, p=2):
+    import argparse
+    import bench as B
+    args = argparse.Namespace(seed=seed, traits=p, blob_style="varied", ntips=ntips, blobs=ntips // 12, graph=graph,
+                              maxclustersize=3)
+    return B.build_network_workload(args, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph,n_ranks", [("bethe", 2), ("cliquetree", 3), ("joingraph", 2)])
+def test_cluster_graph_cut_across_two_engines_equals_one_engine(graph, n_ranks):
+    """cfg5 across devices, rehearsed on one (third bullet): the engines of a
+    pgbp_group with the device listed n_ranks times hold the same level-3 network's cluster graph; NetworkCut runs
+    calibrate! with every traversal cut by spanning-tree subtrees -- postorder in the owned subtrees, the subtree roots
+    exchanged (pgbp_pack_beliefs / pgbp_unpack_beliefs), the top on every rank, preorder in the owned subtrees, and, on
+    a loopy graph, the owned records exchanged for the next spanning tree.  Every belief equals the single-engine run's BIT
+    FOR BIT (independent messages in another order, nothing else), so do the calibration flags and the iteration the
+    automatic stop is reached at."""
+    from pgbp_amd.sharding import NetworkCut
+    net, (cn, ed, sn), st, fam, X, rates, mu, sched = _small_network(graph)
+    loopy = len(ed) > len(cn) - 1
+    lib = pgbp_amd.load()
+
+    def prepare(cgb):
+        cgb.lg_setup(fam, X)
+        cgb.assignfactors_lg_(rates, mu)
+        if loopy and graph == "joingraph":
+            from pgbp_amd.regularization import regularizebeliefs_onschedule_
+            regularizebeliefs_onschedule_(cgb)
+        elif loopy:
+            assert lib.pgbp_regularize_bycluster(cgb._eng) == 0
+        cgb.pull()
+        return cgb._packed[0].copy()
+
+    one = pgbp_amd.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+    start = prepare(one)
+    niter = 3 if loopy else 1
+    one.set_schedule(sched)
+    res = (L.Result * 1)()
+    o = one._opts()
+    assert lib.pgbp_calibrate(one._eng, niter, C.byref(o), res) == 0 and res[0].succ
+    want = np.zeros((1, len(start)))
+    assert lib.pgbp_get_beliefs(one._eng, L.f64p(want)) == 0
+    flags_one = np.zeros(2 * one.nsepsets, np.int32)
+    assert lib.pgbp_get_residuals(one._eng, None, L.i32p(flags_one), None, None) == 0
+
+    grp = EngineGroup(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, n_ranks, [0] * n_ranks)
+    ranks = [pgbp_amd.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None,
+                                                     n_sites=1, engine=grp.engine(r)) for r in range(n_ranks)]
+    for b in ranks:   # the same start on every rank (the regularisation walk is deterministic; upload the one state)
+        b._packed[0, :] = start
+        b._upload(snapshot_factors=True)
+    cut = NetworkCut(ranks, sched)
+    assert all(len(c["sub"]) >= 4 * n_ranks for c in cut.cuts), [len(c["sub"]) for c in cut.cuts]
+    succ, iscal, _ = cut.calibrate(niter)
+    assert succ
+    got = cut.gather()
+    scale = np.maximum(1.0, np.abs(want[0]))
+    assert np.max(np.abs(got - want[0]) / scale) <= 1e-11, float(np.max(np.abs(got - want[0]) / scale))
+    assert iscal == bool(flags_one.all())
+    # what crossed between the ranks: per traversal the subtree roots (the boundary buffer), plus, on a loopy graph, the
+    # records inside the owned subtrees
+    n_trav = niter * len(sched)
+    root_doubles = sum(int(ranks[0]._poff[i + 1] - ranks[0]._poff[i]) for t in range(len(sched)) for x in cut.roots[t] for i in x)
+    owned_doubles = sum(int(ranks[0]._poff[i + 1] - ranks[0]._poff[i]) for t in range(len(sched)) for x in cut.owned[t] for i in x)
+    assert cut.exchanged_doubles == niter * (root_doubles + (owned_doubles if len(sched) > 1 else 0))
+    assert n_trav > 0 and root_doubles > 0
+    for b in ranks:
+        b._eng = None
+    grp.close()

@@ -861,7 +861,7 @@ def test_julia_shim_and_ctypes_mirror_agree_with_the_header():
     assert {"pgbp_desc", "pgbp_opts", "pgbp_result", "pgbp_lg_families", "pgbp_lg_params"} <= set(structs)
     jl = open(os.path.join(ROOT, "phylogaussianbeliefprop.jl_amd", "julia", "PGBPDevice.jl")).read()
     jkind = {"Int32": "i32", "Cint": "i32", "Int64": "i64", "UInt64": "u64", "Float64": "f64", "Cdouble": "f64",
-             "Cvoid": "void", "Cstring": "ptr"}
+             "Cvoid": "void", "Cstring": "ptr", "Ptr": "ptr"}   # ("Ptr": a return type `::Ptr{...}` cut at the brace)
 
     def jl_kind(t):
         t = t.strip()

@@ -17,19 +17,37 @@ usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv 
                several kernels joined by '+': bp_level_generic+bp_chunk_generic+bp_fast16 for the network workload)
   calibrates:  how many calibrate!() iterations the profiled program ran and nothing else on that kernel (e.g.
                `tools/level_times.py run` = 8): adds launches_per_calibrate and hbm_bytes_per_calibrate
+  last_n:      count only the last last_n launches of these kernels (dispatch order): the network workload's one-off
+               regularisation walk sends its messages through the same kernels before the timed iterations
+usage: ... [copy_kernel [kernel [calibrates [last_n]]]]
 """
 import csv
 import json
 import sys
 
 
+LAST = [0]   # > 0: of the kernels asked for, only the last LAST[0] launches in dispatch order count (what ran before
+             # them on the same kernels -- the one-off regularisation walk of the network workload -- is not the path)
+KEEP = [None]
+
+
 def per_kernel(path, counter):
-    d = {}
+    rows = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             name = name.split("<")[0]
-            d.setdefault(name, []).append(float(r["Counter_Value"]))
+            k = int(r["Dispatch_Id"])
+            e = rows.setdefault(k, [name, 0.0])
+            e[1] += float(r["Counter_Value"])
+    order = sorted(rows)
+    if LAST[0] > 0 and KEEP[0]:
+        mine = [k for k in order if rows[k][0] in KEEP[0]]
+        drop = set(mine[:-LAST[0]]) if len(mine) > LAST[0] else set()
+        order = [k for k in order if k not in drop]
+    d = {}
+    for k in order:
+        d.setdefault(rows[k][0], []).append(rows[k][1])
     return d
 
 
@@ -40,6 +58,8 @@ def main():
         ck = "pgbp::" + ck
     kname = sys.argv[6] if len(sys.argv) > 6 else "bp_fast16"
     ncal = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+    LAST[0] = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    KEEP[0] = {"pgbp::" + x for x in kname.split("+")}
     F = per_kernel(f_csv, "FETCH_SIZE")
     W = per_kernel(w_csv, "WRITE_SIZE")
     have_cal = copy_bytes > 0 and ck in F and ck in W   # copy_bytes 0: calibrated elsewhere (tools/copy8_microbench.hip)
