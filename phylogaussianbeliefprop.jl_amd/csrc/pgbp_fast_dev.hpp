@@ -147,6 +147,127 @@ __device__ __forceinline__ int eliminate2(Frag& f, const int a, const int b, con
   return bad;
 }
 
+// ---- The same elimination on TWO wavefronts (pgbp_loop.hip): the PIVOT wavefront keeps the integrated columns -- the
+// chain strip -> D^-1 -> next pivot's columns -> strip -- and publishes every pivot in a strip of its own (P / 2 strips per
+// record, nothing is ever overwritten inside a pass) followed by a progress word; the KEPT wavefront follows it round by
+// round on the kept block, h_S, the quadratic form and the determinant.  Same operands, same operations in the same order
+// as eliminate_round above on each entry: bit-identical.
+// progress word: `base + r` = the strips of rounds 0 .. r - 1 are published (r = 1 .. P / 2); the LDS unit serves a
+// wavefront's accesses in order, so a wavefront that reads the word after it was written finds the strips behind it.
+__device__ __forceinline__ void progress_store(int* word, int value, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int progress_wait(int* word, int at_least) {
+  int v;
+  do {
+    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  } while (v < at_least);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  return v;
+}
+
+template <int R>
+__device__ __forceinline__ void publish_pivot_strip(const Frag& f, const int a, const int b, const bool act,
+                                                    double* __restrict__ strips) {
+  double* strip = strips + R * kColStrip;
+  if (act && b == R) {
+    double* dst = strip + a * kColStride;
+    *reinterpret_cast<double4*>(dst) = make_double4(f.w[0][0], f.w[1][0], f.w[2][0], f.w[3][0]);
+    *reinterpret_cast<double4*>(dst + 4) = make_double4(f.w[0][1], f.w[1][1], f.w[2][1], f.w[3][1]);
+    if (a == R) *reinterpret_cast<double2*>(strip + 8 * kColStride) = make_double2(f.h[0], f.h[1]);
+  }
+}
+
+// the pivot wavefront's rounds: f.w[0..3][0..1], f.h[0..1] only
+template <int P, int R>
+__device__ __forceinline__ void pivot_rounds(Frag& f, const int a, const int b, const bool act, const int lane,
+                                             double* __restrict__ strips, int* word, const int base) {
+  if constexpr (R == 0) {
+    publish_pivot_strip<0>(f, a, b, act, strips);
+    progress_store(word, base + 1, lane);
+  }
+  if constexpr (R < P / 2 - 1) {   // (the last pivot's round has nothing left to update on this side)
+    wave_sync_lds();
+    const double* strip = strips + R * kColStrip;
+    const double4 xr0 = *reinterpret_cast<const double4*>(strip + a * kColStride);
+    const double4 xr1 = *reinterpret_cast<const double4*>(strip + a * kColStride + 4);
+    const double2 xc0 = *reinterpret_cast<const double2*>(strip + b * kColStride);
+    const double2 xc1 = *reinterpret_cast<const double2*>(strip + b * kColStride + 4);
+    const double2 p0 = *reinterpret_cast<const double2*>(strip + R * kColStride);
+    const double2 p1 = *reinterpret_cast<const double2*>(strip + R * kColStride + 4);
+    const double2 hk = *reinterpret_cast<const double2*>(strip + 8 * kColStride);
+    const double d00 = p0.x, d01 = p1.x, d11 = p1.y;
+    const double det = fma(d00, d11, -(d01 * d01));
+    double rdet = __builtin_amdgcn_rcp(det);
+    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+    const double e00 = d11 * rdet, e01 = -(d01 * rdet), e11 = d00 * rdet;
+    const double xc0v[2] = {xc0.x, xc0.y}, xc1v[2] = {xc1.x, xc1.y};
+    const double xr0v[4] = {xr0.x, xr0.y, xr0.z, xr0.w}, xr1v[4] = {xr1.x, xr1.y, xr1.z, xr1.w};
+    const double g0 = fma(e00, hk.x, e01 * hk.y), g1 = fma(e01, hk.x, e11 * hk.y);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double y0 = fma(e00, xc0v[j], e01 * xc1v[j]);
+      const double y1 = fma(e01, xc0v[j], e11 * xc1v[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.w[i][j] = fma(-xr0v[i], y0, fma(-xr1v[i], y1, f.w[i][j]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f.h[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, f.h[i]));
+    publish_pivot_strip<R + 1>(f, a, b, act, strips);
+    progress_store(word, base + R + 2, lane);
+    pivot_rounds<P, R + 1>(f, a, b, act, lane, strips, word, base);
+  }
+}
+
+// the kept wavefront's rounds: w22 = (W[S_a][S_b]) block of the lane, hs = h_S entries; returns potrf's info
+template <int P, int R>
+__device__ __forceinline__ int kept_rounds(double (&w22)[2][2], double (&hs)[2], const int a, const int b,
+                                           const double* __restrict__ strips, int* word, const int base, int bad, double& mant,
+                                           int& expo, double& quad) {
+  if constexpr (R == P / 2) {
+    return bad;
+  } else {
+    progress_wait(word, base + R + 1);
+    const double* strip = strips + R * kColStrip;
+    const double2 xr0 = *reinterpret_cast<const double2*>(strip + a * kColStride + 2);   // rows S_a of the pivot's columns
+    const double2 xr1 = *reinterpret_cast<const double2*>(strip + a * kColStride + 6);
+    const double2 xc0 = *reinterpret_cast<const double2*>(strip + b * kColStride + 2);   // rows S_b: the columns of my block
+    const double2 xc1 = *reinterpret_cast<const double2*>(strip + b * kColStride + 6);
+    const double2 p0 = *reinterpret_cast<const double2*>(strip + R * kColStride);
+    const double2 p1 = *reinterpret_cast<const double2*>(strip + R * kColStride + 4);
+    const double2 hk = *reinterpret_cast<const double2*>(strip + 8 * kColStride);
+    const double d00 = p0.x, d01 = p1.x, d11 = p1.y;
+    const double det = fma(d00, d11, -(d01 * d01));
+    const int bad_here = __builtin_amdgcn_readfirstlane(!(d00 > 0.0) ? 2 * R + 1 : (!(det > 0.0) ? 2 * R + 2 : 0));
+    bad = bad ? bad : bad_here;
+    double rdet = __builtin_amdgcn_rcp(det);
+    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+    rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+    const double e00 = d11 * rdet, e01 = -(d01 * rdet), e11 = d00 * rdet;
+    const double xc0v[2] = {xc0.x, xc0.y}, xc1v[2] = {xc1.x, xc1.y};
+    const double xr0v[2] = {xr0.x, xr0.y}, xr1v[2] = {xr1.x, xr1.y};
+    const double g0 = fma(e00, hk.x, e01 * hk.y), g1 = fma(e01, hk.x, e11 * hk.y);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double y0 = fma(e00, xc0v[j], e01 * xc1v[j]);
+      const double y1 = fma(e01, xc0v[j], e11 * xc1v[j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w22[i][j] = fma(-xr0v[i], y0, fma(-xr1v[i], y1, w22[i][j]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hs[i] = fma(-xr0v[i], g0, fma(-xr1v[i], g1, hs[i]));
+    quad = fma(hk.x, g0, fma(hk.y, g1, quad));
+    int e;
+    mant *= frexp(det, &e);
+    expo += e;
+    // (as in eliminate_round: these chains would otherwise sink to where they are used, every round's det live until then)
+    asm volatile("; round done" : "+v"(quad), "+v"(mant), "+v"(expo));
+    return kept_rounds<P, R + 1>(w22, hs, a, b, strips, word, base, bad, mant, expo, quad);
+  }
+}
+
 }  // namespace
 
 // 2 x 2 block of a lane as (x, y, z, w) = (T(2a,2b), T(2a+1,2b), T(2a,2b+1), T(2a+1,2b+1))
