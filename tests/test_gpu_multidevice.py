@@ -435,3 +435,49 @@ def test_cluster_graph_cut_across_two_engines_equals_one_engine(graph, n_ranks):
     for b in ranks:
         b._eng = None
     grp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntips,p", [(30, 16), (25, 3)])
+def test_exchange_buffer_round_trip_and_argument_checks(ntips, p):
+    """pgbp_pack_beliefs / pgbp_unpack_beliefs (the exchange buffer of a cut cluster graph): the packed buffer holds the
+    listed records back to back in the order of the list, exactly as pgbp_get_belief returns each (in the block-packed device
+    layout too: 16 traits); unpacked into another engine they overwrite those beliefs and nothing else; a bad index is a size
+    of -1 and PGBP_ERR_INVALID, an empty list is a no-op."""
+    tr, prob, packs, lls = _problem(ntips, p, 2, 400 + ntips)
+    lib = pgbp_amd.load()
+    a = pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packs, n_sites=2)
+    assert pgbp_amd.calibrate_(a, prob.schedule, 1)[0]      # (the state now lives in the layout the traversal chose)
+    rng = np.random.default_rng(5)
+    nb = len(prob.dims)
+    lst = np.ascontiguousarray(rng.permutation(nb)[: max(3, nb // 3)], np.int32)
+    n = int(lib.pgbp_packed_beliefs_size(a._eng, len(lst), L.i32p(lst)))
+    assert n == sum(int(a._poff[i + 1] - a._poff[i]) for i in lst)
+    for site in (0, 1):
+        buf = np.zeros(n)
+        assert lib.pgbp_pack_beliefs(a._eng, site, len(lst), L.i32p(lst), L.f64p(buf)) == 0
+        at = 0
+        for i in lst:
+            ln = int(a._poff[i + 1] - a._poff[i])
+            rec = np.zeros(ln)
+            assert lib.pgbp_get_belief(a._eng, site, int(i), L.f64p(rec)) == 0
+            assert np.array_equal(buf[at:at + ln], rec), int(i)
+            at += ln
+        b = pgbp_amd.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packs, n_sites=2)
+        before = np.zeros((2, len(packs[0])))
+        assert lib.pgbp_get_beliefs(b._eng, L.f64p(before)) == 0
+        assert lib.pgbp_unpack_beliefs(b._eng, site, len(lst), L.i32p(lst), L.f64p(buf)) == 0
+        after = np.zeros_like(before)
+        assert lib.pgbp_get_beliefs(b._eng, L.f64p(after)) == 0
+        want = before.copy()
+        at = 0
+        for i in lst:
+            ln = int(a._poff[i + 1] - a._poff[i])
+            want[site, a._poff[i]:a._poff[i] + ln] = buf[at:at + ln]
+            at += ln
+        assert np.array_equal(after, want)
+    bad = np.array([0, nb], np.int32)
+    assert lib.pgbp_packed_beliefs_size(a._eng, 2, L.i32p(bad)) == -1
+    assert lib.pgbp_pack_beliefs(a._eng, 0, 2, L.i32p(bad), L.f64p(np.zeros(4096))) == 1
+    assert lib.pgbp_pack_beliefs(a._eng, 2, 1, L.i32p(lst), L.f64p(np.zeros(4096))) == 1        # site out of range
+    assert lib.pgbp_pack_beliefs(a._eng, 0, 0, None, None) == 0
