@@ -308,11 +308,12 @@ int ensure_layout(pgbp_engine* e, bool want_bs16, bool want_sm = false) {
 
 // layout wanted by the traversals of the current schedule
 // The postorder of tree 0 writes every sepset and, straight after a reset, would read only zeros from them: true when
-// that traversal runs entirely on the register-resident kernel (which honours DevState::sep_zero) and the schedule
-// tree spans every sepset (a clique tree, the Bethe graph of a tree).
+// that traversal runs entirely on kernels that honour DevState::sep_zero (the register-resident ones; the thread-per-site
+// ones of the site-minor layout) and the schedule tree spans every sepset (a clique tree, the Bethe graph of a tree).
 bool fresh_sepsets_shortcut(const pgbp_engine* e) {
   const Plan& p = e->plan;
-  return !e->layout_sm && p.all_fast && !p.trees.empty() && (int)p.trees[0].pa.size() == p.n_sepsets;
+  // (the site-minor layout belongs to the thread-per-site kernels, which honour it too)
+  return (e->layout_sm || p.all_fast) && !p.trees.empty() && (int)p.trees[0].pa.size() == p.n_sepsets;
 }
 
 bool want_bs16(const pgbp_engine* e) {
@@ -505,7 +506,7 @@ int reset_from_factors_async(pgbp_engine* e, bool skip_sepsets = false) {
   if (e->layout_sm) {  // cluster elements come first and are contiguous over sites
     const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
     HIPCHK(e, hipMemcpyAsync(e->d_pool_sm, e->d_fpool_sm, sizeof(double) * (size_t)nc, hipMemcpyDeviceToDevice, e->st));
-    HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));
+    if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));
     return PGBP_OK;
   }
   if (e->layout_bs16)  // packed records use about half of their slots: copy what is in use
@@ -1324,7 +1325,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
                                e->d_bm_kind, e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->d_bm_Rinv,
                                e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, p.n_clusters, p.n_sites, e->st);
     const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
-    HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
+    if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
     launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
     if (also_factors) e->have_factors = true;
     return PGBP_OK;
@@ -1532,7 +1533,7 @@ static int lg_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
     launch_lg_fill_uni_sm(e->lg, e->lgp, e->d_pool_sm, also_factors ? e->d_fpool_sm : nullptr, e->d_packed_off, e->d_bdim,
                           p.n_clusters, p.n_sites, e->st);
     const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
-    HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
+    if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
   } else {
     if (e->layout_sm) {
       const int rc0 = ensure_site_minor(e, false);

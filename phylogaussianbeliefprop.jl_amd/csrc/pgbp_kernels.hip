@@ -959,6 +959,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     }
     // ---- divide! and mult!
     auto sep = [&](int t) -> double& { return *bel(m.sep_b, m.sep_off, t); };
+    const bool sz = S.sep_zero != 0;   // straight after a reset: the sepset is 1 (all zeros) and is not read (pgbp_engine.hip: fresh_sepsets_shortcut)
     auto to = [&](int t) -> double& { return *bel(m.to_b, m.to_off, t); };
     auto res = [&](int t) -> double& { return *rsd(en.msg, m.res_off, t); };
     int up[2] = {0, 0};
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
         for (int a = 0; a < 2; ++a) {
           if (a < s) {
             const int o = a + b * s;
-            const double dJ = mJs[a][b] - sep(o);
+            const double dJ = mJs[a][b] - (sz ? 0.0 : sep(o));
             sep(o) = mJs[a][b];
             res(o) = dJ;
             to(up[a] + up[b] * mt) += dJ;
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
           }
         }
         const int o = s * s + b;
-        const double dh = mh[b] - sep(o);
+        const double dh = mh[b] - (sz ? 0.0 : sep(o));
         sep(o) = mh[b];
         res(o) = dh;
         to(mt * mt + up[b]) += dh;
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
       }
     }
     const int og = s * s + s;
-    const double dg = gmsg - sep(og);
+    const double dg = gmsg - (sz ? 0.0 : sep(og));
     sep(og) = gmsg;
     to(mt * mt + mt) += dg;
     *mword(S.status, en.msg) = 0;
@@ -1102,23 +1103,24 @@ __global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* 
     }
     // ---- divide! and mult!
     auto sep = [&](int t) -> double& { return *bel(m.sep_b, m.sep_off, t); };
+    const bool sz = S.sep_zero != 0;   // straight after a reset: the sepset is 1 (all zeros) and is not read (pgbp_engine.hip: fresh_sepsets_shortcut)
     auto to = [&](int t) -> double& { return *bel(m.to_b, m.to_off, t); };
     double maxJ = 0.0, maxh = 0.0;
     if (s == 1) {
       const int u = S.idx[m.up_map];
-      const double dJ = mJ - sep(0);
+      const double dJ = mJ - (sz ? 0.0 : sep(0));
       sep(0) = mJ;
       *rsd(en.msg, m.res_off, 0) = dJ;
       to(u + u * mt) += dJ;
       maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
-      const double dh = mh - sep(1);
+      const double dh = mh - (sz ? 0.0 : sep(1));
       sep(1) = mh;
       *rsd(en.msg, m.res_off, 1) = dh;
       to(mt * mt + u) += dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
     const int og = s * s + s;
-    const double dg = gmsg - sep(og);
+    const double dg = gmsg - (sz ? 0.0 : sep(og));
     sep(og) = gmsg;
     to(mt * mt + mt) += dg;
     *mword(S.status, en.msg) = 0;
