@@ -432,6 +432,24 @@ def test_cluster_graph_cut_across_two_engines_equals_one_engine(graph, n_ranks):
     owned_doubles = sum(int(ranks[0]._poff[i + 1] - ranks[0]._poff[i]) for t in range(len(sched)) for x in cut.owned[t] for i in x)
     assert cut.exchanged_doubles == niter * (root_doubles + (owned_doubles if len(sched) > 1 else 0))
     assert n_trav > 0 and root_doubles > 0
+    if loopy:
+        # the automatic stop (src/calibration.jl:51-57): the cut run reaches calibration at the iteration and schedule tree the
+        # single engine reaches it at, each message's flag read from the rank that sent it last
+        one._packed[0, :] = start
+        one._upload(snapshot_factors=True)
+        assert lib.pgbp_reset_flags(one._eng, 1) == 0
+        oa = one._opts(auto=True)
+        res2 = (L.Result * 1)()
+        assert lib.pgbp_calibrate(one._eng, 60, C.byref(oa), res2) == 0 and res2[0].succ
+        for b in ranks:
+            b._packed[0, :] = start
+            b._upload(snapshot_factors=True)
+            assert lib.pgbp_reset_flags(b._eng, 1) == 0
+        cut.last_writer = {}
+        succ, iscal, reached = cut.calibrate(60, auto=True)
+        assert succ and iscal == bool(res2[0].iscal)
+        if res2[0].iscal:
+            assert reached == (res2[0].iter_reached, res2[0].tree_reached), (reached, res2[0].iter_reached, res2[0].tree_reached)
     for b in ranks:
         b._eng = None
     grp.close()
