@@ -145,7 +145,10 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 // returns 0: message applied; 1: the task ends here (the sender is downstream of a failure, or J_I is not positive definite)
-template <bool WAVE>
+// KI, KK: the frame of this instance (KI integrated + KK kept rows / columns + h): 8 + 8 covers every small message; the
+// loop launches, where occupancy does not matter, also have 4 + 4, 4 + 8 and 8 + 4 (half the straight-line code of a message
+// of a 4-trait network: clusters of one to three nodes)
+template <bool WAVE, int KI, int KK>
 __device__ __forceinline__ int small_message(const DevState& S, const GRec* __restrict__ recs, const GLoad& cur, const int site,
                                              const int lane, unsigned long long seq_base, double* __restrict__ pool,
                                              double* __restrict__ rpool, SmallFrame& F, double& gmsg_io
@@ -166,17 +169,17 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   double* __restrict__ sep = pool + grec_i64(rv, 4);
   double* __restrict__ to = pool + grec_i64(rv, 2);
   double* __restrict__ res = rpool + grec_i64(rv, 6);
-  const bool is_int = lane < kSmallI;
-  const int fi = lane & 7;
-  const bool kept_live = lane >= kSmallI && lane < kSmallI + kSmallK && fi < s;
+  const bool is_int = lane < KI;
+  const int fi = KI == 8 ? (lane & 7) : (is_int ? lane : lane - KI);   // row of the message (kept lanes) / pivot index (integrated lanes)
+  const bool kept_live = lane >= KI && lane < KI + KK && fi < s;
   const bool row_live = is_int ? fi < ni : kept_live;
   // ---- receiver / sepset operands of the kept lanes (row a = fi of the message): requested first
   const int up_lane = __shfl(cur.ub, fi);   // (inline map: lane l holds up[l & 15])
   const int ua = u0 >= 0 ? u0 + fi : up_lane;
-  double psep[kSmallK], pto[kSmallK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
-  int ubv[kSmallK];
+  double psep[KK], pto[KK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
+  int ubv[KK];
 #pragma unroll
-  for (int b = 0; b < kSmallK; ++b) {
+  for (int b = 0; b < KK; ++b) {
     psep[b] = 0.0;
     pto[b] = 0.0;
     ubv[b] = u0 >= 0 ? u0 + b : __builtin_amdgcn_readlane(cur.ub, b);
@@ -202,9 +205,9 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     const int q = is_int ? fi : ni + fi;                       // place in the order "integrated first, kept last"
     const int pq = __shfl(cur.pb, q < kGInlPerm ? q : 0);      // (inline map: lane l holds perm[l])
     const int pi = k0 >= 0 ? (q < ni ? (q < k0 ? q : q + s) : k0 + (q - ni)) : pq;
-    double X[kSmallI], Y[kSmallI], Z[kSmallK], hv = 0.0;
+    double X[KI], Y[KI], Z[KK], hv = 0.0;
 #pragma unroll
-    for (int j = 0; j < kSmallI; ++j) {
+    for (int j = 0; j < KI; ++j) {
       X[j] = 0.0;
       Y[j] = 0.0;
       const int cj = k0 >= 0 ? (j < k0 ? j : j + s) : __builtin_amdgcn_readlane(cur.pb, j);
@@ -214,7 +217,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
       }
     }
 #pragma unroll
-    for (int b = 0; b < kSmallK; ++b) {
+    for (int b = 0; b < KK; ++b) {
       Z[b] = 0.0;
       const int cb = k0 >= 0 ? k0 + b : __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
       if (b < s && row_live) Z[b] = is_int ? from[cb + pi * mf] : from[pi + cb * mf];   // J_SI' for a pivot row, J_S for a kept one
@@ -224,14 +227,14 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66), on the entries as stored
     bool nz = is_int && fabs(hv) > PGBP_EPS;
 #pragma unroll
-    for (int j = 0; j < kSmallI; ++j) nz |= fabs(X[j]) > PGBP_EPS;
+    for (int j = 0; j < KI; ++j) nz |= fabs(X[j]) > PGBP_EPS;
     fake = ni == 0 || !__any(nz);
     // Symmetric(J_I): its upper triangle only (:68)
 #pragma unroll
-    for (int j = 0; j < kSmallI; ++j) F.row[j] = (is_int && j < fi) ? Y[j] : X[j];
+    for (int j = 0; j < KI; ++j) F.row[j] = (is_int && j < fi) ? Y[j] : X[j];
 #pragma unroll
-    for (int b = 0; b < kSmallK; ++b) F.row[kSmallI + b] = Z[b];
-    F.row[kSmallI + kSmallK] = hv;
+    for (int b = 0; b < KK; ++b) F.row[KI + b] = Z[b];
+    F.row[KI + KK] = hv;
   }
   PGBP_GST(2);
   if (__builtin_amdgcn_readfirstlane(poisoned)) {
@@ -245,10 +248,10 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     double mant = 1.0, quad = 0.0;
     int expo = 0, info = 0;
 #pragma unroll
-    for (int k = 0; k < kSmallI; ++k) {
+    for (int k = 0; k < KI; ++k) {
       if (k < ni && info == 0) {
         const double d = readlane_f64(F.row[k], k);
-        const double hk = readlane_f64(F.row[kSmallI + kSmallK], k);
+        const double hk = readlane_f64(F.row[KI + KK], k);
         if (!(d > 0.0)) {
           info = k + 1;
         } else {
@@ -261,7 +264,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
           quad += hk * hk * rd;
           const double f = F.row[k] * rd;
 #pragma unroll
-          for (int j = k + 1; j <= kSmallI + kSmallK; ++j) {
+          for (int j = k + 1; j <= KI + KK; ++j) {
             const double pkj = readlane_f64(F.row[j], k);
             F.row[j] -= f * pkj;   // (rows <= k are dead from here on: no guard)
           }
@@ -287,9 +290,9 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   double maxJ = 0.0, maxh = 0.0;
   if (kept_live) {
 #pragma unroll
-    for (int b = 0; b < kSmallK; ++b) {
+    for (int b = 0; b < KK; ++b) {
       if (b < s) {
-        const double msg = F.row[kSmallI + b];
+        const double msg = F.row[KI + b];
         const double dJ = msg - psep[b];
         sep[fi + b * s] = msg;
         res[fi + b * s] = dJ;
@@ -297,7 +300,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
     }
-    const double msgh = F.row[kSmallI + kSmallK];
+    const double msgh = F.row[KI + KK];
     const double dh = msgh - pseph;
     sep[s * s + fi] = msgh;
     res[s * s + fi] = dh;
@@ -324,7 +327,8 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
 // the kernel).  Dependent loads of a message: record (fetched ahead) -> operands.
 // SMALL_ONLY: every message of the launch fits the register-resident body (the planner's promise: Traversal::level_small,
 // Chunk::small_only) -- the in-LDS body is not compiled in, which leaves the wide levels more wavefronts per SIMD.
-template <bool WAVE, bool SMALL_ONLY = false>
+// SPEC: the loop launches pick the smallest frame a message fits (small_message<WAVE, KI, KK>)
+template <bool WAVE, bool SMALL_ONLY = false, bool SPEC = false>
 __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __restrict__ recs, GLoad cur, const int site,
                                              const int lane, unsigned long long seq_base, int32_t* perm, double* W) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
@@ -351,11 +355,19 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
     if (SMALL_ONLY || (((dims >> 24) & 255) <= kSmallI && s <= kSmallK && !(en_reuse && !small_prev))) {
       // the register-resident path (small_message); a reused marginal stays in the path that computed it
       small_prev = true;
+      const int nim = (dims >> 24) & 255;
+      int done;
 #ifdef PGBP_GSTAMP
-      const int done = small_message<WAVE>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, gst);
+#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, gst)
 #else
-      const int done = small_message<WAVE>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg);
+#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg)
 #endif
+      // (a reused marginal has the dimensions of the message that computed it: the same instance, the same frame)
+      if (SPEC && nim <= 4 && s <= 4) done = PGBP_SMALL(4, 4);
+      else if (SPEC && nim <= 4) done = PGBP_SMALL(4, kSmallK);
+      else if (SPEC && s <= 4) done = PGBP_SMALL(kSmallI, 4);
+      else done = PGBP_SMALL(kSmallI, kSmallK);
+#undef PGBP_SMALL
       if (done) return;
       mf = dims & 255;
       ni = (dims >> 24) & 255;
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, 
       if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
     }
     if (ri >= 0)
-      generic_task<true, SMALL_ONLY>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles);
+      generic_task<true, SMALL_ONLY, true>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles);
     if (g + 1 < g1) __syncthreads();
     ri = ri_next;
     cur = nxt;
