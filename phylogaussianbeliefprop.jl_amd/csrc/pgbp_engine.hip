@@ -39,6 +39,7 @@ struct DevTraversal {
   FEntry* d_centries = nullptr;      // Traversal::centries: the groups of the chunks of fused levels
   int32_t* d_chunk_wg_off = nullptr; // Traversal::chunk_wg_off
   int32_t* d_cgroups = nullptr;      // Traversal::cgroups as first records of the tasks (Traversal::task_grec)
+  int32_t* d_cgroups_task = nullptr; // Traversal::cgroups as they are (task ids): the thread-per-site chunk kernel
   GRec* d_grecs = nullptr;           // Traversal::grecs
 };
 
@@ -332,6 +333,7 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_centries) (void)hipFree(d.d_centries);
       if (d.d_chunk_wg_off) (void)hipFree(d.d_chunk_wg_off);
       if (d.d_cgroups) (void)hipFree(d.d_cgroups);
+      if (d.d_cgroups_task) (void)hipFree(d.d_cgroups_task);
       if (d.d_grecs) (void)hipFree(d.d_grecs);
     }
     v->clear();
@@ -416,17 +418,20 @@ void launch_loop_or_tail(pgbp_engine* e, const DevState& S, const FEntry* recs, 
 // levels [L0, L1) of one traversal: one launch per level (two where a level mixes fast-class and generic tasks)
 void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, const DevTraversal& d, int L0, int L1,
                     unsigned long long seq_base, unsigned long long stop_below, bool kl, int* launches) {
-  const bool chunks_on = !kl && !e->layout_sm && tuning().tail;
-  const bool uni = e->plan.max_dim <= 2 && e->plan.n_sites >= 8;  // many tiny problems: lanes = sites (bp_level_uni), no loop mode
+  const bool uni = e->plan.max_dim <= 2 && e->plan.n_sites >= 8;  // many tiny problems: lanes = sites (bp_level_uni / uni1)
+  // (the loop mode of the thread-per-site kernels exists for sepsets of at most one variable: bp_chunk_uni1)
+  const bool chunks_on = !kl && tuning().tail && (uni ? e->max_s <= 1 : !e->layout_sm);
   size_t next_chunk = 0;
   for (int L = L0; L < L1; ++L) {
     if (chunks_on) {
       // a chunk of fused levels starting here (and ending inside the range): one launch, one workgroup per tree of tasks
       while (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 < L) ++next_chunk;
-      if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1 &&
-          !(tr.chunks[next_chunk].generic && uni)) {
+      if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1) {
         const Traversal::Chunk& ch = tr.chunks[next_chunk];
-        if (ch.generic)
+        if (uni)   // (the planner builds chunks of tasks for such plans: pgbp_plan.cpp, plan_uni)
+          launch_chunk_uni1(S, d.d_task_off, d.d_entries, d.d_cgroups_task + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0,
+                            ch.n_wg, e->plan.n_sites, seq_base, stop_below, e->st);
+        else if (ch.generic)
           launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
                                e->plan.n_sites, seq_base, stop_below, ch.max_mf, ch.small_only != 0, e->st);
         else
@@ -961,6 +966,7 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       for (int32_t& t : grp_recs)
         if (t >= 0) t = tr.task_grec[t];
       if ((rc = upload(e, &d.d_cgroups, grp_recs))) break;
+      if ((rc = upload(e, &d.d_cgroups_task, tr.cgroups))) break;
       if ((rc = upload(e, &d.d_grecs, tr.grecs))) break;
     }
     if (rc == PGBP_OK) {

@@ -105,6 +105,7 @@ constexpr int kTailWaves = 8;      // records per step of the tail launch (one w
 constexpr int kGenericMaxDim = 64;    // largest sender the wave-per-task generic kernel's lane grids handle
 constexpr int kChunkMaxTasks = 384;   // a level joins a chunk of fused levels if it has at most this many tasks, all fast-class
 constexpr int kChunkGenericMaxTasks = 768;  // ... of generic-class tasks (cfg5: 384 / 768 / 1 536 / 3 072 tasks: 1.559 / 1.541 / 1.552 / 1.690 ms join graph, 1.876 / 1.824 / 1.836 / 1.978 Bethe)
+constexpr int kChunkUniMaxThreads = 65536;  // ... of a batch of univariate sites (thread-per-site kernels): tasks x sites of a level that joins a chunk
 constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x (perm + mf x (mf + 1)) doubles of LDS per workgroup
 constexpr int kChunkDepth = 4;        // levels per chunk
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic

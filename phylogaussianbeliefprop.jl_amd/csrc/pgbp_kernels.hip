@@ -1017,14 +1017,11 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
 // two variables -- cfg4): every element a message needs is loaded by its ROLE (the kept diagonal entry, the pivot, the
 // coupling ...), its index computed on the scalar unit, instead of loading the record and picking elements by runtime
 // indices; one thread = one site, lanes = consecutive sites.  Expressions and their order are those of bp_level_uni.
+// (the body: one task of one site; a `return` ends the task)
 template <bool SM>
-__global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* __restrict__ task_off,
-                                                     const Entry* __restrict__ entries, int task0, int n_sites,
-                                                     unsigned long long seq_base, unsigned long long stop_below) {
-  const int site = blockIdx.y * blockDim.x + threadIdx.x;
-  if (site >= n_sites) return;
-  if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  const int task = task0 + blockIdx.x;
+__device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __restrict__ task_off,
+                                          const Entry* __restrict__ entries, const int task, const int site,
+                                          unsigned long long seq_base) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   const int64_t ns = S.n_sites;
@@ -1143,6 +1140,39 @@ __global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* 
   }
 }
 
+template <bool SM>
+__global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* __restrict__ task_off,
+                                                     const Entry* __restrict__ entries, int task0, int n_sites,
+                                                     unsigned long long seq_base, unsigned long long stop_below) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  uni1_task<SM>(S, task_off, entries, task0 + blockIdx.x, site, seq_base);
+}
+
+// LOOP MODE of the same body: a chunk of fused narrow levels (pgbp_plan.cpp: build_chunks, plans of univariate site batches).
+// Workgroup (b, y) = one dependency-closed tree of tasks for the 64 sites [64 y, 64 y + 64): wavefront w runs the task
+// grp_tasks[g][w] (-1: none) of every group g of its walk, lanes = sites, with a workgroup barrier in between -- the
+// stores of a level are complete (vmcnt) and visible (same CU, same vector L1) before the next level's loads of the same
+// sites.  A level launch costs 6 - 15 us whatever it holds; a fused level its tasks.
+template <bool SM>
+__global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_uni1(DevState S, const int32_t* __restrict__ task_off,
+                                                                 const Entry* __restrict__ entries,
+                                                                 const int32_t* __restrict__ grp_tasks,
+                                                                 const int32_t* __restrict__ wg_off, int n_sites,
+                                                                 unsigned long long seq_base, unsigned long long stop_below) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int site = blockIdx.y * 64 + lane;
+  // (a stopped or padding lane skips the work, never a barrier)
+  const bool live = site < n_sites && !((S.fail[site < n_sites ? site : 0] >> kInfoBits) < stop_below);
+  const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
+  for (int g = g0; g < g1; ++g) {
+    const int t = grp_tasks[(int64_t)g * kTailWaves + wave];
+    if (t >= 0 && live) uni1_task<SM>(S, task_off, entries, t, site, seq_base);
+    if (g + 1 < g1) __syncthreads();
+  }
+}
+
 void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
                       int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s, hipStream_t st) {
   if (ntasks <= 0) return;
@@ -1155,6 +1185,16 @@ void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry*
     if (S.sm) hipLaunchKernelGGL(bp_level_uni<true>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
     else hipLaunchKernelGGL(bp_level_uni<false>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
   }
+}
+
+// a chunk of fused levels of a univariate site batch (every sepset <= 1 variable): n_wg trees of tasks x blocks of 64 sites
+void launch_chunk_uni1(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const int32_t* d_grp_tasks,
+                       const int32_t* d_wg_off, int n_wg, int n_sites, unsigned long long seq_base,
+                       unsigned long long stop_below, hipStream_t st) {
+  if (n_wg <= 0) return;
+  const dim3 grid(n_wg, (n_sites + 63) / 64), block(kTailWaves * 64);
+  if (S.sm) hipLaunchKernelGGL(bp_chunk_uni1<true>, grid, block, 0, st, S, d_task_off, d_entries, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
+  else hipLaunchKernelGGL(bp_chunk_uni1<false>, grid, block, 0, st, S, d_task_off, d_entries, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
 }
 
 size_t generic_lds_bytes(int max_mf) {

@@ -368,6 +368,17 @@ void link_chains(std::vector<FEntry>& recs, const std::vector<FPro>& pros, const
 static void build_chunks(const Plan& p, Traversal& tr, bool postorder);
 static void build_grecs(const Plan& p, Traversal& tr);
 
+// many tiny problems: every belief dimension <= 2 and at least 8 sites run on the thread-per-site kernels (lanes = sites),
+// whatever the class of their tasks (pgbp_engine.hip: enqueue_levels) ...
+// ... and their loop mode (bp_chunk_uni1) takes sepsets of at most one variable: such plans get chunks of TASKS over all
+// of their narrow levels and no single-workgroup tail
+static bool plan_uni(const Plan& p) {
+  if (!(p.max_dim <= 2 && p.n_sites >= 8)) return false;
+  for (int k = 0; k < p.n_sepsets; ++k)
+    if (p.dims[p.n_clusters + k] > 1) return false;
+  return true;
+}
+
 // Reorder the tasks of every level so that fast-class tasks come first, pack them into groups of kFastMaxWaves records
 // (first fit, largest task first: no wave of a workgroup idles beside a shorter task), set the receiver load/store
 // flags of the generic tasks, and cut the tail (Traversal::tail_levels).
@@ -494,7 +505,9 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
     const int nt = tr.level_off[L + 1] - tr.level_off[L];
     return nt > 0 && tr.level_nfast[L] == nt && tr.level_nrecs[L] <= kTailWaves;
   };
-  if (postorder) {
+  if (plan_uni(p)) {
+    // (the thread-per-site kernels have no single-workgroup tail: their narrow levels are all fused as chunks)
+  } else if (postorder) {
     while (tr.tail_levels < nlev && tail_ok(nlev - 1 - tr.tail_levels)) ++tr.tail_levels;
   } else {
     while (tr.tail_levels < nlev && tail_ok(tr.tail_levels)) ++tr.tail_levels;
@@ -596,9 +609,13 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   for (int t = 0; t < ntasks; ++t)
     for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e)
       level_mf[task_level[t]] = std::max(level_mf[task_level[t]], p.msgs[tr.entries[e].msg].mf);
-  auto all_fast = [&](int L) { return tr.level_nfast[L] == tr.level_off[L + 1] - tr.level_off[L]; };
+  const bool uni = plan_uni(p);   // chunks of TASKS (one wavefront = one task of 64 sites), whatever the tasks' class
+  auto all_fast = [&](int L) { return !uni && tr.level_nfast[L] == tr.level_off[L + 1] - tr.level_off[L]; };
   auto eligible = [&](int L) {
     const int nt = tr.level_off[L + 1] - tr.level_off[L];
+    // (a level of a site batch joins a chunk while its launch could not fill the chip: tasks x sites threads)
+    static const long long uni_max = [] { const char* v = getenv("PGBP_CHUNK_UNI_MAX_THREADS"); return v ? atoll(v) : (long long)kChunkUniMaxThreads; }();
+    if (uni) return nt > 0 && (long long)nt * p.n_sites <= uni_max;
     return nt > 0 && nt <= (all_fast(L) ? max_tasks : max_tasks_generic) && tr.level_nbig[L] == 0 &&
            (all_fast(L) || (tr.level_nfast[L] == 0 && level_mf[L] <= kChunkGenericMaxMf));   // (a generic chunk walks message
            // records, which the fast-class tasks of a mixed level do not have)
