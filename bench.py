@@ -372,7 +372,7 @@ def run_sites(args, torch, dist, rank, world, local_rank, emit=True):
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
                                      "profiles/pmc_traffic_sites_latest.json)",
                      "algorithmic_bytes_per_launch": bytes_per_cal / max(1, n_launches_per_cal),
-                     "kernel": "bp_level_uni1", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate (calibrate_only)"},
+                     "kernel": "bp_level_uni1 (level launches) + bp_chunk_uni1 (fused narrow levels)", "note": "rank 0's algorithmic bytes (168 B per univariate message) / wall time of its calibrate (calibrate_only)"},
         "ll_evals_per_s": world * ns * 3 / (ms_ll.value * 1e-3),
         "ll_eval_note": "problem log-likelihoods per second: device factor fill + postorder + root integrate (score() body)",
         "loglik_sum": float(full.sum()), "loglik_max_rel_err_vs_pruning": max(rel, rel_all), "loglik_gather": gather_via}

@@ -40,7 +40,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p6 -- python3 bench.py --
 step "cfg4 pmc write"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p7 -- python3 bench.py --workload sites --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc4_w.txt 2>&1 || exit 1
 F=$(find /tmp/p6 -name "*counter_collection.csv" | head -1); W=$(find /tmp/p7 -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py $F $W 0 $out/cfg4_pmc_traffic.json none bp_level_uni1 > $out/cfg4_pmc_traffic.txt 2>&1; rm -rf /tmp/p6 /tmp/p7
+python3 tools/pmc_traffic.py $F $W 0 $out/cfg4_pmc_traffic.json none bp_level_uni1+bp_chunk_uni1 > $out/cfg4_pmc_traffic.txt 2>&1; rm -rf /tmp/p6 /tmp/p7
 step "cfg5 kernel stats (join graph)"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -- python3 bench.py --workload network --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_cfg5_joingraph_under_profiler.json 2>$out/e8.txt || exit 1
 keep_stats /tmp/p8 cfg5_joingraph_kernel_stats.csv; rm -rf /tmp/p8
