@@ -33,6 +33,7 @@ __attribute__((constructor(101))) void pgbp_default_environment() { setenv("HIP_
 struct DevTraversal {
   int32_t* d_task_off = nullptr;
   Entry* d_entries = nullptr;
+  URec* d_urecs = nullptr;           // the entries as self-contained records (plans of univariate site batches: bp_level_uni1)
   FEntry* d_fentries = nullptr;
   FPro* d_fpros = nullptr;           // Traversal::fpros / cpros (null: no record of the traversal has a prologue)
   FPro* d_cpros = nullptr;
@@ -327,6 +328,7 @@ void free_traversals(pgbp_engine* e) {
     for (auto& d : *v) {
       if (d.d_task_off) (void)hipFree(d.d_task_off);
       if (d.d_entries) (void)hipFree(d.d_entries);
+      if (d.d_urecs) (void)hipFree(d.d_urecs);
       if (d.d_fentries) (void)hipFree(d.d_fentries);
       if (d.d_fpros) (void)hipFree(d.d_fpros);
       if (d.d_cpros) (void)hipFree(d.d_cpros);
@@ -428,8 +430,8 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
       while (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 < L) ++next_chunk;
       if (next_chunk < tr.chunks.size() && tr.chunks[next_chunk].level0 == L && tr.chunks[next_chunk].level1 <= L1) {
         const Traversal::Chunk& ch = tr.chunks[next_chunk];
-        if (uni)   // (the planner builds chunks of tasks for such plans: pgbp_plan.cpp, plan_uni)
-          launch_chunk_uni1(S, d.d_task_off, d.d_entries, d.d_cgroups_task + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0,
+        if (uni && d.d_urecs)   // (the planner builds chunks of tasks for such plans: pgbp_plan.cpp, plan_uni)
+          launch_chunk_uni1(S, d.d_task_off, d.d_urecs, d.d_cgroups_task + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0,
                             ch.n_wg, e->plan.n_sites, seq_base, stop_below, e->st);
         else if (ch.generic)
           launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
@@ -448,7 +450,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
                   e->plan.n_sites, seq_base, stop_below, stop_below, e->st);
     const int nbig = tr.level_nbig[L];
     if (uni)
-      launch_level_uni(S, d.d_task_off, d.d_entries, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->max_s, e->st);
+      launch_level_uni(S, d.d_task_off, d.d_entries, d.d_urecs, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->max_s, e->st);
     else {
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st);
@@ -955,6 +957,27 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       DevTraversal& d = dir == 0 ? e->dpost[t] : e->dpre[t];
       if ((rc = upload(e, &d.d_task_off, tr.task_off))) break;
       if ((rc = upload(e, &d.d_entries, tr.entries))) break;
+      if (e->plan.max_dim <= 2 && e->plan.n_sites >= 8 && e->max_s <= 1) {
+        // thread-per-site kernel for sepsets of at most one variable: every entry as ONE record (URec)
+        const Plan& pl = e->plan;
+        std::vector<URec> ur(tr.entries.size());
+        for (size_t q = 0; q < tr.entries.size(); ++q) {
+          const Entry& en = tr.entries[q];
+          const MsgDesc& m = pl.msgs[en.msg];
+          URec& r = ur[q];
+          r = URec{};
+          r.msg = en.msg; r.seq = en.seq; r.reuse = en.reuse; r.from_b = m.from_b; r.to_b = m.to_b;
+          r.mf = m.mf; r.s = m.s; r.mt = m.mt; r.ni = m.ni;
+          r.k = m.s >= 1 ? pl.idxpool[m.keep_map] : 0;
+          r.i0 = m.ni >= 1 ? pl.idxpool[m.int_map] : 0;
+          r.i1 = m.ni >= 2 ? pl.idxpool[m.int_map + 1] : 0;
+          r.u = m.s >= 1 ? pl.idxpool[m.up_map] : 0;
+          r.from_off = m.from_off; r.sep_off = m.sep_off; r.to_off = m.to_off; r.res_off = m.res_off;
+          r.from_p = pl.packed_off[m.from_b]; r.sep_p = pl.packed_off[m.sep_b]; r.to_p = pl.packed_off[m.to_b];
+          r.res_p = pl.rpacked_off[en.msg];
+        }
+        if ((rc = upload(e, &d.d_urecs, ur))) break;
+      }
       if ((rc = upload(e, &d.d_fentries, tr.fentries))) break;
       if (tr.has_pro) {
         if ((rc = upload(e, &d.d_fpros, tr.fpros))) break;

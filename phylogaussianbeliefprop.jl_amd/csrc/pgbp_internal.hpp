@@ -38,6 +38,21 @@ struct Entry {
 };
 constexpr int kTLoad = 1, kTStore = 2;
 
+// One message of a task of the thread-per-site kernel for sepsets of at most one variable (bp_level_uni1 / bp_chunk_uni1),
+// everything it needs resolved: entry + descriptor + the three index maps' single indices + the record offsets in both
+// layouts (plain: per-site record offsets; site-minor: packed offsets).  A level's launch is five dependent reads long
+// otherwise -- task, entries, descriptor, index maps, operands -- and a narrow level IS that chain.  Parallel to
+// Traversal::entries (same index).
+struct URec {
+  int32_t msg, seq, reuse, from_b, to_b;
+  int32_t mf, s, mt, ni;
+  int32_t k, i0, i1, u;   // keep index (s = 1), integrated indices, update index in the receiver (s = 1)
+  int32_t pad[3];
+  int64_t from_off, sep_off, to_off, res_off;   // plain layout
+  int64_t from_p, sep_p, to_p, res_p;           // site-minor layout
+};
+static_assert(sizeof(URec) == 128, "URec layout");
+
 // Self-contained record of one message for the wave-per-task kernels (bp_level_generic, bp_chunk_generic in
 // pgbp_kernels.hip): descriptor, position in its task and -- for senders of up to kGInlPerm variables and sepsets of
 // up to kGInlUp -- the two index maps, in ONE 128-byte line.  A wavefront fetches it with one dword load per lane

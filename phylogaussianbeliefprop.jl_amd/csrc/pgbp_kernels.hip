@@ -1020,13 +1020,13 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
 // (the body: one task of one site; a `return` ends the task)
 template <bool SM>
 __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __restrict__ task_off,
-                                          const Entry* __restrict__ entries, const int task, const int site,
+                                          const URec* __restrict__ urecs, const int task, const int site,
                                           unsigned long long seq_base) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   const int64_t ns = S.n_sites;
-  auto bel = [&](int b, int64_t plain_off, int t) -> double* {
-    if constexpr (SM) return S.pool + (S.packed_off[b] + t) * ns + site;
+  auto bel = [&](int64_t packed, int64_t plain_off, int t) -> double* {
+    if constexpr (SM) return S.pool + (packed + t) * ns + site;
     else return pool + plain_off + t;
   };
   auto mword = [&](int32_t* base, int msg) -> int32_t* {
@@ -1037,30 +1037,29 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
     if constexpr (SM) return base + (int64_t)c * ns + site;
     else return base + (int64_t)site * S.n_clusters + c;
   };
-  auto rsd = [&](int msg, int64_t plain_off, int t) -> double* {
-    if constexpr (SM) return S.rpool + (S.rpacked_off[msg] + t) * ns + site;
+  auto rsd = [&](int64_t packed, int64_t plain_off, int t) -> double* {
+    if constexpr (SM) return S.rpool + (packed + t) * ns + site;
     else return rpool + plain_off + t;
   };
   const int e0 = task_off[task], e1 = task_off[task + 1];
   double mJ = 0.0, mh = 0.0, gmsg = 0.0;   // the message (s = 1)
   for (int e = e0; e < e1; ++e) {
-    const Entry en = entries[e];
-    const MsgDesc m = S.msgs[en.msg];
+    const URec m = urecs[e];   // (one record: entry, descriptor, index maps, offsets)
     if (*cword(S.poison, m.from_b)) {
       *cword(S.poison, m.to_b) = 1;
       return;
     }
     const int mf = m.mf, s = m.s, mt = m.mt, ni = m.ni;
-    auto from = [&](int t) -> double { return *bel(m.from_b, m.from_off, t); };
-    if (!en.reuse) {
+    auto from = [&](int t) -> double { return *bel(m.from_p, m.from_off, t); };
+    if (!m.reuse) {
       gmsg = from(mf * mf + mf);
       int info = 0;
       if (s == 1) {
-        const int k = S.idx[m.keep_map];
+        const int k = m.k;
         mJ = from(k + k * mf);
         mh = from(mf * mf + k);
         if (ni == 1) {
-          const int i = S.idx[m.int_map];
+          const int i = m.i0;
           const double Jii = from(i + i * mf), Jki = from(k + i * mf), hi = from(mf * mf + i);
           // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66)
           if (fabs(hi) > PGBP_EPS || fabs(Jii) > PGBP_EPS || fabs(Jki) > PGBP_EPS) {
@@ -1080,8 +1079,8 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
         }
       } else if (ni > 0) {
         // an empty sepset: every variable of the sender (one or two) is integrated, the message is its constant
-        const int i0 = S.idx[m.int_map];
-        const int i1 = ni == 2 ? S.idx[m.int_map + 1] : 0;
+        const int i0 = m.i0;
+        const int i1 = ni == 2 ? m.i1 : 0;
         const double d0 = from(i0 + i0 * mf), y0 = from(mf * mf + i0);
         const double u01 = ni == 2 ? from(i0 + i1 * mf) : 0.0;          // upper entry (row i0 < i1)
         const double J10 = ni == 2 ? from(i1 + i0 * mf) : 0.0, J11 = ni == 2 ? from(i1 + i1 * mf) : 0.0;
@@ -1104,27 +1103,27 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
         }
       }
       if (info) {
-        *mword(S.status, en.msg) = info;
+        *mword(S.status, m.msg) = info;
         *cword(S.poison, m.to_b) = 1;
-        atomicMin(&S.fail[site], ((seq_base + (unsigned long long)en.seq) << kInfoBits) | (unsigned long long)info);
+        atomicMin(&S.fail[site], ((seq_base + (unsigned long long)m.seq) << kInfoBits) | (unsigned long long)info);
         return;
       }
     }
     // ---- divide! and mult!
-    auto sep = [&](int t) -> double& { return *bel(m.sep_b, m.sep_off, t); };
+    auto sep = [&](int t) -> double& { return *bel(m.sep_p, m.sep_off, t); };
     const bool sz = S.sep_zero != 0;   // straight after a reset: the sepset is 1 (all zeros) and is not read (pgbp_engine.hip: fresh_sepsets_shortcut)
-    auto to = [&](int t) -> double& { return *bel(m.to_b, m.to_off, t); };
+    auto to = [&](int t) -> double& { return *bel(m.to_p, m.to_off, t); };
     double maxJ = 0.0, maxh = 0.0;
     if (s == 1) {
-      const int u = S.idx[m.up_map];
+      const int u = m.u;
       const double dJ = mJ - (sz ? 0.0 : sep(0));
       sep(0) = mJ;
-      *rsd(en.msg, m.res_off, 0) = dJ;
+      *rsd(m.res_p, m.res_off, 0) = dJ;
       to(u + u * mt) += dJ;
       maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       const double dh = mh - (sz ? 0.0 : sep(1));
       sep(1) = mh;
-      *rsd(en.msg, m.res_off, 1) = dh;
+      *rsd(m.res_p, m.res_off, 1) = dh;
       to(mt * mt + u) += dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
@@ -1132,22 +1131,22 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
     const double dg = gmsg - (sz ? 0.0 : sep(og));
     sep(og) = gmsg;
     to(mt * mt + mt) += dg;
-    *mword(S.status, en.msg) = 0;
+    *mword(S.status, m.msg) = 0;
     if (S.update_resnorm) {
       const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
-      *mword(S.flags, en.msg) = ok ? 1 : 0;
+      *mword(S.flags, m.msg) = ok ? 1 : 0;
     }
   }
 }
 
 template <bool SM>
 __global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* __restrict__ task_off,
-                                                     const Entry* __restrict__ entries, int task0, int n_sites,
+                                                     const URec* __restrict__ urecs, int task0, int n_sites,
                                                      unsigned long long seq_base, unsigned long long stop_below) {
   const int site = blockIdx.y * blockDim.x + threadIdx.x;
   if (site >= n_sites) return;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  uni1_task<SM>(S, task_off, entries, task0 + blockIdx.x, site, seq_base);
+  uni1_task<SM>(S, task_off, urecs, task0 + blockIdx.x, site, seq_base);
 }
 
 // LOOP MODE of the same body: a chunk of fused narrow levels (pgbp_plan.cpp: build_chunks, plans of univariate site batches).
@@ -1157,7 +1156,7 @@ __global__ __launch_bounds__(256) void bp_level_uni1(DevState S, const int32_t* 
 // sites.  A level launch costs 6 - 15 us whatever it holds; a fused level its tasks.
 template <bool SM>
 __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_uni1(DevState S, const int32_t* __restrict__ task_off,
-                                                                 const Entry* __restrict__ entries,
+                                                                 const URec* __restrict__ urecs,
                                                                  const int32_t* __restrict__ grp_tasks,
                                                                  const int32_t* __restrict__ wg_off, int n_sites,
                                                                  unsigned long long seq_base, unsigned long long stop_below) {
@@ -1168,19 +1167,20 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_uni1(DevState S, con
   const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
   for (int g = g0; g < g1; ++g) {
     const int t = grp_tasks[(int64_t)g * kTailWaves + wave];
-    if (t >= 0 && live) uni1_task<SM>(S, task_off, entries, t, site, seq_base);
+    if (t >= 0 && live) uni1_task<SM>(S, task_off, urecs, t, site, seq_base);
     if (g + 1 < g1) __syncthreads();
   }
 }
 
-void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
-                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s, hipStream_t st) {
+void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const URec* d_urecs, int task0,
+                      int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s,
+                      hipStream_t st) {
   if (ntasks <= 0) return;
   const int bs = n_sites >= 256 ? 256 : 64;
   const dim3 grid(ntasks, (n_sites + bs - 1) / bs);
-  if (max_s <= 1) {   // every sepset of the engine holds at most one variable
-    if (S.sm) hipLaunchKernelGGL(bp_level_uni1<true>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
-    else hipLaunchKernelGGL(bp_level_uni1<false>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
+  if (max_s <= 1 && d_urecs) {   // every sepset of the engine holds at most one variable
+    if (S.sm) hipLaunchKernelGGL(bp_level_uni1<true>, grid, dim3(bs), 0, st, S, d_task_off, d_urecs, task0, n_sites, seq_base, stop_below);
+    else hipLaunchKernelGGL(bp_level_uni1<false>, grid, dim3(bs), 0, st, S, d_task_off, d_urecs, task0, n_sites, seq_base, stop_below);
   } else {
     if (S.sm) hipLaunchKernelGGL(bp_level_uni<true>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
     else hipLaunchKernelGGL(bp_level_uni<false>, grid, dim3(bs), 0, st, S, d_task_off, d_entries, task0, n_sites, seq_base, stop_below);
@@ -1188,13 +1188,13 @@ void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry*
 }
 
 // a chunk of fused levels of a univariate site batch (every sepset <= 1 variable): n_wg trees of tasks x blocks of 64 sites
-void launch_chunk_uni1(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const int32_t* d_grp_tasks,
+void launch_chunk_uni1(const DevState& S, const int32_t* d_task_off, const URec* d_urecs, const int32_t* d_grp_tasks,
                        const int32_t* d_wg_off, int n_wg, int n_sites, unsigned long long seq_base,
                        unsigned long long stop_below, hipStream_t st) {
   if (n_wg <= 0) return;
   const dim3 grid(n_wg, (n_sites + 63) / 64), block(kTailWaves * 64);
-  if (S.sm) hipLaunchKernelGGL(bp_chunk_uni1<true>, grid, block, 0, st, S, d_task_off, d_entries, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
-  else hipLaunchKernelGGL(bp_chunk_uni1<false>, grid, block, 0, st, S, d_task_off, d_entries, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
+  if (S.sm) hipLaunchKernelGGL(bp_chunk_uni1<true>, grid, block, 0, st, S, d_task_off, d_urecs, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
+  else hipLaunchKernelGGL(bp_chunk_uni1<false>, grid, block, 0, st, S, d_task_off, d_urecs, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
 }
 
 size_t generic_lds_bytes(int max_mf) {

@@ -99,11 +99,12 @@ constexpr int kLdsMaxDim = 128;   // largest working matrix [J | h] that fits a 
 int64_t big_ws_doubles(int max_mf);   // doubles of one workspace slab for a working matrix of dimension max_mf (0: fits LDS)
 
 // thread-per-(site, task) kernel for graphs whose beliefs all have dimension <= 2 (univariate batches)
-void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, int task0, int ntasks,
-                      int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s, hipStream_t st);
+void launch_level_uni(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const URec* d_urecs, int task0,
+                      int ntasks, int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_s,
+                      hipStream_t st);
 // loop mode of the thread-per-site body (sepsets of at most one variable): n_wg trees of tasks (groups of kTailWaves task
 // ids, -1: none; workgroup b walks [d_wg_off[b], d_wg_off[b + 1])) x blocks of 64 sites
-void launch_chunk_uni1(const DevState& S, const int32_t* d_task_off, const Entry* d_entries, const int32_t* d_grp_tasks,
+void launch_chunk_uni1(const DevState& S, const int32_t* d_task_off, const URec* d_urecs, const int32_t* d_grp_tasks,
                        const int32_t* d_wg_off, int n_wg, int n_sites, unsigned long long seq_base,
                        unsigned long long stop_below, hipStream_t st);
 // (max_s: the engine's largest sepset dimension; <= 1 selects the instance that loads a message's elements by role)
