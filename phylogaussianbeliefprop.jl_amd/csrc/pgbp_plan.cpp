@@ -614,10 +614,10 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   auto eligible = [&](int L) {
     const int nt = tr.level_off[L + 1] - tr.level_off[L];
     // (a level of a site batch joins a chunk while its launch could not fill the chip: tasks x sites threads)
-    // (measured, three repetitions each: 65 536 threads best for 8 000 sites; 262 144 another 2 % for 1 000 -- the fewer the
-    // sites, the less a level's own launch has to do)
+    // (measured, three repetitions each: 65 536 threads best for 2 000 and 8 000 sites; 262 144 another 2 % for 1 000 -- the
+    // fewer the sites, the less a level's own launch has to do)
     static const long long uni_env = [] { const char* v = getenv("PGBP_CHUNK_UNI_MAX_THREADS"); return v ? atoll(v) : -1ll; }();
-    const long long uni_max = uni_env >= 0 ? uni_env : (long long)kChunkUniMaxThreads * (p.n_sites < 2048 ? 4 : 1);
+    const long long uni_max = uni_env >= 0 ? uni_env : (long long)kChunkUniMaxThreads * (p.n_sites <= 1024 ? 4 : 1);
     if (uni) return nt > 0 && (long long)nt * p.n_sites <= uni_max;
     return nt > 0 && nt <= (all_fast(L) ? max_tasks : max_tasks_generic) && tr.level_nbig[L] == 0 &&
            (all_fast(L) || (tr.level_nfast[L] == 0 && level_mf[L] <= kChunkGenericMaxMf));   // (a generic chunk walks message
