@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
+#include <cstdlib>
 
 #include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
@@ -607,6 +609,229 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* _
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
   generic_task<false, SMALL_ONLY>(S, recs, load_grec(recs, rec0 + blockIdx.x, threadIdx.x), site, threadIdx.x, seq_base,
                       reinterpret_cast<int32_t*>(lds), lds + kPermDoubles);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FOUR small tasks per wavefront (the wide levels of a network's cluster graphs: cfg5).  small_message keeps one row of the
+// 16 x 17 frame per lane, i.e. 16 of a wavefront's 64 lanes work and a wide level is bound by the instruction issue of its
+// wavefronts.  Here every ROW OF 16 LANES (a DPP row) runs its own task: integrated variable k in lane k of the
+// row, kept variable a in lane 8 + a.  What small_message holds wave-uniform (the record's words, pointers, dimensions, the
+// pivot's status) is per row here, in vector registers; the record's words and inline maps are read by each lane from the
+// record itself (one 128-byte line); the pivot row travels by v_mov_b64_dpp row_newbcast:k (lane k of EACH row to its 16
+// lanes: one instruction where v_readlane needs two and serves one row); `any` / `all` over a row come from one ballot.
+// A row whose task ends (last message, poisoned sender, failed pivot) leaves the loop; the wavefront ends with its longest
+// task.  Arithmetic, its order and every store are those of small_message<false, 8, 8> (launch modes fuzz: bit-identical).
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);   // row_newbcast:K
+}
+__device__ __forceinline__ bool row_any(bool p, int lane) {
+  return ((__ballot(p) >> (lane & 48)) & 0xffffull) != 0;   // (inside a branch that whole rows take or skip)
+}
+__device__ __forceinline__ int byte_of(unsigned long long w, int k) { return (int)((w >> (8 * k)) & 255ull); }
+__device__ __forceinline__ double log_by_table_lane(const double2* __restrict__ tab, double x) {   // log_by_table, index per lane
+  int e;
+  const double m = frexp(x, &e);
+  const double2 t = tab[(__double2hiint(m) >> 13) & 127];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+  p = fma(p, r, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  return fma((double)e, 0.69314718055994530941723212145818, t.y) + fma(p * r, r, r);
+}
+
+template <int KI, int KK>
+struct Small4 {
+  template <int k>
+  static __device__ __forceinline__ void pivot(double (&row)[KI + KK + 1], const int ni, int& info, double& mant, int& expo,
+                                               double& quad) {
+    if (k < ni && info == 0) {
+      const double d = row_bcast<k>(row[k]);
+      const double hk = row_bcast<k>(row[KI + KK]);
+      if (!(d > 0.0)) {
+        info = k + 1;
+      } else {
+        double rd = __builtin_amdgcn_rcp(d);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        int ex;
+        mant *= frexp(d, &ex);
+        expo += ex;
+        quad += hk * hk * rd;
+        const double f = row[k] * rd;
+#pragma unroll
+        for (int j = k + 1; j <= KI + KK; ++j) {
+          const double pkj = row_bcast<k>(row[j]);
+          row[j] -= f * pkj;
+        }
+      }
+    }
+    if constexpr (k + 1 < KI) pivot<k + 1>(row, ni, info, mant, expo, quad);
+  }
+};
+
+__global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __restrict__ recs, int rec0, int ntasks,
+                                                      unsigned long long seq_base, unsigned long long stop_below) {
+  constexpr int KI = kSmallI, KK = kSmallK;
+  static_assert(KI == 8 && KK == 8, "a row of 16 lanes = 8 integrated + 8 kept variables");
+  const int site = blockIdx.y;
+  if ((S.fail[site] >> kInfoBits) < stop_below) return;
+  const int lane = threadIdx.x, fi = lane & 7;
+  const bool is_int = (lane & 8) == 0, first = (lane & 15) == 0;
+  const int task = blockIdx.x * 4 + (lane >> 4);
+  double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
+  double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
+  int32_t* __restrict__ poison = S.poison + (int64_t)site * S.n_clusters;
+  double row[KI + KK + 1];
+#pragma unroll
+  for (int j = 0; j <= KI + KK; ++j) row[j] = 0.0;
+  double gmsg = 0.0;
+  int ri = rec0 + task;
+  bool alive = task < ntasks;
+  while (alive) {
+    // ---- the record: 128 bytes, every lane of the row reads the words it needs (same line, same addresses over the row)
+    const unsigned char* __restrict__ rb = reinterpret_cast<const unsigned char*>(recs + ri);
+    const longlong2 o01 = *reinterpret_cast<const longlong2*>(rb);        // from_off, to_off
+    const longlong2 o23 = *reinterpret_cast<const longlong2*>(rb + 16);   // sep_off, res_off
+    const int4 w8 = *reinterpret_cast<const int4*>(rb + 32);              // msg, seq, from_b, to_b
+    const int next = *reinterpret_cast<const int*>(rb + 60);
+    const uint2 df = *reinterpret_cast<const uint2*>(rb + 64);            // dims, flags
+    const ulonglong2 pw = *reinterpret_cast<const ulonglong2*>(rb + offsetof(GRec, perm));   // perm[0 .. 15]
+    const unsigned long long uw = *reinterpret_cast<const unsigned long long*>(rb + offsetof(GRec, up));   // up[0 .. 7]
+    int touch = 0;   // the next record of the task: its line requested now, read at the top of the next turn
+    if (next >= 0) touch = *reinterpret_cast<const int*>(recs + next);
+    const int en_msg = w8.x, en_seq = w8.y, from_b = w8.z, to_b = w8.w;
+    const int mf = df.x & 255, mt = (df.x >> 8) & 255, s = (df.x >> 16) & 255, ni = (df.x >> 24) & 255;
+    const int k0 = (df.y & 255) == 255 ? -1 : (int)(df.y & 255), u0 = ((df.y >> 8) & 255) == 255 ? -1 : (int)((df.y >> 8) & 255);
+    const bool en_reuse = ((df.y >> 16) & 255) != 0;
+    const int poisoned = poison[from_b];
+    double* __restrict__ sep = pool + o23.x;
+    double* __restrict__ to = pool + o01.y;
+    double* __restrict__ res = rpool + o23.y;
+    const bool kept_live = !is_int && fi < s;
+    const bool row_live = is_int ? fi < ni : kept_live;
+    // ---- receiver / sepset operands of the kept lanes (row a = fi of the message)
+    const int ua = u0 >= 0 ? u0 + fi : byte_of(uw, fi);
+    double psep[KK], pto[KK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
+#pragma unroll
+    for (int b = 0; b < KK; ++b) {
+      psep[b] = 0.0;
+      pto[b] = 0.0;
+      const int ub = u0 >= 0 ? u0 + b : byte_of(uw, b);
+      if (b < s && kept_live) {
+        psep[b] = sep[fi + b * s];
+        pto[b] = to[ua + ub * mt];
+      }
+    }
+    if (kept_live) {
+      pseph = sep[s * s + fi];
+      ptoh = to[mt * mt + ua];
+    }
+    if (first) {
+      pre_sepg = sep[s * s + s];
+      pre_tog = to[mt * mt + mt];
+    }
+    const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];
+    bool fake = false;
+    if (!en_reuse) {
+      const double* __restrict__ from = pool + o01.x;
+      const int q = is_int ? fi : ni + fi;                       // place in the order "integrated first, kept last"
+      const int pq = q < 8 ? byte_of(pw.x, q) : byte_of(pw.y, q & 7);
+      const int pi = k0 >= 0 ? (q < ni ? (q < k0 ? q : q + s) : k0 + (q - ni)) : pq;
+      double X[KI], Y[KI], Z[KK], hv = 0.0;
+#pragma unroll
+      for (int j = 0; j < KI; ++j) {
+        X[j] = 0.0;
+        Y[j] = 0.0;
+        const int cj = k0 >= 0 ? (j < k0 ? j : j + s) : byte_of(pw.x, j);
+        if (j < ni && row_live) {
+          X[j] = from[pi + cj * mf];
+          if (is_int) Y[j] = from[cj + pi * mf];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < KK; ++b) {
+        Z[b] = 0.0;
+        const int t = ni + b;                                    // (<= 15: ni <= 8)
+        const int cb = k0 >= 0 ? k0 + b : (t < 8 ? byte_of(pw.x, t) : byte_of(pw.y, t & 7));
+        if (b < s && row_live) Z[b] = is_int ? from[cb + pi * mf] : from[pi + cb * mf];
+      }
+      if (row_live) hv = from[mf * mf + pi];
+      gmsg = from[mf * mf + mf];
+      bool nz = is_int && fabs(hv) > PGBP_EPS;
+#pragma unroll
+      for (int j = 0; j < KI; ++j) nz |= fabs(X[j]) > PGBP_EPS;
+      fake = ni == 0 || !row_any(nz, lane);
+#pragma unroll
+      for (int j = 0; j < KI; ++j) row[j] = (is_int && j < fi) ? Y[j] : X[j];
+#pragma unroll
+      for (int b = 0; b < KK; ++b) row[KI + b] = Z[b];
+      row[KI + KK] = hv;
+    }
+    if (poisoned) {
+      if (first) {
+        poison[to_b] = 1;
+        for (int qn = next; qn >= 0; qn = recs[qn].next) poison[recs[qn].to_b] = 1;
+      }
+      break;
+    }
+    if (!en_reuse && !fake) {
+      double mant = 1.0, quad = 0.0;
+      int expo = 0, info = 0;
+      Small4<KI, KK>::template pivot<0>(row, ni, info, mant, expo, quad);
+      if (info != 0) {
+        if (first) {
+          S.status[(int64_t)site * S.n_msgs + en_msg] = info;
+          poison[to_b] = 1;
+          for (int qn = next; qn >= 0; qn = recs[qn].next) poison[recs[qn].to_b] = 1;
+          atomicMin(&S.fail[site], ((seq_base + (unsigned long long)(unsigned int)en_seq) << kInfoBits) |
+                                       (unsigned long long)(unsigned int)info);
+        }
+        break;
+      }
+      const double logdet = log_by_table_lane(S.logtab, mant) + (double)expo * 0.69314718055994530941723212145818;
+      gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
+    }
+    // ---- divide! and mult!: kept lane 8 + a of the row owns row a of the message
+    double maxJ = 0.0, maxh = 0.0;
+    if (kept_live) {
+#pragma unroll
+      for (int b = 0; b < KK; ++b) {
+        if (b < s) {
+          const int ub = u0 >= 0 ? u0 + b : byte_of(uw, b);
+          const double msg = row[KI + b];
+          const double dJ = msg - psep[b];
+          sep[fi + b * s] = msg;
+          res[fi + b * s] = dJ;
+          to[ua + ub * mt] = pto[b] + dJ;
+          maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+        }
+      }
+      const double msgh = row[KI + KK];
+      const double dh = msgh - pseph;
+      sep[s * s + fi] = msgh;
+      res[s * s + fi] = dh;
+      to[mt * mt + ua] = ptoh + dh;
+      maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
+    }
+    if (first) {
+      const double dg = gmsg - pre_sepg;
+      sep[s * s + s] = gmsg;
+      to[mt * mt + mt] = pre_tog + dg;
+      S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
+    }
+    if (S.update_resnorm) {
+      const bool bad = !(maxh <= thr_h && maxJ <= thr_J);
+      const bool any_bad = row_any(bad, lane);
+      if (first) S.flags[(int64_t)site * S.n_msgs + en_msg] = any_bad ? 0 : 1;
+    }
+    asm volatile("" ::"v"(touch));
+    if (next < 0) break;
+    __threadfence_block();   // the next message of the task may read or read-modify-write what this one wrote
+    ri = next;
+  }
 }
 
 // LOOP MODE of the same task body: a chunk of fused narrow levels (pgbp_plan.cpp: build_chunks) of generic-class tasks.
@@ -1207,7 +1432,15 @@ void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int n
                           unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
                           hipStream_t st) {
   if (ntasks <= 0) return;
-  if (small_only)
+  // four tasks per wavefront from the width at which a level is bound by instruction issue, not by one message's latency
+  static const int small4_min = [] {
+    const char* v = std::getenv("PGBP_SMALL4_MIN");
+    return v ? std::atoi(v) : kSmall4MinTasks;
+  }();
+  if (small_only && small4_min >= 0 && ntasks >= small4_min)
+    hipLaunchKernelGGL(bp_level_small4, dim3((ntasks + 3) / 4, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, ntasks, seq_base,
+                       stop_below);
+  else if (small_only)
     hipLaunchKernelGGL(bp_level_generic<true>, dim3(ntasks, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, seq_base, stop_below);
   else
     hipLaunchKernelGGL(bp_level_generic<false>, dim3(ntasks, n_sites), dim3(kWave), generic_lds_bytes(max_mf), st, S, d_recs, rec0,

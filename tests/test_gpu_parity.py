@@ -1299,15 +1299,19 @@ def test_launch_modes_differential_fuzz(P, env):
     assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
-@pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}, {"PGBP_MIXED_FAST_MIN": "0"}],
-                         ids=["default", "level_launches_only", "mixed_levels_always_split"])
+@pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}, {"PGBP_MIXED_FAST_MIN": "0"},
+                                 {"PGBP_SMALL4_MIN": "0"}, {"PGBP_SMALL4_MIN": "0", "PGBP_NO_CHUNKS": "1"}],
+                         ids=["default", "level_launches_only", "mixed_levels_always_split",
+                              "four_tasks_per_wavefront", "four_tasks_per_wavefront_level_launches_only"])
 def test_network_differential_fuzz(P, env):
     """tests/fuzz_gpu_vs_c_oracle_networks.py: random level-3 networks, clique tree / Bethe / join graphs, every spanning
     tree of the schedule, 1 - 9 traits (and 18 - 22), damaged clusters: the wave-per-task kernels (both message bodies,
     level and chunk launches, the large-belief kernel) against the plain-C sequential engine -- beliefs, flags, (succ,
     iscal) and the first failure of the reference's order; once more with every level as its own launch, and with every
     mixed level split into a register-resident and a wave-per-task launch however few fast-class tasks it has (such a level
-    must not enter a generic chunk: its fast-class tasks have no message records)."""
+    must not enter a generic chunk: its fast-class tasks have no message records); and with every level launch of small
+    messages, however narrow, on bp_level_small4 (four tasks per wavefront, one per row of 16 lanes: the default only from
+    kSmall4MinTasks tasks on, which these small networks never reach), with and without the chunks."""
     import os
     import subprocess
     import sys
