@@ -21,6 +21,9 @@ namespace pgbp {
 
 #define PGBP_LOG2PI 1.8378770664093454835606594728112
 #define PGBP_EPS 2.220446049250313e-16
+#ifndef PGBP_SMALL_DPP
+#define PGBP_SMALL_DPP 1   // small_message: pivot rows by DPP row broadcast (0: by v_readlane, the form before)
+#endif
 
 static constexpr int kPermDoubles = PGBP_MAX_DIM / 2;  // PGBP_MAX_DIM int32 at the front of LDS
 
@@ -146,6 +149,43 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// the pivot row of a frame held one row per lane: lane K of each ROW OF 16 LANES to that row's lanes, one instruction
+// (v_mov_b64_dpp row_newbcast:K) where two v_readlane serve a single row and go through scalar registers
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);   // row_newbcast:K
+}
+// the KI pivots of a frame (columns 0 .. KI - 1 integrated, KI .. KI + KK - 1 kept, KI + KK = h), straight-line: every row of
+// 16 lanes that enters eliminates its own frame (bp_level_small4: four tasks; small_message: the task sits in lanes 0 .. 15)
+template <int KI, int KK>
+struct Small4 {
+  template <int k, class Row>
+  static __device__ __forceinline__ void pivot(Row& row, const int ni, int& info, double& mant, int& expo, double& quad) {
+    if (k < ni && info == 0) {
+      const double d = row_bcast<k>(row[k]);
+      const double hk = row_bcast<k>(row[KI + KK]);
+      if (!(d > 0.0)) {
+        info = k + 1;
+      } else {
+        double rd = __builtin_amdgcn_rcp(d);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        int ex;
+        mant *= frexp(d, &ex);
+        expo += ex;
+        quad += hk * hk * rd;
+        const double f = row[k] * rd;
+#pragma unroll
+        for (int j = k + 1; j <= KI + KK; ++j) {
+          const double pkj = row_bcast<k>(row[j]);
+          row[j] -= f * pkj;
+        }
+      }
+    }
+    if constexpr (k + 1 < KI) pivot<k + 1>(row, ni, info, mant, expo, quad);
+  }
+};
+
 // returns 0: message applied; 1: the task ends here (the sender is downstream of a failure, or J_I is not positive definite)
 // KI, KK: the frame of this instance (KI integrated + KK kept rows / columns + h): 8 + 8 covers every small message; the
 // loop launches, where occupancy does not matter, also have 4 + 4, 4 + 8 and 8 + 4 (half the straight-line code of a message
@@ -249,6 +289,11 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   if (!en_reuse && !fake) {
     double mant = 1.0, quad = 0.0;
     int expo = 0, info = 0;
+    if (PGBP_SMALL_DPP) {
+      // (the other three rows of the wavefront hold zero frames: their lanes stop at the first pivot, nothing of theirs is used)
+      Small4<KI, KK>::template pivot<0>(F.row, ni, info, mant, expo, quad);
+      info = __builtin_amdgcn_readfirstlane(info);
+    } else {
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       if (k < ni && info == 0) {
@@ -272,6 +317,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
           }
         }
       }
+    }
     }
     if (info != 0) {
       if (lane == 0) {
@@ -621,10 +667,6 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* _
 // lanes: one instruction where v_readlane needs two and serves one row); `any` / `all` over a row come from one ballot.
 // A row whose task ends (last message, poisoned sender, failed pivot) leaves the loop; the wavefront ends with its longest
 // task.  Arithmetic, its order and every store are those of small_message<false, 8, 8> (launch modes fuzz: bit-identical).
-template <int K>
-__device__ __forceinline__ double row_bcast(double v) {
-  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);   // row_newbcast:K
-}
 __device__ __forceinline__ bool row_any(bool p, int lane) {
   return ((__ballot(p) >> (lane & 48)) & 0xffffull) != 0;   // (inside a branch that whole rows take or skip)
 }
@@ -641,36 +683,6 @@ __device__ __forceinline__ double log_by_table_lane(const double2* __restrict__ 
   p = fma(p, r, -0.5);
   return fma((double)e, 0.69314718055994530941723212145818, t.y) + fma(p * r, r, r);
 }
-
-template <int KI, int KK>
-struct Small4 {
-  template <int k>
-  static __device__ __forceinline__ void pivot(double (&row)[KI + KK + 1], const int ni, int& info, double& mant, int& expo,
-                                               double& quad) {
-    if (k < ni && info == 0) {
-      const double d = row_bcast<k>(row[k]);
-      const double hk = row_bcast<k>(row[KI + KK]);
-      if (!(d > 0.0)) {
-        info = k + 1;
-      } else {
-        double rd = __builtin_amdgcn_rcp(d);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        int ex;
-        mant *= frexp(d, &ex);
-        expo += ex;
-        quad += hk * hk * rd;
-        const double f = row[k] * rd;
-#pragma unroll
-        for (int j = k + 1; j <= KI + KK; ++j) {
-          const double pkj = row_bcast<k>(row[j]);
-          row[j] -= f * pkj;
-        }
-      }
-    }
-    if constexpr (k + 1 < KI) pivot<k + 1>(row, ni, info, mant, expo, quad);
-  }
-};
 
 __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __restrict__ recs, int rec0, int ntasks,
                                                       unsigned long long seq_base, unsigned long long stop_below) {
