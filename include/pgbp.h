@@ -228,8 +228,9 @@ int  pgbp_regularize_bycluster(pgbp_engine* e);
  * results[n_sites]: succ, fail_* filled. */
 int  pgbp_traverse(pgbp_engine* e, int32_t tree, int32_t dir, const pgbp_opts* opts, pgbp_result* results);
 /* calibrate!(beliefs, schedule, niter; ...) (src/calibration.jl:35-84). results[n_sites].
- * With auto_stop the loop ends after the first schedule tree at which EVERY site is calibrated
- * (n_sites == 1: exactly the reference's `auto`). */
+ * With auto_stop EVERY SITE stops at the first schedule tree at which that site is calibrated, exactly the reference's
+ * `auto` run on that site alone (the device skips the site's later traversals; results[s].iter_reached / tree_reached say
+ * where it stopped); the call returns when every site has reached calibration or failed, or after niter iterations. */
 int  pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_result* results);
 /* integratebelief!(obj, beliefindex) (src/clustergraphbeliefs.jl:194, src/beliefupdates.jl:168-200) for
  * every site: mu[n_sites * m] (may be NULL), norm[n_sites], info[n_sites] (0 ok, >0 not PD, may be NULL).
@@ -398,7 +399,8 @@ int  pgbp_group_set_schedule(pgbp_group* g, int32_t n_trees, const int32_t* tree
 int  pgbp_group_set_beliefs(pgbp_group* g, const double* packed, int32_t snapshot_factors);
 int  pgbp_group_get_beliefs(pgbp_group* g, double* packed);
 int  pgbp_group_reset_from_factors(pgbp_group* g);
-/* calibrate! on every site; results[n_sites_total].  With auto_stop each shard stops once all ITS sites are calibrated. */
+/* calibrate! on every site; results[n_sites_total].  With auto_stop every site stops at its own first calibrated tree
+ * (pgbp_calibrate). */
 int  pgbp_group_calibrate(pgbp_group* g, int32_t niter, const pgbp_opts* opts, pgbp_result* results);
 int  pgbp_group_integrate(pgbp_group* g, int32_t belief, double* mu, double* norm, int32_t* info);
 /* f->data = [n_sites_total][n_rows][p]; per-site parameter sets (m->per_site) = [n_sites_total][...]; each shard takes its

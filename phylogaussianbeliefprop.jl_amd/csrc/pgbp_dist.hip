@@ -159,8 +159,8 @@ int pgbp_group_reset_from_factors(pgbp_group* g) {
 
 int pgbp_group_calibrate(pgbp_group* g, int32_t niter, const pgbp_opts* opts, pgbp_result* results) {
   if (!g || !results) return PGBP_ERR_INVALID;
-  // every shard runs the reference's loop on its own sites; with auto_stop a shard stops when all ITS sites are
-  // calibrated (pgbp_calibrate's rule applied per device)
+  // every shard runs the reference's loop on its own sites; with auto_stop every site stops at its own first calibrated
+  // schedule tree (pgbp_calibrate), whichever device holds it
   return for_shards(g, [&](int i) { return pgbp_calibrate(g->eng[i], niter, opts, results + g->first[i]); });
 }
 

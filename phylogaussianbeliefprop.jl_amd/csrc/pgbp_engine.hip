@@ -1190,50 +1190,50 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   DevState S = dev_state(e, opts);
   int pairs_done = 0;
   bool stop = false;
-  std::vector<int32_t> now(ns);
+  std::vector<int32_t> now;
   std::vector<unsigned long long> keys(ns);
-  // `auto` on one site: kAhead schedule trees are enqueued per host round trip.  The device halts itself at the first
-  // tree at which calibration is reached (a key without failure information is min-ed into the fail word right behind
-  // that tree's flag reduction, so every traversal enqueued after it returns at its first instruction) and the host
-  // reads back which tree that was: the beliefs are those of src/calibration.jl:53-56, at a fraction of the round trips.
+  // `auto`: kAhead schedule trees are enqueued per host round trip.  The device halts EACH SITE at the first tree at which
+  // that site is calibrated (a key without failure information is min-ed into the site's fail word right behind that
+  // tree's flag reduction, so every traversal enqueued after it returns at its first instruction for that site) and the
+  // host reads back which tree that was: every site's beliefs are those of src/calibration.jl:53-56 run on that site
+  // alone, at a fraction of the round trips.  The loop ends when every site has reached calibration or failed.
   constexpr int kAhead = 4;
-  const bool speculative = auto_stop && ns == 1;
   const unsigned long long stride = seq_stride(e);
   int batch_first = 0;
+  std::vector<char> site_done(ns, 0);
+  int n_done = 0, last_needed = 0;   // last_needed: one past the last tree at which some site was still running
   for (int i = 0; i < niter && !stop; ++i) {
     for (int j = 0; j < nt && !stop; ++j) {
       const unsigned long long pair = (unsigned long long)i * nt + j;
       enqueue_tree(e, S, j, 3, pair, kl);
       launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st, e->layout_sm ? 1 : 0);
       ++pairs_done;
-      if (speculative) {
-        launch_halt_if_calibrated(e->d_iscal_hist + pair * ns, e->d_fail, ((pair + 1) * stride - 1) << kInfoBits, ns, e->st);
-        const bool last = (i == niter - 1 && j == nt - 1);
-        if (pairs_done - batch_first < kAhead && !last) continue;
-        std::vector<int32_t> h((size_t)(pairs_done - batch_first));
-        HIPCHK(e, hipMemcpyAsync(h.data(), e->d_iscal_hist + (size_t)batch_first, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, e->st));
-        HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->st));
-        HIPCHK(e, hipStreamSynchronize(e->st));
-        for (size_t q = 0; q < h.size() && !stop; ++q)
-          if (h[q] != 0) {
-            pairs_done = batch_first + (int)q + 1;   // the trees enqueued behind it did nothing
-            stop = true;
-          }
-        if (is_failure_key(keys[0])) stop = true;
-        batch_first = pairs_done;
-      } else if (auto_stop) {
-        // `auto`: stop after the first tree at which calibration is reached (src/calibration.jl:53-56);
-        // also stop launching once a site has failed
-        HIPCHK(e, hipMemcpyAsync(now.data(), e->d_iscal_hist + pair * ns, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
-        HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost, e->st));
-        HIPCHK(e, hipStreamSynchronize(e->st));
-        bool all_cal = true, any_fail = false;
-        for (int s = 0; s < ns; ++s) {
-          all_cal &= now[s] != 0;
-          any_fail |= is_failure_key(keys[s]);
+      if (!auto_stop) continue;
+      launch_halt_if_calibrated(e->d_iscal_hist + pair * ns, e->d_fail, ((pair + 1) * stride - 1) << kInfoBits, ns, e->st);
+      const bool last = (i == niter - 1 && j == nt - 1);
+      if (pairs_done - batch_first < kAhead && !last) continue;
+      const int nb = pairs_done - batch_first;
+      now.resize((size_t)nb * ns);
+      HIPCHK(e, hipMemcpyAsync(now.data(), e->d_iscal_hist + (size_t)batch_first * ns, sizeof(int32_t) * now.size(), hipMemcpyDeviceToHost, e->st));
+      HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_fail, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost, e->st));
+      HIPCHK(e, hipStreamSynchronize(e->st));
+      for (int s = 0; s < ns; ++s) {
+        if (site_done[s]) continue;
+        int reached = -1;
+        for (int q = 0; q < nb && reached < 0; ++q)
+          if (now[(size_t)q * ns + s] != 0) reached = batch_first + q;
+        if (reached >= 0 || is_failure_key(keys[s])) {
+          site_done[s] = 1;
+          ++n_done;
+          // (a failed site: its traversals stopped on their own somewhere in this batch)
+          last_needed = std::max(last_needed, reached >= 0 ? reached + 1 : pairs_done);
         }
-        if (all_cal || (any_fail && ns == 1)) stop = true;
       }
+      if (n_done == ns) {
+        pairs_done = last_needed;   // the trees enqueued behind it did nothing, for any site
+        stop = true;
+      }
+      batch_first = pairs_done;
     }
   }
   std::vector<int32_t> hist((size_t)std::max(1, pairs_done) * ns, 0);

@@ -1299,6 +1299,87 @@ def test_launch_modes_differential_fuzz(P, env):
     assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
+def test_auto_stop_is_per_site(P):
+    """calibrate!(...; auto=true) on a batch of sites: every site stops at ITS first calibrated schedule tree, as the
+    reference run on that site alone would (src/calibration.jl:53-56) -- the device halts a site's later traversals by
+    itself, the other sites go on.  Three sites of one loopy Bethe graph with data on different scales: per site the
+    (iteration, tree) and the beliefs of the plain-C engine run on that site alone; one site damaged: its failure report,
+    while the others still reach calibration."""
+    from oracle import cengine
+    rng = np.random.default_rng(321)
+    net = P.random_level3_network(60, 5, rng, n_colors=2)
+    cn, ed, sn = P.bethe(net.node2family)
+    p = 2
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    pe = [list(zip(net.length[i], net.gamma[i], net.color[i])) for i in range(net.nnodes)]
+    fam = P.lg_families(st.clusters, st.node2cluster, net.node2family, st.node2fixed, pe, list(range(net.nnodes)), p, n_rates=2)
+    sched = P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)
+    starts = []
+    for scale in (1.0, 300.0, 0.004):
+        rates = scale * np.stack([np.eye(p) + 0.2, 2 * np.eye(p) + 0.4])
+        X = P.simulate_bm_network(net, rates, np.zeros(p), rng)
+        one = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None)
+        one.lg_setup(fam, X)
+        one.assignfactors_lg_(rates, np.zeros(p))
+        assert P.load().pgbp_regularize_bycluster(one._eng) == 0
+        one.pull()
+        starts.append(one._packed[0].copy())
+        del one
+    ns = len(starts)
+
+    def alone(start, niter):
+        ce = cengine.Engine(st.dims, st.sepset_clusters.reshape(-1), st.scope_off, st.scope_idx, start)
+        for it in range(1, niter + 1):
+            for j, spt in enumerate(sched, start=1):
+                succ, iscal = ce.calibrate(spt[2], spt[3], 1, return_iscal=True)
+                if not succ:
+                    return ("failed", it, j), ce
+                if iscal:
+                    return ("reached", it, j), ce
+        return ("no", 0, 0), ce
+
+    want = [alone(s0, 80) for s0 in starts]
+    assert all(w[0][0] == "reached" for w in want)
+    assert len({w[0][1:] for w in want}) > 1, [w[0] for w in want]   # the sites do stop at different trees
+    cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, np.stack(starts), n_sites=ns)
+    P.calibrate_(cgb, sched, 80, auto=True)
+    for s in range(ns):
+        r = cgb.last_results[s]
+        assert (r.succ, r.iscal) == (1, 1) and (r.iter_reached, r.tree_reached) == want[s][0][1:], (s, want[s][0])
+        ref = want[s][1].packed()
+        assert np.max(np.abs(cgb._packed[s] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref))), s
+    # too few iterations for the slowest site: the others are where they stopped, it is (true, false)
+    slow = max(range(ns), key=lambda s: want[s][0][1:])
+    few = want[slow][0][1] - 1
+    if few >= 1:
+        cgb._packed[...] = np.stack(starts)
+        cgb.push()
+        cgb.init_messagecalibrationflags_reset_()
+        P.calibrate_(cgb, sched, few, auto=True)
+        for s in range(ns):
+            r = cgb.last_results[s]
+            w = alone(starts[s], few)[0]
+            assert (r.succ, bool(r.iscal), r.iter_reached, r.tree_reached) == (1, w[0] == "reached", w[1], w[2]), (s, w)
+    # one site damaged: its own first failure, the other sites unaffected
+    bad = [s0.copy() for s0 in starts]
+    snd = int(next(c for c in sched[0][3] if st.dims[c] >= 2 * p))
+    bad[1][cgb._poff[snd]] = -1.0e6
+    cgb._packed[...] = np.stack(bad)
+    cgb.push()
+    cgb.init_messagecalibrationflags_reset_()
+    P.calibrate_(cgb, sched, 80, auto=True, verbose=False)
+    w1, ce1 = alone(bad[1], 80)
+    assert w1[0] == "failed"
+    r = cgb.last_results[1]
+    assert (r.succ, r.iscal, r.fail_iter, r.fail_tree) == (0, 0, w1[1], w1[2])
+    assert (r.fail_edge, r.fail_dir, r.fail_info) == ce1.last_failure()
+    for s in (0, 2):
+        r = cgb.last_results[s]
+        assert (r.succ, r.iscal) == (1, 1) and (r.iter_reached, r.tree_reached) == want[s][0][1:]
+        ref = want[s][1].packed()
+        assert np.max(np.abs(cgb._packed[s] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
+
+
 @pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}, {"PGBP_MIXED_FAST_MIN": "0"},
                                  {"PGBP_SMALL4_MIN": "0"}, {"PGBP_SMALL4_MIN": "0", "PGBP_NO_CHUNKS": "1"}],
                          ids=["default", "level_launches_only", "mixed_levels_always_split",
