@@ -161,6 +161,14 @@ int  pgbp_plan_chains(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* ta
  * fast-class task), records[128 * n_records]. */
 int  pgbp_plan_records(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_records, int32_t* level_first,
                        int32_t* task_first, uint8_t* records);
+/* The ROW form of the postorder levels whose generic-class tasks are all small (at most 8 integrated and 8 kept variables)
+ * and have at most four messages into their receiver: the level's messages one per row of 16 lanes (four rows = one
+ * wavefront of bp_level_small4), the rows of a task consecutive, in the task's order, inside one wavefront.  *n_rows over
+ * the traversal; then (any may be NULL) level_row0[n_levels], level_nrows[n_levels] (a multiple of four; 0: the level has
+ * no row form) and rowmap[2 * n_rows] = pairs {record of pgbp_plan_records or -1 (an empty row), position in the task |
+ * messages of the task << 8}.  mult! into a receiver happens in the order of the positions: the sequential task's sums. */
+int  pgbp_plan_rows(const pgbp_plan* p, int32_t tree, int32_t dir, int64_t* n_rows, int64_t* level_row0,
+                    int32_t* level_nrows, int32_t* rowmap);
 const char* pgbp_plan_last_error(const pgbp_plan* p);
 
 /* ---- engine lifetime ------------------------------------------------------------------ */

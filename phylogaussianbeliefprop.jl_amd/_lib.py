@@ -86,6 +86,7 @@ SYMBOLS = {
     "pgbp_plan_prologues": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P]),
     "pgbp_plan_chains": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P]),
     "pgbp_plan_records": (C.c_int, [_P, C.c_int32, C.c_int32, _I32P, _I32P, _I32P, C.c_void_p]),
+    "pgbp_plan_rows": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32P, _I32P]),
     "pgbp_residual_threshold": (C.c_double, [C.c_double, C.c_double]),
     "pgbp_plan_last_error": (C.c_char_p, [_P]),
     "pgbp_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_P)]),

@@ -42,6 +42,7 @@ struct DevTraversal {
   int32_t* d_cgroups = nullptr;      // Traversal::cgroups as first records of the tasks (Traversal::task_grec)
   int32_t* d_cgroups_task = nullptr; // Traversal::cgroups as they are (task ids): the thread-per-site chunk kernel
   GRec* d_grecs = nullptr;           // Traversal::grecs
+  int32_t* d_rowmap = nullptr;       // Traversal::rowmap
 };
 
 }  // namespace
@@ -337,6 +338,7 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_cgroups) (void)hipFree(d.d_cgroups);
       if (d.d_cgroups_task) (void)hipFree(d.d_cgroups_task);
       if (d.d_grecs) (void)hipFree(d.d_grecs);
+      if (d.d_rowmap) (void)hipFree(d.d_rowmap);
     }
     v->clear();
   }
@@ -452,8 +454,10 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
     if (uni)
       launch_level_uni(S, d.d_task_off, d.d_entries, d.d_urecs, t0 + nf, nt - nf, e->plan.n_sites, seq_base, stop_below, e->max_s, e->st);
     else {
+      const bool rows = d.d_rowmap && !tr.level_nrows.empty() && tr.level_nrows[L] > 0;
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
-                           tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st);
+                           tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st,
+                           rows ? d.d_rowmap + 2 * tr.level_rowbase[L] : nullptr, rows ? tr.level_nrows[L] : 0);
       if (nbig > 0 && ensure_ws(e, (int64_t)nbig * e->plan.n_sites * big_ws_doubles(tr.max_mf_big)) == PGBP_OK)
         launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
                          tr.max_mf_big, e->d_ws, e->st);
@@ -991,6 +995,7 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_cgroups, grp_recs))) break;
       if ((rc = upload(e, &d.d_cgroups_task, tr.cgroups))) break;
       if ((rc = upload(e, &d.d_grecs, tr.grecs))) break;
+      if ((rc = upload(e, &d.d_rowmap, tr.rowmap))) break;
     }
     if (rc == PGBP_OK) {
       const Tree& T = e->plan.trees[t];

@@ -125,8 +125,11 @@ constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x 
 constexpr int kChunkDepth = 4;        // levels per chunk
 constexpr int kSmall4MinTasks = 1024;  // level launches of small generic-class tasks: four tasks per wavefront (bp_level_small4) from this width; PGBP_SMALL4_MIN overrides, -1: never
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
-constexpr size_t kMixedLevelFastMinNarrow = 8192;  // ... where the sepsets have at most 4 variables (cfg5 Bethe: 2 048 / 8 192 / never
-                                                   // split: 1.817 / 1.780 / 1.787 ms per iteration)
+constexpr size_t kMixedLevelFastMinNarrow = (size_t)1 << 30;  // ... where the sepsets have at most 4 variables: never split.  The register-resident
+                                                   // kernel's instance works on 4 lanes of 64 there; with bp_level_small4 (four tasks per wavefront) the
+                                                   // whole level in one launch is the faster (cfg5 on the same box, split from 8 192 / never: join
+                                                   // graph 1.382 / 1.366, Bethe 1.579 / 1.534 ms per iteration; before small4: 2 048 / 8 192 / never =
+                                                   // 1.817 / 1.780 / 1.787)
 
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first
@@ -168,6 +171,12 @@ struct Traversal {
   std::vector<int32_t> level_gbase;  // [n_levels] record of the level's first generic-class task (its tasks follow in order)
   std::vector<int32_t> task_grec;    // [n_tasks] first record of the task (-1: a fast-class task)
   std::vector<uint8_t> level_small;  // [n_levels] every message of the level's generic-class tasks fits the register-resident small-message body
+  // POSTORDER levels whose generic-class tasks are all small and have at most four messages: the level's messages one per
+  // ROW of 16 lanes (bp_level_small4<true>) -- pairs (record, position in its task | messages of the task << 8), -1: an
+  // empty row; the rows of a task are consecutive and never straddle a wavefront (four rows)
+  std::vector<int32_t> rowmap;
+  std::vector<int64_t> level_rowbase;  // [n_levels] first row of the level in rowmap (in rows)
+  std::vector<int32_t> level_nrows;    // [n_levels] rows of the level (a multiple of four), 0: no row form
   std::vector<int32_t> task_off;   // [n_tasks+1]  -> entries
   std::vector<Entry> entries;
   int32_t max_mf = 0;

@@ -684,15 +684,23 @@ __device__ __forceinline__ double log_by_table_lane(const double2* __restrict__ 
   return fma((double)e, 0.69314718055994530941723212145818, t.y) + fma(p * r, r, r);
 }
 
+// ROWS (postorder levels whose tasks have at most four messages: Traversal::rowmap): one MESSAGE per row instead of one
+// task -- the k messages into one receiver sit in k consecutive rows of one wavefront (rowmap: record, position in the
+// task, k), their marginals are computed side by side, and only mult! into the receiver goes in the task's order: position
+// c of every task loads, adds and stores its entries of the receiver in turn c (a wave-wide fence in between), so the
+// receiver's sums are those of the sequential task, bit for bit.  A message that fails (or whose sender is poisoned) ends
+// its task as in the chain: the rows behind it in the task store nothing and report nothing.
+template <bool ROWS>
 __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __restrict__ recs, int rec0, int ntasks,
-                                                      unsigned long long seq_base, unsigned long long stop_below) {
+                                                      const int32_t* __restrict__ rowmap, unsigned long long seq_base,
+                                                      unsigned long long stop_below) {
   constexpr int KI = kSmallI, KK = kSmallK;
   static_assert(KI == 8 && KK == 8, "a row of 16 lanes = 8 integrated + 8 kept variables");
   const int site = blockIdx.y;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  const int lane = threadIdx.x, fi = lane & 7;
+  const int lane = threadIdx.x, fi = lane & 7, wrow = lane >> 4;
   const bool is_int = (lane & 8) == 0, first = (lane & 15) == 0;
-  const int task = blockIdx.x * 4 + (lane >> 4);
+  const int task = blockIdx.x * 4 + wrow;   // ROWS: the row of the level
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   int32_t* __restrict__ poison = S.poison + (int64_t)site * S.n_clusters;
@@ -700,8 +708,24 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
 #pragma unroll
   for (int j = 0; j <= KI + KK; ++j) row[j] = 0.0;
   double gmsg = 0.0;
-  int ri = rec0 + task;
+  int ri = rec0 + task, pos = 0, klen = 1;
   bool alive = task < ntasks;
+  if constexpr (ROWS) {
+    const int2 rm = reinterpret_cast<const int2*>(rowmap)[task];   // (ntasks = rows of the level, a multiple of four)
+    ri = rm.x;
+    alive = rm.x >= 0;
+    pos = rm.y & 255;
+    klen = (rm.y >> 8) & 255;
+  }
+  // ROWS: what the ordered turns at the end need of a row's message
+  bool live = false;
+  int r_mt = 0, r_s = 0, r_u0 = -1, r_ua = 0;
+  unsigned long long r_uw = 0;
+  double* r_to = pool;
+  double r_psep[KK], r_pto[KK], r_pseph = 0.0, r_ptoh = 0.0, r_dg = 0.0, r_pre_tog = 0.0;
+#pragma unroll
+  for (int b = 0; b < KK; ++b) r_psep[b] = r_pto[b] = 0.0;
+  bool r_kept_live = false;
   while (alive) {
     // ---- the record: 128 bytes, every lane of the row reads the words it needs (same line, same addresses over the row)
     const unsigned char* __restrict__ rb = reinterpret_cast<const unsigned char*>(recs + ri);
@@ -713,7 +737,7 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
     const ulonglong2 pw = *reinterpret_cast<const ulonglong2*>(rb + offsetof(GRec, perm));   // perm[0 .. 15]
     const unsigned long long uw = *reinterpret_cast<const unsigned long long*>(rb + offsetof(GRec, up));   // up[0 .. 7]
     int touch = 0;   // the next record of the task: its line requested now, read at the top of the next turn
-    if (next >= 0) touch = *reinterpret_cast<const int*>(recs + next);
+    if (!ROWS && next >= 0) touch = *reinterpret_cast<const int*>(recs + next);
     const int en_msg = w8.x, en_seq = w8.y, from_b = w8.z, to_b = w8.w;
     const int mf = df.x & 255, mt = (df.x >> 8) & 255, s = (df.x >> 16) & 255, ni = (df.x >> 24) & 255;
     const int k0 = (df.y & 255) == 255 ? -1 : (int)(df.y & 255), u0 = ((df.y >> 8) & 255) == 255 ? -1 : (int)((df.y >> 8) & 255);
@@ -724,7 +748,9 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
     double* __restrict__ res = rpool + o23.y;
     const bool kept_live = !is_int && fi < s;
     const bool row_live = is_int ? fi < ni : kept_live;
-    // ---- receiver / sepset operands of the kept lanes (row a = fi of the message)
+    // ---- receiver / sepset operands of the kept lanes (row a = fi of the message); ROWS: the receiver's only in the
+    // task's first row, the others read it in their turn
+    const bool to_now = !ROWS || pos == 0;
     const int ua = u0 >= 0 ? u0 + fi : byte_of(uw, fi);
     double psep[KK], pto[KK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
 #pragma unroll
@@ -734,16 +760,16 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
       const int ub = u0 >= 0 ? u0 + b : byte_of(uw, b);
       if (b < s && kept_live) {
         psep[b] = sep[fi + b * s];
-        pto[b] = to[ua + ub * mt];
+        if (to_now) pto[b] = to[ua + ub * mt];
       }
     }
     if (kept_live) {
       pseph = sep[s * s + fi];
-      ptoh = to[mt * mt + ua];
+      if (to_now) ptoh = to[mt * mt + ua];
     }
     if (first) {
       pre_sepg = sep[s * s + s];
-      pre_tog = to[mt * mt + mt];
+      if (to_now) pre_tog = to[mt * mt + mt];
     }
     const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];
     bool fake = false;
@@ -782,30 +808,36 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
       for (int b = 0; b < KK; ++b) row[KI + b] = Z[b];
       row[KI + KK] = hv;
     }
-    if (poisoned) {
-      if (first) {
-        poison[to_b] = 1;
-        for (int qn = next; qn >= 0; qn = recs[qn].next) poison[recs[qn].to_b] = 1;
-      }
-      break;
-    }
-    if (!en_reuse && !fake) {
+    int info = 0;
+    if (!poisoned && !en_reuse && !fake) {
       double mant = 1.0, quad = 0.0;
-      int expo = 0, info = 0;
+      int expo = 0;
       Small4<KI, KK>::template pivot<0>(row, ni, info, mant, expo, quad);
-      if (info != 0) {
-        if (first) {
-          S.status[(int64_t)site * S.n_msgs + en_msg] = info;
-          poison[to_b] = 1;
-          for (int qn = next; qn >= 0; qn = recs[qn].next) poison[recs[qn].to_b] = 1;
-          atomicMin(&S.fail[site], ((seq_base + (unsigned long long)(unsigned int)en_seq) << kInfoBits) |
-                                       (unsigned long long)(unsigned int)info);
-        }
-        break;
+      if (info == 0) {
+        const double logdet = log_by_table_lane(S.logtab, mant) + (double)expo * 0.69314718055994530941723212145818;
+        gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
       }
-      const double logdet = log_by_table_lane(S.logtab, mant) + (double)expo * 0.69314718055994530941723212145818;
-      gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
     }
+    const bool stops = poisoned || info != 0;   // the task ends at this message
+    bool report = stops;
+    if constexpr (ROWS) {
+      // has a message in front of this one in its task stopped?  (rows wrow - pos .. wrow - 1 of this wavefront)
+      const unsigned long long sm = __ballot(first && stops);
+      const unsigned int four = (unsigned int)((sm & 1) | ((sm >> 15) & 2) | ((sm >> 30) & 4) | ((sm >> 45) & 8));
+      const unsigned int before = (four >> (wrow - pos)) & ((1u << pos) - 1u);
+      report = stops && before == 0;
+      live = !stops && before == 0;
+    }
+    if (report && first) {
+      if (info != 0) S.status[(int64_t)site * S.n_msgs + en_msg] = info;
+      poison[to_b] = 1;
+      if (!ROWS)
+        for (int qn = next; qn >= 0; qn = recs[qn].next) poison[recs[qn].to_b] = 1;
+      if (info != 0)
+        atomicMin(&S.fail[site], ((seq_base + (unsigned long long)(unsigned int)en_seq) << kInfoBits) |
+                                     (unsigned long long)(unsigned int)info);
+    }
+    if (ROWS ? !live : stops) break;
     // ---- divide! and mult!: kept lane 8 + a of the row owns row a of the message
     double maxJ = 0.0, maxh = 0.0;
     if (kept_live) {
@@ -817,7 +849,7 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
           const double dJ = msg - psep[b];
           sep[fi + b * s] = msg;
           res[fi + b * s] = dJ;
-          to[ua + ub * mt] = pto[b] + dJ;
+          if (!ROWS) to[ua + ub * mt] = pto[b] + dJ;
           maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
         }
       }
@@ -825,13 +857,14 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
       const double dh = msgh - pseph;
       sep[s * s + fi] = msgh;
       res[s * s + fi] = dh;
-      to[mt * mt + ua] = ptoh + dh;
+      if (!ROWS) to[mt * mt + ua] = ptoh + dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
     if (first) {
       const double dg = gmsg - pre_sepg;
       sep[s * s + s] = gmsg;
-      to[mt * mt + mt] = pre_tog + dg;
+      if (!ROWS) to[mt * mt + mt] = pre_tog + dg;
+      r_dg = dg;
       S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
     }
     if (S.update_resnorm) {
@@ -839,10 +872,45 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
       const bool any_bad = row_any(bad, lane);
       if (first) S.flags[(int64_t)site * S.n_msgs + en_msg] = any_bad ? 0 : 1;
     }
+    if constexpr (ROWS) {
+      r_mt = mt; r_s = s; r_u0 = u0; r_ua = ua; r_uw = uw; r_to = to; r_kept_live = kept_live;
+#pragma unroll
+      for (int b = 0; b < KK; ++b) { r_psep[b] = psep[b]; r_pto[b] = pto[b]; }
+      r_pseph = pseph; r_ptoh = ptoh; r_pre_tog = pre_tog;
+      break;
+    }
     asm volatile("" ::"v"(touch));
     if (next < 0) break;
     __threadfence_block();   // the next message of the task may read or read-modify-write what this one wrote
     ri = next;
+  }
+  if constexpr (ROWS) {
+    // ---- mult! in the order of each task: turn c = the messages at position c
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      if (!__any(live && klen > c)) break;
+      if (live && pos == c) {
+        if (r_kept_live) {
+#pragma unroll
+          for (int b = 0; b < KK; ++b) {
+            if (b < r_s) {
+              const int ub = r_u0 >= 0 ? r_u0 + b : byte_of(r_uw, b);
+              const double dJ = row[KI + b] - r_psep[b];
+              const double t0 = c == 0 ? r_pto[b] : r_to[r_ua + ub * r_mt];
+              r_to[r_ua + ub * r_mt] = t0 + dJ;
+            }
+          }
+          const double dh = row[KI + KK] - r_pseph;
+          const double t0 = c == 0 ? r_ptoh : r_to[r_mt * r_mt + r_ua];
+          r_to[r_mt * r_mt + r_ua] = t0 + dh;
+        }
+        if (first) {
+          const double t0 = c == 0 ? r_pre_tog : r_to[r_mt * r_mt + r_mt];
+          r_to[r_mt * r_mt + r_mt] = t0 + r_dg;
+        }
+      }
+      __threadfence_block();   // turn c + 1 reads what turn c stored (same wavefront, same vector L1)
+    }
   }
 }
 
@@ -1442,16 +1510,20 @@ size_t generic_lds_bytes(int max_mf) {
 
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
                           unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
-                          hipStream_t st) {
+                          hipStream_t st, const int32_t* d_rowmap, int n_rows) {
   if (ntasks <= 0) return;
   // four tasks per wavefront from the width at which a level is bound by instruction issue, not by one message's latency
   static const int small4_min = [] {
     const char* v = std::getenv("PGBP_SMALL4_MIN");
     return v ? std::atoi(v) : kSmall4MinTasks;
   }();
-  if (small_only && small4_min >= 0 && ntasks >= small4_min)
-    hipLaunchKernelGGL(bp_level_small4, dim3((ntasks + 3) / 4, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, ntasks, seq_base,
-                       stop_below);
+  static const bool rows_on = std::getenv("PGBP_NO_ROWS") == nullptr;
+  if (small_only && small4_min >= 0 && ntasks >= small4_min && d_rowmap && n_rows > 0 && rows_on)
+    hipLaunchKernelGGL(bp_level_small4<true>, dim3(n_rows / 4, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, n_rows, d_rowmap,
+                       seq_base, stop_below);
+  else if (small_only && small4_min >= 0 && ntasks >= small4_min)
+    hipLaunchKernelGGL(bp_level_small4<false>, dim3((ntasks + 3) / 4, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, ntasks,
+                       nullptr, seq_base, stop_below);
   else if (small_only)
     hipLaunchKernelGGL(bp_level_generic<true>, dim3(ntasks, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, seq_base, stop_below);
   else

@@ -79,9 +79,12 @@ __device__ __forceinline__ double log_by_table(const double2* __restrict__ tab, 
 // wave-per-task kernel: block b of the launch runs the task whose first record is d_recs[rec0 + b] (GRec, pgbp_internal.hpp)
 // small_only: every message of these tasks fits the register-resident body (Traversal::level_small): the instance without the
 // in-LDS body (fewer registers: more wavefronts per SIMD on the wide levels, half the code)
+// d_rowmap / n_rows: the level's messages one per row of 16 lanes (Traversal::rowmap: pairs (record, position | k << 8), a
+// multiple of four rows, tasks never straddle a wavefront), nullptr / 0: none -- wide small-only postorder levels then run
+// one message per row with mult! in task order (bp_level_small4<true>)
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
                           unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
-                          hipStream_t st);
+                          hipStream_t st, const int32_t* d_rowmap = nullptr, int n_rows = 0);
 
 // loop mode of the generic task body: n_wg workgroups of kTailWaves wavefronts, workgroup b walks the groups
 // [d_wg_off[b], d_wg_off[b + 1]) of kTailWaves first records of tasks (-1: none) with a workgroup barrier in between

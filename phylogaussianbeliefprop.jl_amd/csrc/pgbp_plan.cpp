@@ -366,7 +366,7 @@ void link_chains(std::vector<FEntry>& recs, const std::vector<FPro>& pros, const
 }
 
 static void build_chunks(const Plan& p, Traversal& tr, bool postorder);
-static void build_grecs(const Plan& p, Traversal& tr);
+static void build_grecs(const Plan& p, Traversal& tr, bool postorder);
 
 // many tiny problems: every belief dimension <= 2 and at least 8 sites run on the thread-per-site kernels (lanes = sites),
 // whatever the class of their tasks (pgbp_engine.hip: enqueue_levels) ...
@@ -519,7 +519,7 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
   tr.task_off.swap(new_task_off);
   tr.entries.swap(new_entries);
   tr.level_off.swap(new_level_off);
-  build_grecs(p, tr);
+  build_grecs(p, tr, postorder);
   build_chunks(p, tr, postorder);
 }
 
@@ -548,7 +548,7 @@ GRec make_grec(const Plan& p, const Entry& en, int32_t next) {
 }
 
 // Records of the generic-class tasks (GRec), on the final task / entry arrays of a traversal.
-static void build_grecs(const Plan& p, Traversal& tr) {
+static void build_grecs(const Plan& p, Traversal& tr, bool postorder) {
   const int nlev = (int)tr.level_off.size() - 1;
   const int ntasks = (int)tr.task_off.size() - 1;
   tr.grecs.clear();
@@ -573,6 +573,55 @@ static void build_grecs(const Plan& p, Traversal& tr) {
         const MsgDesc& m = p.msgs[tr.entries[e].msg];
         if (m.ni > kSmallI || m.s > kSmallK) tr.level_small[L] = 0;
       }
+  }
+  // the row form of the small postorder levels (one message per row of 16 lanes, mult! in task order)
+  tr.rowmap.clear();
+  tr.level_rowbase.assign(nlev, 0);
+  tr.level_nrows.assign(nlev, 0);
+  if (!postorder) return;
+  for (int L = 0; L < nlev; ++L) {
+    const int t0 = tr.level_off[L] + tr.level_nfast[L], t1 = tr.level_off[L + 1];
+    if (t1 <= t0 || !tr.level_small[L] || tr.level_nbig[L] != 0) continue;
+    bool ok = true;
+    std::vector<std::vector<int>> by_len(5);
+    for (int t = t0; t < t1 && ok; ++t) {
+      const int n = tr.task_off[t + 1] - tr.task_off[t];
+      const int32_t to_b = p.msgs[tr.entries[tr.task_off[t]].msg].to_b;
+      ok = n >= 1 && n <= 4;
+      for (int e = tr.task_off[t]; e < tr.task_off[t + 1] && ok; ++e)   // one receiver, no reused marginal, no prologue
+        ok = p.msgs[tr.entries[e].msg].to_b == to_b && tr.entries[e].reuse == 0 && tr.entries[e].pro == 0;
+      if (ok) by_len[n].push_back(t);
+    }
+    if (!ok) continue;
+    tr.level_rowbase[L] = (int64_t)(tr.rowmap.size() / 2);
+    // first fit, longest task first, into wavefronts of four rows; tasks of one length keep their order
+    std::vector<size_t> next(5, 0);
+    size_t left = (size_t)(t1 - t0);
+    int32_t rows = 0;
+    while (left > 0) {
+      int room = 4;
+      for (int len = 4; len >= 1;) {
+        if (len <= room && next[len] < by_len[len].size()) {
+          const int t = by_len[len][next[len]++];
+          int32_t rec = tr.task_grec[t];
+          for (int c = 0; c < len; ++c) {
+            tr.rowmap.push_back(rec);
+            tr.rowmap.push_back(c | (len << 8));
+            rec = tr.grecs[rec].next;
+          }
+          room -= len;
+          --left;
+        } else {
+          --len;
+        }
+      }
+      for (; room > 0; --room) {
+        tr.rowmap.push_back(-1);
+        tr.rowmap.push_back(0);
+      }
+      rows += 4;
+    }
+    tr.level_nrows[L] = rows;
   }
 }
 
@@ -1312,6 +1361,17 @@ int pgbp_plan_records(const pgbp_plan* p, int32_t tree, int32_t dir, int32_t* n_
   if (level_first) std::copy(tr->level_gbase.begin(), tr->level_gbase.end(), level_first);
   if (task_first) std::copy(tr->task_grec.begin(), tr->task_grec.end(), task_first);
   if (records && !tr->grecs.empty()) std::memcpy(records, tr->grecs.data(), tr->grecs.size() * sizeof(pgbp::GRec));
+  return PGBP_OK;
+}
+
+int pgbp_plan_rows(const pgbp_plan* p, int32_t tree, int32_t dir, int64_t* n_rows, int64_t* level_row0, int32_t* level_nrows,
+                   int32_t* rowmap) {
+  const pgbp::Traversal* tr = get_trav(p, tree, dir);
+  if (!tr || !n_rows) return PGBP_ERR_INVALID;
+  *n_rows = (int64_t)(tr->rowmap.size() / 2);
+  if (level_row0) std::copy(tr->level_rowbase.begin(), tr->level_rowbase.end(), level_row0);
+  if (level_nrows) std::copy(tr->level_nrows.begin(), tr->level_nrows.end(), level_nrows);
+  if (rowmap) std::copy(tr->rowmap.begin(), tr->rowmap.end(), rowmap);
   return PGBP_OK;
 }
 

@@ -1448,3 +1448,86 @@ def test_loop_launches_read_nothing_the_pass_before_wrote_except_through_a_chain
                     check_walk(w, chunk_chain[o:o + len(w)])
                 o += len(w)
     lib.pgbp_plan_destroy(pl)
+
+
+@pytest.mark.parametrize("ntips,p,graph", [(300, 4, "joingraph"), (200, 3, "bethe"), (150, 2, "joingraph")])
+def test_row_form_of_small_postorder_levels(ntips, p, graph):
+    """pgbp_plan_rows: on a network's cluster graph (small clusters, a few traits) every postorder level of generic-class
+    tasks has a row form -- each message of the level in exactly one row, the rows of a task consecutive, in the task's order
+    (position 0 .. k - 1, k <= 4), inside ONE wavefront of four rows; empty rows only where a task did not fit; the preorder
+    (one message per task) has none."""
+    import pgbp_amd as P
+    rng = np.random.default_rng(11 * ntips + p)
+
+    class Prob:
+        pass
+    net = P.random_level3_network_varied(ntips, ntips // 4, rng, n_colors=2)
+    cn, ed, sn = P.joingraph(net.node2family, 3) if graph == "joingraph" else P.bethe(net.node2family)
+    st = P.allocate_scopes(cn, ed, sn, net, p)
+    prob = Prob()
+    prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx = st.dims, st.sepset_clusters, st.scope_off, st.scope_idx
+    prob.schedule = [(np.asarray(t[2]), np.asarray(t[3])) for t in P.spanningtrees_clusterlist(len(cn), ed, cn, net.is_leaf)][:1]
+    lib, pl, code, keep = _plan(prob)
+    assert code == 0, lib.pgbp_plan_last_error(pl)
+    assert _set_sched(lib, pl, prob.schedule) == 0, lib.pgbp_plan_last_error(pl)
+    rec_t = np.dtype([("off", "<i8", 4), ("msg", "<i4"), ("seq", "<i4"), ("from_b", "<i4"), ("to_b", "<i4"),
+                      ("maps", "<i4", 3), ("next", "<i4"), ("dims", "u1", 4), ("fl", "u1", 4), ("perm", "u1", 40), ("up", "u1", 16)])
+    assert rec_t.itemsize == 128
+    levels_with_rows = 0
+    for d in (0, 1):
+        lo, to, em, ee, er = _traversal(lib, pl, 0, d)
+        nlev, ntask = len(lo) - 1, len(to) - 1
+        n = C.c_int32()
+        assert lib.pgbp_plan_records(pl, 0, d, C.byref(n), None, None, None) == 0
+        lf, tf = np.zeros(max(1, nlev), np.int32), np.zeros(max(1, ntask), np.int32)
+        raw = np.zeros(max(1, n.value) * 128, np.uint8)
+        assert lib.pgbp_plan_records(pl, 0, d, C.byref(n), L.i32p(lf), L.i32p(tf), raw.ctypes.data) == 0
+        recs = raw.view(rec_t)[:n.value]
+        nr = C.c_int64()
+        assert lib.pgbp_plan_rows(pl, 0, d, C.byref(nr), None, None, None) == 0
+        r0, rn = np.zeros(max(1, nlev), np.int64), np.zeros(max(1, nlev), np.int32)
+        rm = np.zeros(max(1, 2 * nr.value), np.int32)
+        assert lib.pgbp_plan_rows(pl, 0, d, C.byref(nr), r0.ctypes.data_as(C.POINTER(C.c_int64)), L.i32p(rn), L.i32p(rm)) == 0
+        if d == 1:
+            assert nr.value == 0 and not rn.any()
+            continue
+        for Lv in range(nlev):
+            gen = [t for t in range(lo[Lv], lo[Lv + 1]) if tf[t] >= 0]
+            if not gen:
+                assert rn[Lv] == 0
+                continue
+            sizes = [to[t + 1] - to[t] for t in gen]
+            small = True   # every message of the level: at most 8 integrated and 8 kept variables
+            for t in gen:
+                q = int(tf[t])
+                while q >= 0:
+                    small = small and recs[q]["dims"][3] <= 8 and recs[q]["dims"][2] <= 8
+                    q = int(recs[q]["next"])
+            if max(sizes) > 4 or not small:
+                assert rn[Lv] == 0
+                continue
+            assert rn[Lv] > 0 and rn[Lv] % 4 == 0
+            levels_with_rows += 1
+            rows = rm[2 * r0[Lv]: 2 * (r0[Lv] + rn[Lv])].reshape(-1, 2)
+            want = {}
+            for t in gen:
+                q, chain = int(tf[t]), []
+                while q >= 0:
+                    chain.append(q)
+                    q = int(recs[q]["next"])
+                for c, q in enumerate(chain):
+                    want[q] = (c, len(chain), chain)
+            seen = set()
+            for i, (rec, meta) in enumerate(rows):
+                if rec < 0:
+                    continue
+                rec, pos, k = int(rec), int(meta) & 255, int(meta) >> 8
+                assert rec not in seen and want[rec][:2] == (pos, k)
+                seen.add(rec)
+                first = i - pos
+                assert first // 4 == (first + k - 1) // 4, "a task inside one wavefront"
+                assert [int(x) for x in rows[first:first + k, 0]] == want[rec][2], "the rows of a task: its messages in order"
+            assert seen == set(want)
+            assert (rows[:, 0] < 0).sum() < 4 * max(1, (rn[Lv] // 4)) and rn[Lv] <= 4 * len(gen)
+    assert levels_with_rows > 0
+    lib.pgbp_plan_destroy(pl)
