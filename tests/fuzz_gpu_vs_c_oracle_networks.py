@@ -109,6 +109,29 @@ def run(n_cases, seed):
         _, flags = ce.residuals()
         assert np.array_equal(cgb._flags().astype(bool), flags.astype(bool)), desc
         del cgb
+        # now and then the same problem as site 0 of a TWO-site engine beside a rescaled copy (1.5 x the canonical
+        # parameters: another valid start), each site against the C engine on its own start (blockIdx.y = site in every kernel)
+        if case % 4 == 0:
+            starts2 = np.stack([start, 1.5 * start])
+            cgb2 = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, starts2, n_sites=2)
+            cgb2.set_schedule(sched)
+            cgb2.init_messagecalibrationflags_reset_()
+            P.calibrate_(cgb2, sched, niter, verbose=False)
+            for sidx in range(2):
+                ce2 = cengine.Engine(st.dims, np.asarray(st.sepset_clusters).reshape(-1), st.scope_off, st.scope_idx, starts2[sidx])
+                w2 = (True, False)
+                for it in range(niter):
+                    for spt in sched:
+                        if w2[0]:
+                            w2 = ce2.calibrate(spt[2], spt[3], 1, return_iscal=True)
+                r2 = cgb2.last_results[sidx]
+                assert (bool(r2.succ), bool(r2.iscal)) == tuple(bool(x) for x in w2), (desc, sidx)
+                if not w2[0]:
+                    continue
+                a2, b2 = cgb2._packed[sidx], ce2.packed()
+                err = float(np.max(np.abs(a2 - b2))) / max(1.0, float(np.max(np.abs(b2))))
+                assert err <= 1e-8, (desc, sidx, err)
+            del cgb2
     return n_fail, n_loopy, worst
 
 
