@@ -123,6 +123,7 @@ constexpr int kChunkGenericMaxTasks = 768;  // ... of generic-class tasks (cfg5:
 constexpr int kChunkUniMaxThreads = 65536;  // ... of a batch of univariate sites (thread-per-site kernels): tasks x sites of a level that joins a chunk
 constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x (perm + mf x (mf + 1)) doubles of LDS per workgroup
 constexpr int kChunkDepth = 4;        // levels per chunk
+constexpr int kChunkGenericDepth = 6; // ... of generic-class tasks (cfg5 join graph, depth 3 / 4 / 6 / 8: 1.329 / 1.333 / 1.312 / 1.318 ms per iteration)
 constexpr int kSmall4MinTasks = 1024;  // level launches of small generic-class tasks: four tasks per wavefront (bp_level_small4) from this width; PGBP_SMALL4_MIN overrides, -1: never
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
 constexpr size_t kMixedLevelFastMinNarrow = (size_t)1 << 30;  // ... where the sepsets have at most 4 variables: never split.  The register-resident

@@ -634,7 +634,12 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   tr.cgroups.clear();
   // (chain fusion makes tasks that pass through several receivers: the forest below assumes one receiver / sender per task)
   static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
-  static const int depth = [] { const char* v = getenv("PGBP_CHUNK_DEPTH"); return v ? std::max(2, atoi(v)) : kChunkDepth; }();
+  static const int depth_fast = [] { const char* v = getenv("PGBP_CHUNK_DEPTH"); return v ? std::max(2, atoi(v)) : kChunkDepth; }();
+  static const int depth_generic = [] {
+    const char* v = getenv("PGBP_CHUNK_DEPTH_GENERIC");
+    if (!v) v = getenv("PGBP_CHUNK_DEPTH");
+    return v ? std::max(2, atoi(v)) : kChunkGenericDepth;
+  }();
   static const int max_tasks = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkMaxTasks; }();
   static const int max_tasks_generic = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkGenericMaxTasks; }();
   const int nlev = (int)tr.level_off.size() - 1;
@@ -677,24 +682,25 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   // only while the levels stay no wider than 2 x w0 -- a chain of narrow levels is as long as it is whatever the launch
   // count, but a workgroup that owns a widening subtree serialises its lower levels (measured: blind depth 16 on the
   // root end of cfg3 costs 0.25 ms)
-  auto extend = [&](int w0, int n, int w) { return n < depth || (n < 4 * depth && w <= 2 * w0); };
+  auto extend = [&](int depth, int w0, int n, int w) { return n < depth || (n < 4 * depth && w <= 2 * w0); };
   std::vector<std::pair<int, int>> spans;  // chunks as level ranges
   for (int L = lo; L < hi;) {
     if (!eligible(L)) { ++L; continue; }
     int R = L;
     while (R < hi && eligible(R) && all_fast(R) == all_fast(L)) ++R;   // one kernel class per run (and per chunk)
     // the run [L, R): cut into chunks from the root end, so that the odd short chunk is the wide one
+    const int depth = (all_fast(L) || uni) ? depth_fast : depth_generic;   // (wave-per-task chunks only: the thread-per-site ones keep 4)
     if (postorder) {
       for (int b = R; b > L;) {
         int a = b - 1;
-        while (a > L && extend(width(b - 1), b - a, width(a - 1))) --a;
+        while (a > L && extend(depth, width(b - 1), b - a, width(a - 1))) --a;
         spans.push_back({a, b});
         b = a;
       }
     } else {
       for (int a = L; a < R;) {
         int b = a + 1;
-        while (b < R && extend(width(a), b - a, width(b))) ++b;
+        while (b < R && extend(depth, width(a), b - a, width(b))) ++b;
         spans.push_back({a, b});
         a = b;
       }
