@@ -544,8 +544,8 @@ def run_network(args, torch, dist, rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # (cfg3: 87 ms of timed region; 20 steps = 17 ms were as noisy as the round's micro-gains)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ntips", type=int, default=None, help="default: 50000 (tree workload), 20000 (sites workload)")
     ap.add_argument("--traits", type=int, default=None, help="default: 16 (tree workload), 4 (network workload)")
     ap.add_argument("--graph", default=None, choices=["cliquetree", "bethe", "joingraph", "ltrip"],
