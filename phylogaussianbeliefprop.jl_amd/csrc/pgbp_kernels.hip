@@ -190,7 +190,7 @@ struct Small4 {
 // KI, KK: the frame of this instance (KI integrated + KK kept rows / columns + h): 8 + 8 covers every small message; the
 // loop launches, where occupancy does not matter, also have 4 + 4, 4 + 8 and 8 + 4 (half the straight-line code of a message
 // of a 4-trait network: clusters of one to three nodes)
-template <bool WAVE, int KI, int KK>
+template <bool WAVE, int KI, int KK, bool DENSE = false>
 __device__ __forceinline__ int small_message(const DevState& S, const GRec* __restrict__ recs, const GLoad& cur, const int site,
                                              const int lane, unsigned long long seq_base, double* __restrict__ pool,
                                              double* __restrict__ rpool, SmallFrame& F, double& gmsg_io
@@ -220,6 +220,35 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   const int ua = u0 >= 0 ? u0 + fi : up_lane;
   double psep[KK], pto[KK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
   int ubv[KK];
+  if constexpr (DENSE) {
+    // DENSE (the loop launches, whose frame is the smallest the message fits: few unused columns): the operands of a
+    // message are requested in ONE basic block -- every column's load unconditional inside one masked region, an unused
+    // column re-reading column 0 and zeroed afterwards by a wave-uniform select.  A lone wavefront on its SIMD (a narrow
+    // pass) pays the full pipeline latency of every dependent instruction pair; with a branch per column each load was a
+    // serial chain of its own (120 - 190 clocks per load: tools/stamp_generic.py); in one block the chains interleave.
+#pragma unroll
+    for (int b = 0; b < KK; ++b) {
+      const int rl = __builtin_amdgcn_readlane(cur.ub, b);
+      ubv[b] = u0 >= 0 ? u0 + b : rl;
+      psep[b] = 0.0;
+      pto[b] = 0.0;
+    }
+    if (kept_live) {   // (s >= 1 here)
+#pragma unroll
+      for (int b = 0; b < KK; ++b) {
+        const int bb = b < s ? b : 0, ub = b < s ? ubv[b] : ubv[0];
+        psep[b] = sep[fi + bb * s];
+        pto[b] = to[ua + ub * mt];
+      }
+      pseph = sep[s * s + fi];
+      ptoh = to[mt * mt + ua];
+    }
+#pragma unroll
+    for (int b = 0; b < KK; ++b) {
+      psep[b] = b < s ? psep[b] : 0.0;
+      pto[b] = b < s ? pto[b] : 0.0;
+    }
+  } else {
 #pragma unroll
   for (int b = 0; b < KK; ++b) {
     psep[b] = 0.0;
@@ -233,6 +262,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   if (kept_live) {
     pseph = sep[s * s + fi];
     ptoh = to[mt * mt + ua];
+  }
   }
   if (lane == 0) {
     pre_sepg = sep[s * s + s];
@@ -248,6 +278,50 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     const int pq = __shfl(cur.pb, q < kGInlPerm ? q : 0);      // (inline map: lane l holds perm[l])
     const int pi = k0 >= 0 ? (q < ni ? (q < k0 ? q : q + s) : k0 + (q - ni)) : pq;
     double X[KI], Y[KI], Z[KK], hv = 0.0;
+    if constexpr (DENSE) {
+      int cjv[KI], cbv[KK];
+#pragma unroll
+      for (int j = 0; j < KI; ++j) {
+        X[j] = 0.0;
+        Y[j] = 0.0;
+        const int rl = __builtin_amdgcn_readlane(cur.pb, j);
+        cjv[j] = k0 >= 0 ? (j < k0 ? j : j + s) : rl;
+      }
+#pragma unroll
+      for (int b = 0; b < KK; ++b) {
+        Z[b] = 0.0;
+        const int rl = __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
+        cbv[b] = k0 >= 0 ? k0 + b : rl;
+      }
+      if (row_live) {
+        const int rowbase = pi * mf;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+          const int cj = j < ni ? cjv[j] : cjv[0];
+          X[j] = from[pi + cj * mf];
+        }
+        if (is_int) {
+#pragma unroll
+          for (int j = 0; j < KI; ++j) {
+            const int cj = j < ni ? cjv[j] : cjv[0];
+            Y[j] = from[cj + rowbase];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < KK; ++b) {
+          const int cb = b < s ? cbv[b] : cjv[0];   // (an unused kept column: any column of the sender)
+          Z[b] = from[is_int ? cb + rowbase : pi + cb * mf];
+        }
+        hv = from[mf * mf + pi];
+      }
+#pragma unroll
+      for (int j = 0; j < KI; ++j) {
+        X[j] = j < ni ? X[j] : 0.0;
+        Y[j] = j < ni ? Y[j] : 0.0;
+      }
+#pragma unroll
+      for (int b = 0; b < KK; ++b) Z[b] = b < s ? Z[b] : 0.0;
+    } else {
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
       X[j] = 0.0;
@@ -265,6 +339,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
       if (b < s && row_live) Z[b] = is_int ? from[cb + pi * mf] : from[pi + cb * mf];   // J_SI' for a pivot row, J_S for a kept one
     }
     if (row_live) hv = from[mf * mf + pi];
+    }
     gmsg = from[mf * mf + mf + pz];
     // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66), on the entries as stored
     bool nz = is_int && fabs(hv) > PGBP_EPS;
@@ -337,6 +412,20 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   // ---- divide! and mult!: kept lane 8 + a owns row a of the message
   double maxJ = 0.0, maxh = 0.0;
   if (kept_live) {
+    if constexpr (DENSE) {
+      // (one basic block as for the loads: an unused column stores column 0's values to column 0's places once more)
+#pragma unroll
+      for (int b = 0; b < KK; ++b) {
+        const int bb = b < s ? b : 0, ub = b < s ? ubv[b] : ubv[0];
+        const double msg = b < s ? F.row[KI + b] : F.row[KI];
+        const double ps = b < s ? psep[b] : psep[0], pt = b < s ? pto[b] : pto[0];
+        const double dJ = msg - ps;
+        sep[fi + bb * s] = msg;
+        res[fi + bb * s] = dJ;
+        to[ua + ub * mt] = pt + dJ;
+        maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
+      }
+    } else {
 #pragma unroll
     for (int b = 0; b < KK; ++b) {
       if (b < s) {
@@ -347,6 +436,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
         to[ua + ubv[b] * mt] = pto[b] + dJ;
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
+    }
     }
     const double msgh = F.row[KI + KK];
     const double dh = msgh - pseph;
@@ -406,9 +496,9 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
       const int nim = (dims >> 24) & 255;
       int done;
 #ifdef PGBP_GSTAMP
-#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, gst)
+#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_, SPEC>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, gst)
 #else
-#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg)
+#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_, SPEC>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg)
 #endif
       // (a reused marginal has the dimensions of the message that computed it: the same instance, the same frame)
       if (SPEC && nim <= 4 && s <= 4) done = PGBP_SMALL(4, 4);

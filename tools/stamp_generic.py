@@ -46,6 +46,11 @@ def main():
     k = min(n.value, cap)
     t = out[:k].astype(np.int64)
     print("messages stamped", n.value)
+    # PGBP_STAMP_MAX_GRID=n: only the messages of launches of at most n workgroups (the narrow passes: an iteration's critical path)
+    max_grid = int(os.environ.get("PGBP_STAMP_MAX_GRID", "0"))
+    if max_grid > 0:
+        t = t[t[:, 11] <= max_grid]
+        print("messages of launches of at most", max_grid, "workgroups:", len(t))
     dims = t[:, 10]
     mode = (dims >> 24) & 1
     for md in (0, 1):
