@@ -849,17 +849,17 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
       pto[b] = 0.0;
       const int ub = u0 >= 0 ? u0 + b : byte_of(uw, b);
       if (b < s && kept_live) {
-        psep[b] = sep[fi + b * s];
-        if (to_now) pto[b] = to[ua + ub * mt];
+        psep[b] = sep[(unsigned)(fi + b * s)];
+        if (to_now) pto[b] = to[(unsigned)(ua + ub * mt)];
       }
     }
     if (kept_live) {
-      pseph = sep[s * s + fi];
-      if (to_now) ptoh = to[mt * mt + ua];
+      pseph = sep[(unsigned)(s * s + fi)];
+      if (to_now) ptoh = to[(unsigned)(mt * mt + ua)];
     }
     if (first) {
-      pre_sepg = sep[s * s + s];
-      if (to_now) pre_tog = to[mt * mt + mt];
+      pre_sepg = sep[(unsigned)(s * s + s)];
+      if (to_now) pre_tog = to[(unsigned)(mt * mt + mt)];
     }
     const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];
     bool fake = false;
@@ -875,8 +875,8 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
         Y[j] = 0.0;
         const int cj = k0 >= 0 ? (j < k0 ? j : j + s) : byte_of(pw.x, j);
         if (j < ni && row_live) {
-          X[j] = from[pi + cj * mf];
-          if (is_int) Y[j] = from[cj + pi * mf];
+          X[j] = from[(unsigned)(pi + cj * mf)];
+          if (is_int) Y[j] = from[(unsigned)(cj + pi * mf)];
         }
       }
 #pragma unroll
@@ -884,10 +884,10 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
         Z[b] = 0.0;
         const int t = ni + b;                                    // (<= 15: ni <= 8)
         const int cb = k0 >= 0 ? k0 + b : (t < 8 ? byte_of(pw.x, t) : byte_of(pw.y, t & 7));
-        if (b < s && row_live) Z[b] = is_int ? from[cb + pi * mf] : from[pi + cb * mf];
+        if (b < s && row_live) Z[b] = is_int ? from[(unsigned)(cb + pi * mf)] : from[(unsigned)(pi + cb * mf)];
       }
-      if (row_live) hv = from[mf * mf + pi];
-      gmsg = from[mf * mf + mf];
+      if (row_live) hv = from[(unsigned)(mf * mf + pi)];
+      gmsg = from[(unsigned)(mf * mf + mf)];
       bool nz = is_int && fabs(hv) > PGBP_EPS;
 #pragma unroll
       for (int j = 0; j < KI; ++j) nz |= fabs(X[j]) > PGBP_EPS;
@@ -937,23 +937,23 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
           const int ub = u0 >= 0 ? u0 + b : byte_of(uw, b);
           const double msg = row[KI + b];
           const double dJ = msg - psep[b];
-          sep[fi + b * s] = msg;
-          res[fi + b * s] = dJ;
-          if (!ROWS) to[ua + ub * mt] = pto[b] + dJ;
+          sep[(unsigned)(fi + b * s)] = msg;
+          res[(unsigned)(fi + b * s)] = dJ;
+          if (!ROWS) to[(unsigned)(ua + ub * mt)] = pto[b] + dJ;
           maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
         }
       }
       const double msgh = row[KI + KK];
       const double dh = msgh - pseph;
-      sep[s * s + fi] = msgh;
-      res[s * s + fi] = dh;
-      if (!ROWS) to[mt * mt + ua] = ptoh + dh;
+      sep[(unsigned)(s * s + fi)] = msgh;
+      res[(unsigned)(s * s + fi)] = dh;
+      if (!ROWS) to[(unsigned)(mt * mt + ua)] = ptoh + dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
     if (first) {
       const double dg = gmsg - pre_sepg;
-      sep[s * s + s] = gmsg;
-      if (!ROWS) to[mt * mt + mt] = pre_tog + dg;
+      sep[(unsigned)(s * s + s)] = gmsg;
+      if (!ROWS) to[(unsigned)(mt * mt + mt)] = pre_tog + dg;
       r_dg = dg;
       S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
     }
@@ -986,17 +986,17 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
             if (b < r_s) {
               const int ub = r_u0 >= 0 ? r_u0 + b : byte_of(r_uw, b);
               const double dJ = row[KI + b] - r_psep[b];
-              const double t0 = c == 0 ? r_pto[b] : r_to[r_ua + ub * r_mt];
-              r_to[r_ua + ub * r_mt] = t0 + dJ;
+              const double t0 = c == 0 ? r_pto[b] : r_to[(unsigned)(r_ua + ub * r_mt)];
+              r_to[(unsigned)(r_ua + ub * r_mt)] = t0 + dJ;
             }
           }
           const double dh = row[KI + KK] - r_pseph;
-          const double t0 = c == 0 ? r_ptoh : r_to[r_mt * r_mt + r_ua];
-          r_to[r_mt * r_mt + r_ua] = t0 + dh;
+          const double t0 = c == 0 ? r_ptoh : r_to[(unsigned)(r_mt * r_mt + r_ua)];
+          r_to[(unsigned)(r_mt * r_mt + r_ua)] = t0 + dh;
         }
         if (first) {
-          const double t0 = c == 0 ? r_pre_tog : r_to[r_mt * r_mt + r_mt];
-          r_to[r_mt * r_mt + r_mt] = t0 + r_dg;
+          const double t0 = c == 0 ? r_pre_tog : r_to[(unsigned)(r_mt * r_mt + r_mt)];
+          r_to[(unsigned)(r_mt * r_mt + r_mt)] = t0 + r_dg;
         }
       }
       __threadfence_block();   // turn c + 1 reads what turn c stored (same wavefront, same vector L1)
