@@ -190,6 +190,16 @@ struct Small4 {
 // KI, KK: the frame of this instance (KI integrated + KK kept rows / columns + h): 8 + 8 covers every small message; the
 // loop launches, where occupancy does not matter, also have 4 + 4, 4 + 8 and 8 + 4 (half the straight-line code of a message
 // of a 4-trait network: clusters of one to three nodes)
+// element `idx` of a record whose base is wave-uniform (a scalar register pair): the byte offset formed in 32 bits, so that
+// the access is  global_load / store  v, v_offset, s[base]  -- one shift in front of it instead of a sign or zero extension
+// and a 64-bit shift-add (a wavefront alone on its SIMD pays every dependent step of an address in full)
+__device__ __forceinline__ double ld8(const double* __restrict__ base, int idx) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ((unsigned int)idx << 3));
+}
+__device__ __forceinline__ void st8(double* __restrict__ base, int idx, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + ((unsigned int)idx << 3)) = v;
+}
+
 template <bool WAVE, int KI, int KK, bool DENSE = false>
 __device__ __forceinline__ int small_message(const DevState& S, const GRec* __restrict__ recs, const GLoad& cur, const int site,
                                              const int lane, unsigned long long seq_base, double* __restrict__ pool,
@@ -237,11 +247,11 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
 #pragma unroll
       for (int b = 0; b < KK; ++b) {
         const int bb = b < s ? b : 0, ub = b < s ? ubv[b] : ubv[0];
-        psep[b] = sep[(unsigned)(fi + bb * s)];
-        pto[b] = to[(unsigned)(ua + ub * mt)];
+        psep[b] = ld8(sep, fi + bb * s);
+        pto[b] = ld8(to, ua + ub * mt);
       }
-      pseph = sep[(unsigned)(s * s + fi)];
-      ptoh = to[(unsigned)(mt * mt + ua)];
+      pseph = ld8(sep, s * s + fi);
+      ptoh = ld8(to, mt * mt + ua);
     }
 #pragma unroll
     for (int b = 0; b < KK; ++b) {
@@ -255,18 +265,18 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     pto[b] = 0.0;
     ubv[b] = u0 >= 0 ? u0 + b : __builtin_amdgcn_readlane(cur.ub, b);
     if (b < s && kept_live) {
-      psep[b] = sep[(unsigned)(fi + b * s)];
-      pto[b] = to[(unsigned)(ua + ubv[b] * mt)];
+      psep[b] = ld8(sep, fi + b * s);
+      pto[b] = ld8(to, ua + ubv[b] * mt);
     }
   }
   if (kept_live) {
-    pseph = sep[(unsigned)(s * s + fi)];
-    ptoh = to[(unsigned)(mt * mt + ua)];
+    pseph = ld8(sep, s * s + fi);
+    ptoh = ld8(to, mt * mt + ua);
   }
   }
   if (lane == 0) {
-    pre_sepg = sep[(unsigned)(s * s + s)];
-    pre_tog = to[(unsigned)(mt * mt + mt)];
+    pre_sepg = ld8(sep, s * s + s);
+    pre_tog = ld8(to, mt * mt + mt);
   }
   const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];   // (here: behind the stores they could not be moved up)
   double gmsg = gmsg_io;
@@ -298,21 +308,21 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
 #pragma unroll
         for (int j = 0; j < KI; ++j) {
           const int cj = j < ni ? cjv[j] : cjv[0];
-          X[j] = from[(unsigned)(pi + cj * mf)];
+          X[j] = ld8(from, pi + cj * mf);
         }
         if (is_int) {
 #pragma unroll
           for (int j = 0; j < KI; ++j) {
             const int cj = j < ni ? cjv[j] : cjv[0];
-            Y[j] = from[(unsigned)(cj + rowbase)];
+            Y[j] = ld8(from, cj + rowbase);
           }
         }
 #pragma unroll
         for (int b = 0; b < KK; ++b) {
           const int cb = b < s ? cbv[b] : cjv[0];   // (an unused kept column: any column of the sender)
-          Z[b] = from[(unsigned)(is_int ? cb + rowbase : pi + cb * mf)];
+          Z[b] = ld8(from, is_int ? cb + rowbase : pi + cb * mf);
         }
-        hv = from[(unsigned)(mf * mf + pi)];
+        hv = ld8(from, mf * mf + pi);
       }
 #pragma unroll
       for (int j = 0; j < KI; ++j) {
@@ -328,19 +338,19 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
       Y[j] = 0.0;
       const int cj = k0 >= 0 ? (j < k0 ? j : j + s) : __builtin_amdgcn_readlane(cur.pb, j);
       if (j < ni && row_live) {
-        X[j] = from[(unsigned)(pi + cj * mf)];                             // J[this row, integrated column j]
-        if (is_int) Y[j] = from[(unsigned)(cj + pi * mf)];                 // J[integrated row j, this column]: the upper triangle of J_I
+        X[j] = ld8(from, pi + cj * mf);                             // J[this row, integrated column j]
+        if (is_int) Y[j] = ld8(from, cj + pi * mf);                 // J[integrated row j, this column]: the upper triangle of J_I
       }
     }
 #pragma unroll
     for (int b = 0; b < KK; ++b) {
       Z[b] = 0.0;
       const int cb = k0 >= 0 ? k0 + b : __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
-      if (b < s && row_live) Z[b] = is_int ? from[(unsigned)(cb + pi * mf)] : from[(unsigned)(pi + cb * mf)];   // J_SI' for a pivot row, J_S for a kept one
+      if (b < s && row_live) Z[b] = is_int ? ld8(from, cb + pi * mf) : ld8(from, pi + cb * mf);   // J_SI' for a pivot row, J_S for a kept one
     }
-    if (row_live) hv = from[(unsigned)(mf * mf + pi)];
+    if (row_live) hv = ld8(from, mf * mf + pi);
     }
-    gmsg = from[(unsigned)(mf * mf + mf + pz)];
+    gmsg = ld8(from, mf * mf + mf + pz);
     // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66), on the entries as stored
     bool nz = is_int && fabs(hv) > PGBP_EPS;
 #pragma unroll
@@ -420,9 +430,9 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
         const double msg = b < s ? F.row[KI + b] : F.row[KI];
         const double ps = b < s ? psep[b] : psep[0], pt = b < s ? pto[b] : pto[0];
         const double dJ = msg - ps;
-        sep[(unsigned)(fi + bb * s)] = msg;
-        res[(unsigned)(fi + bb * s)] = dJ;
-        to[(unsigned)(ua + ub * mt)] = pt + dJ;
+        st8(sep, fi + bb * s, msg);
+        st8(res, fi + bb * s, dJ);
+        st8(to, ua + ub * mt, pt + dJ);
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
     } else {
@@ -431,24 +441,24 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
       if (b < s) {
         const double msg = F.row[KI + b];
         const double dJ = msg - psep[b];
-        sep[(unsigned)(fi + b * s)] = msg;
-        res[(unsigned)(fi + b * s)] = dJ;
-        to[(unsigned)(ua + ubv[b] * mt)] = pto[b] + dJ;
+        st8(sep, fi + b * s, msg);
+        st8(res, fi + b * s, dJ);
+        st8(to, ua + ubv[b] * mt, pto[b] + dJ);
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
     }
     }
     const double msgh = F.row[KI + KK];
     const double dh = msgh - pseph;
-    sep[(unsigned)(s * s + fi)] = msgh;
-    res[(unsigned)(s * s + fi)] = dh;
-    to[(unsigned)(mt * mt + ua)] = ptoh + dh;
+    st8(sep, s * s + fi, msgh);
+    st8(res, s * s + fi, dh);
+    st8(to, mt * mt + ua, ptoh + dh);
     maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
   }
   if (lane == 0) {
     const double dg = gmsg - pre_sepg;
-    sep[(unsigned)(s * s + s)] = gmsg;
-    to[(unsigned)(mt * mt + mt)] = pre_tog + dg;
+    st8(sep, s * s + s, gmsg);
+    st8(to, mt * mt + mt, pre_tog + dg);
     S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
   }
   if (S.update_resnorm) {
