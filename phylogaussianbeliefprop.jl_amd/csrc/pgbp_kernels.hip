@@ -135,7 +135,7 @@ __device__ __forceinline__ int64_t grec_i64(unsigned int rv, int k) {
 // fixed 16 x 17 frame, one ROW PER LANE: integrated variable k in lane k / column k, kept variable a in lane 8 + a /
 // column 8 + a, h in column 16 (unused rows and columns are zero).  Every operand of the message -- the sender's rows,
 // the sepset's and the receiver's entries this lane will update, the failure mark of the sender -- is requested in one
-// batch at the top; the elimination is straight-line code (the pivot row travels by v_readlane, no LDS, no
+// batch at the top; the elimination is straight-line code (the pivot row travels by a DPP row broadcast, no LDS, no
 // synchronisation); divide! and mult! are done by the kept lanes on their own rows.  Arithmetic and its order are those
 // of the LDS path below (eliminate_leading): W[i][j] -= (W[i][k] / d_k) * W[k][j], log det as a mantissa product.
 // (kSmallI = kSmallK = 8: pgbp_internal.hpp -- the planner tells the launches whose messages all fit)
@@ -753,7 +753,9 @@ __global__ __launch_bounds__(64) void bp_level_generic(DevState S, const GRec* _
   // Failures inside the current traversal only stop what is downstream of them (poison), so that the
   // minimum fail key is the first failure of the reference's sequential order.
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  generic_task<false, SMALL_ONLY>(S, recs, load_grec(recs, rec0 + blockIdx.x, threadIdx.x), site, threadIdx.x, seq_base,
+  // (SMALL_ONLY launches are the narrow ones -- from kSmall4MinTasks tasks on a level runs on bp_level_small4 --: occupancy does
+  // not matter, so they take the size-specialised, one-basic-block instances of the loop launches: SPEC)
+  generic_task<false, SMALL_ONLY, SMALL_ONLY>(S, recs, load_grec(recs, rec0 + blockIdx.x, threadIdx.x), site, threadIdx.x, seq_base,
                       reinterpret_cast<int32_t*>(lds), lds + kPermDoubles);
 }
 
