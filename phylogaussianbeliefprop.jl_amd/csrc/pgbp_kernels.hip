@@ -159,7 +159,10 @@ __device__ __forceinline__ double row_bcast(double v) {
 // 16 lanes that enters eliminates its own frame (bp_level_small4: four tasks; small_message: the task sits in lanes 0 .. 15)
 template <int KI, int KK>
 struct Small4 {
-  template <int k, class Row>
+  // SPREAD (the instances where registers are plentiful: the loop launches): the broadcasts of a pivot row first, each into
+  // a register of its own, then the updates -- with ONE temporary the compiler emits  mov, fma, nop, mov, fma, ...  and a
+  // wavefront alone on its SIMD pays each pair's latency in turn
+  template <int k, class Row, bool SPREAD = false>
   static __device__ __forceinline__ void pivot(Row& row, const int ni, int& info, double& mant, int& expo, double& quad) {
     if (k < ni && info == 0) {
       const double d = row_bcast<k>(row[k]);
@@ -175,14 +178,24 @@ struct Small4 {
         expo += ex;
         quad += hk * hk * rd;
         const double f = row[k] * rd;
+        if constexpr (SPREAD) {
+          double pk[KI + KK + 1];
+#pragma unroll
+          for (int j = k + 1; j <= KI + KK; ++j) pk[j] = row_bcast<k>(row[j]);
+#pragma unroll
+          for (int j = k + 1; j <= KI + KK; ++j) asm volatile("" : "+v"(pk[j]));   // (materialised before the first update)
+#pragma unroll
+          for (int j = k + 1; j <= KI + KK; ++j) row[j] -= f * pk[j];
+        } else {
 #pragma unroll
         for (int j = k + 1; j <= KI + KK; ++j) {
           const double pkj = row_bcast<k>(row[j]);
           row[j] -= f * pkj;
         }
+        }
       }
     }
-    if constexpr (k + 1 < KI) pivot<k + 1>(row, ni, info, mant, expo, quad);
+    if constexpr (k + 1 < KI) pivot<k + 1, Row, SPREAD>(row, ni, info, mant, expo, quad);
   }
 };
 
@@ -376,7 +389,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     int expo = 0, info = 0;
     if (PGBP_SMALL_DPP) {
       // (the other three rows of the wavefront hold zero frames: their lanes stop at the first pivot, nothing of theirs is used)
-      Small4<KI, KK>::template pivot<0>(F.row, ni, info, mant, expo, quad);
+      Small4<KI, KK>::template pivot<0, decltype(F.row), DENSE>(F.row, ni, info, mant, expo, quad);
       info = __builtin_amdgcn_readfirstlane(info);
     } else {
 #pragma unroll
