@@ -927,7 +927,7 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
     if (!poisoned && !en_reuse && !fake) {
       double mant = 1.0, quad = 0.0;
       int expo = 0;
-      Small4<KI, KK>::template pivot<0>(row, ni, info, mant, expo, quad);
+      Small4<KI, KK>::template pivot<0, decltype(row), true>(row, ni, info, mant, expo, quad);
       if (info == 0) {
         const double logdet = log_by_table_lane(S.logtab, mant) + (double)expo * 0.69314718055994530941723212145818;
         gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
