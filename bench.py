@@ -413,9 +413,10 @@ def build_network_workload(args, rank):
     return net, (cn, ed, sn), st, fam, X, rates, mu, sched
 
 
-def run_network(args, torch, dist, rank, world, local_rank):
+def run_network(args, torch, dist, rank, world, local_rank, emit=True):
     """cfg5: loopy belief propagation on a level-3 network.  A step = one calibrate! iteration (every schedule tree,
-    postorder + preorder) from the regularised start; N > 1: one independent replica (its own network) per GPU."""
+    postorder + preorder) from the regularised start; N > 1: one independent replica (its own network) per GPU.
+    Returns the result dict on rank 0 (None elsewhere); emit: print it as the JSON line."""
     import pgbp_amd as P
     from pgbp_amd import _lib as L
     lib = P.load()
@@ -473,7 +474,7 @@ def run_network(args, torch, dist, rank, world, local_rank):
         check(lib.pgbp_sync(eng))
     dt = timed_region(k_steps, dist, torch.cuda.synchronize)
     if rank != 0:
-        return
+        return None
     ms_step = dt / args.steps * 1e3
     net_traffic = load_pmc_traffic(f"pmc_traffic_network_{args.graph}_latest.json")
     default_net = (args.ntips == 20000 and args.traits == 4 and args.seed == 5 and args.blob_style == "varied"
@@ -508,7 +509,7 @@ def run_network(args, torch, dist, rank, world, local_rank):
                      "note": "algorithmic bytes of one calibrate iteration / its wall time; launch-latency-bound (levels per tree >> width)"},
         "host_setup_s": t_host,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         try:
             from oracle import cengine
             cengine.use_native_build()
@@ -538,7 +539,9 @@ def run_network(args, torch, dist, rank, world, local_rank):
                 raise SystemExit(f"parity gate failed (network): cpu reached {reached}, gpu {(r.iter_reached, r.tree_reached)}, belief diff {err:.3e}")
         except ImportError as ex:
             out["cpu_baseline"] = {"value": None, "unit": "messages/s", "cores": 1, "kind": "port", "sample": f"unavailable: {ex}"}
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 def main():
@@ -560,6 +563,8 @@ def main():
     ap.add_argument("--no-sites-block", action="store_true",
                     help="tree workload at the cfg3 size: skip the site_sharded_cfg4 block (the site-sharded configuration, strong scaling, "
                          "with its all-gather inside the timed region) that the default line carries for every --gpus N")
+    ap.add_argument("--no-network-block", action="store_true",
+                    help="tree workload at the cfg3 size: skip the network_cfg5 block (loopy BP on the level-3 network's join graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-reading", action="store_true",
                     help="skip the 25001-tip (50k-clique) side measurement: profiler runs want one workload per kernel name")
@@ -653,8 +658,7 @@ def main():
     check(lib.pgbp_enqueue_loglik(eng, 1, C.byref(opts)))
     check(lib.pgbp_fetch_loglik(eng, L.f64p(norm), L.i32p(info)))
     rel = abs(norm[0] - ll_check) / max(1.0, abs(ll_check))
-    skip_parity = os.environ.get("PGBP_EXPERIMENT_SKIP_PARITY") == "1"  # kernel-ablation builds only
-    if not (info[0] == 0 and rel <= 1e-8) and not skip_parity:
+    if not (info[0] == 0 and rel <= 1e-8):
         raise SystemExit(f"parity gate failed: loglik {norm[0]!r} vs {ll_check!r} (rel {rel:.3e}, info {info[0]})")
 
     # ---- warmup + timed calibrate steps
@@ -674,7 +678,7 @@ def main():
     # after the timed region: no message failed, and the calibrated beliefs still integrate to the right log-likelihood
     mu_, n2, i2 = cgb.integratebelief_(prob.root_cluster, all_sites=True)
     rel2 = abs(n2[0] - ll_check) / max(1.0, abs(ll_check))
-    if not (i2[0] == 0 and rel2 <= 1e-8) and not skip_parity:
+    if not (i2[0] == 0 and rel2 <= 1e-8):
         raise SystemExit(f"post-run parity failed: {n2[0]!r} vs {ll_check!r}")
     ranks_loglik, ranks_gather = None, None
     if world > 1 and dist is not None and os.environ.get("PGBP_BENCH_REHEARSAL") != "1":
@@ -702,11 +706,71 @@ def main():
         ll_evals = nll / (ms.value * 1e-3)
         check(lib.pgbp_fetch_loglik(eng, L.f64p(norm), L.i32p(info)))
         rel3 = abs(norm[0] - ll_check) / max(1.0, abs(ll_check))
-        if not (info[0] == 0 and rel3 <= 1e-8) and not skip_parity:
+        if not (info[0] == 0 and rel3 <= 1e-8):
             raise SystemExit(f"device-fill loglik parity failed: {norm[0]!r} vs {ll_check!r}")
         # same without the fill (factors copied from the resident factor pool)
         check(lib.pgbp_time_enqueued(eng, 1, nll, 1, C.byref(opts), C.byref(ms)))
         ll_evals_nofill = nll / (ms.value * 1e-3)
+        # roofline of one evaluation (the other half of BASELINE.json's metric): what the score() body has to move --
+        # every cluster record written by the fill, the algorithmic bytes of the postorder's messages (SURVEY.md section
+        # 8(d): read the sender, read + write the sepset, read + write the receiver's block, write the residual) and the
+        # root belief read by integratebelief! -- over the time of one evaluation
+        dims64 = np.asarray(prob.dims, np.int64)
+        nc_ = int(prob.nclusters)
+        pa_, ch_ = (np.asarray(x, np.int64) for x in prob.schedule[0][-2:])
+        sep_of = {}
+        sc_ = np.asarray(prob.sepset_clusters, np.int64).reshape(-1, 2)
+        for k, (a_, b_) in enumerate(sc_):
+            sep_of[(int(a_), int(b_))] = k
+            sep_of[(int(b_), int(a_))] = k
+        s_dim = np.array([dims64[nc_ + sep_of[(int(a_), int(b_))]] for a_, b_ in zip(pa_, ch_)], np.int64)
+        mf_post = dims64[ch_]
+        post_bytes = float(8 * np.sum((mf_post * mf_post + mf_post + 1) + 4 * (s_dim * s_dim + s_dim + 1) + (s_dim * s_dim + s_dim)))
+        fill_bytes = float(8 * np.sum(dims64[:nc_] * dims64[:nc_] + dims64[:nc_] + 1))
+        mroot = int(dims64[prob.root_cluster])
+        ll_bytes = fill_bytes + post_bytes + 8.0 * (mroot * mroot + mroot + 1)
+        ll_ms = 1e3 / ll_evals
+        ll_roofline = {"bound": "hbm", "achieved": ll_bytes / (ll_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": ll_bytes / (ll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_eval": ll_ms,
+                       "algorithmic_bytes_per_eval": ll_bytes,
+                       "bytes": {"factor_fill_written": fill_bytes, "postorder_messages": post_bytes,
+                                 "root_integrate_read": 8.0 * (mroot * mroot + mroot + 1)},
+                       "kernels": "bm_tree_fill_fast (assignfactors! on the device, straight into the packed layout the "
+                                  "postorder reads) + bp_fast16 / bp_loop16 (postorder) + integrate_kernel (root); kernel rows: "
+                                  "profiles/r04_*_cfg3_kernel_stats.csv",
+                       "traffic": None}
+        # ---- the DROP-IN call: what a user of the kept-intact API gets (calibrate_ with its write-back, then
+        # integratebelief! at the root), end to end on the host clock, beside the upload of the 0.76 GB belief state and
+        # the eager pull of everything (the round-3 behaviour of every call)
+        import pgbp_amd as _P
+
+        def _wall(fn, reps=3):
+            best = None
+            for _ in range(reps):
+                check(lib.pgbp_sync(eng))
+                t0 = time.perf_counter()
+                fn()
+                check(lib.pgbp_sync(eng))
+                dtw = time.perf_counter() - t0
+                best = dtw if best is None else min(best, dtw)
+            return best * 1e3
+
+        def _lazy_call():
+            assert _P.calibrate_(cgb, prob.schedule, 1)[0]
+            cgb.integratebelief_(prob.root_cluster)
+
+        def _eager_call():
+            assert _P.calibrate_(cgb, prob.schedule, 1, sync=False)[0]
+            cgb.pull()
+        cgb.pull()
+        dropin = {"calibrate_plus_root_integrate_ms": _wall(_lazy_call),
+                  "calibrate_plus_full_pull_ms": _wall(_eager_call, 2),
+                  "set_beliefs_upload_ms": _wall(cgb.push, 2),
+                  "state_bytes": float(8 * cgb._poff[-1]),
+                  "note": "host wall time of the reference-named calls (pgbp_amd.calibrate_ = calibrate!, integratebelief_): the "
+                          "write-back is lazy -- the call moves the result struct, a belief's record crosses the bus when it is "
+                          "first read (pgbp_get_belief), a residual's likewise (pgbp_get_residual); the full pull and the upload "
+                          "are the PCIe-inclusive figures, never `value`"}
         # ---- roofline of the dominant kernel: the HIP events recorded inside the timed steps above
         nl = nl_k
         reps = args.steps
@@ -726,9 +790,11 @@ def main():
                        "clusters": int(prob.nclusters), "sepsets": int(len(prob.dims) - prob.nclusters),
                        "messages_per_step": int(msgs_per_cal), "tree_depth": int(tr.depth().max()),
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
-            "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel), "parity_skipped": skip_parity,
+            "loglik": float(norm[0]), "loglik_rel_err_vs_pruning": float(rel),
             "ranks_loglik": ranks_loglik, "ranks_gather": ranks_gather,
             "ll_evals_per_s": ll_evals, "ll_evals_per_s_without_factor_fill": ll_evals_nofill,
+            "ll_eval": {"value": ll_evals, "unit": "log-likelihood evaluations/s", "roofline": ll_roofline},
+            "dropin": dropin,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # the same with the HBM bytes the counters saw (the packed layout moves about half of the
@@ -761,7 +827,7 @@ def main():
             check2(lib.pgbp_enqueue_loglik(cgb2._eng, 1, C.byref(opts)))
             check2(lib.pgbp_fetch_loglik(cgb2._eng, L.f64p(norm), L.i32p(info)))
             rel4 = abs(norm[0] - ll2) / max(1.0, abs(ll2))
-            if not (info[0] == 0 and rel4 <= 1e-8) and not skip_parity:
+            if not (info[0] == 0 and rel4 <= 1e-8):
                 raise SystemExit(f"parity gate failed (50k-clique reading): {norm[0]!r} vs {ll2!r}")
             check2(lib.pgbp_reset_from_factors(cgb2._eng))
             check2(lib.pgbp_time_enqueued(cgb2._eng, 0, args.warmup, 0, C.byref(opts), C.byref(ms)))
@@ -782,7 +848,7 @@ def main():
             check2(lib.pgbp_enqueue_loglik(cgb2._eng, 1, C.byref(opts)))
             check2(lib.pgbp_fetch_loglik(cgb2._eng, L.f64p(norm), L.i32p(info)))
             rel5 = abs(norm[0] - ll2) / max(1.0, abs(ll2))
-            if not (info[0] == 0 and rel5 <= 1e-8) and not skip_parity:
+            if not (info[0] == 0 and rel5 <= 1e-8):
                 raise SystemExit(f"parity gate failed (cfg2): {norm[0]!r} vs {ll2!r}")
             check2(lib.pgbp_reset_from_factors(cgb2._eng))
             check2(lib.pgbp_time_enqueued(cgb2._eng, 0, args.warmup, 0, C.byref(opts), C.byref(ms)))
@@ -812,7 +878,7 @@ def main():
             checkB(lib.pgbp_fetch_loglik(cgbB._eng, L.f64p(normB), L.i32p(infoB)))
             refB = S.bm_loglik_pruning(tr, Rs[B - 1], mu, X)
             relB = abs(normB[B - 1] - refB) / max(1.0, abs(refB))
-            if not (not infoB.any() and relB <= 1e-8 and abs(normB[0] - ll_check) <= 1e-8 * abs(ll_check)) and not skip_parity:
+            if not (not infoB.any() and relB <= 1e-8 and abs(normB[0] - ll_check) <= 1e-8 * abs(ll_check)):
                 raise SystemExit(f"batched loglik parity failed: {normB[B - 1]!r} vs {refB!r}")
             out["ll_evals_per_s_batched"] = {"parameter_sets_per_pass": B, "value": B * nll / (ms.value * 1e-3),
                                              "ms_per_pass": ms.value / nll, "loglik_rel_err_vs_pruning": float(relB)}
@@ -834,6 +900,18 @@ def main():
             out["site_sharded_cfg4"] = {k: blk[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config",
                                                             "sharded_step", "calibrate_only", "roofline",
                                                             "loglik_max_rel_err_vs_pruning")}
+        barrier()
+    if not args.no_network_block and (args.traits, args.ntips, args.graph) == (16, 50000, "cliquetree"):
+        # BASELINE.json configs[4] (cfg5) beside the headline: loopy BP on the level-3 network's join graph -- one replica
+        # per rank (a cluster graph does not shard without an exchange step: DESIGN.md section 6), its cpu_baseline to
+        # convergence on one rank
+        nargs = argparse.Namespace(**vars(args))
+        nargs.ntips, nargs.traits, nargs.seed, nargs.graph, nargs.maxclustersize = 20000, 4, 5, "joingraph", 3
+        nargs.blobs, nargs.blob_style = (20000 + 11) // 12, "varied"
+        nblk = run_network(nargs, torch, dist, rank, world, local_rank, emit=False)
+        if rank == 0:
+            out["network_cfg5"] = {k: nblk[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "calibrate_auto",
+                                                         "roofline", "host_setup_s", "cpu_baseline") if k in nblk}
         barrier()
     if dist is not None:
         dist.destroy_process_group()

@@ -34,12 +34,14 @@ extern "C" {
 #endif
 
 #define PGBP_VERSION 1
-#define PGBP_MAX_DIM 240 /* largest belief dimension the kernels accept (refused above).  Up to 128 variables the working
+#define PGBP_MAX_DIM 384 /* largest belief dimension the kernels accept (refused above).  Up to 128 variables the working
                             matrix of a message ([J | h]: 128 x 129 doubles = 132 KB) lives in a CU's 160 KB of LDS; above,
                             in a workspace in global memory that stays in the L2 (the 54-node clique of the reference's
-                            documented clique tree, docs/src/man/clustergraphs.md:40-89, has 162 / 216 variables with 3 / 4
-                            traits).  update_residualkldiv / pgbp_residual_kldiv need sepsets of dimension <= 96 (two
-                            systems side by side in LDS), pgbp_free_energy beliefs of dimension <= 139. */
+                            documented clique tree, docs/src/man/clustergraphs.md:40-89, has 162 / 216 / 324 variables with
+                            3 / 4 / 6 traits).  The scores and the KL residuals have the same two paths: in LDS up to 96
+                            (residual_kldiv!: two systems side by side) / 139 (free_energy) variables, in the workspace
+                            above -- no size of the reference's is refused below PGBP_MAX_DIM (src/beliefs.jl:1060-1075 and
+                            src/score.jl:162-182 have no bound). */
 
 enum pgbp_status {
   PGBP_OK = 0,
@@ -213,6 +215,12 @@ int  pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl);
  * Any pointer may be NULL. */
 int  pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_resid, double* kldiv,
                         int32_t* iscalibrated_kl);
+/* The same for ONE directed message of one site -- message 2k + dir is the one RECEIVED by end `dir` of sepset k
+ * (messageresidual[(receiver, sender)], src/clustergraphbeliefs.jl:17-20): rec = dJ (s*s, column-major) then dh (s).
+ * What a host that keeps the reference's objects fetches on first access after a calibrate! instead of downloading
+ * every residual (the lazy write-back of INTEGRATION.md).  Any of the four output pointers may be NULL. */
+int  pgbp_get_residual(pgbp_engine* e, int32_t site, int32_t msg, double* rec, int32_t* iscalibrated_resid, double* kldiv,
+                       int32_t* iscalibrated_kl);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 int  pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off,

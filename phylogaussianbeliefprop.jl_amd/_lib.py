@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGBP_LIB", os.path.join(_HERE, "csrc", "libpgbp.so"))
 
 PGBP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_TREE, ERR_TOO_LARGE, ERR_NO_DEVICE, ERR_STATE = range(7)
-PGBP_MAX_DIM = 240
+PGBP_MAX_DIM = 384
 
 
 class PgbpError(RuntimeError):
@@ -108,6 +108,7 @@ SYMBOLS = {
     "pgbp_reset_from_factors": (C.c_int, [_P]),
     "pgbp_reset_flags": (C.c_int, [_P, C.c_int32]),
     "pgbp_get_residuals": (C.c_int, [_P, _F64P, _I32P, _F64P, _I32P]),
+    "pgbp_get_residual": (C.c_int, [_P, C.c_int32, C.c_int32, _F64P, _I32P, _F64P, _I32P]),
     "pgbp_residual_kldiv": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Opts), _I32P]),
     "pgbp_regularize_bycluster": (C.c_int, [_P]),
     "pgbp_set_schedule": (C.c_int, [_P, C.c_int32, _I32P, _I32P, _I32P]),

@@ -14,6 +14,20 @@ class CanonicalBelief:
     (the constant function 1).  Once the belief belongs to a ClusterGraphBelief, h/J/g are
     views into its packed host mirror of the device state."""
 
+    # h, J, g of a belief that belongs to a device-backed ClusterGraphBelief are read THROUGH its owner: after a device
+    # call the owner only marks its host mirror stale, and the first read of a belief fetches that one record
+    # (clustergraphbeliefs.py: _refresh) -- an alias held since before the call sees the new values, as in the reference,
+    # where every update is in place (SURVEY.md section 8(b): ownership)
+    def _fresh_field(self, name):
+        o = self.__dict__.get("_owner")
+        if o is not None:
+            o._refresh(self.__dict__["_index"])
+        return self.__dict__[name]
+
+    J = property(lambda self: self._fresh_field("_J"), lambda self, v: self.__dict__.__setitem__("_J", v))
+    h = property(lambda self: self._fresh_field("_h"), lambda self, v: self.__dict__.__setitem__("_h", v))
+    g = property(lambda self: self._fresh_field("_g"), lambda self, v: self.__dict__.__setitem__("_g", v))
+
     def __init__(self, nodelabel, ntraits, inscope, btype, metadata):
         self.nodelabel = [int(x) for x in nodelabel]
         self.ntraits = int(ntraits)
@@ -68,12 +82,12 @@ class MessageResidual:
 
     @property
     def iscalibrated_resid(self):
-        return bool(self._o._flags()[self._d])
+        return bool(self._o._residual_words(self._d)[0])
 
     @property
     def kldiv(self):
-        return float(self._o._kldiv()[self._d])
+        return float(self._o._residual_words(self._d)[1])
 
     @property
     def iscalibrated_kl(self):
-        return bool(self._o._klflags()[self._d])
+        return bool(self._o._residual_words(self._d)[2])

@@ -26,7 +26,7 @@ def _traverse(beliefs, spt, direction, verbose, update_residualnorm, update_resi
     _check(beliefs._lib.pgbp_traverse(beliefs._eng, 0, direction, C.byref(o), res), beliefs._eng)
     beliefs.last_results = res
     if sync:
-        beliefs.pull()
+        beliefs._invalidate()   # lazy write-back: beliefs and residuals are fetched when first read
     r = res[beliefs.site]
     if not r.succ:
         ex = _fail_exception(beliefs, r, 0)
@@ -64,7 +64,7 @@ def calibrate_(beliefs, schedule, niter=1, auto=False, info=False, verbose=True,
     _check(beliefs._lib.pgbp_calibrate(beliefs._eng, int(niter), C.byref(o), res), beliefs._eng)
     beliefs.last_results = res
     if sync:
-        beliefs.pull()
+        beliefs._invalidate()   # lazy write-back: beliefs and residuals are fetched when first read
     r = res[beliefs.site]
     if not r.succ:
         ex = _fail_exception(beliefs, r, r.fail_tree - 1)

@@ -77,6 +77,7 @@ class ClusterGraphBelief:
             h[...] = b.h
             g[...] = b.g
             b.J, b.h, b.g = J, h, g
+            b._owner, b._index = self, i
         self._upload(snapshot_factors=True)
 
     @classmethod
@@ -130,6 +131,14 @@ class ClusterGraphBelief:
         self._flg = None
         self._kl = None
         self._klflg = None
+        # LAZY write-back (one site): after a device call the mirror is only marked stale; a belief's record is fetched at
+        # its first read (pgbp_get_belief), a residual's at its first read (pgbp_get_residual), the flag vectors on demand.
+        # _stale: None = the mirror is current, else one bool per belief; _res_have: residual records fetched since the
+        # last device call.  Engines with several sites keep the eager pull.
+        self._stale = None
+        self._n_single = 0
+        self._res_have = None
+        self.lazy = True
         self._schedule = None
         self.site = 0  # which site the belief views / residual views show
         self.belief = _BeliefList(self)
@@ -137,10 +146,58 @@ class ClusterGraphBelief:
         self.last_results = None
 
     @property
-    def _packed(self):
+    def _packed_raw(self):
         if self._packed_arr is None:
             self._packed_arr = np.zeros((self.n_sites, int(self._poff[-1])))
         return self._packed_arr
+
+    @property
+    def _packed(self):
+        """the host mirror as a whole: made current first (what is still stale is fetched in one transfer)"""
+        self._refresh_all()
+        return self._packed_raw
+
+    def _invalidate(self):
+        """the device state changed: drop the host copies.  One site: lazily (nothing moves until something is read);
+        several sites: the eager pull."""
+        if self.n_sites == 1 and self.lazy:
+            self._stale = np.ones(self.nbeliefs, dtype=bool)
+            self._n_single = 0
+            self._res = self._flg = self._kl = self._klflg = None
+            self._res_have = None
+        else:
+            self.pull()
+
+    def _refresh(self, i):
+        if self._stale is None or not self._stale[i]:
+            return
+        self._n_single += 1
+        if self._n_single > 64:   # a caller walking over the beliefs: one transfer of what is left beats thousands of small ones
+            self._refresh_all()
+            return
+        n = int(self._poff[i + 1] - self._poff[i])
+        rec = np.zeros(max(1, n))
+        _check(self._lib.pgbp_get_belief(self._eng, 0, int(i), L.f64p(rec)), self._eng)
+        self._packed_raw[0, self._poff[i]: self._poff[i + 1]] = rec[:n]
+        self._stale[i] = False
+
+    def _refresh_all(self):
+        if self._stale is None:
+            return
+        idx = np.nonzero(self._stale)[0].astype(np.int32)
+        if len(idx) == self.nbeliefs:
+            _check(self._lib.pgbp_get_beliefs(self._eng, L.f64p(self._packed_raw)), self._eng)
+        elif len(idx):
+            # the stale records only, gathered on the device into one buffer (records edited on the host stay as they are)
+            n = int(self._lib.pgbp_packed_beliefs_size(self._eng, len(idx), L.i32p(idx)))
+            buf = np.zeros(max(1, n))
+            _check(self._lib.pgbp_pack_beliefs(self._eng, 0, len(idx), L.i32p(idx), L.f64p(buf)), self._eng)
+            at = 0
+            for i in idx:
+                m = int(self._poff[i + 1] - self._poff[i])
+                self._packed_raw[0, self._poff[i]: self._poff[i + 1]] = buf[at: at + m]
+                at += m
+        self._stale = None
 
     def __del__(self):
         try:
@@ -153,21 +210,26 @@ class ClusterGraphBelief:
 
     def _views(self, site, i):
         m = int(self._dims[i])
-        rec = self._packed[site, self._poff[i]: self._poff[i + 1]]
+        self._refresh(i)
+        rec = self._packed_raw[site, self._poff[i]: self._poff[i + 1]]
         return rec[: m * m].reshape(m, m, order="F"), rec[m * m: m * m + m], rec[m * m + m:]
 
     def _belief_view(self, i):
         if self._objs is not None and self.site == 0:
             return self._objs[i]
         J, h, g = self._views(self.site, i)
+        site_is_lazy = self.n_sites == 1
         b = CanonicalBelief.__new__(CanonicalBelief)
         b.nodelabel, b.ntraits, b.inscope = None, None, None
         b.J, b.h, b.g, b.mu = J, h, g, np.zeros(len(h))
+        if site_is_lazy:
+            b._owner, b._index = self, i
         b.type = bclustertype if i < self.nclusters else bsepsettype
         b.metadata = self._labels[i] if getattr(self, "_labels", None) is not None else i
         return b
 
     def _upload(self, snapshot_factors=False):
+        # (self._packed: whatever of the mirror is stale is fetched first, so an upload never writes old values back)
         _check(self._lib.pgbp_set_beliefs(self._eng, L.f64p(self._packed), int(snapshot_factors)), self._eng)
 
     def push(self):
@@ -175,8 +237,10 @@ class ClusterGraphBelief:
         self._upload(False)
 
     def pull(self):
-        """device -> host mirror: beliefs, residuals, flags (the write-back a Julia shim does)."""
-        _check(self._lib.pgbp_get_beliefs(self._eng, L.f64p(self._packed)), self._eng)
+        """device -> host mirror, everything at once: beliefs, residuals, flags (the eager write-back)."""
+        self._stale = None
+        _check(self._lib.pgbp_get_beliefs(self._eng, L.f64p(self._packed_raw)), self._eng)
+        self._res_have = None
         nm = 2 * self.nsepsets
         self._res = np.zeros((self.n_sites, max(1, int(self._roff[-1]))))
         self._flg = np.zeros((self.n_sites, max(1, nm)), dtype=np.int32)
@@ -185,24 +249,51 @@ class ClusterGraphBelief:
         _check(self._lib.pgbp_get_residuals(self._eng, L.f64p(self._res), L.i32p(self._flg), L.f64p(self._kl),
                                             L.i32p(self._klflg)), self._eng)
 
+    def _fetch_words(self):
+        """flags, kldiv, iscalibrated_kl of every message (no residual record moves)"""
+        nm = 2 * self.nsepsets
+        self._flg = np.zeros((self.n_sites, max(1, nm)), dtype=np.int32)
+        self._kl = np.zeros((self.n_sites, max(1, nm)))
+        self._klflg = np.zeros((self.n_sites, max(1, nm)), dtype=np.int32)
+        _check(self._lib.pgbp_get_residuals(self._eng, None, L.i32p(self._flg), L.f64p(self._kl), L.i32p(self._klflg)), self._eng)
+
     def _residual_record(self, d):
-        if self._res is None:
+        if self._res is None and not (self.n_sites == 1 and self.lazy):
             self.pull()
+        if self._res is None:   # lazy: one record at a time
+            self._res = np.zeros((1, max(1, int(self._roff[-1]))))
+            self._res_have = np.zeros(2 * self.nsepsets, dtype=bool)
+        if self._res_have is not None and not self._res_have[d] and int(self._res_have.sum()) >= 64:
+            # a caller walking over the residuals: the rest in one transfer
+            _check(self._lib.pgbp_get_residuals(self._eng, L.f64p(self._res), None, None, None), self._eng)
+            self._res_have = None
+        if self._res_have is not None and not self._res_have[d]:
+            n = int(self._roff[d + 1] - self._roff[d])
+            rec = np.zeros(max(1, n))
+            _check(self._lib.pgbp_get_residual(self._eng, 0, int(d), L.f64p(rec), None, None, None), self._eng)
+            self._res[0, self._roff[d]: self._roff[d + 1]] = rec[:n]
+            self._res_have[d] = True
         return self._res[self.site, self._roff[d]: self._roff[d + 1]]
+
+    def _residual_words(self, d):
+        """(iscalibrated_resid, kldiv, iscalibrated_kl) of message d"""
+        if self._flg is None:
+            self._fetch_words()
+        return self._flg[self.site][d], self._kl[self.site][d], self._klflg[self.site][d]
 
     def _flags(self):
         if self._flg is None:
-            self.pull()
+            self._fetch_words()
         return self._flg[self.site]
 
     def _kldiv(self):
         if self._kl is None:
-            self.pull()
+            self._fetch_words()
         return self._kl[self.site]
 
     def _klflags(self):
         if getattr(self, "_klflg", None) is None:
-            self.pull()
+            self._fetch_words()
         return self._klflg[self.site]
 
     def residual_kldiv_(self, cluster_to, sepset, cluster_from, atol=1e-5):
@@ -212,7 +303,7 @@ class ClusterGraphBelief:
         o = self._opts(atol=atol)
         _check(self._lib.pgbp_residual_kldiv(self._eng, int(cluster_to), int(sepset), int(cluster_from), C.byref(o),
                                              L.i32p(out)), self._eng)
-        self.pull()
+        self._flg = self._kl = self._klflg = None   # (the beliefs and the residual records are untouched)
         if int(self._dims[sepset]) == 0:
             return True
         return bool(out[self.site])
@@ -254,7 +345,7 @@ class ClusterGraphBelief:
         _check(self._lib.pgbp_propagate(self._eng, int(cluster_to), int(sepset), int(cluster_from), C.byref(o),
                                         L.i32p(info)), self._eng)
         if sync:
-            self.pull()
+            self._invalidate()
         if info[self.site] != 0:
             return self._exception_for(cluster_from, sepset - self.nclusters, int(info[self.site]))
         return None
@@ -291,7 +382,7 @@ class ClusterGraphBelief:
         """init_beliefs_reset_fromfactors! (src/clustergraphbeliefs.jl:126-139)."""
         _check(self._lib.pgbp_reset_from_factors(self._eng), self._eng)
         if sync:
-            self.pull()
+            self._invalidate()
 
     def init_factors_frombeliefs_(self):
         """init_factors_frombeliefs! (src/beliefs.jl:746-761) on the device state."""
@@ -304,7 +395,7 @@ class ClusterGraphBelief:
 
     def iscalibrated_residnorm(self):
         """iscalibrated_residnorm(beliefs) (src/clustergraphbeliefs.jl:168-169)."""
-        self.pull()
+        self._fetch_words()   # (the flag vectors alone: no belief, no residual record moves)
         return bool(np.all(self._flg[self.site][: 2 * self.nsepsets] != 0))
 
     def integratebelief_(self, j, all_sites=False):
@@ -377,7 +468,7 @@ class ClusterGraphBelief:
         _check(self._lib.pgbp_bm_tree_assignfactors(self._eng, L.f64p(Rinv), L.f64p(logdet), L.f64p(mus),
                                                     int(per_site)), self._eng)
         if sync:
-            self.pull()
+            self._invalidate()
 
     def lg_setup(self, fam, data):
         """Static part of assignfactors! for any linear-Gaussian model (include/pgbp.h: pgbp_lg_families).
@@ -426,7 +517,7 @@ class ClusterGraphBelief:
                        L.f64p(th) if ou else None, L.f64p(mu))
         _check(self._lib.pgbp_lg_assignfactors(self._eng, C.byref(m)), self._eng)
         if sync:
-            self.pull()
+            self._invalidate()
 
     def loglik_lg(self, reps=1):
         """The body of score(theta) (src/calibration.jl:195-221) on the device with the parameters of the last

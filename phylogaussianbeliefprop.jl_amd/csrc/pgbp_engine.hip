@@ -43,6 +43,9 @@ struct DevTraversal {
   int32_t* d_cgroups_task = nullptr; // Traversal::cgroups as they are (task ids): the thread-per-site chunk kernel
   GRec* d_grecs = nullptr;           // Traversal::grecs
   int32_t* d_rowmap = nullptr;       // Traversal::rowmap
+  // residual_kldiv! of sepsets beyond the LDS instance (kKlLdsMaxS): the entries concerned, ascending (device copy + host copy)
+  int32_t* d_kl_big = nullptr;
+  std::vector<int32_t> kl_big;
 };
 
 }  // namespace
@@ -122,10 +125,19 @@ struct pgbp_engine {
   bool lg_ready = false, lg_have_params = false, lg_uni_ok = false;
   double *d_lg_R = nullptr, *d_lg_alpha = nullptr, *d_lg_theta = nullptr, *d_lg_mu = nullptr;
   std::string err;
+  // a step of an asynchronous enqueue that could not be issued (a workspace that could not be allocated: ensure_ws has
+  // set `err`): the launches that needed it were skipped; every entry point that enqueued, and the next pgbp_sync /
+  // fetch, returns this code instead of results of messages that never ran
+  int enqueue_rc = PGBP_OK;
 
   int fail(int code, const std::string& msg) {
     err = msg;
     return code;
+  }
+  int take_enqueue_rc() {
+    const int rc = enqueue_rc;
+    enqueue_rc = PGBP_OK;
+    return rc;
   }
 };
 
@@ -339,6 +351,7 @@ void free_traversals(pgbp_engine* e) {
       if (d.d_cgroups_task) (void)hipFree(d.d_cgroups_task);
       if (d.d_grecs) (void)hipFree(d.d_grecs);
       if (d.d_rowmap) (void)hipFree(d.d_rowmap);
+      if (d.d_kl_big) (void)hipFree(d.d_kl_big);
     }
     v->clear();
   }
@@ -362,16 +375,11 @@ int ensure_ws(pgbp_engine* e, int64_t doubles) {
   return PGBP_OK;
 }
 
-constexpr int kKlMaxS = 96;  // residual_kldiv_kernel: [J0 | dJ | h0] of one sepset in a CU's LDS
-
 // Every entry point that launches a message kernel comes through here BEFORE its first launch: the options are sane and
 // the threshold table of DevState::thr is the one of this tolerance (a failed upload is this call's error, not a launch
 // with whatever the table held).
 int check_opts(pgbp_engine* e, const pgbp_opts* o) {
   if (o && !(o->atol >= 0.0)) return e->fail(PGBP_ERR_INVALID, "pgbp_opts.atol must be >= 0");
-  if (o && o->update_residualkldiv && e->max_s > kKlMaxS)
-    return e->fail(PGBP_ERR_TOO_LARGE, "update_residualkldiv needs sepsets of dimension <= " + std::to_string(kKlMaxS) +
-                                           " (this graph: " + std::to_string(e->max_s) + ")");
   const int rc = ensure_thresholds(e, o ? o->atol : 1e-5);
   if (rc != PGBP_OK) e->thr_valid = false;
   return rc;
@@ -458,17 +466,27 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st,
                            rows ? d.d_rowmap + 2 * tr.level_rowbase[L] : nullptr, rows ? tr.level_nrows[L] : 0);
-      if (nbig > 0 && ensure_ws(e, (int64_t)nbig * e->plan.n_sites * big_ws_doubles(tr.max_mf_big)) == PGBP_OK)
-        launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
-                         tr.max_mf_big, e->d_ws, e->st);
+      if (nbig > 0) {
+        if (ensure_ws(e, (int64_t)nbig * e->plan.n_sites * big_ws_doubles(tr.max_mf_big)) == PGBP_OK)
+          launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
+                           tr.max_mf_big, e->d_ws, e->st);
+        else
+          e->enqueue_rc = PGBP_ERR_HIP;   // (these messages never ran: the entry point reports it)
+      }
     }
     if (launches) *launches += (nf > 0) + (nt - nf - nbig > 0) + (nbig > 0);
     if (kl) {  // residual_kldiv! right after the messages of the level (src/calibration.jl:128,154)
       const int e0 = tr.task_off[t0], e1 = tr.task_off[t0 + nt];
       int level_s = 0;   // the largest sepset of THIS level's messages sizes the launch's LDS, not the graph's largest
       for (int q = e0; q < e1; ++q) level_s = std::max(level_s, (int)e->plan.msgs[tr.entries[q].msg].s);
-      launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, level_s, e->d_kldiv, e->d_klflags, e->plan.n_sites,
-                            stop_below, e->st);
+      // the level's entries whose sepset is beyond the LDS instance: a second launch with a workspace slab each
+      const auto b0 = std::lower_bound(d.kl_big.begin(), d.kl_big.end(), e0), b1 = std::lower_bound(d.kl_big.begin(), d.kl_big.end(), e1);
+      const int n_big = (int)(b1 - b0);
+      if (n_big == 0 || ensure_ws(e, (int64_t)n_big * e->plan.n_sites * kldiv_ws_doubles(level_s)) == PGBP_OK)
+        launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, level_s, e->d_kldiv, e->d_klflags, e->plan.n_sites, stop_below, e->st,
+                              d.d_kl_big + (b0 - d.kl_big.begin()), n_big, e->d_ws);
+      else
+        e->enqueue_rc = PGBP_ERR_HIP;
     }
   }
 }
@@ -504,10 +522,11 @@ void integrate_async(pgbp_engine* e, int belief, double* d_mu) {
   if (e->layout_sm)
     launch_integrate_sm(e->d_pool_sm, p.packed_off[belief], p.dims[belief], d_mu, std::max(1, p.max_dim), e->d_norm,
                         e->d_info, p.n_sites, e->st);
-  else if (ensure_ws(e, (int64_t)p.n_sites * big_ws_doubles(p.dims[belief])) == PGBP_OK)   // (a failed allocation: e->err is
-    // set and the caller's status check of the stream reports it)
+  else if (ensure_ws(e, (int64_t)p.n_sites * big_ws_doubles(p.dims[belief])) == PGBP_OK)
     launch_integrate(e->d_pool, p.pool_stride(), p.boff[belief], p.dims[belief], e->layout_bs16 ? 1 : 0, p.fast_p, d_mu,
                      std::max(1, p.max_dim), e->d_norm, e->d_info, p.n_sites, e->d_ws, e->st);
+  else
+    e->enqueue_rc = PGBP_ERR_HIP;   // (e->err is set; the entry point returns the code)
 }
 
 // skip_sepsets: the caller's next traversal overwrites every sepset without reading it (DevState::sep_zero)
@@ -711,7 +730,7 @@ int pgbp_sync(pgbp_engine* e) {
   if (!e) return PGBP_ERR_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipGetLastError());  // a launch that failed since the last check (bad grid, LDS size) surfaces here
-  return PGBP_OK;
+  return e->take_enqueue_rc();   // ... and so does an enqueue step that was skipped for want of a workspace
 }
 
 int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
@@ -945,6 +964,26 @@ int pgbp_get_residuals(pgbp_engine* e, double* packed, int32_t* iscalibrated_res
   return pgbp_sync(e);
 }
 
+int pgbp_get_residual(pgbp_engine* e, int32_t site, int32_t msg, double* rec, int32_t* iscalibrated_resid, double* kldiv,
+                      int32_t* iscalibrated_kl) {
+  DeviceScope device_scope(e);
+  if (!e) return PGBP_ERR_INVALID;
+  const Plan& p = e->plan;
+  if (site < 0 || site >= p.n_sites || msg < 0 || msg >= p.n_msgs())
+    return e->fail(PGBP_ERR_INVALID, "pgbp_get_residual: site or message index out of range");
+  int rc = ensure_layout(e, false);   // the record in the ABI's order; the word arrays as [site][message]
+  if (rc) return rc;
+  const size_t w = (size_t)site * (size_t)p.n_msgs() + (size_t)msg;
+  const int64_t len = p.rpacked_off[msg + 1] - p.rpacked_off[msg];
+  if (rec && len > 0)
+    HIPCHK(e, hipMemcpyAsync(rec, e->d_rpool + (int64_t)site * p.rpool_stride() + p.roff[msg], sizeof(double) * (size_t)len,
+                             hipMemcpyDeviceToHost, e->st));
+  if (iscalibrated_resid) HIPCHK(e, hipMemcpyAsync(iscalibrated_resid, e->d_flags + w, sizeof(int32_t), hipMemcpyDeviceToHost, e->st));
+  if (kldiv) HIPCHK(e, hipMemcpyAsync(kldiv, e->d_kldiv + w, sizeof(double), hipMemcpyDeviceToHost, e->st));
+  if (iscalibrated_kl) HIPCHK(e, hipMemcpyAsync(iscalibrated_kl, e->d_klflags + w, sizeof(int32_t), hipMemcpyDeviceToHost, e->st));
+  return pgbp_sync(e);
+}
+
 int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, const int32_t* pa_j,
                       const int32_t* ch_j) {
   DeviceScope device_scope(e);
@@ -996,6 +1035,10 @@ int pgbp_set_schedule(pgbp_engine* e, int32_t n_trees, const int32_t* tree_off, 
       if ((rc = upload(e, &d.d_cgroups_task, tr.cgroups))) break;
       if ((rc = upload(e, &d.d_grecs, tr.grecs))) break;
       if ((rc = upload(e, &d.d_rowmap, tr.rowmap))) break;
+      d.kl_big.clear();
+      for (size_t q = 0; q < tr.entries.size(); ++q)
+        if (e->plan.msgs[tr.entries[q].msg].s > kKlLdsMaxS) d.kl_big.push_back((int32_t)q);
+      if ((rc = upload(e, &d.d_kl_big, d.kl_big))) break;
     }
     if (rc == PGBP_OK) {
       const Tree& T = e->plan.trees[t];
@@ -1038,7 +1081,7 @@ int pgbp_propagate(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int32_t c
   HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
   if ((rc = reset_fail(e))) return rc;
   DevState S = dev_state(e, opts);
-  if (p.msgs[en.msg].mf > kGenericMaxDim) {
+  if (big_msg(p.msgs[en.msg])) {
     if ((rc = ensure_ws(e, (int64_t)p.n_sites * big_ws_doubles(p.msgs[en.msg].mf)))) return rc;
     launch_level_big(S, e->d_one_task_off, e->d_one_entry, 0, 1, p.n_sites, 0, 0, p.msgs[en.msg].mf, e->d_ws, e->st);
   } else {
@@ -1075,14 +1118,17 @@ int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int3
     return e->fail(PGBP_ERR_INVALID, "pgbp_residual_kldiv: the sepset does not connect these two clusters");
   Entry en{2 * k + dir, 0, 0, 0};
   const int s_msg = p.msgs[en.msg].s;
-  if (s_msg > kKlMaxS)   // whatever opts says: the kernel holds this sepset's [J0 | dJ | h0] in LDS
-    return e->fail(PGBP_ERR_TOO_LARGE, "pgbp_residual_kldiv needs a sepset of dimension <= " + std::to_string(kKlMaxS) +
-                                           " (this one: " + std::to_string(s_msg) + ")");
+  const int32_t toff[2] = {0, 1};   // (d_one_task_off[0] = 0 doubles as the list "entry 0" of the workspace instance)
+  HIPCHK(e, hipMemcpyAsync(e->d_one_task_off, toff, sizeof(toff), hipMemcpyHostToDevice, e->st));
   HIPCHK(e, hipMemcpyAsync(e->d_one_entry, &en, sizeof(en), hipMemcpyHostToDevice, e->st));
+  HIPCHK(e, hipStreamSynchronize(e->st));   // (toff, en: locals)
+  const bool kl_ws = s_msg > kKlLdsMaxS;
+  if (kl_ws && (rc = ensure_ws(e, (int64_t)p.n_sites * kldiv_ws_doubles(s_msg)))) return rc;
   if (e->layout_sm && (rc = ensure_site_minor(e, false))) return rc;
   DevState S = dev_state(e, opts);
   // a standalone call always computes (stop_below = 0; the status of the last attempt of this message still gates)
-  launch_residual_kldiv(S, e->d_one_entry, 0, 1, s_msg, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st);
+  launch_residual_kldiv(S, e->d_one_entry, 0, 1, s_msg, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st,
+                        kl_ws ? e->d_one_task_off : nullptr, kl_ws ? 1 : 0, e->d_ws);
   if (iscalibrated_kl) {
     std::vector<int32_t> all((size_t)p.n_sites * std::max(1, p.n_msgs()));
     HIPCHK(e, hipMemcpyAsync(all.data(), e->d_klflags, sizeof(int32_t) * (size_t)p.n_sites * p.n_msgs(),
@@ -1123,6 +1169,7 @@ static int collect_results(pgbp_engine* e, pgbp_result* results, const std::vect
   HIPCHK(e, hipMemcpyAsync(iscal.data(), e->d_iscal, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipGetLastError());
+  if (const int erc = e->take_enqueue_rc()) return erc;
   const int nt = std::max<int>(1, (int)p.trees.size());
   for (int s = 0; s < ns; ++s) {
     pgbp_result r;
@@ -1267,6 +1314,7 @@ int pgbp_integrate(pgbp_engine* e, int32_t belief, double* mu, double* norm, int
   HIPCHK(e, hipMemcpyAsync(inf.data(), e->d_info, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipGetLastError());
+  if (const int erc = e->take_enqueue_rc()) return erc;
   if (mu && m > 0)
     for (int s = 0; s < ns; ++s)
       std::memcpy(mu + (size_t)s * m, mus.data() + (size_t)s * std::max(1, p.max_dim), sizeof(double) * m);
@@ -1286,27 +1334,34 @@ int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
   }
   const Plan& p = e->plan;
   const int ns = p.n_sites;
-  // the kernel keeps [J | one column of J_t | h] of a belief in LDS: 139 variables at most (right-hand sides in blocks)
-  if (p.max_dim > 139)
-    return e->fail(PGBP_ERR_TOO_LARGE, "pgbp_free_energy needs beliefs of dimension <= 139 (this graph: " +
-                                           std::to_string(p.max_dim) + ")");
+  // beliefs whose [J | one column of J_t | h] does not fit a CU's LDS (more than kFreeEnergyLdsMaxDim variables): a second
+  // launch, their working matrix in the workspace
+  std::vector<int32_t> big;
+  for (int b = 0; b < p.n_beliefs(); ++b)
+    if (p.dims[b] > kFreeEnergyLdsMaxDim) big.push_back(b);
   double *d_contrib = nullptr, *d_out = nullptr;
-  int32_t* d_inf = nullptr;
+  int32_t *d_inf = nullptr, *d_big = nullptr;
   int rc;
-  if ((rc = dev_alloc(e, &d_contrib, (size_t)2 * ns * p.n_beliefs()))) return rc;
-  if ((rc = dev_alloc(e, &d_out, (size_t)3 * ns))) { (void)hipFree(d_contrib); return rc; }
-  if ((rc = dev_alloc(e, &d_inf, (size_t)ns))) { (void)hipFree(d_contrib); (void)hipFree(d_out); return rc; }
+  if (!big.empty()) {
+    if ((rc = ensure_ws(e, (int64_t)big.size() * ns * free_energy_ws_doubles(p.max_dim)))) return rc;
+    if ((rc = upload(e, &d_big, big))) return rc;
+  }
+  if ((rc = dev_alloc(e, &d_contrib, (size_t)2 * ns * p.n_beliefs()))) { if (d_big) (void)hipFree(d_big); return rc; }
+  if ((rc = dev_alloc(e, &d_out, (size_t)3 * ns))) { (void)hipFree(d_contrib); if (d_big) (void)hipFree(d_big); return rc; }
+  if ((rc = dev_alloc(e, &d_inf, (size_t)ns))) { (void)hipFree(d_contrib); (void)hipFree(d_out); if (d_big) (void)hipFree(d_big); return rc; }
   std::vector<int32_t> inf(ns, 0x7fffffff);
   hipError_t herr = hipMemcpyAsync(d_inf, inf.data(), sizeof(int32_t) * ns, hipMemcpyHostToDevice, e->st);
   if (herr == hipSuccess) {
     launch_free_energy(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), e->d_boff, e->d_bdim, p.n_clusters,
-                       p.n_beliefs(), p.max_dim, e->layout_bs16 ? 1 : 0, p.fast_p, d_contrib, d_out, d_inf, ns, e->st);
+                       p.n_beliefs(), p.max_dim, e->layout_bs16 ? 1 : 0, p.fast_p, d_contrib, d_out, d_inf, ns, e->st, d_big,
+                       (int)big.size(), e->d_ws);
     herr = hipMemcpyAsync(out3, d_out, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost, e->st);
   }
   if (herr == hipSuccess) herr = hipMemcpyAsync(inf.data(), d_inf, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st);
   if (herr == hipSuccess) herr = hipStreamSynchronize(e->st);
   if (herr == hipSuccess) herr = hipGetLastError();
   (void)hipFree(d_contrib); (void)hipFree(d_out); (void)hipFree(d_inf);
+  if (d_big) (void)hipFree(d_big);
   if (herr != hipSuccess) return e->fail(PGBP_ERR_HIP, std::string("pgbp_free_energy: ") + hipGetErrorString(herr));
   if (info)
     for (int s = 0; s < ns; ++s) info[s] = inf[s] == 0x7fffffff ? 0 : inf[s];
@@ -1428,7 +1483,7 @@ int pgbp_enqueue_loglik_bm(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
     integrate_async(e, root, nullptr);  // :212
   }
-  return PGBP_OK;
+  return e->take_enqueue_rc();
 }
 
 // ---- device factor assignment (any linear-Gaussian model, trees and networks) ---------------------------
@@ -1632,7 +1687,7 @@ int pgbp_enqueue_loglik_lg(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) 
     const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
     integrate_async(e, root, nullptr);                                // :212
   }
-  return PGBP_OK;
+  return e->take_enqueue_rc();
 }
 
 // ---- benchmarking / zero-copy entry points ---------------------------------------------------
@@ -1675,7 +1730,7 @@ int pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, con
   DevState S = dev_state(e, opts);
   for (int r = 0; r < reps; ++r)
     if ((rc = enqueue_calibrate_once(e, S, reset_each, nullptr))) return rc;
-  return PGBP_OK;
+  return e->take_enqueue_rc();
 }
 
 static void drop_kernel_events(pgbp_engine* e) {
@@ -1715,7 +1770,7 @@ int pgbp_enqueue_calibrate_timed(pgbp_engine* e, int32_t reps, int32_t reset_eac
     HIPCHK(e, hipEventRecord(b, e->st));
   }
   e->kernel_launches = launches;
-  return PGBP_OK;
+  return e->take_enqueue_rc();
 }
 
 int pgbp_fetch_kernel_time(pgbp_engine* e, float* ms_kernels, int32_t* n_launches) {
@@ -1759,7 +1814,7 @@ int pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts) {
   DevState S = dev_state(e, opts);
   for (int r = 0; r < reps; ++r)
     if ((rc = enqueue_loglik_once(e, S))) return rc;
-  return PGBP_OK;
+  return e->take_enqueue_rc();
 }
 
 int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
@@ -1770,6 +1825,7 @@ int pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info) {
   if (info) HIPCHK(e, hipMemcpyAsync(info, e->d_info, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, e->st));
   HIPCHK(e, hipStreamSynchronize(e->st));
   HIPCHK(e, hipGetLastError());
+  if (const int erc = e->take_enqueue_rc()) return erc;
   if (info) {
     // a failed postorder message also invalidates the likelihood
     std::vector<unsigned long long> keys(ns);

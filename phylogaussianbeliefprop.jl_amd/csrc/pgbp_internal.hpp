@@ -118,11 +118,20 @@ constexpr int kFNoBlock = 4;       // accumulate task whose messages are all con
 constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = records per group of a level launch
 constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
 constexpr int kGenericMaxDim = 64;    // largest sender the wave-per-task generic kernel's lane grids handle
-constexpr int kChunkMaxTasks = 384;   // a level joins a chunk of fused levels if it has at most this many tasks, all fast-class
-constexpr int kChunkGenericMaxTasks = 768;  // ... of generic-class tasks (cfg5: 384 / 768 / 1 536 / 3 072 tasks: 1.559 / 1.541 / 1.552 / 1.690 ms join graph, 1.876 / 1.824 / 1.836 / 1.978 Bethe)
+// a message of the large-belief kernel (bp_level_big: descriptors with 32-bit dimensions): its sender is beyond the wave-per-task
+// kernel's lane grids, or its receiver beyond the byte fields of a GRec
+inline bool big_msg(const MsgDesc& m) { return m.mf > kGenericMaxDim || m.mt > 254; }
+constexpr int kChunkMaxTasks = 2400;  // a level joins a chunk of fused levels if it is all fast-class and has at most this many RECORDS (messages):
+                                      // with the trees of a chunk's forest packed into at most kChunkBins workgroups (round 4) a pass of the loop
+                                      // kernel holds up to 8 records per CU and the chip 2 048 per pass -- 7.6 us per fused level at that width
+                                      // against 11.8 - 14.5 us for the level's own launch (cfg3: 384 tasks / 768 / 1 200 / 1 700 / 2 400 / 3 400 / 5 000
+                                      // records: 0.840 / 0.823 / 0.831 / 0.836 / 0.811 - 0.832 / 0.831 / 0.807 ms; cfg2 0.331 / 0.321 / 0.317 / 0.317 /
+                                      // 0.313 / 0.313 / 0.313: flat from 2 400)
+constexpr int kChunkGenericMaxTasks = 1536;  // ... of generic-class tasks (round 4, trees packed into kChunkBins workgroups, cfg5 join graph: 768 / 1 536 / 3 072 tasks: 1.142 / 1.103 / 1.102 ms per iteration; unpacked 1.168; round 2, unpacked: 384 / 768 / 1 536 / 3 072: 1.559 / 1.541 / 1.552 / 1.690)
 constexpr int kChunkUniMaxThreads = 65536;  // ... of a batch of univariate sites (thread-per-site kernels): tasks x sites of a level that joins a chunk
 constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x (perm + mf x (mf + 1)) doubles of LDS per workgroup
 constexpr int kChunkDepth = 4;        // levels per chunk
+constexpr int kChunkBins = 256;       // workgroups of a chunk launch at most (one per CU): above that the trees of its forest share workgroups
 constexpr int kChunkGenericDepth = 6; // ... of generic-class tasks (cfg5 join graph, depth 3 / 4 / 6 / 8: 1.329 / 1.333 / 1.312 / 1.318 ms per iteration)
 constexpr int kSmall4MinTasks = 1024;  // level launches of small generic-class tasks: four tasks per wavefront (bp_level_small4) from this width; PGBP_SMALL4_MIN overrides, -1: never
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic

@@ -1871,14 +1871,21 @@ __device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int l
 
 // kb: columns of J_t per pass (m: one pass, the whole [J | J_t | h] at once; fewer when m x (2m + 1) doubles exceed the
 // LDS a workgroup may have: the elimination of J is then repeated per block of columns, mu kept from the first pass)
+// WS: the beliefs listed in big_idx (more than lds_max_m variables: their [J | J_t | h] does not fit a CU's LDS even a column
+// block at a time), one workgroup each, the working matrix in a workspace slab in global memory (the barriers of the
+// elimination order its accesses: same CU, same vector L1, as in bp_level_big<true>); the LDS instance skips those
+template <bool WS>
 __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restrict__ pool, int64_t pool_stride,
                                                          const double* __restrict__ fpool, int64_t fpool_stride,
                                                          const int64_t* __restrict__ boff,
                                                          const int32_t* __restrict__ dim, int n_clusters,
                                                          int n_beliefs, int bs, int fp, int kb_max,
-                                                         double2* __restrict__ contrib, int32_t* __restrict__ info) {
-  const int lane = threadIdx.x, b = blockIdx.x, site = blockIdx.y;
+                                                         double2* __restrict__ contrib, int32_t* __restrict__ info,
+                                                         const int32_t* __restrict__ big_idx, int lds_max_m,
+                                                         double* __restrict__ ws, int64_t ws_stride) {
+  const int lane = threadIdx.x, b = WS ? big_idx[blockIdx.x] : (int)blockIdx.x, site = blockIdx.y;
   const int m = dim[b];
+  if (!WS && m > lds_max_m) return;
   const bool is_cluster = b < n_clusters;
   const double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[b];
   const double* __restrict__ frec = fpool + (int64_t)site * fpool_stride + (is_cluster ? boff[b] : 0);
@@ -1889,10 +1896,10 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
     return;
   }
   const bool packed = bs && bs16::applies(m, fp);
-  const int kb = is_cluster ? (m < kb_max ? m : kb_max) : 0;   // columns of J_t per pass
+  const int kb = is_cluster ? ((WS || m < kb_max) ? m : kb_max) : 0;   // columns of J_t per pass (workspace: all of them)
   const int ld = (m + kb + 1) | 1;
-  double* W = lds;
-  double* mu = lds + (size_t)m * ld;                            // m doubles behind the working matrix
+  double* W = WS ? ws + ((int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y) * ws_stride : lds;
+  double* mu = W + (size_t)m * ld;                              // m doubles behind the working matrix
   double acc = 0.0, logdet = 0.0;
   for (int c0 = 0; c0 == 0 || c0 < (is_cluster ? m : 0); c0 += (kb > 0 ? kb : m)) {
     const int nb = is_cluster ? (m - c0 < kb ? m - c0 : kb) : 0;  // columns of J_t in this pass
@@ -1963,19 +1970,28 @@ __global__ __launch_bounds__(256) void free_energy_reduce_kernel(const double2* 
   }
 }
 
+int64_t free_energy_ws_doubles(int m) { return (int64_t)m * ((2 * m + 1) | 1) + m; }
+
 void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
                         const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
-                        int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st) {
-  const int mm = max_dim < 1 ? 1 : max_dim;
+                        int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st,
+                        const int32_t* d_big_idx, int n_big, double* d_ws) {
+  const int mm = max_dim < 1 ? 1 : (max_dim > kFreeEnergyLdsMaxDim ? kFreeEnergyLdsMaxDim : max_dim);
   // columns of J_t per pass: all of them while m x (2m + 1) + m doubles fit in 150 KB of LDS (m <= 96), else a block
   const size_t cap = 150 * 1024 / sizeof(double);
   int kb = mm;
   while (kb > 1 && (size_t)mm * (size_t)((mm + kb + 1) | 1) + (size_t)mm > cap) --kb;
   const size_t ldsb = sizeof(double) * ((size_t)mm * (size_t)((mm + kb + 1) | 1) + (size_t)mm);
-  allow_large_lds(reinterpret_cast<const void*>(free_energy_kernel), ldsb);
-  hipLaunchKernelGGL(free_energy_kernel, dim3(n_beliefs, n_sites), dim3(kWave), ldsb, st, pool, pool_stride, fpool,
+  allow_large_lds(reinterpret_cast<const void*>(free_energy_kernel<false>), ldsb);
+  hipLaunchKernelGGL(free_energy_kernel<false>, dim3(n_beliefs, n_sites), dim3(kWave), ldsb, st, pool, pool_stride, fpool,
                      fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p, kb,
-                     reinterpret_cast<double2*>(d_contrib), d_info);
+                     reinterpret_cast<double2*>(d_contrib), d_info, (const int32_t*)nullptr, kFreeEnergyLdsMaxDim,
+                     (double*)nullptr, (int64_t)0);
+  if (n_big > 0)   // beliefs above kFreeEnergyLdsMaxDim variables: n_big * n_sites slabs of free_energy_ws_doubles(max_dim)
+    hipLaunchKernelGGL(free_energy_kernel<true>, dim3(n_big, n_sites), dim3(kWave), 0, st, pool, pool_stride, fpool,
+                       fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p, max_dim,
+                       reinterpret_cast<double2*>(d_contrib), d_info, d_big_idx, kFreeEnergyLdsMaxDim, d_ws,
+                       free_energy_ws_doubles(max_dim));
   hipLaunchKernelGGL(free_energy_reduce_kernel, dim3(n_sites), dim3(256), 0, st,
                      reinterpret_cast<const double2*>(d_contrib), n_beliefs, d_out3);
 }
@@ -1992,15 +2008,21 @@ static int grid_for(int64_t n, int n_sites) {
 //   kl = ( -tr(J0^-1 dJ) + (mu1-mu0)' J1 (mu1-mu0) + logdet J0 - logdet J1 ) / 2
 // If J0 or J1 is not positive definite nothing is written (the reference returns false and leaves kldiv and
 // the flag alone).  Messages that did not run (failed / downstream of a failure) are skipped.
+// WS: the entries listed in big_ent (sepsets of more than kKlLdsMaxS variables), the two systems in a workspace slab in
+// global memory; the LDS instance skips those
+template <bool WS>
 __global__ __launch_bounds__(64) void residual_kldiv_kernel(DevState S, const Entry* __restrict__ entries, int e0,
                                                             double* __restrict__ kldiv, int32_t* __restrict__ klflags,
-                                                            unsigned long long stop_below) {
+                                                            unsigned long long stop_below,
+                                                            const int32_t* __restrict__ big_ent, double* __restrict__ ws,
+                                                            int64_t ws_stride) {
   const int lane = threadIdx.x, site = blockIdx.y;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
-  const int msg = entries[e0 + blockIdx.x].msg;
+  const int msg = entries[WS ? big_ent[blockIdx.x] : e0 + (int)blockIdx.x].msg;
   const MsgDesc m = S.msgs[msg];
   const int s = m.s;
   if (s == 0) return;  // empty message: calibrated from birth
+  if (!WS && s > kKlLdsMaxS) return;
   if (S.status[(int64_t)site * S.n_msgs + msg] != 0) return;
   if (S.poison[(int64_t)site * S.n_clusters + m.from_b] || S.poison[(int64_t)site * S.n_clusters + m.to_b]) return;
   const double* __restrict__ sep = S.pool + (int64_t)site * S.pool_stride + m.sep_off;
@@ -2020,8 +2042,8 @@ __global__ __launch_bounds__(64) void residual_kldiv_kernel(DevState S, const En
   auto dh = [&](int i) { return packed ? res[bs16::h_off(s, i, fp)] : res[(int64_t)s * s + i]; };
 
   const int nc0 = 2 * s + 1, ld0 = nc0 | 1;
-  double* W = lds;
-  double* vec = lds + (size_t)s * ld0;  // mu0, later mu1 - mu0
+  double* W = WS ? ws + ((int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y) * ws_stride : lds;
+  double* vec = W + (size_t)s * ld0;  // mu0, later mu1 - mu0
   for (int idx = lane; idx < s * s; idx += kWave) {
     const int j = idx / s, i = idx - j * s;
     W[i * ld0 + j] = Jm(i, j);
@@ -2062,13 +2084,20 @@ __global__ __launch_bounds__(64) void residual_kldiv_kernel(DevState S, const En
   }
 }
 
+int64_t kldiv_ws_doubles(int s) { return (int64_t)s * ((2 * s + 1) | 1) + s; }
+
 void launch_residual_kldiv(const DevState& S, const Entry* d_entries, int e0, int n_entries, int max_s, double* d_kldiv,
-                           int32_t* d_klflags, int n_sites, unsigned long long stop_below, hipStream_t st) {
+                           int32_t* d_klflags, int n_sites, unsigned long long stop_below, hipStream_t st,
+                           const int32_t* d_big_ent, int n_big, double* d_ws) {
   if (n_entries <= 0 || max_s <= 0) return;
-  const size_t ldsb = sizeof(double) * ((size_t)max_s * (size_t)((2 * max_s + 1) | 1) + (size_t)max_s);
-  allow_large_lds(reinterpret_cast<const void*>(residual_kldiv_kernel), ldsb);
-  hipLaunchKernelGGL(residual_kldiv_kernel, dim3(n_entries, n_sites), dim3(kWave), ldsb, st, S, d_entries, e0, d_kldiv,
-                     d_klflags, stop_below);
+  const int ms = max_s > kKlLdsMaxS ? kKlLdsMaxS : max_s;   // (the LDS a launch asks for: this level's largest sepset that fits)
+  const size_t ldsb = sizeof(double) * (size_t)kldiv_ws_doubles(ms);
+  allow_large_lds(reinterpret_cast<const void*>(residual_kldiv_kernel<false>), ldsb);
+  hipLaunchKernelGGL(residual_kldiv_kernel<false>, dim3(n_entries, n_sites), dim3(kWave), ldsb, st, S, d_entries, e0, d_kldiv,
+                     d_klflags, stop_below, (const int32_t*)nullptr, (double*)nullptr, (int64_t)0);
+  if (n_big > 0)   // sepsets above kKlLdsMaxS variables: n_big * n_sites slabs of kldiv_ws_doubles(max_s)
+    hipLaunchKernelGGL(residual_kldiv_kernel<true>, dim3(n_big, n_sites), dim3(kWave), 0, st, S, d_entries, e0, d_kldiv,
+                       d_klflags, stop_below, d_big_ent, d_ws, kldiv_ws_doubles(max_s));
 }
 
 // ---- regularizebeliefs_bycluster! (src/clustergraphbeliefs.jl:235-275) ------------------------------------

@@ -207,9 +207,14 @@ bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, 
                               const double* d_logdetR, const double* d_mu, int per_site, int bs16, int n_clusters,
                               int n_sites, hipStream_t st);
 
+// d_big_idx / n_big: the beliefs of more than kFreeEnergyLdsMaxDim variables (their working matrix in d_ws: n_big * n_sites
+// slabs of free_energy_ws_doubles(max_dim))
+constexpr int kFreeEnergyLdsMaxDim = 139;   // [J | one column of J_t | h] of a belief in 150 KB of LDS
+int64_t free_energy_ws_doubles(int m);
 void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
                         const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,
-                        int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st);
+                        int fast_p, double* d_contrib, double* d_out3, int32_t* d_info, int n_sites, hipStream_t st,
+                        const int32_t* d_big_idx = nullptr, int n_big = 0, double* d_ws = nullptr);
 
 // sm != 0: the arrays are in the site-minor order [message][site]
 void launch_reset_flags(const MsgDesc* msgs, int32_t* flags, int32_t* klflags, double* kldiv, int n_msgs, int n_sites,
@@ -218,8 +223,13 @@ void launch_transpose_words_i32(const int32_t* src, int32_t* dst, int n, int n_s
 void launch_transpose_words_f64(const double* src, double* dst, int n, int n_sites, int to_sm, hipStream_t st);
 
 // residual_kldiv! (src/beliefs.jl:1060-1075) for the messages entries[e0 .. e0+n_entries) just sent by a level
+// d_big_ent / n_big: the entries (absolute indices into d_entries) whose sepset has more than kKlLdsMaxS variables (their two
+// systems in d_ws: n_big * n_sites slabs of kldiv_ws_doubles(max_s))
+constexpr int kKlLdsMaxS = 96;   // [J0 | dJ | h0] of one sepset in a CU's LDS
+int64_t kldiv_ws_doubles(int s);
 void launch_residual_kldiv(const DevState& S, const Entry* d_entries, int e0, int n_entries, int max_s, double* d_kldiv,
-                           int32_t* d_klflags, int n_sites, unsigned long long stop_below, hipStream_t st);
+                           int32_t* d_klflags, int n_sites, unsigned long long stop_below, hipStream_t st,
+                           const int32_t* d_big_ent = nullptr, int n_big = 0, double* d_ws = nullptr);
 
 // regularizebeliefs_bycluster! (src/clustergraphbeliefs.jl:235-275), plain layout; d_eps: [n_sites][n_clusters] scratch
 void launch_regularize_bycluster(double* pool, int64_t pool_stride, const int64_t* d_boff, const int32_t* d_dim,

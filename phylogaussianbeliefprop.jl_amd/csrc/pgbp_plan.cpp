@@ -428,11 +428,12 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
       std::sort(slow.begin(), slow.end());
       fast.clear();
     }
-    // tasks with a sender of more than kGenericMaxDim variables go last: they run on bp_level_big
+    // tasks with a sender of more than kGenericMaxDim variables go last: they run on bp_level_big (and so do those whose
+    // receiver has more variables than a message record's byte fields hold: big_msg)
     {
       auto is_big = [&](int t) {
         for (int e = tr.task_off[t]; e < tr.task_off[t + 1]; ++e)
-          if (p.msgs[tr.entries[e].msg].mf > kGenericMaxDim) return true;
+          if (big_msg(p.msgs[tr.entries[e].msg])) return true;
         return false;
       };
       std::stable_partition(slow.begin(), slow.end(), [&](int t) { return !is_big(t); });
@@ -476,7 +477,7 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
           same_block = x.to_b == y.to_b && x.up0 == y.up0 && x.s == y.s && x.up0 >= 0;
         }
         bool task_is_big = false;
-        for (int e = e0; e < e1; ++e) task_is_big |= p.msgs[tr.entries[e].msg].mf > kGenericMaxDim;
+        for (int e = e0; e < e1; ++e) task_is_big |= big_msg(p.msgs[tr.entries[e].msg]);
         // A generic-class PREORDER task (one sender, a message to each of its children: different receivers, different
         // sepsets, the sender itself untouched) becomes one task per message: a wavefront works through its messages
         // one after the other at several microseconds each, and on the narrow levels that latency is the level's time.
@@ -673,7 +674,8 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     static const long long uni_env = [] { const char* v = getenv("PGBP_CHUNK_UNI_MAX_THREADS"); return v ? atoll(v) : -1ll; }();
     const long long uni_max = uni_env >= 0 ? uni_env : (long long)kChunkUniMaxThreads * (p.n_sites <= 1024 ? 4 : 1);
     if (uni) return nt > 0 && (long long)nt * p.n_sites <= uni_max;
-    return nt > 0 && nt <= (all_fast(L) ? max_tasks : max_tasks_generic) && tr.level_nbig[L] == 0 &&
+    // (register-resident levels are measured in RECORDS -- wavefront pairs of a pass --, wave-per-task ones in tasks)
+    return nt > 0 && (all_fast(L) ? tr.level_nrecs[L] <= max_tasks : nt <= max_tasks_generic) && tr.level_nbig[L] == 0 &&
            (all_fast(L) || (tr.level_nfast[L] == 0 && level_mf[L] <= kChunkGenericMaxMf));   // (a generic chunk walks message
            // records, which the fast-class tasks of a mixed level do not have)
   };
@@ -746,6 +748,49 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
           const int q = parent_task(t);
           wg_of[t] = q < 0 ? n_wg++ : wg_of[q];
         }
+    }
+    // PACKING: a launch wider than the chip is several generations of workgroups whose passes are mostly empty (a tree of
+    // a narrow chunk holds one to three tasks per level, a pass has room for kTailWaves records).  Above `bins` trees the
+    // trees share workgroups: largest first, each into the workgroup whose walk it lengthens least (passes = sum over the
+    // levels of ceil(slots / kTailWaves)), the emptier one on a tie.  A tree stays whole, so the launch is as dependency-
+    // closed as before; the chains of a walk (link_chains) are found on the merged walk like on any other.
+    {
+      static const int bins_env = [] { const char* v = getenv("PGBP_CHUNK_BINS"); return v ? atoi(v) : -1; }();
+      int bins = bins_env >= 0 ? bins_env : kChunkBins;
+      if (uni) bins = std::max(1, bins * 4 / std::max(1, (p.n_sites + 63) / 64));   // (workgroup = (walk, block of 64 sites), four per CU)
+      if (bins > 0 && n_wg > bins) {
+        const int nl = L1 - L0;
+        const bool by_task = uni || !all_fast(L0);
+        std::vector<int32_t> need((size_t)n_wg * nl, 0), total(n_wg, 0);
+        for (int L = L0; L < L1; ++L)
+          for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) {
+            const int w = by_task ? 1 : task_waves(tr, t);
+            need[(size_t)wg_of[t] * nl + (L - L0)] += w;
+            total[wg_of[t]] += w;
+          }
+        std::vector<int> by_size(n_wg);
+        for (int w = 0; w < n_wg; ++w) by_size[w] = w;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return total[x] > total[y]; });
+        std::vector<int32_t> load((size_t)bins * nl, 0), load_total(bins, 0), bin_of(n_wg, 0);
+        for (int w : by_size) {
+          int best = 0;
+          long best_passes = -1;
+          for (int b = 0; b < bins; ++b) {
+            long passes = 0;
+            for (int l = 0; l < nl; ++l) passes += (load[(size_t)b * nl + l] + need[(size_t)w * nl + l] + kTailWaves - 1) / kTailWaves;
+            if (best_passes < 0 || passes < best_passes || (passes == best_passes && load_total[b] < load_total[best])) {
+              best = b;
+              best_passes = passes;
+            }
+          }
+          bin_of[w] = best;
+          for (int l = 0; l < nl; ++l) load[(size_t)best * nl + l] += need[(size_t)w * nl + l];
+          load_total[best] += total[w];
+        }
+        for (int L = L0; L < L1; ++L)
+          for (int t = tr.level_off[L]; t < tr.level_off[L + 1]; ++t) wg_of[t] = bin_of[wg_of[t]];
+        n_wg = bins;   // (n_wg > bins trees, every one of them non-empty, emptiest workgroup first on a tie: none stays empty)
+      }
     }
     // per workgroup, per level: its tasks, in level order; groups of kTailWaves records (a task never straddles two)
     std::vector<std::vector<int>> tasks_of_wg(n_wg);

@@ -93,7 +93,7 @@ p2.scope_idx[:2] = p2.scope_idx[:2][::-1]
 pl, code, keep = plan(p2.dims, p2.sepset_clusters, p2.scope_off, p2.scope_idx)
 assert code != 0
 lib.pgbp_plan_destroy(pl)
-p3 = S.cliquetree_of_tree(tr, 125)   # dimension 250 > PGBP_MAX_DIM = 240
+p3 = S.cliquetree_of_tree(tr, 200)   # dimension 400 > PGBP_MAX_DIM = 384
 pl, code, keep = plan(p3.dims, p3.sepset_clusters, p3.scope_off, p3.scope_idx)
 assert code != 0
 lib.pgbp_plan_destroy(pl)

@@ -1686,3 +1686,53 @@ def test_first_failure_in_the_wave_per_task_kernels(P, p, where):
     cgb._upload(True)
     cgb.init_messagecalibrationflags_reset_()
     assert P.calibrate_(cgb, sched, 2) == (True, True)
+
+
+def test_lazy_write_back_equals_the_eager_pull_and_keeps_aliases(P):
+    """calibrate! updates the beliefs IN PLACE (src/calibration.jl:35-84; SURVEY.md section 8(b): callers hold aliases, e.g.
+    test_calibration.jl:141-161 reads b[6] after calibrating).  The host mirror moves nothing at the call: a belief's record
+    comes over at its first read (pgbp_get_belief), a residual's at its first read (pgbp_get_residual), the flag vectors on
+    demand.  Here: an alias taken BEFORE the call, a fresh index, a residual, a flag -- each equal, bit for bit, to what
+    the eager pull of a second engine on the same inputs holds; then an edit on the host followed by push() uploads the
+    edited record and nothing stale; a walk over every belief falls back to one transfer."""
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(11)
+    p = 3
+    tr = S.random_tree(60, rng)
+    R = S.random_rate_matrix(p, rng)
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    mk = lambda: P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    lazy, eager = mk(), mk()
+    eager.lazy = False
+    alias = lazy.belief[5]                       # held across the call
+    before = np.array(alias.J, copy=True)
+    assert P.calibrate_(lazy, prob.schedule, 1)[0] and P.calibrate_(eager, prob.schedule, 1)[0]
+    assert lazy._stale is not None and lazy._stale.all() and eager._stale is None
+    E = eager._packed_raw[0]
+    o = lazy._poff
+    m = int(prob.dims[5])
+    assert np.array_equal(np.asarray(alias.J).reshape(-1, order="F"), E[o[5]: o[5] + m * m]) and not np.array_equal(alias.J, before)
+    assert lazy._stale.sum() == lazy.nbeliefs - 1          # one record moved, nothing else
+    b9 = lazy.belief[9]
+    assert np.array_equal(b9.h, eager.belief[9].h) and np.array_equal(b9.g, eager.belief[9].g)
+    mr, mre = lazy.messageresidual[(int(prob.sepset_clusters[0]), int(prob.sepset_clusters[1]))], eager.messageresidual[(int(prob.sepset_clusters[0]), int(prob.sepset_clusters[1]))]
+    assert np.array_equal(mr.dJ, mre.dJ) and np.array_equal(mr.dh, mre.dh) and mr.iscalibrated_resid == mre.iscalibrated_resid
+    assert lazy._res_have.sum() == 1
+    assert lazy.iscalibrated_residnorm() == eager.iscalibrated_residnorm()
+    _, ll = lazy.integratebelief_(prob.root_cluster)
+    assert rel_close(ll, S.bm_loglik_pruning(tr, R, np.zeros(p), X))
+    # an edit on the host, then push(): the stale records are fetched first, the edit goes up, nothing old overwrites the device
+    lazy.belief[9].h[0] += 1.0
+    lazy.push()
+    assert lazy._stale is None
+    lazy.pull()
+    want = eager._packed_raw[0].copy()
+    want[o[9] + int(prob.dims[9]) ** 2] += 1.0
+    assert np.array_equal(lazy._packed_raw[0], want)
+    # a caller that walks over every belief: the mirror switches to one transfer
+    assert P.calibrate_(lazy, prob.schedule, 1)[0]
+    for i in range(lazy.nbeliefs):
+        lazy.belief[i].g
+    assert lazy._stale is None

@@ -165,9 +165,9 @@ def test_plan_rejects_bad_input():
     assert code == L.ERR_INVALID and b"strictly increasing" in lib.pgbp_plan_last_error(pl)
     lib.pgbp_plan_destroy(pl)
     # dimension above PGBP_MAX_DIM is refused, not silently mishandled
-    p3 = S.cliquetree_of_tree(tr, 125)         # internal cliques of dimension 250 > 240
+    p3 = S.cliquetree_of_tree(tr, 200)         # internal cliques of dimension 400 > 384
     lib, pl, code, keep = _plan(p3)
-    assert code == L.ERR_TOO_LARGE and b"PGBP_MAX_DIM=240" in lib.pgbp_plan_last_error(pl)
+    assert code == L.ERR_TOO_LARGE and b"PGBP_MAX_DIM=384" in lib.pgbp_plan_last_error(pl)
     lib.pgbp_plan_destroy(pl)
     lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 40))   # dimension 80: the large-belief kernel's range
     assert code == 0
@@ -997,7 +997,8 @@ def _chunks(lib, pl, tree, d):
                                                 (60, 16, "caterpillar", "cliquetree"), (900, 8, "random", "bethe"),
                                                 (400, 3, "poly4", "cliquetree"), (700, 4, "network", "joingraph"),
                                                 (500, 2, "network", "bethe"), (300, 3, "poly7", "cliquetree"),
-                                                (80, 16, "poly3", "cliquetree"), (120, 6, "poly7", "cliquetree")])
+                                                (80, 16, "poly3", "cliquetree"), (120, 6, "poly7", "cliquetree"),
+                                                (9000, 2, "random", "cliquetree"), (6000, 3, "network", "joingraph")])
 def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
     """Chunks of fused levels (build_chunks in pgbp_plan.cpp): replaying one calibrate iteration launch by launch --
     level launches, chunk launches (their workgroups in ANY order: checked forwards and backwards), the tail -- every
@@ -1048,7 +1049,7 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
         assert not grp[w:, 0].any()
         return tasks
 
-    n_chunk_launches = 0
+    n_chunk_launches = packed_launches = 0
     done = set()
     recv_order = {}
     for d in (0, 1):
@@ -1077,6 +1078,7 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                 assert want == got, "a chunk runs exactly the tasks of its levels"
                 launches.append([[tasks_of(g) for g in w] for w in wgs])
                 n_chunk_launches += 1
+                packed_launches += len(wgs) == 256 and min(lo[L + 1] - lo[L] for L in range(l0, l1)) > 256
                 Lv = l1
             else:
                 launches.append([[[[int(m) for m in em[to[t]:to[t + 1]]]] for t in range(lo[Lv], lo[Lv + 1])]])
@@ -1131,6 +1133,9 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
         assert len(msgs) == want and len(set(msgs)) == len(msgs)
     if ntips >= 800:
         assert n_chunk_launches >= 2
+    if ntips >= 6000:
+        # a forest of more trees than the chip has CUs: its trees share workgroups (kChunkBins), the launch stays closed
+        assert packed_launches >= 1
     lib.pgbp_plan_destroy(pl)
 
 
