@@ -361,6 +361,10 @@ int  pgbp_enqueue_calibrate(pgbp_engine* e, int32_t reps, int32_t reset_each, co
 /* Enqueue one log-likelihood evaluation body: reset from factors, postorder traversal of tree 0,
  * integrate the root cluster (src/calibration.jl:205-212 minus the host-side factor fill). The
  * per-site norms stay on the device until pgbp_fetch_loglik. */
+/* (after an evaluation in which a message of some site failed -- pgbp_fetch_loglik's info[site] != 0 -- the beliefs of THAT
+ * site are unspecified, as after a failed traversal of the reference, which stops at once and leaves its beliefs half
+ * updated (src/calibration.jl:129-132); in particular the sepsets of that site which the stopped postorder did not reach
+ * may still hold an earlier evaluation's values where the engine skipped their reset.  Other sites are unaffected.) */
 int  pgbp_enqueue_loglik(pgbp_engine* e, int32_t reps, const pgbp_opts* opts);
 int  pgbp_fetch_loglik(pgbp_engine* e, double* norm, int32_t* info);
 /* The whole body of score(theta) (src/calibration.jl:195-221) on the device: pgbp_bm_tree_assignfactors with
@@ -478,6 +482,14 @@ int  pgbp_comm_gather_loglik(pgbp_comm* c, pgbp_engine* e, int32_t slot_sites, d
  * touching the other ranks: a launcher takes the minimum of (status == 0) over its ranks and only then lets every rank
  * enter pgbp_comm_create -- a rank that fails there alone would leave its peers blocked inside ncclCommInitRank. */
 int  pgbp_comm_precheck(int32_t device);
+/* The exchange step of a cluster graph CUT across ranks (the loop of src/calibration.jl:46-47 with each traversal,
+ * src/calibration.jl:111-161, cut by spanning-tree subtrees: DESIGN.md section 6): rank r contributes the records (J, h, g;
+ * the packing of pgbp_get_belief) of the beliefs lists[list_off[r] .. list_off[r + 1]) of `site`; ONE ncclAllGather carries
+ * them, and every rank overwrites its copies of the other ranks' beliefs.  Every rank passes the same lists (the cut is a
+ * function of the schedule).  Device to device: the payload never visits the host.  include_self != 0: a rank also
+ * overwrites its own listed beliefs from its own slot (a self-test of the path on one rank). */
+int  pgbp_comm_exchange_beliefs(pgbp_comm* c, pgbp_engine* e, int32_t site, const int32_t* list_off, const int32_t* lists,
+                                int32_t include_self);
 /* The host-side half of pgbp_comm_gather_loglik on its own (no GPU, no RCCL): recv = the gathered buffer, n_ranks slots
  * of 2 * slot_sites + 2 doubles each, a slot = [norm (slot_sites) | info (slot_sites) | succ | iscal] as a rank packs it;
  * outputs as for pgbp_comm_gather_loglik. */

@@ -171,6 +171,7 @@ SYMBOLS = {
     "pgbp_comm_last_error": (C.c_char_p, [_P]),
     "pgbp_comm_gather_loglik": (C.c_int, [_P, _P, C.c_int32, _F64P, _I32P, _I32P, _I32P]),
     "pgbp_comm_precheck": (C.c_int, [C.c_int32]),
+    "pgbp_comm_exchange_beliefs": (C.c_int, [_P, _P, C.c_int32, _I32P, _I32P, C.c_int32]),
     "pgbp_comm_unpack_slots": (C.c_int, [_F64P, C.c_int32, C.c_int32, _F64P, _I32P, _I32P, _I32P]),
 }
 

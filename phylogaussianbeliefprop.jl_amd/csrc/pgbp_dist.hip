@@ -450,6 +450,8 @@ struct pgbp_comm {
   int32_t n_ranks = 1, rank = 0, device = 0;
   double* d_recv = nullptr;
   int64_t recv_cap = 0;
+  double* d_send = nullptr;    // send slot of pgbp_comm_exchange_beliefs
+  int64_t send_cap = 0;
   std::vector<double> h_recv;
   std::string err;
 };
@@ -544,6 +546,7 @@ void pgbp_comm_destroy(pgbp_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->d_send) (void)hipFree(c->d_send);
   if (c->comm) (void)rccl().comm_destroy(c->comm);
   delete c;
 }
@@ -589,6 +592,70 @@ int pgbp_comm_gather_loglik(pgbp_comm* c, pgbp_engine* e, int32_t slot_sites, do
   }
   const int urc = pgbp_comm_unpack_slots(c->h_recv.data(), c->n_ranks, slot_sites, norm_all, info_all, all_succ, all_iscal);
   if (urc) return urc;
+  return PGBP_OK;
+}
+
+// The exchange step of a cluster graph CUT across ranks (sharding.py: NetworkCut): rank r contributes
+// the records of the beliefs lists[list_off[r] .. list_off[r + 1]) of `site` -- gathered on ITS device into the send slot --,
+// ONE ncclAllGather (slot = the largest contribution) puts every rank's slot on every rank, and each rank scatters the other
+// ranks' records into its own engine.  No host copy of the payload; the engine's stream orders everything behind the
+// traversals that produced the records.  include_self != 0: a rank also scatters its own slot back (the single-rank test).
+int pgbp_comm_exchange_beliefs(pgbp_comm* c, pgbp_engine* e, int32_t site, const int32_t* list_off, const int32_t* lists,
+                               int32_t include_self) {
+  if (!c || !e || !list_off || (list_off[c->n_ranks] > 0 && !lists)) return PGBP_ERR_INVALID;
+  if (pgbp::engine_device(e) != c->device) {
+    c->err = "the engine lives on device " + std::to_string(pgbp::engine_device(e)) + ", the communicator on " +
+             std::to_string(c->device);
+    return PGBP_ERR_INVALID;
+  }
+  int64_t slot = 0;
+  std::vector<int64_t> size(c->n_ranks, 0);
+  for (int r = 0; r < c->n_ranks; ++r) {
+    const int32_t n = list_off[r + 1] - list_off[r];
+    if (n < 0) return PGBP_ERR_INVALID;
+    size[r] = n > 0 ? pgbp_packed_beliefs_size(e, n, lists + list_off[r]) : 0;
+    if (size[r] < 0) {
+      c->err = "pgbp_comm_exchange_beliefs: belief index out of range";
+      return PGBP_ERR_INVALID;
+    }
+    slot = std::max(slot, size[r]);
+  }
+  if (slot == 0) return PGBP_OK;
+  (void)hipSetDevice(c->device);
+  auto grow = [&](double** buf, int64_t* cap, int64_t need) {
+    if (need <= *cap) return true;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(buf), sizeof(double) * (size_t)need) != hipSuccess) return false;
+    *cap = need;
+    return true;
+  };
+  if (!grow(&c->d_send, &c->send_cap, slot) || !grow(&c->d_recv, &c->recv_cap, slot * c->n_ranks)) {
+    c->err = "hipMalloc of the exchange buffers failed";
+    return PGBP_ERR_HIP;
+  }
+  hipStream_t st = nullptr;
+  int rc = pgbp::engine_pack_records_device(e, site, list_off[c->rank + 1] - list_off[c->rank], lists + list_off[c->rank],
+                                            c->d_send, 1, &st, nullptr);
+  if (rc) {
+    c->err = pgbp_last_error(e);
+    return rc;
+  }
+  const ncclResult_t nrc = rccl().all_gather(c->d_send, c->d_recv, (size_t)slot, ncclFloat64, c->comm, st);
+  if (nrc != ncclSuccess) {
+    c->err = std::string("ncclAllGather: ") + rccl().error_string(nrc);
+    return PGBP_ERR_HIP;
+  }
+  for (int r = 0; r < c->n_ranks; ++r) {
+    if ((r == c->rank && !include_self) || size[r] == 0) continue;
+    rc = pgbp::engine_pack_records_device(e, site, list_off[r + 1] - list_off[r], lists + list_off[r],
+                                          c->d_recv + (int64_t)r * slot, 0, nullptr, nullptr);
+    if (rc) {
+      c->err = pgbp_last_error(e);
+      return rc;
+    }
+  }
   return PGBP_OK;
 }
 

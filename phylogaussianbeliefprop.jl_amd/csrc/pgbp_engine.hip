@@ -75,6 +75,7 @@ struct pgbp_engine {
   unsigned long long* d_fail = nullptr;
   int32_t* d_poison = nullptr;      // [n_sites][n_clusters]
   int32_t* d_iscal = nullptr;       // [n_sites]
+  int32_t* d_notcal = nullptr;      // [n_sites] DevState::notcal
   int32_t* d_iscal_hist = nullptr;  // [hist_cap][n_sites]
   int64_t hist_cap = 0;
   int64_t* d_boff = nullptr;        // record offset tables for pack/unpack
@@ -117,6 +118,7 @@ struct pgbp_engine {
   // pgbp_bm_tree: static description + last parameters of the device factor fill
   int32_t bm_p = 0, bm_rows = 0, bm_per_site = 0;
   int32_t *d_bm_kind = nullptr, *d_bm_row = nullptr;
+  double* d_bm_data_sm = nullptr;   // [row][site] copy of d_bm_data (p = 1)
   double *d_bm_length = nullptr, *d_bm_data = nullptr, *d_bm_Rinv = nullptr, *d_bm_logdet = nullptr, *d_bm_mu = nullptr;
   // pgbp_lg_families: static description + last parameters of the general linear-Gaussian factor fill
   LgStatic lg{};                  // device pointers (owned: lg_bufs)
@@ -232,6 +234,7 @@ DevState dev_state(pgbp_engine* e, const pgbp_opts* o) {
   S.packed_off = e->d_packed_off;
   S.rpacked_off = e->d_rpacked_off;
   S.sep_zero = 0;
+  S.notcal = nullptr;
   if (e->layout_sm) {
     S.pool = e->d_pool_sm;
     S.rpool = e->d_rpool_sm;
@@ -242,7 +245,8 @@ DevState dev_state(pgbp_engine* e, const pgbp_opts* o) {
 int reset_fail(pgbp_engine* e) {
   const size_t ns = (size_t)e->plan.n_sites;
   HIPCHK(e, hipMemsetAsync(e->d_fail, 0xFF, sizeof(unsigned long long) * ns, e->st));
-  HIPCHK(e, hipMemsetAsync(e->d_poison, 0, sizeof(int32_t) * ns * (size_t)e->plan.n_clusters, e->st));
+  // (either layout: the site-minor one has padded rows)
+  HIPCHK(e, hipMemsetAsync(e->d_poison, 0, sizeof(int32_t) * (size_t)sm_row(e->plan.n_sites) * (size_t)e->plan.n_clusters, e->st));
   return PGBP_OK;
 }
 
@@ -256,7 +260,7 @@ int reset_fail(pgbp_engine* e) {
 int ensure_site_minor(pgbp_engine* e, bool want) {
   const Plan& p = e->plan;
   if (want == e->layout_sm) return PGBP_OK;
-  const size_t ns = (size_t)p.n_sites;
+  const size_t ns = (size_t)sm_row(p.n_sites);   // (rows of the site-minor buffers: padded)
   if (want && !e->d_pool_sm) {
     int rc;
     if ((rc = dev_alloc(e, &e->d_pool_sm, ns * (size_t)p.packed_off.back()))) return rc;
@@ -289,8 +293,7 @@ int ensure_site_minor(pgbp_engine* e, bool want) {
 }
 
 bool want_site_minor(const pgbp_engine* e) {
-  static const bool disabled = getenv("PGBP_DISABLE_SITE_MINOR") != nullptr;  // A/B and debugging aid
-  return !disabled && e->plan.max_dim <= 2 && e->plan.n_sites >= 64;
+  return e->plan.tune.packed_layouts && e->plan.max_dim <= 2 && e->plan.n_sites >= 64;
 }
 
 int ensure_layout(pgbp_engine* e, bool want_bs16, bool want_sm = false) {
@@ -332,8 +335,7 @@ bool fresh_sepsets_shortcut(const pgbp_engine* e) {
 }
 
 bool want_bs16(const pgbp_engine* e) {
-  static const bool disabled = getenv("PGBP_DISABLE_BS16") != nullptr;  // A/B and debugging aid
-  return !disabled && e->plan.all_fast && e->plan.fast_p > 0 && e->plan.fast_p % 2 == 0;  // packed tiles: even P
+  return e->plan.tune.packed_layouts && e->plan.all_fast && e->plan.fast_p > 0 && e->plan.fast_p % 2 == 0;  // packed tiles: even P
 }
 
 void free_traversals(pgbp_engine* e) {
@@ -391,29 +393,10 @@ unsigned long long seq_stride(const pgbp_engine* e) {
   return 2ull * (mx + 1);
 }
 
-// Launch tuning read once from the environment (A/B runs and debugging; the defaults are what was measured best):
-//   PGBP_NO_TAIL=1     no single-workgroup tail launch: every level gets its own launch
-//   PGBP_LOOP=0        the loop launches (tail, chunks) of the packed layout on pgbp_fast.hip's loop mode (one wavefront
-//                      per record) instead of pgbp_loop.hip (two wavefronts per record -- one eliminates, one does
-//                      divide!, mult! and the stores --, sender operands requested half a pass early, what a pass hands
-//                      to the next one through LDS chain slots): bit-identical, 4 % slower on cfg3 and cfg2
-//                      
-struct LaunchTuning {
-  bool tail = true, loop = true;
-  LaunchTuning() {
-    if (const char* v = getenv("PGBP_LOOP")) loop = v[0] != '0';
-    if (getenv("PGBP_NO_TAIL")) tail = false;
-  }
-};
-const LaunchTuning& tuning() {
-  static const LaunchTuning t;
-  return t;
-}
-
 // how many levels at the root end of a traversal the tail launch takes over (0: none)
 int tail_levels(const pgbp_engine* e, const Traversal& tr, bool kl) {
   // residual_kldiv! runs between levels; the site-minor layout belongs to the thread-per-site kernel
-  if (kl || e->layout_sm || !tuning().tail) return 0;
+  if (kl || e->layout_sm || !e->plan.tune.tail) return 0;
   return tr.tail_levels;
 }
 
@@ -421,7 +404,7 @@ int tail_levels(const pgbp_engine* e, const Traversal& tr, bool kl) {
 void launch_loop_or_tail(pgbp_engine* e, const DevState& S, const FEntry* recs, const FPro* pros, int ngroups, int split,
                          unsigned long long seq_base, unsigned long long stop_a, unsigned long long stop_b,
                          const int32_t* d_wg_off, int n_wg) {
-  if (tuning().loop && S.bs16 && e->plan.fast_p % 2 == 0)
+  if (e->plan.tune.loop2 && S.bs16 && e->plan.fast_p % 2 == 0)
     launch_loop16(S, recs, pros, ngroups, split, e->plan.n_sites, seq_base, stop_a, stop_b, e->st, d_wg_off, n_wg);
   else
     launch_fast16(S, recs, pros, kFastTail, ngroups, split, e->plan.n_sites, seq_base, stop_a, stop_b, e->st, d_wg_off, n_wg);
@@ -432,7 +415,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
                     unsigned long long seq_base, unsigned long long stop_below, bool kl, int* launches) {
   const bool uni = e->plan.max_dim <= 2 && e->plan.n_sites >= 8;  // many tiny problems: lanes = sites (bp_level_uni / uni1)
   // (the loop mode of the thread-per-site kernels exists for sepsets of at most one variable: bp_chunk_uni1)
-  const bool chunks_on = !kl && tuning().tail && (uni ? e->max_s <= 1 : !e->layout_sm);
+  const bool chunks_on = !kl && e->plan.tune.tail && (uni ? e->max_s <= 1 : !e->layout_sm);
   size_t next_chunk = 0;
   for (int L = L0; L < L1; ++L) {
     if (chunks_on) {
@@ -465,7 +448,8 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
       const bool rows = d.d_rowmap && !tr.level_nrows.empty() && tr.level_nrows[L] > 0;
       launch_level_generic(S, d.d_grecs, tr.level_gbase[L], nt - nf - nbig, e->plan.n_sites, seq_base, stop_below,
                            tr.max_mf, nbig == 0 && tr.level_small[L] != 0, e->st,
-                           rows ? d.d_rowmap + 2 * tr.level_rowbase[L] : nullptr, rows ? tr.level_nrows[L] : 0);
+                           rows ? d.d_rowmap + 2 * tr.level_rowbase[L] : nullptr, rows ? tr.level_nrows[L] : 0,
+                           e->plan.tune.small4_min);
       if (nbig > 0) {
         if (ensure_ws(e, (int64_t)nbig * e->plan.n_sites * big_ws_doubles(tr.max_mf_big)) == PGBP_OK)
           launch_level_big(S, d.d_task_off, d.d_entries, t0 + nt - nbig, nbig, e->plan.n_sites, seq_base, stop_below,
@@ -516,6 +500,26 @@ void enqueue_tree(pgbp_engine* e, const DevState& S, int tree, int dirs, unsigne
   if (dirs & 2) enqueue_levels(e, S, T.pre, e->dpre[tree], nq, nlev_pre, seq_base, stop_pre, kl, n_launches);
 }
 
+// One iteration of calibrate! on one schedule tree (postorder + preorder) followed by iscalibrated_residnorm(beliefs) into
+// `d_out` [n_sites].  Thread-per-site engines whose tree holds every sepset: the message kernels mark the sites with a false
+// flag themselves (DevState::notcal) and the all-flags reduction is a kernel of n_sites threads instead of one over
+// n_sites x n_messages words.
+void enqueue_pair_and_iscal(pgbp_engine* e, const DevState& S, int tree, unsigned long long pair, bool kl, int32_t* d_out,
+                            int* n_launches = nullptr) {
+  const Plan& p = e->plan;
+  const bool fused = e->layout_sm && !kl && S.update_resnorm != 0 && (int)p.trees[tree].pa.size() == p.n_sepsets;
+  if (fused) {
+    (void)hipMemsetAsync(e->d_notcal, 0, sizeof(int32_t) * (size_t)p.n_sites, e->st);
+    DevState S1 = S;
+    S1.notcal = e->d_notcal;
+    enqueue_tree(e, S1, tree, 3, pair, kl, n_launches);
+    launch_iscal_from_notcal(e->d_notcal, d_out, p.n_sites, e->st);
+  } else {
+    enqueue_tree(e, S, tree, 3, pair, kl, n_launches);
+    launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, d_out, e->st, e->layout_sm ? 1 : 0);
+  }
+}
+
 // integratebelief! of one belief in whatever layout the state is in
 void integrate_async(pgbp_engine* e, int belief, double* d_mu) {
   const Plan& p = e->plan;
@@ -534,7 +538,7 @@ int reset_from_factors_async(pgbp_engine* e, bool skip_sepsets = false) {
   if (!e->have_factors) return e->fail(PGBP_ERR_STATE, "no factors: call pgbp_set_beliefs(snapshot) or pgbp_init_factors_frombeliefs first");
   const Plan& p = e->plan;
   if (e->layout_sm) {  // cluster elements come first and are contiguous over sites
-    const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
+    const int64_t nc = p.packed_off[p.n_clusters] * sm_row(p.n_sites), nall = p.packed_off.back() * sm_row(p.n_sites);
     HIPCHK(e, hipMemcpyAsync(e->d_pool_sm, e->d_fpool_sm, sizeof(double) * (size_t)nc, hipMemcpyDeviceToDevice, e->st));
     if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));
     return PGBP_OK;
@@ -585,7 +589,7 @@ void pgbp_destroy(pgbp_engine* e) {
   for (void* p : {(void*)e->d_pool, (void*)e->d_fpool, (void*)e->d_rpool, (void*)e->d_msgs, (void*)e->d_idx,
                   (void*)e->d_flags, (void*)e->d_status, (void*)e->d_kldiv, (void*)e->d_klflags, (void*)e->d_nb_off, (void*)e->d_nb_msg, (void*)e->d_sepcl, (void*)e->d_eps, (void*)e->d_thr, (void*)e->d_logtab, (void*)e->d_pool_sm, (void*)e->d_fpool_sm, (void*)e->d_rpool_sm, (void*)e->d_flags_alt, (void*)e->d_status_alt,
                   (void*)e->d_klflags_alt, (void*)e->d_poison_alt, (void*)e->d_kldiv_alt, (void*)e->d_fail, (void*)e->d_poison,
-                  (void*)e->d_iscal,
+                  (void*)e->d_iscal, (void*)e->d_notcal,
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
                   (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_one_rec, (void*)e->d_bdim, (void*)e->d_rdim,
@@ -600,6 +604,7 @@ void pgbp_destroy(pgbp_engine* e) {
   if (e->d_ws) (void)hipFree(e->d_ws);
   if (e->d_xbuf) (void)hipFree(e->d_xbuf);
   if (e->d_xoff) (void)hipFree(e->d_xoff);
+  if (e->d_bm_data_sm) (void)hipFree(e->d_bm_data_sm);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
 }
@@ -636,15 +641,17 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   const Plan& p = e->plan;
   const size_t ns = (size_t)p.n_sites;
   const size_t nm = (size_t)p.n_msgs();
+  const size_t nsw = (size_t)sm_row(p.n_sites);   // the per-message / per-cluster word arrays serve both layouts (a switch swaps
+                                                   // them with their twins): sized for the padded rows of the site-minor one
   if ((rc = dev_alloc(e, &e->d_pool, ns * p.pool_stride()))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_fpool, ns * p.cluster_stride()))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_rpool, ns * p.rpool_stride()))) return bail(rc);
   if ((rc = upload(e, &e->d_msgs, p.msgs))) return bail(rc);
   if ((rc = upload(e, &e->d_idx, p.idxpool))) return bail(rc);
-  if ((rc = dev_alloc(e, &e->d_flags, ns * nm))) return bail(rc);
-  if ((rc = dev_alloc(e, &e->d_status, ns * nm))) return bail(rc);
-  if ((rc = dev_alloc(e, &e->d_kldiv, ns * nm))) return bail(rc);
-  if ((rc = dev_alloc(e, &e->d_klflags, ns * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_flags, nsw * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_status, nsw * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_kldiv, nsw * nm))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_klflags, nsw * nm))) return bail(rc);
   {
     std::vector<int32_t> nb_off(p.n_clusters + 1, 0), nb_msg(nm);
     for (int k = 0; k < p.n_sepsets; ++k) {
@@ -676,8 +683,9 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
     }
   }
   if ((rc = dev_alloc(e, &e->d_fail, ns))) return bail(rc);
-  if ((rc = dev_alloc(e, &e->d_poison, ns * (size_t)p.n_clusters))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_poison, nsw * (size_t)p.n_clusters))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_iscal, ns))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_notcal, ns))) return bail(rc);
   if ((rc = upload(e, &e->d_boff, p.boff))) return bail(rc);
   if ((rc = upload(e, &e->d_packed_off, p.packed_off))) return bail(rc);
   if ((rc = upload(e, &e->d_roff, p.roff))) return bail(rc);
@@ -701,8 +709,11 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
   if (hipMemsetAsync(e->d_pool, 0, ns * p.pool_stride() * sizeof(double), e->st) != hipSuccess ||
       hipMemsetAsync(e->d_fpool, 0, ns * p.cluster_stride() * sizeof(double), e->st) != hipSuccess ||
       hipMemsetAsync(e->d_rpool, 0, ns * p.rpool_stride() * sizeof(double), e->st) != hipSuccess ||
-      hipMemsetAsync(e->d_status, 0, ns * nm * sizeof(int32_t), e->st) != hipSuccess ||
-      hipMemsetAsync(e->d_poison, 0, ns * (size_t)p.n_clusters * sizeof(int32_t), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_status, 0, nsw * nm * sizeof(int32_t), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_flags, 0, nsw * nm * sizeof(int32_t), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_klflags, 0, nsw * nm * sizeof(int32_t), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_kldiv, 0, nsw * nm * sizeof(double), e->st) != hipSuccess ||
+      hipMemsetAsync(e->d_poison, 0, nsw * (size_t)p.n_clusters * sizeof(int32_t), e->st) != hipSuccess ||
       hipMemsetAsync(e->d_fail, 0xFF, ns * sizeof(unsigned long long), e->st) != hipSuccess) {
     e->err = "hipMemsetAsync failed";
     return bail(PGBP_ERR_HIP);
@@ -738,7 +749,7 @@ int pgbp_init_factors_frombeliefs(pgbp_engine* e) {
   if (!e) return PGBP_ERR_INVALID;
   const Plan& p = e->plan;
   if (e->layout_sm)
-    HIPCHK(e, hipMemcpyAsync(e->d_fpool_sm, e->d_pool_sm, sizeof(double) * (size_t)p.packed_off[p.n_clusters] * p.n_sites,
+    HIPCHK(e, hipMemcpyAsync(e->d_fpool_sm, e->d_pool_sm, sizeof(double) * (size_t)p.packed_off[p.n_clusters] * (size_t)sm_row(p.n_sites),
                              hipMemcpyDeviceToDevice, e->st));
   else
     launch_copy_strided(e->d_pool, p.pool_stride(), e->d_fpool, p.cluster_stride(), p.cluster_stride(), p.n_sites,
@@ -1257,8 +1268,7 @@ int pgbp_calibrate(pgbp_engine* e, int32_t niter, const pgbp_opts* opts, pgbp_re
   for (int i = 0; i < niter && !stop; ++i) {
     for (int j = 0; j < nt && !stop; ++j) {
       const unsigned long long pair = (unsigned long long)i * nt + j;
-      enqueue_tree(e, S, j, 3, pair, kl);
-      launch_reduce_flags(e->d_flags, p.n_msgs(), ns, e->d_iscal_hist + pair * ns, e->st, e->layout_sm ? 1 : 0);
+      enqueue_pair_and_iscal(e, S, j, pair, kl, e->d_iscal_hist + pair * ns);
       ++pairs_done;
       if (!auto_stop) continue;
       launch_halt_if_calibrated(e->d_iscal_hist + pair * ns, e->d_fail, ((pair + 1) * stride - 1) << kInfoBits, ns, e->st);
@@ -1397,6 +1407,13 @@ int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
   const size_t nd = (size_t)p.n_sites * t->n_rows * t->p;
   if ((rc = dev_alloc(e, &e->d_bm_data, nd))) return rc;
   if (nd) HIPCHK(e, hipMemcpy(e->d_bm_data, t->data, nd * sizeof(double), hipMemcpyHostToDevice));
+  if (e->d_bm_data_sm) (void)hipFree(e->d_bm_data_sm);
+  e->d_bm_data_sm = nullptr;
+  if (t->p == 1 && t->n_rows > 0) {   // univariate batches: [row][site] copy for the thread-per-site fill
+    if ((rc = dev_alloc(e, &e->d_bm_data_sm, (size_t)t->n_rows * (size_t)sm_row(p.n_sites)))) return rc;
+    launch_transpose_words_f64(e->d_bm_data, e->d_bm_data_sm, t->n_rows, p.n_sites, 1, e->st);
+    HIPCHK(e, hipStreamSynchronize(e->st));
+  }
   if ((rc = dev_alloc(e, &e->d_bm_Rinv, (size_t)p.n_sites * t->p * t->p))) return rc;
   if ((rc = dev_alloc(e, &e->d_bm_logdet, (size_t)p.n_sites))) return rc;
   if ((rc = dev_alloc(e, &e->d_bm_mu, (size_t)p.n_sites * t->p))) return rc;
@@ -1411,9 +1428,9 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
   const Plan& p = e->plan;
   if (e->layout_sm && e->bm_p == 1) {  // univariate batch, site-minor state
     launch_bm_tree_fill_uni_sm(e->d_pool_sm, also_factors ? e->d_fpool_sm : nullptr, e->d_packed_off, e->d_bdim,
-                               e->d_bm_kind, e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->d_bm_Rinv,
+                               e->d_bm_kind, e->d_bm_length, e->d_bm_row, e->d_bm_data_sm, e->bm_rows, e->d_bm_Rinv,
                                e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, p.n_clusters, p.n_sites, e->st);
-    const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
+    const int64_t nc = p.packed_off[p.n_clusters] * sm_row(p.n_sites), nall = p.packed_off.back() * sm_row(p.n_sites);
     if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
     launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
     if (also_factors) e->have_factors = true;
@@ -1608,7 +1625,15 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
   if ((rc = dev_alloc(e, &e->d_lg_alpha, ns))) return rc;
   if ((rc = dev_alloc(e, &e->d_lg_theta, ns * pp))) return rc;
   if ((rc = dev_alloc(e, &e->d_lg_mu, ns * pp))) return rc;
-  e->lg = LgStatic{pp, K, f->n_rates, f->n_rows, d_off, d_fam, d_np, d_cp, d_row, d_pp, d_len, d_gam, d_col, d_data, d_cm, d_pm};
+  double* d_data_sm = nullptr;
+  if (uni_ok && f->n_rows > 0) {   // the thread-per-site fill reads the tip data with lanes = sites: keep a [row][site] copy
+    if ((rc = dev_alloc(e, &d_data_sm, (size_t)f->n_rows * (size_t)sm_row(p.n_sites)))) return rc;
+    keep(d_data_sm);
+    launch_transpose_words_f64(d_data, d_data_sm, f->n_rows, p.n_sites, 1, e->st);
+    HIPCHK(e, hipStreamSynchronize(e->st));
+  }
+  e->lg = LgStatic{pp, K, f->n_rates, f->n_rows, d_off, d_fam, d_np, d_cp, d_row, d_pp, d_len, d_gam, d_col, d_data, d_cm, d_pm,
+                   d_data_sm};
   e->lg_ready = true;
   e->lg_uni_ok = uni_ok;
   return PGBP_OK;
@@ -1621,7 +1646,7 @@ static int lg_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
   if (e->layout_sm && e->lg_uni_ok) {
     launch_lg_fill_uni_sm(e->lg, e->lgp, e->d_pool_sm, also_factors ? e->d_fpool_sm : nullptr, e->d_packed_off, e->d_bdim,
                           p.n_clusters, p.n_sites, e->st);
-    const int64_t nc = p.packed_off[p.n_clusters] * (int64_t)p.n_sites, nall = p.packed_off.back() * (int64_t)p.n_sites;
+    const int64_t nc = p.packed_off[p.n_clusters] * sm_row(p.n_sites), nall = p.packed_off.back() * sm_row(p.n_sites);
     if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
   } else {
     if (e->layout_sm) {
@@ -1709,12 +1734,11 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
       HIPCHK(e, hipEventCreate(&b));
       HIPCHK(e, hipEventRecord(a, e->st));
     }
-    enqueue_tree(e, S, j, 3, (unsigned long long)j, false, n_launches);
+    enqueue_pair_and_iscal(e, S, j, (unsigned long long)j, false, e->d_iscal, n_launches);
     if (ev) {
       HIPCHK(e, hipEventRecord(b, e->st));
       ev->push_back({a, b});
     }
-    launch_reduce_flags(e->d_flags, p.n_msgs(), p.n_sites, e->d_iscal, e->st, e->layout_sm ? 1 : 0);
   }
   return PGBP_OK;
 }
@@ -1925,6 +1949,24 @@ int engine_pack_gather_slot(pgbp_engine* e, int32_t slot_sites, double** d_slot,
   *d_slot = e->d_gather;
   *st = e->st;
   if (n_sites) *n_sites = ns;
+  return PGBP_OK;
+}
+// the records of the listed beliefs of one site <-> a device buffer of the CALLER (pgbp_comm's send slot / a rank's part of
+// its receive buffer), on the engine's stream: the device halves of pgbp_pack_beliefs / pgbp_unpack_beliefs
+int engine_pack_records_device(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, double* d_buf, int to_buf,
+                               hipStream_t* st, int64_t* total) {
+  if (!e || n < 0 || (n > 0 && (!beliefs || !d_buf))) return PGBP_ERR_INVALID;
+  DeviceScope device_scope(e);
+  int64_t tot = 0;
+  int rc = xbuf_prepare(e, site, n, beliefs, &tot);
+  if (rc) return rc;
+  if (n > 0) {
+    if (!to_buf) e->sym_known = false;
+    launch_pack_records(e->d_pool + (int64_t)site * e->plan.pool_stride(), e->d_xoff, e->d_xoff + n, n, d_buf, to_buf, e->st);
+    HIPCHK(e, hipGetLastError());
+  }
+  if (st) *st = e->st;
+  if (total) *total = tot;
   return PGBP_OK;
 }
 int engine_fail(pgbp_engine* e, int code, const std::string& msg) { return e->fail(code, msg); }

@@ -11,6 +11,15 @@
 namespace pgbp {
 
 constexpr int kRecAlign = 16;  // records padded to 16 doubles = 128 B (one L2 line)
+// site-minor layout: element t of belief b of site s at pool[(packed_off[b] + t) * sm_row(n_sites) + s] -- the row of one
+// element padded to 32 entries, so that every row of doubles (and of 32-bit words) starts on a 128-byte line whatever the number
+// of sites: with 1 000 sites (a rank's share of cfg4 at 8 GPUs) the unpadded rows of 8 000 bytes start mid-line and every
+// wavefront's 512-byte access touches five lines instead of four (measured: 6.19 us per problem and sharded step at 1 000
+// problems against 5.70 at 1 008 and 5.69 at 1 024: profiles/r04_cfg4_row_alignment.txt)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int64_t sm_row(int64_t n_sites) { return (n_sites + 31) / 32 * 32; }
 constexpr int kWave = 64;
 
 // One directed message (sepset k, direction dir); static for the life of the engine.
@@ -133,13 +142,35 @@ constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x 
 constexpr int kChunkDepth = 4;        // levels per chunk
 constexpr int kChunkBins = 256;       // workgroups of a chunk launch at most (one per CU): above that the trees of its forest share workgroups
 constexpr int kChunkGenericDepth = 6; // ... of generic-class tasks (cfg5 join graph, depth 3 / 4 / 6 / 8: 1.329 / 1.333 / 1.312 / 1.318 ms per iteration)
-constexpr int kSmall4MinTasks = 1024;  // level launches of small generic-class tasks: four tasks per wavefront (bp_level_small4) from this width; PGBP_SMALL4_MIN overrides, -1: never
+constexpr int kSmall4MinTasksDefault = 1024;  // level launches of small generic-class tasks: four tasks per wavefront (bp_level_small4) from this width; PGBP_TUNING small4_min=n overrides, -1: never
 constexpr size_t kMixedLevelFastMin = 2048;  // fewer fast-class tasks than this in a level that also has generic ones: all generic
 constexpr size_t kMixedLevelFastMinNarrow = (size_t)1 << 30;  // ... where the sepsets have at most 4 variables: never split.  The register-resident
                                                    // kernel's instance works on 4 lanes of 64 there; with bp_level_small4 (four tasks per wavefront) the
                                                    // whole level in one launch is the faster (cfg5 on the same box, split from 8 192 / never: join
                                                    // graph 1.382 / 1.366, Bethe 1.579 / 1.534 ms per iteration; before small4: 2 048 / 8 192 / never =
                                                    // 1.817 / 1.780 / 1.787)
+
+// Launch tuning of ONE plan / engine, read ONCE when the plan is built (plan_build) from the single environment variable
+// PGBP_TUNING -- comma-separated `key` or `key=value` tokens -- and carried in the plan: what the differential fuzz of the
+// launch modes switches (tests/test_gpu_parity.py), plus the few numeric thresholds worth re-sweeping on other trees.
+// Everything else that used to be an environment switch of a finished experiment is gone (DESIGN.md section 4 keeps
+// the measurements).  Unknown tokens are an error of pgbp_create / pgbp_plan_create.
+struct Tuning {
+  bool tail = true;            // no_tail: no single-workgroup tail and no chunks: one launch per level
+  bool chunks = true;          // no_chunks: no chunks of fused levels
+  bool prologues = true;       // no_prologue: Bethe graphs of trees on the two-level schedule (no prologue fusion)
+  bool chain_fusion = false;   // chain_fusion: unary clusters passed through inside one task of the wave-per-task kernel (opt-in)
+  bool loop2 = true;           // loop=0: tail and chunks of the packed layout on bp_fast16's own loop mode (one wavefront per record)
+  bool packed_layouts = true;  // plain_layout: keep the ABI's record layout on the device (no BS16, no site-minor)
+  long long mixed_fast_min = -1;   // mixed_fast_min=n: a level with both task classes splits from n fast-class tasks on (-1: default)
+  int small4_min = kSmall4MinTasksDefault;   // small4_min=n: four tasks per wavefront from n tasks on (-1: never)
+  int chunk_bins = -1;         // chunk_bins=n: workgroups of a chunk launch at most (0: one per tree of its forest; -1: kChunkBins)
+  int chunk_max_recs = -1, chunk_max_tasks = -1;   // chunk_max_recs / chunk_max_tasks=n: widest fused level (-1: defaults)
+  long long chunk_uni_max = -1;   // chunk_uni_max=n: site batches: a level joins a chunk while tasks x sites <= n
+  int chunk_depth = -1, chunk_depth_generic = -1;   // chunk_depth / chunk_depth_generic=n: levels per chunk (-1: kChunkDepth / kChunkGenericDepth)
+};
+// parses PGBP_TUNING; false + message on an unknown token
+bool read_tuning(Tuning& t, std::string& err);
 
 struct Traversal {
   std::vector<int32_t> level_off;  // [n_levels+1] -> tasks; inside a level the fast-class tasks come first
@@ -216,6 +247,7 @@ struct Plan {
   std::vector<int32_t> idxpool;
   std::vector<Tree> trees;
   int32_t max_dim = 0;
+  Tuning tune;         // PGBP_TUNING as read when the plan was built
   int32_t fast_p = 0;  // sepset dimension the register-resident kernel is instantiated for (0: none)
   bool all_fast = false;  // every task of every scheduled traversal runs on the register-resident kernel
   std::string err;

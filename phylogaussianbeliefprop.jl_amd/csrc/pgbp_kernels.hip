@@ -849,7 +849,11 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
     const int4 w8 = *reinterpret_cast<const int4*>(rb + 32);              // msg, seq, from_b, to_b
     const int next = *reinterpret_cast<const int*>(rb + 60);
     const uint2 df = *reinterpret_cast<const uint2*>(rb + 64);            // dims, flags
-    const ulonglong2 pw = *reinterpret_cast<const ulonglong2*>(rb + offsetof(GRec, perm));   // perm[0 .. 15]
+    // perm[0 .. 15]: the field sits at byte 72 of the record -- 8-byte aligned, not 16: two 8-byte loads, not one 16-byte load
+    // through a pointer that promises an alignment the address does not have
+    ulonglong2 pw;
+    pw.x = *reinterpret_cast<const unsigned long long*>(rb + offsetof(GRec, perm));
+    pw.y = *reinterpret_cast<const unsigned long long*>(rb + offsetof(GRec, perm) + 8);
     const unsigned long long uw = *reinterpret_cast<const unsigned long long*>(rb + offsetof(GRec, up));   // up[0 .. 7]
     int touch = 0;   // the next record of the task: its line requested now, read at the top of the next turn
     if (!ROWS && next >= 0) touch = *reinterpret_cast<const int*>(recs + next);
@@ -1280,7 +1284,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   // element t of a belief / residual record: plain (this site's pool + padded offset) or site-minor (SM: lanes =
   // consecutive sites read consecutive doubles)
-  const int64_t ns = S.n_sites;
+  const int64_t ns = sm_row(S.n_sites);   // (row stride of the site-minor layout)
   auto bel = [&](int b, int64_t plain_off, int t) -> double* {
     if constexpr (SM) return S.pool + (S.packed_off[b] + t) * ns + site;
     else return pool + plain_off + t;
@@ -1429,6 +1433,7 @@ __global__ __launch_bounds__(256) void bp_level_uni(DevState S, const int32_t* _
     if (S.update_resnorm) {
       const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
       *mword(S.flags, en.msg) = ok ? 1 : 0;
+      if (!ok && S.notcal) S.notcal[site] = 1;
     }
   }
 }
@@ -1444,7 +1449,7 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
                                           unsigned long long seq_base) {
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
-  const int64_t ns = S.n_sites;
+  const int64_t ns = sm_row(S.n_sites);   // (row stride of the site-minor layout)
   auto bel = [&](int64_t packed, int64_t plain_off, int t) -> double* {
     if constexpr (SM) return S.pool + (packed + t) * ns + site;
     else return pool + plain_off + t;
@@ -1555,6 +1560,7 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
     if (S.update_resnorm) {
       const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
       *mword(S.flags, m.msg) = ok ? 1 : 0;
+      if (!ok && S.notcal) S.notcal[site] = 1;   // (every writer stores the same 1: no atomic)
     }
   }
 }
@@ -1625,15 +1631,11 @@ size_t generic_lds_bytes(int max_mf) {
 
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
                           unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
-                          hipStream_t st, const int32_t* d_rowmap, int n_rows) {
+                          hipStream_t st, const int32_t* d_rowmap, int n_rows, int small4_min) {
   if (ntasks <= 0) return;
   // four tasks per wavefront from the width at which a level is bound by instruction issue, not by one message's latency
-  static const int small4_min = [] {
-    const char* v = std::getenv("PGBP_SMALL4_MIN");
-    return v ? std::atoi(v) : kSmall4MinTasks;
-  }();
-  static const bool rows_on = std::getenv("PGBP_NO_ROWS") == nullptr;
-  if (small_only && small4_min >= 0 && ntasks >= small4_min && d_rowmap && n_rows > 0 && rows_on)
+  // (small4_min: Tuning::small4_min of the engine's plan)
+  if (small_only && small4_min >= 0 && ntasks >= small4_min && d_rowmap && n_rows > 0)
     hipLaunchKernelGGL(bp_level_small4<true>, dim3(n_rows / 4, n_sites), dim3(kWave), 0, st, S, d_recs, rec0, n_rows, d_rowmap,
                        seq_base, stop_below);
   else if (small_only && small4_min >= 0 && ntasks >= small4_min)
@@ -2267,8 +2269,8 @@ __global__ __launch_bounds__(256) void site_minor_kernel(double* __restrict__ pl
     const int64_t p0 = poff[r], len = poff[r + 1] - p0;
     double* __restrict__ rec = plain + (int64_t)site * plain_stride + off[r];
     for (int64_t t = 0; t < len; ++t) {
-      if (to_sm) sm[(p0 + t) * n_sites + site] = rec[t];
-      else rec[t] = sm[(p0 + t) * n_sites + site];
+      if (to_sm) sm[(p0 + t) * sm_row(n_sites) + site] = rec[t];
+      else rec[t] = sm[(p0 + t) * sm_row(n_sites) + site];
     }
   }
 }
@@ -2289,7 +2291,7 @@ __global__ __launch_bounds__(256) void integrate_sm_kernel(const double* __restr
                                                            int n_sites) {
   const int site = blockIdx.x * blockDim.x + threadIdx.x;
   if (site >= n_sites) return;
-  const int64_t ns = n_sites;
+  const int64_t ns = sm_row(n_sites);
   auto E = [&](int t) { return pool[(p0 + t) * ns + site]; };
   double g = E(m * m + m);
   int bad = 0;
@@ -2341,7 +2343,7 @@ __global__ __launch_bounds__(256) void bm_tree_fill_uni_sm_kernel(double* __rest
                                                                   int n_clusters, int n_sites) {
   const int site = blockIdx.y * blockDim.x + threadIdx.x;
   if (site >= n_sites) return;
-  const int64_t ns = n_sites;
+  const int64_t ns = sm_row(n_sites);
   const double rinv = Rinv_all[per_site ? site : 0], mu = mu_all[per_site ? site : 0];
   const double g_base = -0.5 * (PGBP_LOG2PI + logdetR_all[per_site ? site : 0]);
   for (int c = blockIdx.x; c < n_clusters; c += gridDim.x) {
@@ -2354,7 +2356,7 @@ __global__ __launch_bounds__(256) void bm_tree_fill_uni_sm_kernel(double* __rest
       double g = g_base - 0.5 * log(length[c]);
       double x = 0.0;
       if (k >= 1) {
-        x = (k >= 2) ? data[((int64_t)site * n_rows + row[c])] : mu;
+        x = (k >= 2) ? data[(int64_t)row[c] * ns + site] : mu;   // (tip data as [row][site]: a wavefront reads one line, not 64)
         if (k == 3) x -= mu;
         g -= 0.5 * j * x * x;
       }
@@ -2509,7 +2511,7 @@ __global__ __launch_bounds__(256) void reset_flags_sm_kernel(const MsgDesc* __re
   if (site >= n_sites) return;
   for (int d = blockIdx.x; d < n_msgs; d += gridDim.x) {
     const bool empty = msgs[d].s == 0;
-    const int64_t o = (int64_t)d * n_sites + site;
+    const int64_t o = (int64_t)d * sm_row(n_sites) + site;
     flags[o] = empty ? 1 : 0;
     klflags[o] = empty ? 1 : 0;
     if (empty) kldiv[o] = 0.0;
@@ -2547,7 +2549,7 @@ __global__ __launch_bounds__(256) void reduce_flags_sm_kernel(const int32_t* __r
   const int site = blockIdx.y * blockDim.x + threadIdx.x;
   if (site >= n_sites) return;
   int bad = 0;
-  for (int d = blockIdx.x; d < n_msgs; d += gridDim.x) bad |= (flags[(int64_t)d * n_sites + site] == 0);
+  for (int d = blockIdx.x; d < n_msgs; d += gridDim.x) bad |= (flags[(int64_t)d * sm_row(n_sites) + site] == 0);
   if (bad) iscal[site] = 0;
 }
 
@@ -2562,6 +2564,14 @@ __global__ void halt_if_calibrated_kernel(const int32_t* __restrict__ iscal, uns
 void launch_halt_if_calibrated(const int32_t* d_iscal, unsigned long long* d_fail, unsigned long long key, int n_sites,
                                hipStream_t st) {
   hipLaunchKernelGGL(halt_if_calibrated_kernel, dim3((n_sites + 63) / 64), dim3(64), 0, st, d_iscal, d_fail, key, n_sites);
+}
+
+__global__ void iscal_from_notcal_kernel(const int32_t* __restrict__ notcal, int32_t* __restrict__ iscal, int n_sites) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n_sites) iscal[s] = notcal[s] == 0 ? 1 : 0;
+}
+void launch_iscal_from_notcal(const int32_t* d_notcal, int32_t* d_iscal, int n_sites, hipStream_t st) {
+  hipLaunchKernelGGL(iscal_from_notcal_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, st, d_notcal, d_iscal, n_sites);
 }
 
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st, int sm) {
@@ -2585,7 +2595,7 @@ __global__ __launch_bounds__(256) void transpose_words_kernel(const T* __restric
   const int site = blockIdx.y * blockDim.x + threadIdx.x;
   if (site >= n_sites) return;
   for (int d = blockIdx.x; d < n; d += gridDim.x) {
-    const int64_t a = (int64_t)site * n + d, b = (int64_t)d * n_sites + site;
+    const int64_t a = (int64_t)site * n + d, b = (int64_t)d * sm_row(n_sites) + site;
     if (to_sm) dst[b] = src[a];
     else dst[a] = src[b];
   }

@@ -42,6 +42,11 @@ struct DevState {
   int32_t n_sites;
   const int64_t* packed_off;
   const int64_t* rpacked_off;
+  // thread-per-site kernels only, may be null: notcal[site] is set by a message whose residual-norm flag comes out false.  When
+  // a postorder + preorder pair over a spanning tree that holds EVERY sepset has run (each of the 2 n_sepsets flags rewritten
+  // once), iscalibrated_residnorm(beliefs) (src/clustergraphbeliefs.jl:168-169) of a site is "no message set the mark": the
+  // engine then skips the reduction over the flag array (80 M words per calibrate of a 1 000-site batch on a 20 000-tip tree)
+  int32_t* notcal;
   // every sepset this launch touches is known to hold the constant 1 (J = h = g = 0: straight after a reset, in a
   // postorder that overwrites all of them): the register-resident kernel then does not read them
   int32_t sep_zero;
@@ -84,7 +89,8 @@ __device__ __forceinline__ double log_by_table(const double2* __restrict__ tab, 
 // one message per row with mult! in task order (bp_level_small4<true>)
 void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int ntasks, int n_sites,
                           unsigned long long seq_base, unsigned long long stop_below, int max_mf, bool small_only,
-                          hipStream_t st, const int32_t* d_rowmap = nullptr, int n_rows = 0);
+                          hipStream_t st, const int32_t* d_rowmap = nullptr, int n_rows = 0,
+                          int small4_min = kSmall4MinTasksDefault);
 
 // loop mode of the generic task body: n_wg workgroups of kTailWaves wavefronts, workgroup b walks the groups
 // [d_wg_off[b], d_wg_off[b + 1]) of kTailWaves first records of tasks (-1: none) with a workgroup barrier in between
@@ -155,6 +161,7 @@ void launch_integrate_sm(const double* pool_sm, int64_t packed_off_b, int m, dou
                          int32_t* d_info, int n_sites, hipStream_t st);
 // assignfactors! for a univariate BM on a tree (pgbp_bm_tree, p = 1) straight into the site-minor layout;
 // fpool_sm may be null (beliefs only)
+// (d_data: [row][site], rows padded to sm_row(n_sites): the transposed copy the engine keeps for this kernel)
 void launch_bm_tree_fill_uni_sm(double* pool_sm, double* fpool_sm, const int64_t* d_poff, const int32_t* d_dim,
                                 const int32_t* d_kind, const double* d_length, const int32_t* d_row, const double* d_data,
                                 int n_rows, const double* d_Rinv, const double* d_logdetR, const double* d_mu, int per_site,
@@ -183,6 +190,7 @@ struct LgStatic {
   const int32_t* color;
   const double* data;
   const unsigned long long *child_mask, *parent_mask;  // null: complete data
+  const double* data_sm;   // univariate batches: the tip data once more as [row][site] (rows padded: sm_row), lanes = sites read a line
 };
 struct LgParams {
   int32_t model, per_site;
@@ -237,6 +245,8 @@ void launch_regularize_bycluster(double* pool, int64_t pool_stride, const int64_
                                  const int32_t* d_idx, const int32_t* d_sepcl, double* d_eps, int n_clusters,
                                  int n_sepsets, int n_sites, hipStream_t st);
 void launch_reduce_flags(const int32_t* flags, int n_msgs, int n_sites, int32_t* d_iscal, hipStream_t st, int sm = 0);
+// iscal[site] = notcal[site] == 0 (DevState::notcal)
+void launch_iscal_from_notcal(const int32_t* d_notcal, int32_t* d_iscal, int n_sites, hipStream_t st);
 // fail[site] = min(fail[site], key) where iscal[site] != 0 (key carries info = 0: a halt, not a failure)
 void launch_halt_if_calibrated(const int32_t* d_iscal, unsigned long long* d_fail, unsigned long long key, int n_sites,
                                hipStream_t st);
@@ -245,6 +255,8 @@ __host__ __device__ inline bool is_failure_key(unsigned long long key) { return 
 
 // engine internals used by pgbp_dist.hip (defined in pgbp_engine.hip)
 int engine_pack_gather_slot(pgbp_engine* e, int32_t slot_sites, double** d_slot, hipStream_t* st, int32_t* n_sites);
+int engine_pack_records_device(pgbp_engine* e, int32_t site, int32_t n, const int32_t* beliefs, double* d_buf, int to_buf,
+                               hipStream_t* st, int64_t* total);
 int engine_fail(pgbp_engine* e, int code, const std::string& msg);
 int engine_device(const pgbp_engine* e);
 int engine_n_sites(const pgbp_engine* e);

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void lg_fill_uni_sm_kernel(LgStatic F, LgParam
                                                              const int32_t* __restrict__ dim, int n_clusters, int n_sites) {
   const int site = blockIdx.y * blockDim.x + threadIdx.x;
   if (site >= n_sites) return;
-  const int64_t ns = n_sites, ps = M.per_site ? site : 0;
+  const int64_t ns = sm_row(n_sites), ps = M.per_site ? site : 0;
   const int K = F.K;
   const double* __restrict__ R = M.R + ps * F.n_rates;
   const double mu = M.mu[ps];
@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void lg_fill_uni_sm_kernel(LgStatic F, LgParam
       const int np = F.n_parents[f], cpos = F.child_pos[f];
       if (F.child_mask && !(F.child_mask[f] & 1ull)) continue;   // the trait is missing / out of scope below: factor = 1
       double V = 0.0, z = 0.0;
+      // q_k of the first parents, kept from the one evaluation of the edge coefficients (an exp() each under the OU model:
+      // they were worked out four times per tree-edge family, and the fill took three times what its stores need)
+      double qk0 = 0.0, qk1 = 0.0, qk2 = 0.0, qk3 = 0.0;
       if (np == 0) {
         V = R[F.color[(int64_t)f * K]];
         z = mu;
@@ -254,9 +257,19 @@ __global__ __launch_bounds__(256) void lg_fill_uni_sm_kernel(LgStatic F, LgParam
           V += vc * R[F.color[(int64_t)f * K + k]];
           z += wc * theta;
           if (F.parent_pos[(int64_t)f * K + k] < 0) z += qc * mu;
+          if (k == 0) qk0 = qc; else if (k == 1) qk1 = qc; else if (k == 2) qk2 = qc; else if (k == 3) qk3 = qc;
         }
-        if (cpos < 0) z -= F.data[(int64_t)site * F.n_rows + F.data_row[f]];
+        if (cpos < 0) z -= F.data_sm[(int64_t)F.data_row[f] * ns + site];   // ([row][site]: one line per wavefront, not 64)
       }
+      auto q_of = [&](int k) -> double {   // (the same value lg_coefs returns: same inputs, same expression)
+        if (k == 0) return qk0;
+        if (k == 1) return qk1;
+        if (k == 2) return qk2;
+        if (k == 3) return qk3;
+        double qc, vc, wc;
+        lg_coefs(M.model, alpha, F.length[(int64_t)f * K + k], F.gamma[(int64_t)f * K + k], qc, vc, wc);
+        return qc;
+      };
       const double j = 1.0 / V;
       g += -0.5 * (PGBP_LOG2PI + log(V) + z * j * z);
       if (!(V > 0.0)) g = NAN;
@@ -264,22 +277,12 @@ __global__ __launch_bounds__(256) void lg_fill_uni_sm_kernel(LgStatic F, LgParam
       for (int a = 0; a <= np; ++a) {
         const int pa = a == 0 ? cpos : F.parent_pos[(int64_t)f * K + a - 1];
         if (pa < 0) continue;
-        double ca = 1.0;
-        if (a > 0) {
-          double qc, vc, wc;
-          lg_coefs(M.model, alpha, F.length[(int64_t)f * K + a - 1], F.gamma[(int64_t)f * K + a - 1], qc, vc, wc);
-          ca = -qc;
-        }
+        const double ca = a > 0 ? -q_of(a - 1) : 1.0;
         if (pa == 0) h0 += ca * j * z; else h1 += ca * j * z;
         for (int b = 0; b <= np; ++b) {
           const int pb = b == 0 ? cpos : F.parent_pos[(int64_t)f * K + b - 1];
           if (pb < 0) continue;
-          double cb = 1.0;
-          if (b > 0) {
-            double qc, vc, wc;
-            lg_coefs(M.model, alpha, F.length[(int64_t)f * K + b - 1], F.gamma[(int64_t)f * K + b - 1], qc, vc, wc);
-            cb = -qc;
-          }
+          const double cb = b > 0 ? -q_of(b - 1) : 1.0;
           const double v = ca * cb * j;
           if (pa == 0 && pb == 0) J00 += v;
           else if (pa == 1 && pb == 0) J10 += v;

@@ -21,6 +21,45 @@ namespace pgbp {
 
 static int64_t pad_to(int64_t n, int64_t a) { return (n + a - 1) / a * a; }
 
+bool read_tuning(Tuning& t, std::string& err) {
+  t = Tuning{};
+  const char* v = getenv("PGBP_TUNING");   // the library's one tuning variable (the other getenv: PGBP_RCCL_LIB, pgbp_dist.hip)
+  if (!v) return true;
+  std::string all(v);
+  size_t at = 0;
+  while (at <= all.size()) {
+    size_t end = all.find(',', at);
+    if (end == std::string::npos) end = all.size();
+    std::string tok = all.substr(at, end - at);
+    at = end + 1;
+    while (!tok.empty() && tok.front() == ' ') tok.erase(tok.begin());
+    while (!tok.empty() && tok.back() == ' ') tok.pop_back();
+    if (tok.empty()) continue;
+    const size_t eq = tok.find('=');
+    const std::string key = tok.substr(0, eq), val = eq == std::string::npos ? "" : tok.substr(eq + 1);
+    const long long num = val.empty() ? 0 : atoll(val.c_str());
+    if (key == "no_tail") t.tail = false;
+    else if (key == "no_chunks") t.chunks = false;
+    else if (key == "no_prologue") t.prologues = false;
+    else if (key == "chain_fusion") t.chain_fusion = true;
+    else if (key == "loop") t.loop2 = num != 0;
+    else if (key == "plain_layout") t.packed_layouts = false;
+    else if (key == "mixed_fast_min") t.mixed_fast_min = num;
+    else if (key == "small4_min") t.small4_min = (int)num;
+    else if (key == "chunk_bins") t.chunk_bins = (int)num;
+    else if (key == "chunk_max_recs") t.chunk_max_recs = (int)num;
+    else if (key == "chunk_max_tasks") t.chunk_max_tasks = (int)num;
+    else if (key == "chunk_uni_max") t.chunk_uni_max = num;
+    else if (key == "chunk_depth") t.chunk_depth = (int)num;
+    else if (key == "chunk_depth_generic") t.chunk_depth_generic = (int)num;
+    else {
+      err = "PGBP_TUNING: unknown token '" + tok + "'";
+      return false;
+    }
+  }
+  return true;
+}
+
 int plan_build(Plan& p, const pgbp_desc* d) {
   if (!d || d->n_clusters <= 0 || d->n_sepsets < 0 || !d->dims || d->n_sites < 1) {
     p.err = "invalid description (null pointers, no clusters, or n_sites < 1)";
@@ -30,6 +69,7 @@ int plan_build(Plan& p, const pgbp_desc* d) {
     p.err = "invalid description: sepset arrays missing";
     return PGBP_ERR_INVALID;
   }
+  if (!read_tuning(p.tune, p.err)) return PGBP_ERR_INVALID;
   p.n_clusters = d->n_clusters;
   p.n_sepsets = d->n_sepsets;
   p.n_sites = d->n_sites;
@@ -421,8 +461,7 @@ static void finalize_traversal(const Plan& p, Traversal& tr, bool postorder) {
     // launch: loopy cluster graphs of networks, where hybrid families sit beside tree-edge clusters in every level).
     // (measured: polytomy trees with 8 and 16 traits prefer 2 048 to 8 192 by 2 - 5 %; cfg5, 4 traits -- where the fast
     // kernel's instance works on 4 lanes of 64 -- prefers 8 192 by 2 %)
-    static const long long mixed_env = [] { const char* v = getenv("PGBP_MIXED_FAST_MIN"); return v ? atoll(v) : -1ll; }();
-    const size_t mixed_min = mixed_env >= 0 ? (size_t)mixed_env : (p.fast_p <= 4 ? kMixedLevelFastMinNarrow : kMixedLevelFastMin);
+    const size_t mixed_min = p.tune.mixed_fast_min >= 0 ? (size_t)p.tune.mixed_fast_min : (p.fast_p <= 4 ? kMixedLevelFastMinNarrow : kMixedLevelFastMin);
     if (!slow.empty() && fast.size() < mixed_min) {
       slow.insert(slow.end(), fast.begin(), fast.end());
       std::sort(slow.begin(), slow.end());
@@ -634,15 +673,11 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
   tr.cpros.clear();
   tr.cgroups.clear();
   // (chain fusion makes tasks that pass through several receivers: the forest below assumes one receiver / sender per task)
-  static const bool off = getenv("PGBP_NO_CHUNKS") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
-  static const int depth_fast = [] { const char* v = getenv("PGBP_CHUNK_DEPTH"); return v ? std::max(2, atoi(v)) : kChunkDepth; }();
-  static const int depth_generic = [] {
-    const char* v = getenv("PGBP_CHUNK_DEPTH_GENERIC");
-    if (!v) v = getenv("PGBP_CHUNK_DEPTH");
-    return v ? std::max(2, atoi(v)) : kChunkGenericDepth;
-  }();
-  static const int max_tasks = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkMaxTasks; }();
-  static const int max_tasks_generic = [] { const char* v = getenv("PGBP_CHUNK_MAX_TASKS"); return v ? std::max(1, atoi(v)) : kChunkGenericMaxTasks; }();
+  const bool off = !p.tune.chunks || !p.tune.tail || p.tune.chain_fusion;
+  const int depth_fast = p.tune.chunk_depth >= 2 ? p.tune.chunk_depth : kChunkDepth;
+  const int depth_generic = p.tune.chunk_depth_generic >= 2 ? p.tune.chunk_depth_generic : kChunkGenericDepth;
+  const int max_tasks = p.tune.chunk_max_recs > 0 ? p.tune.chunk_max_recs : kChunkMaxTasks;
+  const int max_tasks_generic = p.tune.chunk_max_tasks > 0 ? p.tune.chunk_max_tasks : kChunkGenericMaxTasks;
   const int nlev = (int)tr.level_off.size() - 1;
   if (off || nlev <= 0) return;
   const int ntasks = (int)tr.task_off.size() - 1;
@@ -671,8 +706,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     // (a level of a site batch joins a chunk while its launch could not fill the chip: tasks x sites threads)
     // (measured, three repetitions each: 65 536 threads best for 2 000 and 8 000 sites; 262 144 another 2 % for 1 000 -- the
     // fewer the sites, the less a level's own launch has to do)
-    static const long long uni_env = [] { const char* v = getenv("PGBP_CHUNK_UNI_MAX_THREADS"); return v ? atoll(v) : -1ll; }();
-    const long long uni_max = uni_env >= 0 ? uni_env : (long long)kChunkUniMaxThreads * (p.n_sites <= 1024 ? 4 : 1);
+    const long long uni_max = p.tune.chunk_uni_max >= 0 ? p.tune.chunk_uni_max : (long long)kChunkUniMaxThreads * (p.n_sites <= 1024 ? 4 : 1);
     if (uni) return nt > 0 && (long long)nt * p.n_sites <= uni_max;
     // (register-resident levels are measured in RECORDS -- wavefront pairs of a pass --, wave-per-task ones in tasks)
     return nt > 0 && (all_fast(L) ? tr.level_nrecs[L] <= max_tasks : nt <= max_tasks_generic) && tr.level_nbig[L] == 0 &&
@@ -755,8 +789,7 @@ static void build_chunks(const Plan& p, Traversal& tr, bool postorder) {
     // levels of ceil(slots / kTailWaves)), the emptier one on a tie.  A tree stays whole, so the launch is as dependency-
     // closed as before; the chains of a walk (link_chains) are found on the merged walk like on any other.
     {
-      static const int bins_env = [] { const char* v = getenv("PGBP_CHUNK_BINS"); return v ? atoi(v) : -1; }();
-      int bins = bins_env >= 0 ? bins_env : kChunkBins;
+      int bins = p.tune.chunk_bins >= 0 ? p.tune.chunk_bins : kChunkBins;
       if (uni) bins = std::max(1, bins * 4 / std::max(1, (p.n_sites + 63) / 64));   // (workgroup = (walk, block of 64 sites), four per CU)
       if (bins > 0 && n_wg > bins) {
         const int nl = L1 - L0;
@@ -926,17 +959,6 @@ static void build_traversals(const Plan& p, Tree& t, int fuse) {
       hp = std::max(hp, chained_edge[i] ? h : h + 1);
       nlev = std::max(nlev, h + 1);
     }
-    // PGBP_POSTORDER_ALAP=1 (opt-in, measured 1 % slower on cfg3: 0.889 - 0.899 against 0.886 ms): every message into a
-    // cluster X goes out in the level just below X's own (height(X) - 1) instead of the level of its sender's height.
-    // All of X's children then form ONE task: X's block is loaded and stored once however different the heights of its
-    // children and their deltas are added in exactly the reference's order (src/calibration.jl:121) -- but a leaf
-    // clique's streaming message then shares a workgroup with eliminations, and a workgroup lives as long as its slowest
-    // wavefront: the mixed levels take as many workgroup lifetimes as before for fewer eliminations each.
-    // (A receiver with more children than a fast-class task has wavefronts keeps the height order.)
-    static const bool post_alap_env = getenv("PGBP_POSTORDER_ALAP") != nullptr;
-    if (!fuse && post_alap_env)
-      for (int i = 0; i < n; ++i)
-        if (nchild[t.pa[i]] <= kFastMaxWaves) lvl[i] = hnode[t.pa[i]] - 1;
     // tasks: group by (level, target parent); entries in reference order (decreasing i)
     std::vector<std::vector<int>> bylevel(nlev);
     for (int i = n - 1; i >= 0; --i)
@@ -988,10 +1010,10 @@ static void build_traversals(const Plan& p, Tree& t, int fuse) {
   // possible); both take as many levels as the tree is deep.  Default: AS LATE AS POSSIBLE, the mirror image of the
   // postorder -- the levels near the root are then as narrow as the postorder's last ones (they join the single-workgroup
   // tail launch), and the bulk of the messages sits in a few very wide levels at the leaf end, instead of a bell of
-  // mid-sized levels that each pay a full launch latency.  PGBP_PREORDER_ASAP=1 (or chain fusion) keeps the depth order.
+  // mid-sized levels that each pay a full launch latency.  Chain fusion keeps the depth order (a fused chain starts where its
+  // first message may).
   {
-    static const bool asap_env = getenv("PGBP_PREORDER_ASAP") != nullptr;
-    const bool alap = fuse != 1 && !asap_env;
+    const bool alap = fuse != 1;
     auto height = [&](int cluster) {
       auto it = hnode.find(cluster);
       return it == hnode.end() ? 0 : it->second;
@@ -1173,9 +1195,9 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
     // register-resident kernel runs the whole tree: on a mixed schedule (cfg5's Bethe graph: hybrid families beside
     // tree edges in every level) the levels go to the wave-per-task kernel whole, where a prologue is one more message
     // for the same wavefront -- half the levels at twice the time each (measured: 1.86 against 1.78 ms per iteration).
-    // The univariate site batches run on the thread-per-site kernel and keep the plain levels.  PGBP_NO_PROLOGUE=1: A/B.
+    // The univariate site batches run on the thread-per-site kernel and keep the plain levels.  (PGBP_TUNING no_prologue: A/B.)
     if (tree_all_fast(T)) {
-      static const bool no_pro = getenv("PGBP_NO_PROLOGUE") != nullptr || getenv("PGBP_CHAIN_FUSION") != nullptr;
+      const bool no_pro = !p.tune.prologues || p.tune.chain_fusion;
       const bool uni = p.max_dim <= 2 && p.n_sites >= 8;
       if (!no_pro && !uni && p.fast_p > 0) {
         std::unordered_map<int, int> nch, par, only;
@@ -1203,12 +1225,12 @@ int plan_set_schedule(Plan& p, int32_t n_trees, const int32_t* tree_off, const i
         }
       }
     }
-    // Chain fusion is OPT-IN (PGBP_CHAIN_FUSION=1): measured on the cfg5 network (Bethe graph, 20 000 tips) it trades
+    // Chain fusion is OPT-IN (PGBP_TUNING chain_fusion): measured on the cfg5 network (Bethe graph, 20 000 tips) it trades
     // 398 launches for 152 but a fused level lasts as long as its longest chain (about 5 us per message inside a wave
     // against about 10 us per launch): 4.8 ms per iteration against 3.9 ms.  It pays on path-like
     // schedule trees (nodesubtree_clusterlist schedules).  Schedules that the register-resident kernel runs whole and
     // the thread-per-site kernel of univariate batches always keep the plain levels.
-    static const bool fuse_on = getenv("PGBP_CHAIN_FUSION") != nullptr;
+    const bool fuse_on = p.tune.chain_fusion;
     const bool uni_batch = p.max_dim <= 2 && p.n_sites >= 8;
     if (fuse_on && !uni_batch && !tree_all_fast(T)) build_traversals(p, T, 1);
     // the tail launch walks the postorder's last levels and the preorder's first ones as ONE sequence of passes

@@ -33,6 +33,8 @@ mutable struct DeviceClusterGraphBelief
     offsets::Vector{Int}
     schedule_set::Any
     keep::Any                          # arrays the device factor fill's static table points into
+    stale::BitVector                   # lazy write-back: beliefs whose Julia arrays are older than the device's (fetch!)
+    stale_residuals::Bool              # ... and the same for the message residuals as a whole (fetch_residual!)
 end
 
 check(h, rc) = rc == 0 || error(unsafe_string(@ccall LIB.pgbp_last_error(h::Ptr{Cvoid})::Cstring))
@@ -59,7 +61,7 @@ function DeviceClusterGraphBelief(cgb::PGBP.ClusterGraphBelief; device::Integer=
         rc == 0 || error(unsafe_string(@ccall LIB.pgbp_last_error(C_NULL::Ptr{Cvoid})::Cstring))
     end
     offsets = cumsum(vcat(0, [m*m + m + 1 for m in Int.(dims)]))
-    obj = DeviceClusterGraphBelief(cgb, h[], zeros(offsets[end]), offsets, nothing, nothing)
+    obj = DeviceClusterGraphBelief(cgb, h[], zeros(offsets[end]), offsets, nothing, nothing, falses(nb), false)
     push!(obj); finalizer(o -> @ccall(LIB.pgbp_destroy(o.handle::Ptr{Cvoid})::Cvoid), obj)
     return obj
 end
@@ -73,8 +75,40 @@ function Base.push!(o::DeviceClusterGraphBelief)
     check(o.handle, @ccall LIB.pgbp_set_beliefs(o.handle::Ptr{Cvoid}, o.packed::Ptr{Float64}, 1::Int32)::Cint)
 end
 
+"""
+LAZY write-back.  `calibrate!(o, ...; pull = :lazy)` moves only the result struct across the bus and marks every belief of
+`o.cgb` stale; `o[j]` (= `fetch!(o, j)`) brings belief j's record over (pgbp_get_belief, a few KB) into the SAME Julia arrays
+`o.cgb.belief[j].{J,h,g}` and returns that belief, so `calibrate!` followed by `integratebelief!(o, rootj)` or by reading a
+handful of beliefs costs kilobytes instead of the whole state (0.76 GB at 50 000 tips x 16 traits).  `pull = :eager` (the
+default, the reference's semantics for callers that read `o.cgb.belief[j]` directly) downloads everything as before.
+"""
+function fetch!(o::DeviceClusterGraphBelief, j::Integer)
+    x = o.cgb.belief[j]
+    o.stale[j] || return x
+    m = length(x.h); rec = zeros(m*m + m + 1)
+    check(o.handle, @ccall LIB.pgbp_get_belief(o.handle::Ptr{Cvoid}, Int32(0)::Int32, Int32(j - 1)::Int32, rec::Ptr{Float64})::Cint)
+    copyto!(x.J, 1, rec, 1, m*m); copyto!(x.h, 1, rec, m*m + 1, m); x.g[1] = rec[m*m + m + 1]
+    o.stale[j] = false
+    return x
+end
+Base.getindex(o::DeviceClusterGraphBelief, j::Integer) = fetch!(o, j)
+"the residual of the message `key = (receiver label, sender label)` (src/clustergraphbeliefs.jl:17-20), fetched alone (pgbp_get_residual)"
+function fetch_residual!(o::DeviceClusterGraphBelief, key)
+    mr = o.cgb.messageresidual[key]
+    o.stale_residuals || return mr
+    j = PGBP.sepsetindex(key[1], key[2], o.cgb); k = j - o.cgb.nclusters
+    dir = o.cgb.belief[j].metadata == key ? 1 : 2          # message 2(k-1) + dir - 1 is the one received by the sepset's end `dir`
+    s = length(mr.Δh); rec = zeros(max(s*s + s, 1)); flag = Ref(Int32(0)); kl = Ref(0.0); klflag = Ref(Int32(0))
+    check(o.handle, @ccall LIB.pgbp_get_residual(o.handle::Ptr{Cvoid}, Int32(0)::Int32, Int32(2*(k-1) + dir - 1)::Int32,
+        rec::Ptr{Float64}, flag::Ref{Int32}, kl::Ref{Float64}, klflag::Ref{Int32})::Cint)
+    copyto!(mr.ΔJ, 1, rec, 1, s*s); copyto!(mr.Δh, 1, rec, s*s + 1, s)
+    mr.iscalibrated_resid[1] = flag[] != 0; mr.kldiv[1] = kl[]; mr.iscalibrated_kl[1] = klflag[] != 0
+    return mr
+end
+
 "device -> the SAME Julia arrays (aliases held by callers stay valid), residuals and flags included"
 function pull!(o::DeviceClusterGraphBelief)
+    fill!(o.stale, false); o.stale_residuals = false
     check(o.handle, @ccall LIB.pgbp_get_beliefs(o.handle::Ptr{Cvoid}, o.packed::Ptr{Float64})::Cint)
     for (i, x) in enumerate(o.cgb.belief)
         m = length(x.h); p = o.offsets[i]
@@ -138,12 +172,16 @@ end
 "calibrate!(beliefs, schedule, niter; auto, info, verbose, ...) -> (succ, iscal)   (src/calibration.jl:35-60)"
 function PGBP.calibrate!(o::DeviceClusterGraphBelief, schedule::AbstractVector, niter::Integer=1;
         auto::Bool=false, info::Bool=false, verbose::Bool=true,
-        update_residualnorm::Bool=true, update_residualkldiv::Bool=false)
+        update_residualnorm::Bool=true, update_residualkldiv::Bool=false, pull::Symbol=:eager)
     set_schedule!(o, schedule)
     r = Ref(Result(0,0,0,0,0,0,0,0,0,0))
     check(o.handle, @ccall LIB.pgbp_calibrate(o.handle::Ptr{Cvoid}, niter::Int32,
         Ref(Opts(auto, update_residualnorm, update_residualkldiv, 0, 1e-5))::Ref{Opts}, r::Ref{Result})::Cint)
-    pull!(o)
+    if pull === :lazy          # nothing but `r` crosses the bus: o[j] / fetch_residual!(o, key) fetch what is read
+        fill!(o.stale, true); o.stale_residuals = true
+    else
+        pull!(o)
+    end
     res = r[]
     if res.succ == 0
         report_failure(o, schedule[res.fail_tree], res, verbose)

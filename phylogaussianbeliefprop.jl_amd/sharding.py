@@ -236,10 +236,13 @@ class Comm:
         self.lib = L.load()
         self.n_ranks, self.rank = int(n_ranks), int(rank)
         self._c = C.c_void_p()
+        if self.n_ranks > 1 and (bcast is None or allmin is None):
+            # (without them a rank that fails alone would leave its peers inside the broadcast or the collective create)
+            raise ValueError("Comm: n_ranks > 1 needs both bcast and allmin of the group that launched the ranks")
         # 1. what can fail on this rank alone (RCCL not loadable, no such device), agreed on by all ranks
         code = self.lib.pgbp_comm_precheck(int(device))
         why = self.lib.pgbp_comm_last_error(None).decode() if code != 0 else ""
-        if n_ranks > 1 and allmin is not None:
+        if n_ranks > 1:
             if allmin(1 if code == 0 else 0) == 0:
                 raise L.PgbpError(code or L.ERR_NO_DEVICE, why or "pgbp_comm: another rank cannot open its communicator")
         elif code != 0:
@@ -258,15 +261,35 @@ class Comm:
             ident = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(raw[1:1 + self.ID_BYTES])
         if status != 0:
             raise L.PgbpError(int(status), msg or "pgbp_comm_unique_id failed on rank 0")
-        # 3. the collective create
-        code = self.lib.pgbp_comm_create(ident, self.n_ranks, self.rank, int(device), C.byref(self._c))
+        # 3. the collective create, agreed on again: a rank whose ncclCommInitRank (or its allocations) failed must not leave
+        # the others to walk into the first all-gather without it
+        code = self._create(ident, int(device))
+        why = self.lib.pgbp_comm_last_error(None).decode() if code != 0 else ""
+        if n_ranks > 1 and allmin(1 if code == 0 else 0) == 0:
+            self.close()
+            raise L.PgbpError(code or L.ERR_HIP, why or "pgbp_comm: another rank could not create its communicator")
         if code != 0:
-            raise L.PgbpError(code, self.lib.pgbp_comm_last_error(None).decode())
+            raise L.PgbpError(code, why)
+
+    def _create(self, ident, device):
+        return self.lib.pgbp_comm_create(ident, self.n_ranks, self.rank, device, self._C.byref(self._c))
 
     def close(self):
         if self._c:
             self.lib.pgbp_comm_destroy(self._c)
             self._c = None
+
+    def exchange_beliefs(self, engine, lists, site=0, include_self=False):
+        """pgbp_comm_exchange_beliefs: lists[r] = the belief indices rank r contributes (the same lists on every rank);
+        one ncclAllGather, device to device; afterwards this rank's engine holds the other ranks' records"""
+        L = self._L
+        off = np.zeros(self.n_ranks + 1, np.int32)
+        for r in range(self.n_ranks):
+            off[r + 1] = off[r] + len(lists[r])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int32) for x in lists]) if off[-1] else np.zeros(1, np.int32))
+        code = self.lib.pgbp_comm_exchange_beliefs(self._c, engine, int(site), L.i32p(off), L.i32p(flat), int(include_self))
+        if code != 0:
+            raise L.PgbpError(code, self.lib.pgbp_comm_last_error(self._c).decode())
 
     def gather_loglik(self, engine, slot_sites):
         """-> (norm [n_ranks, slot_sites], info [n_ranks, slot_sites], all_succ, all_iscal) on every rank"""
@@ -382,14 +405,28 @@ class NetworkCut:
     are those of the single-engine run bit for bit.  The exchanges are pgbp_pack_beliefs / pgbp_unpack_beliefs through the
     host here (one process, engines side by side); between processes the packed buffer is what an all-gather carries.
     `beliefs`: one ClusterGraphBelief per rank over the same graph, same state.  A subtree is a tree of its rank's schedule
-    of its own (the planner takes trees, not forests): its launches are narrower than the uncut traversal's."""
+    of its own (the planner takes trees, not forests): its launches are narrower than the uncut traversal's.
 
-    def __init__(self, beliefs, schedule, min_subtrees=4):
-        self.ranks = list(beliefs)
-        self.K = len(self.ranks)
+    BETWEEN PROCESSES (one process per GPU, the driver's launch): `beliefs` = [this rank's ClusterGraphBelief], `rank`,
+    `n_ranks`, and two callables of the group that launched the ranks -- `exchange(lists)`: lists[r] = the belief indices
+    rank r contributes; afterwards this rank's engine holds the other ranks' records (CommExchange: ONE ncclAllGather behind
+    the C ABI, pgbp_comm_exchange_beliefs, device to device; HostExchange: pgbp_pack_beliefs -> an all-gather of the
+    launcher's group -> pgbp_unpack_beliefs, the one-GPU rehearsal) -- and `allmin(int)`: the minimum over the ranks (the
+    AND of the ranks' calibration flags, and of their traversals' success).  Every rank computes the same cut."""
+
+    def __init__(self, beliefs, schedule, min_subtrees=4, rank=None, n_ranks=None, exchange=None, allmin=None):
+        self.rank = rank
+        if rank is None:
+            self.ranks = dict(enumerate(beliefs))
+            self.K = len(self.ranks)
+        else:
+            assert len(beliefs) == 1 and n_ranks is not None and exchange is not None and allmin is not None
+            self.ranks = {int(rank): beliefs[0]}
+            self.K = int(n_ranks)
+        self._exchange_fn, self._allmin = exchange, allmin
         self.schedule = [(np.asarray(t[-2], np.int32), np.asarray(t[-1], np.int32)) for t in schedule]
         self.cuts = [cut_spanning_tree(pa, ch, self.K, min_subtrees) for pa, ch in self.schedule]
-        b0 = self.ranks[0]
+        b0 = next(iter(self.ranks.values()))
         sep_of = {}
         for k, (a, c) in enumerate(b0._sepcl):
             sep_of[(min(int(a), int(c)), max(int(a), int(c)))] = b0.nclusters + k
@@ -404,11 +441,11 @@ class NetworkCut:
                 per_rank[r].append(cut["top"])
             for r in range(self.K):
                 for (k, _root, edges) in cut["sub"]:
-                    if k == r:
-                        entry["sub"][r].append(len(per_rank[r]))
+                    if k == r and len(edges[0]) > 0:   # (a boundary child that is a leaf has no edge of its own: nothing to
+                        entry["sub"][r].append(len(per_rank[r]))   # traverse, only its root to exchange)
                         per_rank[r].append(edges)
             self.tree_index.append(entry)
-        for r, b in enumerate(self.ranks):
+        for r, b in self.ranks.items():
             b.set_schedule(per_rank[r])
         # exchange lists
         self.roots = []        # [t][rank] -> belief indices of the roots of its subtrees
@@ -431,7 +468,12 @@ class NetworkCut:
     def _exchange(self, idx):
         import ctypes as C
         from . import _lib as L
-        for r, b in enumerate(self.ranks):
+        if self._exchange_fn is not None:      # between processes: one all-gather
+            self._exchange_fn(idx)
+            b = self.ranks[self.rank]
+            self.exchanged_doubles += sum(int(b._poff[i + 1] - b._poff[i]) for x in idx for i in x)
+            return
+        for r, b in self.ranks.items():
             if len(idx[r]) == 0:
                 continue
             lst = np.ascontiguousarray(idx[r], np.int32)
@@ -441,7 +483,7 @@ class NetworkCut:
             if code != 0:
                 raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
             self.exchanged_doubles += n
-            for q, o in enumerate(self.ranks):
+            for q, o in self.ranks.items():
                 if q == r:
                     continue
                 code = o._lib.pgbp_unpack_beliefs(o._eng, 0, len(lst), L.i32p(lst), L.f64p(buf))
@@ -470,44 +512,52 @@ class NetworkCut:
         o = opts if opts is not None else L.Opts(0, 1, 0, 0, 1e-5)
         cut, ix = self.cuts[t], self.tree_index[t]
         ok = True
-        subs = {r: [e for (k, _root, e) in cut["sub"] if k == r] for r in range(self.K)}
+        subs = {r: [e for (k, _root, e) in cut["sub"] if k == r and len(e[0]) > 0] for r in range(self.K)}
+        mine = sorted(self.ranks)                                 # (one process: every rank; between processes: this one)
         for r in range(self.K):                                   # 1
             for j, tree in enumerate(ix["sub"][r]):
-                ok &= self._traverse(r, tree, 0, o)
+                if r in self.ranks:
+                    ok &= self._traverse(r, tree, 0, o)
                 self._note(r, subs[r][j], 0)
         self._exchange(self.roots[t])                             # 2
-        for r in range(self.K):                                   # 3 (every rank; rank 0 speaks for the top's flags)
+        for r in mine:                                            # 3 (every rank; rank 0 speaks for the top's flags)
             ok &= self._traverse(r, ix["top"][r], 0, o)
             ok &= self._traverse(r, ix["top"][r], 1, o)
         self._note(0, cut["top"], 0)
         self._note(0, cut["top"], 1)
         for r in range(self.K):                                   # 4
             for j, tree in enumerate(ix["sub"][r]):
-                ok &= self._traverse(r, tree, 1, o)
+                if r in self.ranks:
+                    ok &= self._traverse(r, tree, 1, o)
                 self._note(r, subs[r][j], 1)
         if len(self.schedule) > 1:                                # 5
             self._exchange(self.owned[t])
+        if self._allmin is not None:                              # a message that failed on any rank fails the traversal on all
+            ok = bool(self._allmin(1 if ok else 0))
         return ok
 
     def iscalibrated_residnorm(self):
         """iscalibrated_residnorm over every message residual (src/beliefs.jl:994-1003), each read from the rank that
         sent the message last; a message never sent is not calibrated"""
         from . import _lib as L
-        b0 = self.ranks[0]
+        b0 = next(iter(self.ranks.values()))
         nm = 2 * b0.nsepsets
-        flags = []
-        for b in self.ranks:
+        flags = {}
+        for r, b in self.ranks.items():
             f = np.zeros(b.n_sites * nm, np.int32)
             code = b._lib.pgbp_get_residuals(b._eng, None, L.i32p(f), None, None)
             if code != 0:
                 raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
-            flags.append(f[:nm])
+            flags[r] = f[:nm]
+        ok = True
         for k, (a, c) in enumerate(b0._sepcl):
             for mid, key in ((2 * k, (int(a), int(c))), (2 * k + 1, (int(c), int(a)))):   # (receiver, sender)
                 r = self.last_writer.get(key)
-                if r is None or not flags[r][mid]:
-                    return False
-        return True
+                if r is None or (r in flags and not flags[r][mid]):   # (between processes: each rank answers for what it sent)
+                    ok = False
+        if self._allmin is not None:
+            ok = bool(self._allmin(1 if ok else 0))
+        return ok
 
     def calibrate(self, niter=1, auto=False, opts=None):
         """-> (succ, iscal, (iteration, tree) reached if auto stopped there else None)"""
@@ -522,7 +572,9 @@ class NetworkCut:
     def gather(self):
         """the calibrated beliefs [packed_size], every record from the rank that owns it after the last traversal (one
         spanning tree: exchange B was skipped; several: any rank holds everything)"""
-        b0 = self.ranks[0]
+        if self.rank is not None and len(self.schedule) == 1:
+            self._exchange(self.owned[0])      # between processes: what the ranks own goes to every rank once, at the end
+        b0 = self.ranks[min(self.ranks)]
         from . import _lib as L
         out = np.zeros(int(b0._lib.pgbp_packed_size(b0._eng)))
         full = np.zeros((1, len(out)))
@@ -530,7 +582,7 @@ class NetworkCut:
         if code != 0:
             raise L.PgbpError(code, b0._lib.pgbp_last_error(b0._eng).decode())
         out[:] = full[0]
-        if len(self.schedule) == 1:
+        if len(self.schedule) == 1 and self.rank is None:
             for r in range(1, self.K):
                 lst = self.owned[0][r]
                 if len(lst) == 0:
@@ -547,3 +599,46 @@ class NetworkCut:
                     out[b0._poff[i]:b0._poff[i] + ln] = buf[at:at + ln]
                     at += ln
         return out
+
+
+class CommExchange:
+    """NetworkCut's exchange between processes through pgbp_comm: ONE ncclAllGather per exchange, device to device."""
+
+    def __init__(self, comm, belief):
+        self.comm, self.b = comm, belief
+
+    def __call__(self, lists):
+        self.comm.exchange_beliefs(self.b._eng, lists)
+
+
+class HostExchange:
+    """The same through the launcher's own group (torch.distributed, e.g. gloo): pgbp_pack_beliefs -> all_gather of the padded
+    host buffers -> pgbp_unpack_beliefs.  What the one-GPU rehearsal of the cut uses (two RCCL ranks cannot share a device)."""
+
+    def __init__(self, dist, belief, rank, n_ranks):
+        self.dist, self.b, self.rank, self.K = dist, belief, int(rank), int(n_ranks)
+
+    def __call__(self, lists):
+        import torch
+        from . import _lib as L
+        b = self.b
+        size = [int(b._lib.pgbp_packed_beliefs_size(b._eng, len(x), L.i32p(np.ascontiguousarray(x, np.int32)))) if len(x) else 0
+                for x in lists]
+        slot = max(size)
+        if slot == 0:
+            return
+        mine = np.ascontiguousarray(lists[self.rank], np.int32)
+        buf = np.zeros(slot)
+        if len(mine):
+            code = b._lib.pgbp_pack_beliefs(b._eng, 0, len(mine), L.i32p(mine), L.f64p(buf))
+            if code != 0:
+                raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())
+        got = [torch.zeros(slot, dtype=torch.float64) for _ in range(self.K)]
+        self.dist.all_gather(got, torch.from_numpy(buf))
+        for r in range(self.K):
+            if r == self.rank or size[r] == 0:
+                continue
+            lst = np.ascontiguousarray(lists[r], np.int32)
+            code = b._lib.pgbp_unpack_beliefs(b._eng, 0, len(lst), L.i32p(lst), L.f64p(np.ascontiguousarray(got[r].numpy())))
+            if code != 0:
+                raise L.PgbpError(code, b._lib.pgbp_last_error(b._eng).decode())

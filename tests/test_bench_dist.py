@@ -257,3 +257,81 @@ def test_cut_of_a_spanning_tree_partitions_its_edges():
             assert max(load) - min(load) <= biggest
     whole = cut_spanning_tree([0, 1], [1, 2], 2)
     assert whole["sub"] == [] and len(whole["top"][0]) == 2
+
+
+def _comm_create_fails_on_one_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    """2 gloo ranks: the precheck passes everywhere, then rank 1's pgbp_comm_create fails -- BOTH ranks must raise (the second
+    agreement of Comm.__init__), nobody may walk on into a collective."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgbp_amd import _lib as L
+        from pgbp_amd.sharding import Comm
+
+        def bcast(raw):
+            t = torch.zeros(1 + Comm.ID_BYTES, dtype=torch.uint8)
+            if raw is not None:
+                t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            return bytes(t.numpy().tobytes())
+
+        def allmin(v):
+            t = torch.tensor([int(v)], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+
+        class FakeLib:   # the precheck and rank 0's unique id succeed without a GPU; the create fails on rank 1 only
+            def __init__(self, real):
+                self._real = real
+
+            def pgbp_comm_precheck(self, device):
+                return 0
+
+            def pgbp_comm_unique_id(self, ident):
+                return 0
+
+            def pgbp_comm_last_error(self, c):
+                return b"ncclCommInitRank: injected failure" if rank == 1 else b""
+
+            def pgbp_comm_create(self, ident, n, r, device, out):
+                return L.ERR_HIP if rank == 1 else 0
+
+            def pgbp_comm_destroy(self, c):
+                return None
+
+        orig = L.load
+        L.load = lambda: FakeLib(None)
+        try:
+            try:
+                Comm(world, rank, 0, bcast, allmin)
+                q.put((rank, "no error"))
+            except L.PgbpError as ex:
+                q.put((rank, "raised: " + ex.msg))
+            try:
+                Comm(world, rank, 0, bcast, None)
+                q.put((rank, "no ValueError"))
+            except ValueError:
+                q.put((rank, "ValueError"))
+        finally:
+            L.load = orig
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_create_failure_on_one_rank_is_raised_by_every_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_comm_create_fails_on_one_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(4))
+    assert [g for g in got if g[0] == 0] == [(0, "ValueError"), (0, "raised: pgbp_comm: another rank could not create its communicator")]
+    assert [g for g in got if g[0] == 1] == [(1, "ValueError"), (1, "raised: ncclCommInitRank: injected failure")]

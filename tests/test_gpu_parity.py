@@ -1254,38 +1254,42 @@ def test_calibration_level3_joingraph_loopy_run_on_device(P, caplog, variant):
 
 
 def test_chain_fusion_opt_in_differential_fuzz(P):
-    """PGBP_CHAIN_FUSION=1 (opt-in, read once per process -> child process): unary clusters of a schedule tree are
+    """PGBP_TUNING=chain_fusion (opt-in, read when an engine is created; a child process keeps the variable out of this one): unary clusters of a schedule tree are
     passed through inside one task of the generic kernel (pgbp_plan.cpp build_traversals).  The differential fuzz
     against the plain-C sequential engine (beliefs 1e-8, flags, first failure) must hold unchanged."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, PGBP_CHAIN_FUSION="1")
+    env = dict(os.environ, PGBP_TUNING="chain_fusion")
     out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "80", "77"], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "80 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
 @pytest.mark.parametrize("env", [
-    {"PGBP_NO_TAIL": "1"},
-    {"PGBP_PREORDER_ASAP": "1"},
-    {"PGBP_NO_PROLOGUE": "1"},
-    {"PGBP_NO_PROLOGUE": "1", "PGBP_NO_TAIL": "1"},
-    {"PGBP_POSTORDER_ALAP": "1"},
-    {"PGBP_NO_CHUNKS": "1"},
-    {"PGBP_LOOP": "0"},
-    {"PGBP_LOOP": "0", "PGBP_NO_PROLOGUE": "1"},
-], ids=["levels_only", "asap_preorder", "no_prologues", "no_prologues_levels_only", "alap_postorder", "no_chunks",
-        "one_wave_per_record_loops", "one_wave_per_record_loops_no_prologues"])
+    {"PGBP_TUNING": "no_tail"},
+    {"PGBP_TUNING": "no_prologue"},
+    {"PGBP_TUNING": "no_prologue,no_tail"},
+    {"PGBP_TUNING": "no_chunks"},
+    {"PGBP_TUNING": "loop=0"},
+    {"PGBP_TUNING": "loop=0,no_prologue"},
+    {"PGBP_TUNING": "chunk_bins=3"},
+    {"PGBP_TUNING": "chunk_bins=2,no_prologue"},
+    {"PGBP_TUNING": "chunk_bins=0"},
+], ids=["levels_only", "no_prologues", "no_prologues_levels_only", "no_chunks",
+        "one_wave_per_record_loops", "one_wave_per_record_loops_no_prologues", "chunks_packed_into_3_workgroups",
+        "chunks_packed_into_2_workgroups_no_prologues", "chunks_one_workgroup_per_tree"])
 def test_launch_modes_differential_fuzz(P, env):
     """The launch modes of the register-resident kernel (pgbp_fast.hip: one group per workgroup; chunks of fused levels;
     the single-workgroup tail) run the same message body, with or without PROLOGUES (a Bethe graph's variable-to-factor
-    messages riding in the record of the factor's own message).  The tuning variables are read once per process, hence
-    child processes: the level launches alone (no tail, no chunks), without the chunks, the depth-ordered preorder, the
-    as-late-as-possible postorder, the two-level schedule without prologues, and the tail and chunks on pgbp_fast.hip's own
-    loop mode (one wavefront per record, PGBP_LOOP=0) instead of pgbp_loop.hip (the default: two wavefronts per record,
-    sender operands requested half a pass early, chains through LDS).  Same differential fuzz against the
+    messages riding in the record of the factor's own message).  PGBP_TUNING is read when an engine is created (child
+    processes keep it out of this one): the level launches alone (no tail, no chunks), without the chunks, the two-level
+    schedule without prologues, the tail and chunks on pgbp_fast.hip's own loop mode (one wavefront per record, loop=0)
+    instead of pgbp_loop.hip (the default: two wavefronts per record, sender operands requested half a pass early, chains
+    through LDS), and -- round 4 -- the trees of every chunk's forest PACKED into 3 or 2 workgroups (the default packs only
+    above 256 trees, which these small cases never have; chunk_bins=0: one workgroup per tree, the round-3 launches): same
+    messages, same order inside every task, so the packed launches must pass the same fuzz.  Same differential fuzz against the
     plain-C sequential engine as for the defaults: random trees (polytomies: tasks of 3 and 4 messages beside tasks of 1
     and 2 in one group; caterpillars: the whole traversal in the tail), clique trees and Bethe graphs, 1-16 traits (packed
     and plain layouts, odd instances), 1-3 sites, injected non-positive-definite blocks (first failure of the reference's
@@ -1380,10 +1384,12 @@ def test_auto_stop_is_per_site(P):
         assert np.max(np.abs(cgb._packed[s] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
 
 
-@pytest.mark.parametrize("env", [{}, {"PGBP_NO_CHUNKS": "1"}, {"PGBP_MIXED_FAST_MIN": "0"},
-                                 {"PGBP_SMALL4_MIN": "0"}, {"PGBP_SMALL4_MIN": "0", "PGBP_NO_CHUNKS": "1"}],
+@pytest.mark.parametrize("env", [{}, {"PGBP_TUNING": "no_chunks"}, {"PGBP_TUNING": "mixed_fast_min=0"},
+                                 {"PGBP_TUNING": "small4_min=0"}, {"PGBP_TUNING": "small4_min=0,no_chunks"},
+                                 {"PGBP_TUNING": "chunk_bins=3"}],
                          ids=["default", "level_launches_only", "mixed_levels_always_split",
-                              "four_tasks_per_wavefront", "four_tasks_per_wavefront_level_launches_only"])
+                              "four_tasks_per_wavefront", "four_tasks_per_wavefront_level_launches_only",
+                              "chunks_packed_into_3_workgroups"])
 def test_network_differential_fuzz(P, env):
     """tests/fuzz_gpu_vs_c_oracle_networks.py: random level-3 networks, clique tree / Bethe / join graphs, every spanning
     tree of the schedule, 1 - 9 traits (and 18 - 22), damaged clusters: the wave-per-task kernels (both message bodies,
@@ -1392,7 +1398,8 @@ def test_network_differential_fuzz(P, env):
     mixed level split into a register-resident and a wave-per-task launch however few fast-class tasks it has (such a level
     must not enter a generic chunk: its fast-class tasks have no message records); and with every level launch of small
     messages, however narrow, on bp_level_small4 (four tasks per wavefront, one per row of 16 lanes: the default only from
-    kSmall4MinTasks tasks on, which these small networks never reach), with and without the chunks."""
+    kSmall4MinTasksDefault tasks on, which these small networks never reach), with and without the chunks; and with the trees of
+    every chunk's forest packed into 3 workgroups (round 4: the default packs only above 256 trees)."""
     import os
     import subprocess
     import sys

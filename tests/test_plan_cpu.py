@@ -164,6 +164,14 @@ def test_plan_rejects_bad_input():
     lib, pl, code, keep = _plan(p2)
     assert code == L.ERR_INVALID and b"strictly increasing" in lib.pgbp_plan_last_error(pl)
     lib.pgbp_plan_destroy(pl)
+    # an unknown token of PGBP_TUNING is an error of the create call, not a silently ignored typo
+    os.environ["PGBP_TUNING"] = "no_tail,chunk_binz=3"
+    try:
+        lib, pl, code, keep = _plan(S.cliquetree_of_tree(tr, 2))
+        assert code == L.ERR_INVALID and b"chunk_binz=3" in lib.pgbp_plan_last_error(pl)
+        lib.pgbp_plan_destroy(pl)
+    finally:
+        del os.environ["PGBP_TUNING"]
     # dimension above PGBP_MAX_DIM is refused, not silently mishandled
     p3 = S.cliquetree_of_tree(tr, 200)         # internal cliques of dimension 400 > 384
     lib, pl, code, keep = _plan(p3)
@@ -469,10 +477,10 @@ def _check_traversal(lo, to, em, ee, pa, ch, sepcl, d):
 
 
 def test_fused_chain_schedule_invariants_subprocess():
-    """Chain fusion is opt-in through PGBP_CHAIN_FUSION, read once per process: the checks run in a child process."""
+    """Chain fusion is opt-in through PGBP_TUNING=chain_fusion (read when a plan is built): the checks run in a child process."""
     import subprocess
     import sys
-    env = dict(os.environ, PGBP_CHAIN_FUSION="1")
+    env = dict(os.environ, PGBP_TUNING="chain_fusion")
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_plan_cpu as T\n"
             "for g, s in [('bethe_tree', 1), ('bethe_net', 2), ('join_net', 3), ('bethe_net', 4), ('nodesubtrees', 5), ('path', 6)]:\n"
             "    T._fused_chain_schedule_invariants(g, s, True)\n"
@@ -557,9 +565,9 @@ def test_planner_under_address_and_undefined_sanitizers(tmp_path):
     for fuse in (False, True):
         env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
                    UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-        env.pop("PGBP_CHAIN_FUSION", None)
+        env.pop("PGBP_TUNING", None)
         if fuse:
-            env["PGBP_CHAIN_FUSION"] = "1"
+            env["PGBP_TUNING"] = "chain_fusion"
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize_plan.py"), so], env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "sanitized planner ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
@@ -993,18 +1001,23 @@ def _chunks(lib, pl, tree, d):
     return out
 
 
-@pytest.mark.parametrize("ntips,p,kind,graph", [(3000, 16, "random", "cliquetree"), (800, 4, "random", "cliquetree"),
-                                                (60, 16, "caterpillar", "cliquetree"), (900, 8, "random", "bethe"),
-                                                (400, 3, "poly4", "cliquetree"), (700, 4, "network", "joingraph"),
-                                                (500, 2, "network", "bethe"), (300, 3, "poly7", "cliquetree"),
-                                                (80, 16, "poly3", "cliquetree"), (120, 6, "poly7", "cliquetree"),
-                                                (9000, 2, "random", "cliquetree"), (6000, 3, "network", "joingraph")])
-def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
+@pytest.mark.parametrize("ntips,p,kind,graph,tuning", [
+    (3000, 16, "random", "cliquetree", ""), (800, 4, "random", "cliquetree", ""), (60, 16, "caterpillar", "cliquetree", ""),
+    (900, 8, "random", "bethe", ""), (400, 3, "poly4", "cliquetree", ""), (700, 4, "network", "joingraph", ""),
+    (500, 2, "network", "bethe", ""), (300, 3, "poly7", "cliquetree", ""), (80, 16, "poly3", "cliquetree", ""),
+    (120, 6, "poly7", "cliquetree", ""), (9000, 2, "random", "cliquetree", ""), (6000, 3, "network", "joingraph", ""),
+    # the trees of every chunk's forest packed into a handful of workgroups (PGBP_TUNING, read when the plan is built)
+    (3000, 16, "random", "cliquetree", "chunk_bins=5"), (900, 8, "random", "bethe", "chunk_bins=2"),
+    (700, 4, "network", "joingraph", "chunk_bins=3"), (400, 3, "poly4", "cliquetree", "chunk_bins=1"),
+    (800, 4, "random", "cliquetree", "chunk_bins=0")])
+def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph, tuning, monkeypatch):
     """Chunks of fused levels (build_chunks in pgbp_plan.cpp): replaying one calibrate iteration launch by launch --
     level launches, chunk launches (their workgroups in ANY order: checked forwards and backwards), the tail -- every
     message finds what it depends on done either by an earlier launch or by an earlier step of its OWN workgroup; what a
     workgroup writes no other workgroup of the launch reads or writes; every message runs exactly once."""
     rng = np.random.default_rng(ntips + p)
+    if tuning:
+        monkeypatch.setenv("PGBP_TUNING", tuning)
     if kind == "network":
         # loopy cluster graphs of a level-3 network: generic-class tasks (hybrid families, 2-node sepsets), several trees
         import pgbp_amd as P
@@ -1079,6 +1092,8 @@ def test_fused_chunks_are_dependency_closed(ntips, p, kind, graph):
                 launches.append([[tasks_of(g) for g in w] for w in wgs])
                 n_chunk_launches += 1
                 packed_launches += len(wgs) == 256 and min(lo[L + 1] - lo[L] for L in range(l0, l1)) > 256
+                if tuning.startswith("chunk_bins=") and int(tuning.split("=")[1]) > 0:
+                    assert len(wgs) <= int(tuning.split("=")[1])
                 Lv = l1
             else:
                 launches.append([[[[int(m) for m in em[to[t]:to[t + 1]]]] for t in range(lo[Lv], lo[Lv + 1])]])

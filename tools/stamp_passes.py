@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Experiment: where a pass of bp_fast16's level and loop modes (PGBP_LOOP=0: tail / fused chunks on one wavefront per record)
+"""Experiment: where a pass of bp_fast16's level and loop modes (PGBP_TUNING=loop=0: tail / fused chunks on one wavefront per record)
 spends its time (the streaming mode of round 2 is gone; bp_loop16 has tools/stamp_loop.py).
 Needs the instrumented build (clock stamps of the phases of every pass of the first 64 workgroups of each launch):
   make -C phylogaussianbeliefprop.jl_amd/csrc FASTFLAGS="-DPGBP_STAMP -DPGBP_ONLY_P16" -B ../../build/obj/pgbp_fast.o && make ... ; cp libpgbp.so build/libpgbp_stamp.so
-  PGBP_LIB=build/libpgbp_stamp.so PGBP_LOOP=0 python tools/stamp_passes.py
+  PGBP_LIB=build/libpgbp_stamp.so PGBP_TUNING=loop=0 python tools/stamp_passes.py
 Phases (shader clocks, medians over waves that did an elimination):
   0 top -> 1 operands waited for (streaming: vmcnt(0)) -> 2 loads issued, elimination starts -> 3 elimination done
   -> 4 marginal handed over -> 5 barrier 1 passed -> 6 tiles waited for -> 7 divide done -> 8 barrier 2 passed
