@@ -1632,8 +1632,32 @@ int pgbp_lg_setup(pgbp_engine* e, const pgbp_lg_families* f) {
     launch_transpose_words_f64(d_data, d_data_sm, f->n_rows, p.n_sites, 1, e->st);
     HIPCHK(e, hipStreamSynchronize(e->st));
   }
+  // one record per cluster where every cluster holds exactly one family with at most one parent and there are no scope masks
+  LgSimpleFam* d_simple = nullptr;
+  if (uni_ok && !f->child_mask && !f->parent_mask && f->n_families == nc) {
+    std::vector<LgSimpleFam> sf(nc);
+    bool simple = true;
+    for (int c = 0; c < nc && simple; ++c) {
+      if (count[c + 1] - count[c] != 1) { simple = false; break; }
+      const int i = fam[count[c]];
+      const int np = f->n_parents[i];
+      if (np > 1) { simple = false; break; }
+      LgSimpleFam r{};
+      r.np = np; r.cpos = f->child_pos[i]; r.row = f->data_row[i];
+      r.ppos = np > 0 ? f->parent_pos[(size_t)i * K] : -1;
+      r.color = f->color[(size_t)i * K];
+      r.length = np > 0 ? f->length[(size_t)i * K] : 0.0;
+      r.gamma = np > 0 ? f->gamma[(size_t)i * K] : 0.0;
+      if (r.cpos > 1 || r.ppos > 1) { simple = false; break; }
+      sf[c] = r;
+    }
+    if (simple) {
+      if ((rc = upload(e, &d_simple, sf))) return rc;
+      keep(d_simple);
+    }
+  }
   e->lg = LgStatic{pp, K, f->n_rates, f->n_rows, d_off, d_fam, d_np, d_cp, d_row, d_pp, d_len, d_gam, d_col, d_data, d_cm, d_pm,
-                   d_data_sm};
+                   d_data_sm, d_simple};
   e->lg_ready = true;
   e->lg_uni_ok = uni_ok;
   return PGBP_OK;

@@ -191,7 +191,16 @@ struct LgStatic {
   const double* data;
   const unsigned long long *child_mask, *parent_mask;  // null: complete data
   const double* data_sm;   // univariate batches: the tip data once more as [row][site] (rows padded: sm_row), lanes = sites read a line
+  // univariate batches whose clusters all hold exactly ONE family with at most one parent and no scope mask (the clique tree of
+  // a tree: cfg4): that family per cluster as one 48-byte record, or null (lg_fill_uni_sm_kernel then walks the general tables)
+  const struct LgSimpleFam* simple;
 };
+struct LgSimpleFam {
+  int32_t np, cpos, ppos, row, color, pad;   // parents (0: a root prior), positions of child / parent in the cluster (-1: fixed), data row, rate
+  double length, gamma;
+  double pad2[2];
+};
+static_assert(sizeof(LgSimpleFam) == 56 || sizeof(LgSimpleFam) == 64, "LgSimpleFam");
 struct LgParams {
   int32_t model, per_site;
   const double *R, *alpha, *theta, *mu;  // device pointers

@@ -304,6 +304,96 @@ __global__ __launch_bounds__(256) void lg_fill_uni_sm_kernel(LgStatic F, LgParam
   }
 }
 
+// The same when every cluster holds exactly one family with at most one parent (LgStatic::simple): the family comes as one
+// record, the loops over families, parents and pairs of in-scope nodes are gone -- the SAME operations in the SAME order as
+// lg_fill_uni_sm_kernel performs for such a family (sums that start from 0.0 included), so the records are bit for bit the
+// same; what is saved is a third of the instructions of a kernel bound by instruction issue (40 M threads of an exp, a log,
+// a division and the bookkeeping of three nested loops each).
+__global__ __launch_bounds__(256) void lg_fill_uni_simple_sm_kernel(LgStatic F, LgParams M, double* __restrict__ pool,
+                                                                    double* __restrict__ fpool,
+                                                                    const int64_t* __restrict__ poff,
+                                                                    const int32_t* __restrict__ dim, int n_clusters,
+                                                                    int n_sites) {
+  const int site = blockIdx.y * blockDim.x + threadIdx.x;
+  if (site >= n_sites) return;
+  const int64_t ns = sm_row(n_sites), ps = M.per_site ? site : 0;
+  const double* __restrict__ R = M.R + ps * F.n_rates;
+  const double mu = M.mu[ps];
+  const double theta = M.theta ? M.theta[ps] : 0.0;
+  const double alpha = (M.model == PGBP_LG_OU) ? M.alpha[ps] : 0.0;
+  for (int c = blockIdx.x; c < n_clusters; c += gridDim.x) {
+    const LgSimpleFam f = F.simple[c];
+    const int m = dim[c];
+    double J00 = 0, J10 = 0, J01 = 0, J11 = 0, h0 = 0, h1 = 0, g = 0;
+    double V = 0.0, z = 0.0, q = 0.0;
+    if (f.np == 0) {
+      V = R[f.color];
+      z = mu;
+    } else {
+      double qc, vc, wc;
+      lg_coefs(M.model, alpha, f.length, f.gamma, qc, vc, wc);
+      V += vc * R[f.color];
+      z += wc * theta;
+      if (f.ppos < 0) z += qc * mu;
+      q = qc;
+      if (f.cpos < 0) z -= F.data_sm[(int64_t)f.row * ns + site];
+    }
+    const double j = 1.0 / V;
+    g += -0.5 * (PGBP_LOG2PI + log(V) + z * j * z);
+    if (!(V > 0.0)) g = NAN;
+    // in-scope nodes: the child (coefficient 1), then the parent (coefficient -q)
+    if (f.cpos >= 0) {
+      const double ca = 1.0;
+      if (f.cpos == 0) h0 += ca * j * z; else h1 += ca * j * z;
+      {
+        const double v = ca * 1.0 * j;
+        if (f.cpos == 0) J00 += v; else J11 += v;
+      }
+      if (f.np > 0 && f.ppos >= 0) {
+        const double v = ca * (-q) * j;
+        if (f.cpos == 0 && f.ppos == 0) J00 += v;
+        else if (f.cpos == 1 && f.ppos == 0) J10 += v;
+        else if (f.cpos == 0 && f.ppos == 1) J01 += v;
+        else J11 += v;
+      }
+    }
+    if (f.np > 0 && f.ppos >= 0) {
+      const double ca = -q;
+      if (f.ppos == 0) h0 += ca * j * z; else h1 += ca * j * z;
+      if (f.cpos >= 0) {
+        const double v = ca * 1.0 * j;
+        if (f.ppos == 0 && f.cpos == 0) J00 += v;
+        else if (f.ppos == 1 && f.cpos == 0) J10 += v;
+        else if (f.ppos == 0 && f.cpos == 1) J01 += v;
+        else J11 += v;
+      }
+      {
+        const double v = ca * (-q) * j;
+        if (f.ppos == 0) J00 += v; else J11 += v;
+      }
+    }
+    const int64_t p0 = poff[c];
+    if (m == 2) {
+      const double v[7] = {J00, J10, J01, J11, h0, h1, g};
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        pool[(p0 + t) * ns + site] = v[t];
+        if (fpool) fpool[(p0 + t) * ns + site] = v[t];
+      }
+    } else if (m == 1) {
+      const double v[3] = {J00, h0, g};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        pool[(p0 + t) * ns + site] = v[t];
+        if (fpool) fpool[(p0 + t) * ns + site] = v[t];
+      }
+    } else {
+      pool[p0 * ns + site] = g;
+      if (fpool) fpool[p0 * ns + site] = g;
+    }
+  }
+}
+
 void launch_lg_fill(const LgStatic& F, const LgParams& M, double* pool, int64_t pool_stride, double* fpool,
                     int64_t fpool_stride, const int64_t* d_boff, const int32_t* d_dim, int bs16, int fast_p, int max_dim,
                     int n_clusters, int n_sites, hipStream_t st) {
@@ -325,7 +415,14 @@ void launch_lg_fill_uni_sm(const LgStatic& F, const LgParams& M, double* pool_sm
                            const int32_t* d_dim, int n_clusters, int n_sites, hipStream_t st) {
   if (n_clusters <= 0) return;
   const int bs = n_sites >= 256 ? 256 : 64;
-  const int gx = n_clusters < 16384 ? n_clusters : 16384;
+  // (one cluster per workgroup up to 2^20 of them: with a grid-stride loop over a capped grid the workgroups that take one
+  // cluster more than the others set the kernel's time -- 40 000 clusters over 16 384 workgroups: three rounds for 2.44 of work)
+  const int gx = n_clusters < (1 << 20) ? n_clusters : (1 << 20);
+  if (F.simple) {
+    hipLaunchKernelGGL(lg_fill_uni_simple_sm_kernel, dim3(gx, (n_sites + bs - 1) / bs), dim3(bs), 0, st, F, M, pool_sm, fpool_sm,
+                       d_poff, d_dim, n_clusters, n_sites);
+    return;
+  }
   hipLaunchKernelGGL(lg_fill_uni_sm_kernel, dim3(gx, (n_sites + bs - 1) / bs), dim3(bs), 0, st, F, M, pool_sm, fpool_sm,
                      d_poff, d_dim, n_clusters, n_sites);
 }

@@ -561,6 +561,20 @@ def test_residual_kldiv_on_the_muller_clique_tree_with_sepsets_beyond_the_lds(p)
     root = P.default_rootcluster(cn, net.is_leaf)
     spt = P.spanningtree_clusterlist(len(cn), ed, root)
     sched = [(np.asarray(spt[2]), np.asarray(spt[3]))]
+    # calibrate once; then disturb a few large cliques and calibrate once more with the KL residuals on: in that second
+    # iteration every sepset starts from a calibrated marginal (positive definite) and moves by a visible amount -- after a
+    # first calibrate!() from the factors most "beliefs before" are 0 or singular and residual_kldiv! leaves nearly every
+    # message alone (563 of 663 here)
+    assert P.calibrate_(cgb, sched, 1)[0]
+    order = np.argsort(-st.dims[:len(cn)])
+    for i in order[:12]:
+        m = int(st.dims[i])
+        rec = np.zeros(m * m + m + 1)
+        assert cgb._lib.pgbp_get_belief(cgb._eng, 0, int(i), L.f64p(rec)) == 0
+        Jm = rec[:m * m].reshape(m, m)
+        Jm[np.diag_indices(m)] *= 1.05
+        rec[m * m: m * m + m] *= 1.02
+        assert cgb._lib.pgbp_set_belief(cgb._eng, 0, int(i), L.f64p(rec)) == 0
     assert P.calibrate_(cgb, sched, 1, update_residualkldiv=True)[0]
     cgb.pull()
     nc = len(cn)
@@ -612,7 +626,7 @@ def test_residual_kldiv_on_the_muller_clique_tree_with_sepsets_beyond_the_lds(p)
             big += 1
             if biggest is None or s_ > biggest[0]:
                 biggest = (s_, int(c), nc + k, int(a), got)
-    assert checked >= 500 and (big >= 1 or p == 2) and illcond <= checked // 10, (checked, big, skipped, illcond)
+    assert checked >= 400 and (big >= 1 or p == 2) and illcond <= checked // 4, (checked, big, skipped, illcond)
     if biggest is None:
         return
     # the standalone call on the largest sepset (workspace instance, one entry)

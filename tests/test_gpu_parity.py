@@ -1724,7 +1724,9 @@ def test_lazy_write_back_equals_the_eager_pull_and_keeps_aliases(P):
     assert lazy._stale.sum() == lazy.nbeliefs - 1          # one record moved, nothing else
     b9 = lazy.belief[9]
     assert np.array_equal(b9.h, eager.belief[9].h) and np.array_equal(b9.g, eager.belief[9].g)
-    mr, mre = lazy.messageresidual[(int(prob.sepset_clusters[0]), int(prob.sepset_clusters[1]))], eager.messageresidual[(int(prob.sepset_clusters[0]), int(prob.sepset_clusters[1]))]
+    sc0 = np.asarray(prob.sepset_clusters).reshape(-1, 2)[0]
+    key = (int(sc0[0]), int(sc0[1]))
+    mr, mre = lazy.messageresidual[key], eager.messageresidual[key]
     assert np.array_equal(mr.dJ, mre.dJ) and np.array_equal(mr.dh, mre.dh) and mr.iscalibrated_resid == mre.iscalibrated_resid
     assert lazy._res_have.sum() == 1
     assert lazy.iscalibrated_residnorm() == eager.iscalibrated_residnorm()

@@ -1,8 +1,12 @@
 set -o pipefail
-mkdir -p gpurun_out/r04l
-export TMPDIR=/tmp
-timeout -k 10 1100 python -m pytest tests/ -q -m gpu > gpurun_out/r04l/pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/r04l/pytest_gpu.log
-tail -6 gpurun_out/r04l/pytest_gpu.log
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -- python3 $GRAFT_REPO_ROOT/bench.py --workload sites --sites 125 --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r04l/bench_cfg4_125_prof.json 2>$GRAFT_REPO_ROOT/gpurun_out/r04l/e2.txt; f=$(find /tmp/p5 -name "*kernel_stats.csv" | head -1); cp $f $GRAFT_REPO_ROOT/gpurun_out/r04l/cfg4_125_kernel_stats.csv
-cd $GRAFT_REPO_ROOT
-cut -c1-150 gpurun_out/r04l/cfg4_125_kernel_stats.csv | head -8
+mkdir -p gpurun_out/r04n
+timeout -k 10 1100 python -m pytest tests/ -q -m gpu > gpurun_out/r04n/pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/r04n/pytest_gpu.log
+tail -6 gpurun_out/r04n/pytest_gpu.log
+for s in 125 125 1000; do
+  python3 bench.py --workload sites --sites $s --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r04n/sites_$s.json 2>gpurun_out/r04n/err_$s.txt || exit 1
+  python3 - gpurun_out/r04n/sites_$s.json $s <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); n=int(sys.argv[2])*8
+print(sys.argv[2], "step ms", round(d['ms_per_step'],4), "cal ms", round(d['calibrate_only']['ms_per_step'],4), "ll/s", round(d['ll_evals_per_s']))
+PY
+done

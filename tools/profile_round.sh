@@ -53,6 +53,14 @@ bash tools/pmc_network.sh $tag bethe > /dev/null 2>&1; cp $PWD/gpurun_out/${tag}
 step "cfg5 level times"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p9b -- python3 tools/level_times.py run-network joingraph > $out/lt5_run.txt 2>&1 || exit 1
 python3 tools/level_times.py parse /tmp/p9b $out/cfg5_joingraph_level_times.json > $out/cfg5_joingraph_level_times.txt 2>&1; rm -rf /tmp/p9b
+step "cfg4 at a rank's share of 8 GPUs (1 000 problems)"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5b -- python3 bench.py --workload sites --sites 125 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_cfg4_125_sites_under_profiler.json 2>$out/e5b.txt || exit 1
+keep_stats /tmp/p5b cfg4_125_sites_kernel_stats.csv; rm -rf /tmp/p5b
+for s in 1000 500 250 125; do python3 bench.py --workload sites --sites $s --no-cpu-baseline 2>>$out/e5c.txt; done > $out/bench_cfg4_strong_scaling_projection.jsonl || exit 1
+step "seam microbenchmark"
+[ -x build/exp/grid_barrier ] && { timeout -k 10 120 build/exp/grid_barrier 0 200; timeout -k 10 120 build/exp/grid_barrier 128 200; } > $out/grid_barrier_microbench.txt 2>&1
+step "Mueller clique tree: large beliefs, KL residuals, free energy"
+python3 tools/time_muller.py 2 3 4 6 > $out/muller_cliquetree_times.jsonl 2>$out/e_muller.txt
 step "plain bench lines"
 python3 bench.py > $out/bench_default.json 2>$out/e10.txt || exit 1
 python3 bench.py --workload sites > $out/bench_cfg4.json 2>$out/e11.txt || exit 1

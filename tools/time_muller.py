@@ -17,7 +17,7 @@ import pgbp_amd as P  # noqa: E402
 
 
 def main():
-    ps = [int(x) for x in sys.argv[1:]] or [2, 3, 4]
+    ps = [int(x) for x in sys.argv[1:]] or [2, 3, 4, 6]
     net, names = P.read_newick(open(os.path.join(ROOT, "tests", "golden", "muller_2022.phy")).read())
     cn, ed, sn = P.cliquetree(net.node2family)
     lib = P.load()
@@ -39,12 +39,26 @@ def main():
         assert lib.pgbp_time_enqueued(cgb._eng, 0, 3, 0, C.byref(opts), C.byref(ms)) == 0      # warm-up
         reps = 20
         assert lib.pgbp_time_enqueued(cgb._eng, 0, reps, 0, C.byref(opts), C.byref(ms)) == 0
+        # round 4: the same with residual_kldiv! after every message (sepsets above 96 variables on the workspace instance of
+        # the kernel), and free_energy (beliefs above 139 variables on its workspace instance)
+        import time
+        okl = cgb._opts(update_residualkldiv=True)
+        assert lib.pgbp_enqueue_calibrate(cgb._eng, 1, 0, C.byref(okl)) == 0 and lib.pgbp_sync(cgb._eng) == 0
+        t0 = time.perf_counter()
+        assert lib.pgbp_enqueue_calibrate(cgb._eng, 3, 0, C.byref(okl)) == 0 and lib.pgbp_sync(cgb._eng) == 0
+        ms_kl = (time.perf_counter() - t0) / 3 * 1e3
+        cgb.init_factors_frombeliefs_()
+        t0 = time.perf_counter()
+        fe = cgb.free_energy()
+        ms_fe = (time.perf_counter() - t0) * 1e3
         ll, info = cgb.loglik_lg()
         big = sorted(int(d) for d in st.dims[:len(cn)])[-3:]
         print(json.dumps({"workload": f"Mueller et al. clique tree, {p} traits", "cliques": len(cn), "messages_per_calibrate": 2 * len(ed),
                           "largest_beliefs": big, "beliefs_above_64": int((st.dims[:len(cn)] > 64).sum()),
                           "beliefs_above_128": int((st.dims[:len(cn)] > 128).sum()),
-                          "ms_per_calibrate": ms.value / reps, "loglik": float(ll[0]), "info": int(info[0])}), flush=True)
+                          "largest_sepset": int(st.dims[len(cn):].max()), "ms_per_calibrate": ms.value / reps,
+                          "ms_per_calibrate_with_residual_kldiv": ms_kl, "free_energy_ms": ms_fe, "free_energy": fe[2],
+                          "loglik": float(ll[0]), "info": int(info[0])}), flush=True)
 
 
 if __name__ == "__main__":
