@@ -709,7 +709,10 @@ static void launch_fill_p(double* pool, int64_t pool_stride, double* fpool, int6
                           const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
                           const double* d_data, int n_rows, const double* d_Rinv, const double* d_logdetR,
                           const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
-  const int gx = std::min((n_clusters + 3) / 4, 16384);
+  // (a grid-stride loop: as many workgroups as give every one the same number of rounds -- 25 000 groups of four clusters over
+  // a grid capped at 16 384 were two rounds for 1.53 rounds of work)
+  const int nb = (n_clusters + 3) / 4, rounds = (nb + 16383) / 16384;
+  const int gx = (nb + rounds - 1) / std::max(1, rounds);
   if constexpr (!ODD) {
     if (bs16) {
       hipLaunchKernelGGL((bm_tree_fill_fast<P, true, false>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,

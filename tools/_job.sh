@@ -1,12 +1,4 @@
 set -o pipefail
-mkdir -p gpurun_out/r04n
-timeout -k 10 1100 python -m pytest tests/ -q -m gpu > gpurun_out/r04n/pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/r04n/pytest_gpu.log
-tail -6 gpurun_out/r04n/pytest_gpu.log
-for s in 125 125 1000; do
-  python3 bench.py --workload sites --sites $s --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r04n/sites_$s.json 2>gpurun_out/r04n/err_$s.txt || exit 1
-  python3 - gpurun_out/r04n/sites_$s.json $s <<'PY'
-import json,sys
-d=json.load(open(sys.argv[1])); n=int(sys.argv[2])*8
-print(sys.argv[2], "step ms", round(d['ms_per_step'],4), "cal ms", round(d['calibrate_only']['ms_per_step'],4), "ll/s", round(d['ll_evals_per_s']))
-PY
-done
+bash tools/profile_round.sh r04 > gpurun_out/prof_r04_stdout.txt 2>&1; echo "rc $?"
+tail -30 gpurun_out/prof_r04/log.txt
+ls gpurun_out/prof_r04 | head -80
