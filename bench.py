@@ -421,7 +421,9 @@ def run_network(args, torch, dist, rank, world, local_rank, emit=True):
     from pgbp_amd import _lib as L
     lib = P.load()
     t0 = time.time()
-    net, (cn, ed, sn), st, fam, X, rates, mu, sched = build_network_workload(args, rank)
+    # (as a block of the default line every rank runs the SAME replica -- rank 0's network, the one the parity gate and the
+    # committed PMC passes are about; the standalone workload gives every rank a network of its own)
+    net, (cn, ed, sn), st, fam, X, rates, mu, sched = build_network_workload(args, rank if emit else 0)
     cgb = P.ClusterGraphBelief.from_arrays(st.dims, st.sepset_clusters, st.scope_off, st.scope_idx, None, device=local_rank)
     cgb.lg_setup(fam, X)
     cgb.assignfactors_lg_(rates, mu)                      # assignfactors! on the device (heterogeneous BM, hybrid nodes)

@@ -1604,12 +1604,15 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_uni1(DevState S, con
                                                                  const URec* __restrict__ urecs,
                                                                  const int32_t* __restrict__ grp_tasks,
                                                                  const int32_t* __restrict__ wg_off, int n_sites,
-                                                                 unsigned long long seq_base, unsigned long long stop_below) {
+                                                                 unsigned long long seq_base, unsigned long long stop_below,
+                                                                 int ny) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int site = blockIdx.y * 64 + lane;
+  // (one-dimensional grid, walk-major: the ny site blocks of a walk in consecutive workgroups, as in bp_level_uni1)
+  const int walk = (int)(blockIdx.x / (unsigned)ny), yb = (int)(blockIdx.x % (unsigned)ny);
+  const int site = yb * 64 + lane;
   // (a stopped or padding lane skips the work, never a barrier)
   const bool live = site < n_sites && !((S.fail[site < n_sites ? site : 0] >> kInfoBits) < stop_below);
-  const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
+  const int g0 = wg_off[walk], g1 = wg_off[walk + 1];
   for (int g = g0; g < g1; ++g) {
     const int t = grp_tasks[(int64_t)g * kTailWaves + wave];
     if (t >= 0 && live) uni1_task<SM>(S, task_off, urecs, t, site, seq_base);
@@ -1642,9 +1645,10 @@ void launch_chunk_uni1(const DevState& S, const int32_t* d_task_off, const URec*
                        const int32_t* d_wg_off, int n_wg, int n_sites, unsigned long long seq_base,
                        unsigned long long stop_below, hipStream_t st) {
   if (n_wg <= 0) return;
-  const dim3 grid(n_wg, (n_sites + 63) / 64), block(kTailWaves * 64);
-  if (S.sm) hipLaunchKernelGGL(bp_chunk_uni1<true>, grid, block, 0, st, S, d_task_off, d_urecs, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
-  else hipLaunchKernelGGL(bp_chunk_uni1<false>, grid, block, 0, st, S, d_task_off, d_urecs, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below);
+  const int ny = (n_sites + 63) / 64;
+  const dim3 grid((unsigned)n_wg * (unsigned)ny), block(kTailWaves * 64);   // (n_wg <= a few thousand walks: no overflow)
+  if (S.sm) hipLaunchKernelGGL(bp_chunk_uni1<true>, grid, block, 0, st, S, d_task_off, d_urecs, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below, ny);
+  else hipLaunchKernelGGL(bp_chunk_uni1<false>, grid, block, 0, st, S, d_task_off, d_urecs, d_grp_tasks, d_wg_off, n_sites, seq_base, stop_below, ny);
 }
 
 size_t generic_lds_bytes(int max_mf) {

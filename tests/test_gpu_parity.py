@@ -1745,3 +1745,64 @@ def test_lazy_write_back_equals_the_eager_pull_and_keeps_aliases(P):
     for i in range(lazy.nbeliefs):
         lazy.belief[i].g
     assert lazy._stale is None
+
+
+def test_fused_calibration_flag_of_site_minor_batches(P):
+    """iscalibrated_residnorm(beliefs) (src/clustergraphbeliefs.jl:168-169) of a univariate site batch in the site-minor layout
+    (>= 64 sites): after a postorder + preorder pair over a tree that holds every sepset the engine takes it from the marks
+    the message kernels set (DevState::notcal) instead of reducing the 2 n_sepsets x n_sites flag array.  It must equal the
+    AND of the flags per site -- some sites calibrated, others not (their data moved between two calibrations), one site
+    with a damaged cluster (failed: (false, false)) -- and calibrate!(...; auto = true) must stop every site where the C
+    engine run on that site alone stops it."""
+    from pgbp_amd import synth as S
+    from pgbp_amd import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    ns = 96
+    tr = S.random_tree(40, rng)
+    prob = S.cliquetree_of_tree(tr, 1)
+    sig = rng.uniform(0.5, 2.0, size=ns)
+    mu = rng.normal(size=ns)
+    X = S.simulate_bm_uni_sites(tr, sig, mu, rng)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, None, n_sites=ns)
+    cgb.set_schedule(prob.schedule)
+    cgb.bm_tree_setup(*S.bm_tree_table(tr, prob), X[:, :, None])
+    cgb.assignfactors_bm_(sig[:, None, None], mu[:, None])
+    lib = P.load()
+    res = (L.Result * ns)()
+    o = cgb._opts()
+    assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o), res) == 0
+    nm = 2 * cgb.nsepsets
+
+    def flags_and():
+        f = np.zeros((ns, nm), np.int32)
+        assert lib.pgbp_get_residuals(cgb._eng, None, L.i32p(f), None, None) == 0
+        return f.all(axis=1)
+    assert all(r.succ for r in res) and [bool(r.iscal) for r in res] == list(flags_and()) and not any(r.iscal for r in res)
+    assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o), res) == 0      # a tree: calibrated after the second pair
+    assert [bool(r.iscal) for r in res] == list(flags_and()) and all(r.iscal for r in res)
+    # move the beliefs of every third site (new factors for them would do the same: here, one cluster's h), calibrate once:
+    # those sites are not calibrated in that pair, the others stay so
+    cgb.pull()
+    moved = np.arange(ns) % 3 == 0
+    i0 = int(np.argmax(prob.dims[:cgb.nclusters]))
+    for s_ in np.nonzero(moved)[0]:
+        J, h, g = cgb._views(int(s_), i0)
+        h[0] += 0.5
+    cgb.push()
+    assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o), res) == 0
+    got = np.array([bool(r.iscal) for r in res])
+    assert np.array_equal(got, flags_and()) and not got[moved].any() and got[~moved].all()
+    # a damaged site fails alone; auto stops every other site at its own first calibrated tree
+    cgb.pull()
+    J, h, g = cgb._views(5, i0)
+    J[0, 0] = -abs(J[0, 0]) - 1.0
+    cgb.push()
+    oa = cgb._opts(auto=True)
+    assert lib.pgbp_calibrate(cgb._eng, 6, C.byref(oa), res) == 0
+    assert not res[5].succ and not res[5].iscal and res[5].fail_info > 0
+    ok = [s_ for s_ in range(ns) if s_ != 5]
+    assert all(res[s_].succ and res[s_].iscal for s_ in ok)
+    assert {(res[s_].iter_reached, res[s_].tree_reached) for s_ in ok if not moved[s_]} == {(1, 1)}
+    assert {(res[s_].iter_reached, res[s_].tree_reached) for s_ in ok if moved[s_]} <= {(1, 1), (2, 1)}
+    assert np.array_equal(flags_and()[ok], np.ones(len(ok), bool))

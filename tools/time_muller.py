@@ -42,12 +42,16 @@ def main():
         # round 4: the same with residual_kldiv! after every message (sepsets above 96 variables on the workspace instance of
         # the kernel), and free_energy (beliefs above 139 variables on its workspace instance)
         import time
-        okl = cgb._opts(update_residualkldiv=True)
-        assert lib.pgbp_enqueue_calibrate(cgb._eng, 1, 0, C.byref(okl)) == 0 and lib.pgbp_sync(cgb._eng) == 0
-        t0 = time.perf_counter()
-        assert lib.pgbp_enqueue_calibrate(cgb._eng, 3, 0, C.byref(okl)) == 0 and lib.pgbp_sync(cgb._eng) == 0
-        ms_kl = (time.perf_counter() - t0) / 3 * 1e3
-        cgb.init_factors_frombeliefs_()
+        from pgbp_amd import _lib as L
+        res = (L.Result * 1)()
+
+        def wall(o, n):   # pgbp_calibrate (the entry point that honours update_residualkldiv), host wall clock
+            assert lib.pgbp_calibrate(cgb._eng, 1, C.byref(o), res) == 0 and res[0].succ
+            t0 = time.perf_counter()
+            assert lib.pgbp_calibrate(cgb._eng, n, C.byref(o), res) == 0 and res[0].succ
+            return (time.perf_counter() - t0) / n * 1e3
+        ms_plain = wall(cgb._opts(), 3)
+        ms_kl = wall(cgb._opts(update_residualkldiv=True), 3)
         t0 = time.perf_counter()
         fe = cgb.free_energy()
         ms_fe = (time.perf_counter() - t0) * 1e3
@@ -57,7 +61,8 @@ def main():
                           "largest_beliefs": big, "beliefs_above_64": int((st.dims[:len(cn)] > 64).sum()),
                           "beliefs_above_128": int((st.dims[:len(cn)] > 128).sum()),
                           "largest_sepset": int(st.dims[len(cn):].max()), "ms_per_calibrate": ms.value / reps,
-                          "ms_per_calibrate_with_residual_kldiv": ms_kl, "free_energy_ms": ms_fe, "free_energy": fe[2],
+                          "ms_per_pgbp_calibrate_wall": ms_plain, "ms_per_pgbp_calibrate_wall_with_residual_kldiv": ms_kl,
+                          "free_energy_ms": ms_fe, "minus_free_energy": -fe[2],
                           "loglik": float(ll[0]), "info": int(info[0])}), flush=True)
 
 
