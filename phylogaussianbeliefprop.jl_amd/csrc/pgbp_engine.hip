@@ -428,7 +428,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
                             ch.n_wg, e->plan.n_sites, seq_base, stop_below, e->st);
         else if (ch.generic)
           launch_chunk_generic(S, d.d_grecs, d.d_cgroups + ch.group0 * kTailWaves, d.d_chunk_wg_off + ch.wg0, ch.n_wg,
-                               e->plan.n_sites, seq_base, stop_below, ch.max_mf, ch.small_only != 0, e->st);
+                               e->plan.n_sites, seq_base, stop_below, ch.max_mf, ch.small_only != 0, e->plan.tune.pair2, e->st);
         else
           launch_loop_or_tail(e, S, d.d_centries + ch.group0 * kTailWaves, d.d_cpros ? d.d_cpros + ch.group0 * kTailWaves : nullptr,
                               ch.n_groups, INT32_MAX, seq_base, stop_below, stop_below, d.d_chunk_wg_off + ch.wg0, ch.n_wg);

@@ -160,6 +160,7 @@ struct Tuning {
   bool chunks = true;          // no_chunks: no chunks of fused levels
   bool prologues = true;       // no_prologue: Bethe graphs of trees on the two-level schedule (no prologue fusion)
   bool chain_fusion = false;   // chain_fusion: unary clusters passed through inside one task of the wave-per-task kernel (opt-in)
+  bool pair2 = true;           // pair=0: chunks of small messages on bp_chunk_generic (one wavefront per task) instead of bp_chunk_pair
   bool loop2 = true;           // loop=0: tail and chunks of the packed layout on bp_fast16's own loop mode (one wavefront per record)
   bool packed_layouts = true;  // plain_layout: keep the ABI's record layout on the device (no BS16, no site-minor)
   long long mixed_fast_min = -1;   // mixed_fast_min=n: a level with both task classes splits from n fast-class tasks on (-1: default)

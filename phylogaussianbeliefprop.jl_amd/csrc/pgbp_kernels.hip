@@ -16,13 +16,15 @@
 
 #include "pgbp_bs16.hpp"
 #include "pgbp_kernels.hpp"
+#include "pgbp_small_dev.hpp"
 
 namespace pgbp {
 
-#define PGBP_LOG2PI 1.8378770664093454835606594728112
-#define PGBP_EPS 2.220446049250313e-16
 #ifndef PGBP_SMALL_DPP
 #define PGBP_SMALL_DPP 1   // small_message: pivot rows by DPP row broadcast (0: by v_readlane, the form before)
+#endif
+#ifndef PGBP_SMALL_SETTLE
+#define PGBP_SMALL_SETTLE 1   // small_message: the operands' arrival is stated once, in front of the stores (0: the form before)
 #endif
 
 static constexpr int kPermDoubles = PGBP_MAX_DIM / 2;  // PGBP_MAX_DIM int32 at the front of LDS
@@ -109,118 +111,23 @@ __device__ __forceinline__ int eliminate_leading(double* W, int ld, int mf, int 
   return 0;
 }
 
-// ---- the record of a message (GRec, pgbp_internal.hpp) as a wavefront holds it: one dword per lane (lanes 0 .. 31 =
-// the 128 bytes of the record) and this lane's byte of the two inline index maps.  Three vector loads with addresses
-// that depend on the record index alone, so the record of the NEXT message (of the task, or of the workgroup's next step
-// in the loop mode) is in flight beside the current message at the cost of three registers.
-struct GLoad {
-  unsigned int rv;
-  int pb, ub;
-};
-__device__ __forceinline__ GLoad load_grec(const GRec* __restrict__ recs, int ri, int lane) {
-  const unsigned char* b = reinterpret_cast<const unsigned char*>(recs + ri);
-  GLoad l;
-  l.rv = reinterpret_cast<const unsigned int*>(b)[lane & 31];
-  l.pb = b[offsetof(GRec, perm) + (lane < kGInlPerm ? lane : 0)];
-  l.ub = b[offsetof(GRec, up) + (lane & (kGInlUp - 1))];
-  return l;
-}
-__device__ __forceinline__ int grec_dw(unsigned int rv, int k) { return __builtin_amdgcn_readlane((int)rv, k); }
-__device__ __forceinline__ int64_t grec_i64(unsigned int rv, int k) {
-  return (int64_t)(((unsigned long long)(unsigned int)grec_dw(rv, k + 1) << 32) | (unsigned int)grec_dw(rv, k));
-}
-
-// ---- SMALL messages in registers: at most kSmallI integrated and kSmallK kept variables (a level-3 network's cluster
-// graphs: clusters of up to three nodes, sepsets of one or two; a handful of traits).  The augmented sender sits in a
-// fixed 16 x 17 frame, one ROW PER LANE: integrated variable k in lane k / column k, kept variable a in lane 8 + a /
-// column 8 + a, h in column 16 (unused rows and columns are zero).  Every operand of the message -- the sender's rows,
-// the sepset's and the receiver's entries this lane will update, the failure mark of the sender -- is requested in one
-// batch at the top; the elimination is straight-line code (the pivot row travels by a DPP row broadcast, no LDS, no
-// synchronisation); divide! and mult! are done by the kept lanes on their own rows.  Arithmetic and its order are those
-// of the LDS path below (eliminate_leading): W[i][j] -= (W[i][k] / d_k) * W[k][j], log det as a mantissa product.
-// (kSmallI = kSmallK = 8: pgbp_internal.hpp -- the planner tells the launches whose messages all fit)
-struct SmallFrame {
-  double row[kSmallI + kSmallK + 1];
-};
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, l);
-  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), l);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// the pivot row of a frame held one row per lane: lane K of each ROW OF 16 LANES to that row's lanes, one instruction
-// (v_mov_b64_dpp row_newbcast:K) where two v_readlane serve a single row and go through scalar registers
-template <int K>
-__device__ __forceinline__ double row_bcast(double v) {
-  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);   // row_newbcast:K
-}
-// the KI pivots of a frame (columns 0 .. KI - 1 integrated, KI .. KI + KK - 1 kept, KI + KK = h), straight-line: every row of
-// 16 lanes that enters eliminates its own frame (bp_level_small4: four tasks; small_message: the task sits in lanes 0 .. 15)
-template <int KI, int KK>
-struct Small4 {
-  // SPREAD (the instances where registers are plentiful: the loop launches): the broadcasts of a pivot row first, each into
-  // a register of its own, then the updates -- with ONE temporary the compiler emits  mov, fma, nop, mov, fma, ...  and a
-  // wavefront alone on its SIMD pays each pair's latency in turn
-  template <int k, class Row, bool SPREAD = false>
-  static __device__ __forceinline__ void pivot(Row& row, const int ni, int& info, double& mant, int& expo, double& quad) {
-    if (k < ni && info == 0) {
-      const double d = row_bcast<k>(row[k]);
-      const double hk = row_bcast<k>(row[KI + KK]);
-      if (!(d > 0.0)) {
-        info = k + 1;
-      } else {
-        double rd = __builtin_amdgcn_rcp(d);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        int ex;
-        mant *= frexp(d, &ex);
-        expo += ex;
-        quad += hk * hk * rd;
-        const double f = row[k] * rd;
-        if constexpr (SPREAD) {
-          double pk[KI + KK + 1];
-#pragma unroll
-          for (int j = k + 1; j <= KI + KK; ++j) pk[j] = row_bcast<k>(row[j]);
-#pragma unroll
-          for (int j = k + 1; j <= KI + KK; ++j) asm volatile("" : "+v"(pk[j]));   // (materialised before the first update)
-#pragma unroll
-          for (int j = k + 1; j <= KI + KK; ++j) row[j] -= f * pk[j];
-        } else {
-#pragma unroll
-        for (int j = k + 1; j <= KI + KK; ++j) {
-          const double pkj = row_bcast<k>(row[j]);
-          row[j] -= f * pkj;
-        }
-        }
-      }
-    }
-    if constexpr (k + 1 < KI) pivot<k + 1, Row, SPREAD>(row, ni, info, mant, expo, quad);
-  }
-};
-
 // returns 0: message applied; 1: the task ends here (the sender is downstream of a failure, or J_I is not positive definite)
 // KI, KK: the frame of this instance (KI integrated + KK kept rows / columns + h): 8 + 8 covers every small message; the
 // loop launches, where occupancy does not matter, also have 4 + 4, 4 + 8 and 8 + 4 (half the straight-line code of a message
 // of a 4-trait network: clusters of one to three nodes)
-// element `idx` of a record whose base is wave-uniform (a scalar register pair): the byte offset formed in 32 bits, so that
-// the access is  global_load / store  v, v_offset, s[base]  -- one shift in front of it instead of a sign or zero extension
-// and a 64-bit shift-add (a wavefront alone on its SIMD pays every dependent step of an address in full)
-__device__ __forceinline__ double ld8(const double* __restrict__ base, int idx) {
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ((unsigned int)idx << 3));
-}
-__device__ __forceinline__ void st8(double* __restrict__ base, int idx, double v) {
-  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + ((unsigned int)idx << 3)) = v;
-}
-
 template <bool WAVE, int KI, int KK, bool DENSE = false>
 __device__ __forceinline__ int small_message(const DevState& S, const GRec* __restrict__ recs, const GLoad& cur, const int site,
                                              const int lane, unsigned long long seq_base, double* __restrict__ pool,
-                                             double* __restrict__ rpool, SmallFrame& F, double& gmsg_io
+                                             double* __restrict__ rpool, SmallFrame& F, double& gmsg_io, const int pend
 #ifdef PGBP_GSTAMP
                                              , unsigned int* gst
 #endif
 ) {
+  // ---- DECODE: everything that depends on the record alone (static plan data, resident since the previous message) -- the
+  // record's words into scalar registers, the three or four pointers, this lane's role, rows and columns from the inline
+  // maps.  No access to a belief yet: the synchronisation that makes the previous message's (task: fence) or the previous
+  // level's (loop mode: workgroup barrier) stores visible comes BEHIND the decode (`pend`), so these ~ 150 instructions run
+  // while those stores are still on their way to the L2 instead of after their acknowledgement.
   const unsigned int rv = cur.rv;
   const int next = grec_dw(rv, 15);
   const int en_msg = grec_dw(rv, 8), en_seq = grec_dw(rv, 9), from_b = grec_dw(rv, 10);
@@ -228,21 +135,72 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   const int mf = dims & 255, mt = (dims >> 8) & 255, s = (dims >> 16) & 255, ni = (dims >> 24) & 255;
   const int k0 = (fl & 255) == 255 ? -1 : (fl & 255), u0 = ((fl >> 8) & 255) == 255 ? -1 : ((fl >> 8) & 255);
   const bool en_reuse = ((fl >> 16) & 255) != 0;
-  int pz = 0;
-  asm volatile("" : "+v"(pz));   // (vector loads of wave-uniform words: see generic_task)
-  const int poisoned = S.poison[(int64_t)site * S.n_clusters + from_b + pz];
   double* __restrict__ sep = pool + grec_i64(rv, 4);
   double* __restrict__ to = pool + grec_i64(rv, 2);
   double* __restrict__ res = rpool + grec_i64(rv, 6);
+  const double* __restrict__ from = pool + grec_i64(rv, 0);
   const bool is_int = lane < KI;
   const int fi = KI == 8 ? (lane & 7) : (is_int ? lane : lane - KI);   // row of the message (kept lanes) / pivot index (integrated lanes)
   const bool kept_live = lane >= KI && lane < KI + KK && fi < s;
   const bool row_live = is_int ? fi < ni : kept_live;
-  // ---- receiver / sepset operands of the kept lanes (row a = fi of the message): requested first
   const int up_lane = __shfl(cur.ub, fi);   // (inline map: lane l holds up[l & 15])
-  const int ua = u0 >= 0 ? u0 + fi : up_lane;
+  int ua = u0 >= 0 ? u0 + fi : up_lane;
+  int ubv[KK], cjv[KI], cbv[KK];
+#pragma unroll
+  for (int b = 0; b < KK; ++b) {
+    const int rl = __builtin_amdgcn_readlane(cur.ub, b);
+    ubv[b] = u0 >= 0 ? u0 + b : rl;
+  }
+  // position of this lane's variable in the sender, and of every column's (wave-uniform)
+  const int q = is_int ? fi : ni + fi;                       // place in the order "integrated first, kept last"
+  const int pq = __shfl(cur.pb, q < kGInlPerm ? q : 0);      // (inline map: lane l holds perm[l])
+  int pi = k0 >= 0 ? (q < ni ? (q < k0 ? q : q + s) : k0 + (q - ni)) : pq;
+#pragma unroll
+  for (int j = 0; j < KI; ++j) {
+    const int rl = __builtin_amdgcn_readlane(cur.pb, j);
+    cjv[j] = k0 >= 0 ? (j < k0 ? j : j + s) : rl;
+  }
+#pragma unroll
+  for (int b = 0; b < KK; ++b) {
+    const int rl = __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
+    cbv[b] = k0 >= 0 ? k0 + b : rl;
+  }
+  // byte offsets of this lane's operands (DENSE: an unused column stands for column 0, see below); the sepset's and the
+  // receiver's serve the loads at the top and the stores at the end
+  unsigned int osep[KK], oto[KK], oX[KI], oY[KI], oZ[KK];
+  const int rowbase = pi * mf;
+#pragma unroll
+  for (int b = 0; b < KK; ++b) {
+    const int bb = (!DENSE || b < s) ? b : 0, ub = (!DENSE || b < s) ? ubv[b] : ubv[0];
+    osep[b] = (unsigned int)(fi + bb * s) << 3;
+    oto[b] = (unsigned int)(ua + ub * mt) << 3;
+    const int cb = (!DENSE || b < s) ? cbv[b] : cjv[0];   // (DENSE, an unused kept column: any column of the sender)
+    oZ[b] = (unsigned int)(is_int ? cb + rowbase : pi + cb * mf) << 3;   // J_SI' for a pivot row, J_S for a kept one
+  }
+#pragma unroll
+  for (int j = 0; j < KI; ++j) {
+    const int cj = (!DENSE || j < ni) ? cjv[j] : cjv[0];
+    oX[j] = (unsigned int)(pi + cj * mf) << 3;      // J[this row, integrated column j]
+    oY[j] = (unsigned int)(cj + rowbase) << 3;      // J[integrated row j, this column]: the upper triangle of J_I
+  }
+  unsigned int oseph = (unsigned int)(s * s + fi) << 3, otoh = (unsigned int)(mt * mt + ua) << 3,
+               ofh = (unsigned int)(mf * mf + pi) << 3;
+  if (pend != 0) {
+    // (the decode is pinned in front of the synchronisation: nothing of it may sink behind the wait)
+#pragma unroll
+    for (int b = 0; b < KK; ++b) asm volatile("" : "+v"(osep[b]), "+v"(oto[b]), "+v"(oZ[b]));
+#pragma unroll
+    for (int j = 0; j < KI; ++j) asm volatile("" : "+v"(oX[j]), "+v"(oY[j]));
+    asm volatile("" : "+v"(oseph), "+v"(otoh), "+v"(ofh));
+    asm volatile("" : "+s"(sep), "+s"(to), "+s"(res), "+s"(from));
+    if (pend == 1) __syncthreads();        // loop mode: the previous level of this workgroup's trees
+    else __threadfence_block();            // the previous message of this task
+  }
+  int pz = 0;
+  asm volatile("" : "+v"(pz));   // (vector loads of wave-uniform words: see generic_task)
+  const int poisoned = S.poison[(int64_t)site * S.n_clusters + from_b + pz];
+  // ---- receiver / sepset operands of the kept lanes (row a = fi of the message): requested first
   double psep[KK], pto[KK], pseph = 0.0, ptoh = 0.0, pre_sepg = 0.0, pre_tog = 0.0;
-  int ubv[KK];
   if constexpr (DENSE) {
     // DENSE (the loop launches, whose frame is the smallest the message fits: few unused columns): the operands of a
     // message are requested in ONE basic block -- every column's load unconditional inside one masked region, an unused
@@ -251,20 +209,17 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     // serial chain of its own (120 - 190 clocks per load: tools/stamp_generic.py); in one block the chains interleave.
 #pragma unroll
     for (int b = 0; b < KK; ++b) {
-      const int rl = __builtin_amdgcn_readlane(cur.ub, b);
-      ubv[b] = u0 >= 0 ? u0 + b : rl;
       psep[b] = 0.0;
       pto[b] = 0.0;
     }
     if (kept_live) {   // (s >= 1 here)
 #pragma unroll
       for (int b = 0; b < KK; ++b) {
-        const int bb = b < s ? b : 0, ub = b < s ? ubv[b] : ubv[0];
-        psep[b] = ld8(sep, fi + bb * s);
-        pto[b] = ld8(to, ua + ub * mt);
+        psep[b] = ld8o(sep, osep[b]);
+        pto[b] = ld8o(to, oto[b]);
       }
-      pseph = ld8(sep, s * s + fi);
-      ptoh = ld8(to, mt * mt + ua);
+      pseph = ld8o(sep, oseph);
+      ptoh = ld8o(to, otoh);
     }
 #pragma unroll
     for (int b = 0; b < KK; ++b) {
@@ -276,66 +231,43 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   for (int b = 0; b < KK; ++b) {
     psep[b] = 0.0;
     pto[b] = 0.0;
-    ubv[b] = u0 >= 0 ? u0 + b : __builtin_amdgcn_readlane(cur.ub, b);
     if (b < s && kept_live) {
-      psep[b] = ld8(sep, fi + b * s);
-      pto[b] = ld8(to, ua + ubv[b] * mt);
+      psep[b] = ld8o(sep, osep[b]);
+      pto[b] = ld8o(to, oto[b]);
     }
   }
   if (kept_live) {
-    pseph = ld8(sep, s * s + fi);
-    ptoh = ld8(to, mt * mt + ua);
+    pseph = ld8o(sep, oseph);
+    ptoh = ld8o(to, otoh);
   }
   }
   if (lane == 0) {
     pre_sepg = ld8(sep, s * s + s);
     pre_tog = ld8(to, mt * mt + mt);
   }
-  const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];   // (here: behind the stores they could not be moved up)
+  const double thr_h = S.thr[s], thr_J = S.thr[PGBP_MAX_DIM + 1 + s];
   double gmsg = gmsg_io;
   bool fake = false;
   if (!en_reuse) {
-    const double* __restrict__ from = pool + grec_i64(rv, 0);
-    // position of this lane's variable in the sender, and of every column's (wave-uniform)
-    const int q = is_int ? fi : ni + fi;                       // place in the order "integrated first, kept last"
-    const int pq = __shfl(cur.pb, q < kGInlPerm ? q : 0);      // (inline map: lane l holds perm[l])
-    const int pi = k0 >= 0 ? (q < ni ? (q < k0 ? q : q + s) : k0 + (q - ni)) : pq;
     double X[KI], Y[KI], Z[KK], hv = 0.0;
     if constexpr (DENSE) {
-      int cjv[KI], cbv[KK];
 #pragma unroll
       for (int j = 0; j < KI; ++j) {
         X[j] = 0.0;
         Y[j] = 0.0;
-        const int rl = __builtin_amdgcn_readlane(cur.pb, j);
-        cjv[j] = k0 >= 0 ? (j < k0 ? j : j + s) : rl;
       }
 #pragma unroll
-      for (int b = 0; b < KK; ++b) {
-        Z[b] = 0.0;
-        const int rl = __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
-        cbv[b] = k0 >= 0 ? k0 + b : rl;
-      }
+      for (int b = 0; b < KK; ++b) Z[b] = 0.0;
       if (row_live) {
-        const int rowbase = pi * mf;
 #pragma unroll
-        for (int j = 0; j < KI; ++j) {
-          const int cj = j < ni ? cjv[j] : cjv[0];
-          X[j] = ld8(from, pi + cj * mf);
-        }
+        for (int j = 0; j < KI; ++j) X[j] = ld8o(from, oX[j]);
         if (is_int) {
 #pragma unroll
-          for (int j = 0; j < KI; ++j) {
-            const int cj = j < ni ? cjv[j] : cjv[0];
-            Y[j] = ld8(from, cj + rowbase);
-          }
+          for (int j = 0; j < KI; ++j) Y[j] = ld8o(from, oY[j]);
         }
 #pragma unroll
-        for (int b = 0; b < KK; ++b) {
-          const int cb = b < s ? cbv[b] : cjv[0];   // (an unused kept column: any column of the sender)
-          Z[b] = ld8(from, is_int ? cb + rowbase : pi + cb * mf);
-        }
-        hv = ld8(from, mf * mf + pi);
+        for (int b = 0; b < KK; ++b) Z[b] = ld8o(from, oZ[b]);
+        hv = ld8o(from, ofh);
       }
 #pragma unroll
       for (int j = 0; j < KI; ++j) {
@@ -349,19 +281,17 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     for (int j = 0; j < KI; ++j) {
       X[j] = 0.0;
       Y[j] = 0.0;
-      const int cj = k0 >= 0 ? (j < k0 ? j : j + s) : __builtin_amdgcn_readlane(cur.pb, j);
       if (j < ni && row_live) {
-        X[j] = ld8(from, pi + cj * mf);                             // J[this row, integrated column j]
-        if (is_int) Y[j] = ld8(from, cj + pi * mf);                 // J[integrated row j, this column]: the upper triangle of J_I
+        X[j] = ld8o(from, oX[j]);
+        if (is_int) Y[j] = ld8o(from, oY[j]);
       }
     }
 #pragma unroll
     for (int b = 0; b < KK; ++b) {
       Z[b] = 0.0;
-      const int cb = k0 >= 0 ? k0 + b : __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
-      if (b < s && row_live) Z[b] = is_int ? ld8(from, cb + pi * mf) : ld8(from, pi + cb * mf);   // J_SI' for a pivot row, J_S for a kept one
+      if (b < s && row_live) Z[b] = ld8o(from, oZ[b]);
     }
-    if (row_live) hv = ld8(from, mf * mf + pi);
+    if (row_live) hv = ld8o(from, ofh);
     }
     gmsg = ld8(from, mf * mf + mf + pz);
     // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66), on the entries as stored
@@ -432,6 +362,18 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
   }
   gmsg_io = gmsg;
   PGBP_GST(5);
+  // Every operand requested at the top arrived during the elimination.  Said ONCE, here: loads and stores share one in-order
+  // counter, so a wait the compiler places for one of these registers further down, behind the first stores (the thresholds
+  // before the flag, lane 0's two g words), is a wait for every store issued before it -- a round trip to the L2 in the
+  // middle of the store sequence and a second one for the flag behind it.
+#if PGBP_SMALL_SETTLE
+  double thr_hv = thr_h, thr_Jv = thr_J;
+#pragma unroll
+  for (int b = 0; b < KK; ++b) asm volatile("" : "+v"(psep[b]), "+v"(pto[b]));
+  asm volatile("" : "+v"(pseph), "+v"(ptoh), "+v"(pre_sepg), "+v"(pre_tog), "+v"(gmsg), "+v"(thr_hv), "+v"(thr_Jv));
+#else
+  const double thr_hv = thr_h, thr_Jv = thr_J;
+#endif
   // ---- divide! and mult!: kept lane 8 + a owns row a of the message
   double maxJ = 0.0, maxh = 0.0;
   if (kept_live) {
@@ -439,13 +381,12 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
       // (one basic block as for the loads: an unused column stores column 0's values to column 0's places once more)
 #pragma unroll
       for (int b = 0; b < KK; ++b) {
-        const int bb = b < s ? b : 0, ub = b < s ? ubv[b] : ubv[0];
         const double msg = b < s ? F.row[KI + b] : F.row[KI];
         const double ps = b < s ? psep[b] : psep[0], pt = b < s ? pto[b] : pto[0];
         const double dJ = msg - ps;
-        st8(sep, fi + bb * s, msg);
-        st8(res, fi + bb * s, dJ);
-        st8(to, ua + ub * mt, pt + dJ);
+        st8o(sep, osep[b], msg);
+        st8o(res, osep[b], dJ);
+        st8o(to, oto[b], pt + dJ);
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
     } else {
@@ -454,18 +395,18 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
       if (b < s) {
         const double msg = F.row[KI + b];
         const double dJ = msg - psep[b];
-        st8(sep, fi + b * s, msg);
-        st8(res, fi + b * s, dJ);
-        st8(to, ua + ubv[b] * mt, pto[b] + dJ);
+        st8o(sep, osep[b], msg);
+        st8o(res, osep[b], dJ);
+        st8o(to, oto[b], pto[b] + dJ);
         maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       }
     }
     }
     const double msgh = F.row[KI + KK];
     const double dh = msgh - pseph;
-    st8(sep, s * s + fi, msgh);
-    st8(res, s * s + fi, dh);
-    st8(to, mt * mt + ua, ptoh + dh);
+    st8o(sep, oseph, msgh);
+    st8o(res, oseph, dh);
+    st8o(to, otoh, ptoh + dh);
     maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
   }
   if (lane == 0) {
@@ -475,7 +416,7 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
     S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
   }
   if (S.update_resnorm) {
-    const bool lane_ok = maxh <= thr_h && maxJ <= thr_J;
+    const bool lane_ok = maxh <= thr_hv && maxJ <= thr_Jv;
     const bool ok = __all(lane_ok);
     if (lane == 0) S.flags[(int64_t)site * S.n_msgs + en_msg] = ok ? 1 : 0;
   }
@@ -491,7 +432,11 @@ __device__ __forceinline__ int small_message(const DevState& S, const GRec* __re
 // SPEC: the loop launches pick the smallest frame a message fits (small_message<WAVE, KI, KK>)
 template <bool WAVE, bool SMALL_ONLY = false, bool SPEC = false>
 __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __restrict__ recs, GLoad cur, const int site,
-                                             const int lane, unsigned long long seq_base, int32_t* perm, double* W) {
+                                             const int lane, unsigned long long seq_base, int32_t* perm, double* W,
+                                             int pend = 0) {
+  // pend: a synchronisation owed before the first access to a belief -- 1: the workgroup barrier between two levels of the
+  // loop mode (every wavefront of the workgroup runs it exactly once per pass, here or in the kernel's loop), 2: the fence
+  // between two messages of a task.  The register-resident body runs it behind its decode (small_message).
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   int mf = 0, ni = 0, ld = 1;
@@ -519,9 +464,9 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
       const int nim = (dims >> 24) & 255;
       int done;
 #ifdef PGBP_GSTAMP
-#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_, SPEC>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, gst)
+#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_, SPEC>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, pend, gst)
 #else
-#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_, SPEC>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg)
+#define PGBP_SMALL(KI_, KK_) small_message<WAVE, KI_, KK_, SPEC>(S, recs, cur, site, lane, seq_base, pool, rpool, frame, gmsg, pend)
 #endif
       // (a reused marginal has the dimensions of the message that computed it: the same instance, the same frame)
       if (SPEC && nim <= 4 && s <= 4) done = PGBP_SMALL(4, 4);
@@ -547,12 +492,15 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
       }
 #endif
       if (next < 0) return;
-      __threadfence_block();
+      pend = 2;   // (the fence: behind the next message's decode)
       cur = nxt;
       continue;
     }
     if constexpr (SMALL_ONLY) __builtin_unreachable();
     small_prev = false;
+    if (pend == 1) __syncthreads();
+    else if (pend == 2) __threadfence_block();
+    pend = 0;
     // the sender sits downstream of a failed message?  Requested with the operands (a vector load: in the loop mode the
     // mark may have been stored by another wavefront of this workgroup one level ago, which the scalar cache does not
     // see), looked at before anything of this message is recorded or stored
@@ -752,7 +700,7 @@ __device__ __forceinline__ void generic_task(const DevState& S, const GRec* __re
     }
 #endif
     if (next < 0) return;
-    __threadfence_block();  // the next message of the task may read or read-modify-write what this one wrote
+    pend = 2;  // the next message of the task may read or read-modify-write what this one wrote
     cur = nxt;
   }
 }
@@ -931,7 +879,7 @@ __global__ __launch_bounds__(64) void bp_level_small4(DevState S, const GRec* __
     if (!poisoned && !en_reuse && !fake) {
       double mant = 1.0, quad = 0.0;
       int expo = 0;
-      Small4<KI, KK>::template pivot<0, decltype(row), true>(row, ni, info, mant, expo, quad);
+      Small4<KI, KK>::template pivot<0, decltype(row), (KI + KK <= 8)>(row, ni, info, mant, expo, quad);
       if (info == 0) {
         const double logdet = log_by_table_lane(S.logtab, mant) + (double)expo * 0.69314718055994530941723212145818;
         gmsg += 0.5 * ((double)ni * PGBP_LOG2PI - logdet + quad);
@@ -1057,12 +1005,19 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, 
     int ri_next = -1;
     GLoad nxt = {0u, 0, 0};
     if (g + 1 < g1) {
-      ri_next = grp_recs[(int64_t)(g + 1) * kTailWaves + wave];
+      // (slot i of pass k runs on wavefront (i + k) mod 8: where a level has a task or two -- the top of every tree --,
+      // consecutive passes fall to different wavefronts, and the one whose turn is next has its record decoded and waits
+      // at the barrier while the current one still works: small_message, `pend`)
+      ri_next = grp_recs[(int64_t)(g + 1) * kTailWaves + ((wave - (g + 1 - g0)) & (kTailWaves - 1))];
       if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
     }
+    // the barrier between pass g - 1 and pass g: a wavefront with a task runs it behind the decode of the task's first
+    // message (generic_task: pend), one without runs it here -- once per pass and wavefront either way
     if (ri >= 0)
-      generic_task<true, SMALL_ONLY, true>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles);
-    if (g + 1 < g1) __syncthreads();
+      generic_task<true, SMALL_ONLY, true>(S, recs, cur, site, lane, seq_base, reinterpret_cast<int32_t*>(scratch), scratch + kPermDoubles,
+                                           g > g0 ? 1 : 0);
+    else if (g > g0)
+      __syncthreads();
     ri = ri_next;
     cur = nxt;
   }
@@ -1678,10 +1633,12 @@ void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int n
 
 void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* d_grp_recs, const int32_t* d_wg_off, int n_wg,
                           int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
-                          bool small_only, hipStream_t st) {
+                          bool small_only, bool pair, hipStream_t st) {
   if (n_wg <= 0) return;
   const size_t per_wave = generic_lds_bytes(max_mf) / sizeof(double);
-  if (small_only)
+  if (small_only && pair)
+    launch_chunk_pair(S, d_recs, d_grp_recs, d_wg_off, n_wg, n_sites, seq_base, stop_below, st);   // pgbp_pair.hip
+  else if (small_only)
     hipLaunchKernelGGL(bp_chunk_generic<true>, dim3(n_wg, n_sites), dim3(kTailWaves * 64), 0, st, S, d_recs, d_grp_recs, d_wg_off,
                        0, seq_base, stop_below);
   else

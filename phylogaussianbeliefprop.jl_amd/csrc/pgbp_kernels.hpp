@@ -95,9 +95,11 @@ void launch_level_generic(const DevState& S, const GRec* d_recs, int rec0, int n
 // loop mode of the generic task body: n_wg workgroups of kTailWaves wavefronts, workgroup b walks the groups
 // [d_wg_off[b], d_wg_off[b + 1]) of kTailWaves first records of tasks (-1: none) with a workgroup barrier in between
 // (a chunk of fused levels)
+void launch_chunk_pair(const DevState& S, const GRec* d_recs, const int32_t* d_grp_recs, const int32_t* d_wg_off, int n_wg,
+                       int n_sites, unsigned long long seq_base, unsigned long long stop_below, hipStream_t st);
 void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* d_grp_recs, const int32_t* d_wg_off, int n_wg,
                           int n_sites, unsigned long long seq_base, unsigned long long stop_below, int max_mf,
-                          bool small_only, hipStream_t st);
+                          bool small_only, bool pair, hipStream_t st);
 
 // tasks with a belief of dimension 65 .. PGBP_MAX_DIM: one workgroup of 256 threads per task, the sender in up to 132 KB of LDS
 // (a sender of more than kLdsMaxDim variables: the working matrix in d_ws, ntasks * n_sites slabs of big_ws_doubles(max_mf))

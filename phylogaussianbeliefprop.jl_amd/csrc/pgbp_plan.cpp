@@ -42,6 +42,7 @@ bool read_tuning(Tuning& t, std::string& err) {
     else if (key == "no_chunks") t.chunks = false;
     else if (key == "no_prologue") t.prologues = false;
     else if (key == "chain_fusion") t.chain_fusion = true;
+    else if (key == "pair") t.pair2 = num != 0;
     else if (key == "loop") t.loop2 = num != 0;
     else if (key == "plain_layout") t.packed_layouts = false;
     else if (key == "mixed_fast_min") t.mixed_fast_min = num;

@@ -1386,10 +1386,12 @@ def test_auto_stop_is_per_site(P):
 
 @pytest.mark.parametrize("env", [{}, {"PGBP_TUNING": "no_chunks"}, {"PGBP_TUNING": "mixed_fast_min=0"},
                                  {"PGBP_TUNING": "small4_min=0"}, {"PGBP_TUNING": "small4_min=0,no_chunks"},
-                                 {"PGBP_TUNING": "chunk_bins=3"}],
+                                 {"PGBP_TUNING": "chunk_bins=3"}, {"PGBP_TUNING": "pair=0"},
+                                 {"PGBP_TUNING": "pair=0,chunk_bins=3"}],
                          ids=["default", "level_launches_only", "mixed_levels_always_split",
                               "four_tasks_per_wavefront", "four_tasks_per_wavefront_level_launches_only",
-                              "chunks_packed_into_3_workgroups"])
+                              "chunks_packed_into_3_workgroups", "chunks_one_wavefront_per_task",
+                              "chunks_one_wavefront_per_task_packed_into_3_workgroups"])
 def test_network_differential_fuzz(P, env):
     """tests/fuzz_gpu_vs_c_oracle_networks.py: random level-3 networks, clique tree / Bethe / join graphs, every spanning
     tree of the schedule, 1 - 9 traits (and 18 - 22), damaged clusters: the wave-per-task kernels (both message bodies,
@@ -1399,7 +1401,9 @@ def test_network_differential_fuzz(P, env):
     must not enter a generic chunk: its fast-class tasks have no message records); and with every level launch of small
     messages, however narrow, on bp_level_small4 (four tasks per wavefront, one per row of 16 lanes: the default only from
     kSmall4MinTasksDefault tasks on, which these small networks never reach), with and without the chunks; and with the trees of
-    every chunk's forest packed into 3 workgroups (round 4: the default packs only above 256 trees)."""
+    every chunk's forest packed into 3 workgroups (round 4: the default packs only above 256 trees); and with the chunks of
+    small messages on bp_chunk_generic (pair=0: one wavefront per task) instead of the default bp_chunk_pair (round 4: a
+    provider and a consumer wavefront per task, hand-over through LDS sequence numbers)."""
     import os
     import subprocess
     import sys
