@@ -155,6 +155,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
       if (64 * t < len && i < len) stage[i] = raw[t];
     }
     wave_sync_lds();
+    PGBP_PST(7);
     double X[KI], Y[KI], Z[KK], hv = 0.0;
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
@@ -300,7 +301,7 @@ __device__ __forceinline__ int pair_consume(const DevState& S, const GLoad& cur,
   const unsigned int e = cnt + 1;
   cnt = e;
   PGBP_PST(3);
-  while (lds_acquire(&slot->pub) < e) __builtin_amdgcn_s_sleep(1);
+  while (lds_acquire(&slot->pub) < e) {}   // (no s_sleep: the provider runs on another SIMD, and every 64 clocks of the hand-over are on the pass)
   PGBP_PST(4);
   if (lds_acquire(&slot->abort_at) == e) {
     if (lane == 0) __hip_atomic_store(&slot->ack, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -369,17 +370,18 @@ __global__ __launch_bounds__(kPairWaves * 64) void bp_chunk_pair(DevState S, con
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   unsigned int cnt = 0;   // messages of this pair so far: both of its wavefronts count alike
   const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
-  int ri = grp_recs[(int64_t)g0 * kTailWaves + pair];
+  // slot i of pass k runs on pair (i + k) mod 8 (bp_chunk_generic).  The task index of pass g + 2 is requested (a scalar load)
+  // and the record of pass g + 1 (whose index came in a pass ago) is requested at the top of pass g: nothing of it is waited
+  // for between a pass's last store and the barrier
+  auto task_of = [&](int g) { return grp_recs[(int64_t)g * kTailWaves + ((pair - (g - g0)) & (kTailWaves - 1))]; };
+  int ri = task_of(g0);
+  int ri_next = g0 + 1 < g1 ? task_of(g0 + 1) : -1;
   GLoad cur = {0u, 0, 0};
   if (ri >= 0) cur = load_grec(recs, ri, lane);
   for (int g = g0; g < g1; ++g) {
-    int ri_next = -1;
     GLoad nxt = {0u, 0, 0};
-    if (g + 1 < g1) {
-      // (slot i of pass k runs on pair (i + k) mod 8: bp_chunk_generic)
-      ri_next = grp_recs[(int64_t)(g + 1) * kTailWaves + ((pair - (g + 1 - g0)) & (kTailWaves - 1))];
-      if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
-    }
+    if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
+    const int ri_next2 = g + 2 < g1 ? task_of(g + 2) : -1;
     int pend = g > g0 ? 1 : 0;
     if (ri >= 0) {
       // the task: its messages in order, the record of the next one requested beside the current one
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void bp_chunk_pair(DevState S, con
       settle(nxt);
     }
     ri = ri_next;
+    ri_next = ri_next2;
     cur = nxt;
   }
 }

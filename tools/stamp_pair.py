@@ -57,6 +57,10 @@ def main():
             d.append(int(np.median((cur - prev) & 0xFFFFFFFF)))
             prev = cur
         print(f"{name}: n {len(sel)} phases {d} total {int(np.median((sel[:, 6] - sel[:, 0]) & 0xFFFFFFFF))}")
+    sel = t[(role == 0) & (t[:, 7] != 0)]
+    if len(sel):
+        print("provider: past the barrier -> sender record staged in LDS (7):", int(np.median(sel[:, 7] - sel[:, 2])),
+              " staged -> frame built (3):", int(np.median(sel[:, 3] - sel[:, 7])))
     # pair the two halves of a message: same workgroup, same pair of wavefronts, same sequence number, close in time
     # (a slot keeps its LAST writer: the halves of one message of one launch are at most a pass apart)
     prov, cons = t[role == 0], t[role == 1]
