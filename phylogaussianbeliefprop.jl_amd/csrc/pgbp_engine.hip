@@ -120,6 +120,7 @@ struct pgbp_engine {
   int32_t *d_bm_kind = nullptr, *d_bm_row = nullptr;
   double* d_bm_data_sm = nullptr;   // [row][site] copy of d_bm_data (p = 1)
   double *d_bm_length = nullptr, *d_bm_data = nullptr, *d_bm_Rinv = nullptr, *d_bm_logdet = nullptr, *d_bm_mu = nullptr;
+  double2* d_bm_ithl = nullptr;    // [n_clusters] (1 / t, (p / 2) log t): launch_bm_ithl at set-up
   // pgbp_lg_families: static description + last parameters of the general linear-Gaussian factor fill
   LgStatic lg{};                  // device pointers (owned: lg_bufs)
   LgParams lgp{};
@@ -593,7 +594,7 @@ void pgbp_destroy(pgbp_engine* e) {
                   (void*)e->d_iscal_hist, (void*)e->d_boff, (void*)e->d_packed_off, (void*)e->d_roff,
                   (void*)e->d_rpacked_off, (void*)e->d_mu, (void*)e->d_norm, (void*)e->d_info,
                   (void*)e->d_one_task_off, (void*)e->d_one_entry, (void*)e->d_one_rec, (void*)e->d_bdim, (void*)e->d_rdim,
-                  (void*)e->d_symflag, (void*)e->d_bm_kind, (void*)e->d_bm_row, (void*)e->d_bm_length,
+                  (void*)e->d_symflag, (void*)e->d_bm_kind, (void*)e->d_bm_row, (void*)e->d_bm_length, (void*)e->d_bm_ithl,
                   (void*)e->d_bm_data, (void*)e->d_bm_Rinv, (void*)e->d_bm_logdet, (void*)e->d_bm_mu})
     if (p) (void)hipFree(p);
   for (void* p : e->lg_bufs)
@@ -1404,6 +1405,10 @@ int pgbp_bm_tree_setup(pgbp_engine* e, const pgbp_bm_tree* t) {
   if ((rc = upload(e, &e->d_bm_kind, std::vector<int32_t>(t->kind, t->kind + nc)))) return rc;
   if ((rc = upload(e, &e->d_bm_row, std::vector<int32_t>(t->data_row, t->data_row + nc)))) return rc;
   if ((rc = upload(e, &e->d_bm_length, std::vector<double>(t->length, t->length + nc)))) return rc;
+  if (e->d_bm_ithl) (void)hipFree(e->d_bm_ithl);
+  e->d_bm_ithl = nullptr;
+  if ((rc = dev_alloc(e, &e->d_bm_ithl, (size_t)nc))) return rc;
+  launch_bm_ithl(e->d_bm_length, e->d_bm_kind, t->p, e->d_bm_ithl, nc, e->st);
   const size_t nd = (size_t)p.n_sites * t->n_rows * t->p;
   if ((rc = dev_alloc(e, &e->d_bm_data, nd))) return rc;
   if (nd) HIPCHK(e, hipMemcpy(e->d_bm_data, t->data, nd * sizeof(double), hipMemcpyHostToDevice));
@@ -1444,7 +1449,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
   bool done = false;
   if (e->bm_p == p.fast_p)  // lane-blocked instance: every cluster has dimension 0, p or 2p (checked at setup)
     done = launch_bm_tree_fill_fast(e->d_pool, p.pool_stride(), fp, p.cluster_stride(), e->d_boff, e->d_bdim, e->d_bm_kind,
-                                    e->d_bm_length, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv,
+                                    e->d_bm_ithl, e->d_bm_row, e->d_bm_data, e->bm_rows, e->bm_p, e->d_bm_Rinv,
                                     e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, e->layout_bs16 ? 1 : 0, p.n_clusters,
                                     p.n_sites, e->st);
   if (!done) {

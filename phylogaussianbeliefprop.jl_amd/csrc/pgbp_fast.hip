@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
                                                          const int64_t* __restrict__ boff,
                                                          const int32_t* __restrict__ dim,
                                                          const int32_t* __restrict__ kind,
-                                                         const double* __restrict__ length,
+                                                         const double2* __restrict__ ithl,
                                                          const int32_t* __restrict__ row,
                                                          const double* __restrict__ data, int n_rows,
                                                          const double* __restrict__ Rinv_all,
@@ -648,8 +648,11 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
       }
       continue;
     }
-    const double tlen = length[c], it = 1.0 / tlen;
-    double g = g_base - 0.5 * (double)PR * log(tlen);
+    // (1 / t, (p / 2) log t) of the cluster's branch: formed once, when the tree is set up (bm_ithl_kernel) -- a division and a
+    // log() less in every wavefront of every evaluation
+    const double2 il = ithl[c];
+    const double it = il.x;
+    double g = g_base - il.y;
     double jv0 = 0.0, jv1 = 0.0;
     if (k >= 1) {
       // absorbed vector v: mu on the parent (1), the tip's data on the child (2), their difference (3)
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
 
 template <int P, bool ODD>
 static void launch_fill_p(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride, const int64_t* d_boff,
-                          const int32_t* d_dim, const int32_t* d_kind, const double* d_length, const int32_t* d_row,
+                          const int32_t* d_dim, const int32_t* d_kind, const double2* d_length, const int32_t* d_row,
                           const double* d_data, int n_rows, const double* d_Rinv, const double* d_logdetR,
                           const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
   // (a grid-stride loop: as many workgroups as give every one the same number of rounds -- 25 000 groups of four clusters over
@@ -726,8 +729,25 @@ static void launch_fill_p(double* pool, int64_t pool_stride, double* fpool, int6
                      per_site, n_clusters);
 }
 
+// (1 / t, (p / 2) log t) per cluster: what every evaluation of the fill needs of a branch length, formed once
+__global__ void bm_ithl_kernel(const double* __restrict__ length, const int32_t* __restrict__ kind, int p,
+                               double2* __restrict__ out, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double2 v = make_double2(0.0, 0.0);
+  if (kind[c] >= 0) {
+    const double tlen = length[c];
+    v.x = 1.0 / tlen;
+    v.y = 0.5 * (double)p * log(tlen);
+  }
+  out[c] = v;
+}
+void launch_bm_ithl(const double* d_length, const int32_t* d_kind, int p, double2* d_out, int n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(bm_ithl_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_length, d_kind, p, d_out, n);
+}
+
 bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride,
-                              const int64_t* d_boff, const int32_t* d_dim, const int32_t* d_kind, const double* d_length,
+                              const int64_t* d_boff, const int32_t* d_dim, const int32_t* d_kind, const double2* d_length,
                               const int32_t* d_row, const double* d_data, int n_rows, int p, const double* d_Rinv,
                               const double* d_logdetR, const double* d_mu, int per_site, int bs16, int n_clusters,
                               int n_sites, hipStream_t st) {

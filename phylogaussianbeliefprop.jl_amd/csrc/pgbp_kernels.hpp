@@ -221,10 +221,11 @@ void launch_lg_fill_uni_sm(const LgStatic& F, const LgParams& M, double* pool_sm
 // as its kind implies; fpool may be null (beliefs only: the score() body of src/calibration.jl:205 does not touch the
 // factors).  Returns false if p has no instance.
 bool launch_bm_tree_fill_fast(double* pool, int64_t pool_stride, double* fpool, int64_t fpool_stride,
-                              const int64_t* d_boff, const int32_t* d_dim, const int32_t* d_kind, const double* d_length,
+                              const int64_t* d_boff, const int32_t* d_dim, const int32_t* d_kind, const double2* d_ithl,
                               const int32_t* d_row, const double* d_data, int n_rows, int p, const double* d_Rinv,
                               const double* d_logdetR, const double* d_mu, int per_site, int bs16, int n_clusters,
                               int n_sites, hipStream_t st);
+void launch_bm_ithl(const double* d_length, const int32_t* d_kind, int p, double2* d_out, int n, hipStream_t st);
 
 // d_big_idx / n_big: the beliefs of more than kFreeEnergyLdsMaxDim variables (their working matrix in d_ws: n_big * n_sites
 // slabs of free_energy_ws_doubles(max_dim))
