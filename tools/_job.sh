@@ -1,11 +1,9 @@
 set -o pipefail
-mkdir -p gpurun_out/r04y
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fused_into_the_postorder or device_factor_fill" > gpurun_out/r04y/pytest.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -15 gpurun_out/r04y/pytest.log
+mkdir -p gpurun_out/r04z
+PGBP_LIB=$PWD/build/libpgbp_fwdcheck.so timeout -k 10 900 python3 tests/fuzz_gpu_vs_c_oracle_networks.py 60 17 > gpurun_out/r04z/fuzz_chk.log 2>&1; echo "fuzz with check rc $?"; grep -c "FWD MISMATCH" gpurun_out/r04z/fuzz_chk.log; tail -2 gpurun_out/r04z/fuzz_chk.log
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "network_differential_fuzz or level3 or loopy or cfg5" > gpurun_out/r04z/pytest.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -5 gpurun_out/r04z/pytest.log
 [ $rc -eq 0 ] || exit 1
-bash tools/sweep_env.sh r04y/ll "--no-cpu-baseline --no-network-block --no-sites-block" "PGBP_TUNING=fused_fill=0" "-" "PGBP_TUNING=fused_fill=2" "PGBP_TUNING=fused_fill=0" "-" || exit 1
-python3 - <<'PY'
-import json
-for i in (1,2,3,4,5):
-    d=json.loads(open(f'gpurun_out/r04y/ll_{i}.json').read().strip().splitlines()[-1])
-    print(i, d['ms_per_step'], d['ll_evals_per_s'], d['ll_eval']['roofline']['ms_per_eval'], d['ll_evals_per_s_batched']['value'], d['loglik'])
-PY
+PGBP_LIB=$PWD/build/libpgbp_pstamp.so timeout -k 10 300 python3 tools/stamp_pair.py joingraph > gpurun_out/r04z/stamps_jg.txt 2>gpurun_out/r04z/err.txt; echo rc $?; cat gpurun_out/r04z/stamps_jg.txt; tail -3 gpurun_out/r04z/err.txt
+B=$PWD/build/libpgbp_prev.so
+bash tools/sweep_env.sh r04z/jg "--workload network --no-cpu-baseline" "PGBP_LIB=$B" "-" "PGBP_LIB=$B" "-" || exit 1
+bash tools/sweep_env.sh r04z/be "--workload network --graph bethe --no-cpu-baseline" "PGBP_LIB=$B" "-" || exit 1
