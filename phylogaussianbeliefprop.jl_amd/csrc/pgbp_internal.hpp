@@ -136,7 +136,7 @@ constexpr int kChunkMaxTasks = 2400;  // a level joins a chunk of fused levels i
                                       // against 11.8 - 14.5 us for the level's own launch (cfg3: 384 tasks / 768 / 1 200 / 1 700 / 2 400 / 3 400 / 5 000
                                       // records: 0.840 / 0.823 / 0.831 / 0.836 / 0.811 - 0.832 / 0.831 / 0.807 ms; cfg2 0.331 / 0.321 / 0.317 / 0.317 /
                                       // 0.313 / 0.313 / 0.313: flat from 2 400)
-constexpr int kChunkGenericMaxTasks = 1536;  // ... of generic-class tasks (round 4, trees packed into kChunkBins workgroups, cfg5 join graph: 768 / 1 536 / 3 072 tasks: 1.142 / 1.103 / 1.102 ms per iteration; unpacked 1.168; round 2, unpacked: 384 / 768 / 1 536 / 3 072: 1.559 / 1.541 / 1.552 / 1.690)
+constexpr int kChunkGenericMaxTasks = 4096;  // ... of generic-class tasks (round 4 with bp_chunk_pair, trees packed into kChunkBins workgroups, cfg5 join graph / Bethe: 1 536 / 3 072 / 4 096 / 6 144 / 8 192 tasks: 0.988 / 0.964 / 0.958 / 0.961 / 0.980 and 1.214 / 1.174 / 1.175 / 1.200 / 1.205 ms per iteration; one wavefront per task: 768 / 1 536 / 3 072: 1.142 / 1.103 / 1.102, unpacked 1.168; round 2, unpacked: 384 / 768 / 1 536 / 3 072: 1.559 / 1.541 / 1.552 / 1.690)
 constexpr int kChunkUniMaxThreads = 65536;  // ... of a batch of univariate sites (thread-per-site kernels): tasks x sites of a level that joins a chunk
 constexpr int kChunkGenericMaxMf = 24;  // generic-class chunks: 8 wavefronts x (perm + mf x (mf + 1)) doubles of LDS per workgroup
 constexpr int kChunkDepth = 4;        // levels per chunk

@@ -1,9 +1,4 @@
 set -o pipefail
-mkdir -p gpurun_out/r04z
-PGBP_LIB=$PWD/build/libpgbp_fwdcheck.so timeout -k 10 900 python3 tests/fuzz_gpu_vs_c_oracle_networks.py 60 17 > gpurun_out/r04z/fuzz_chk.log 2>&1; echo "fuzz with check rc $?"; grep -c "FWD MISMATCH" gpurun_out/r04z/fuzz_chk.log; tail -2 gpurun_out/r04z/fuzz_chk.log
-timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "network_differential_fuzz or level3 or loopy or cfg5" > gpurun_out/r04z/pytest.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -5 gpurun_out/r04z/pytest.log
-[ $rc -eq 0 ] || exit 1
-PGBP_LIB=$PWD/build/libpgbp_pstamp.so timeout -k 10 300 python3 tools/stamp_pair.py joingraph > gpurun_out/r04z/stamps_jg.txt 2>gpurun_out/r04z/err.txt; echo rc $?; cat gpurun_out/r04z/stamps_jg.txt; tail -3 gpurun_out/r04z/err.txt
-B=$PWD/build/libpgbp_prev.so
-bash tools/sweep_env.sh r04z/jg "--workload network --no-cpu-baseline" "PGBP_LIB=$B" "-" "PGBP_LIB=$B" "-" || exit 1
-bash tools/sweep_env.sh r04z/be "--workload network --graph bethe --no-cpu-baseline" "PGBP_LIB=$B" "-" || exit 1
+mkdir -p gpurun_out/r04aa
+bash tools/sweep_env.sh r04aa/jg2 "--workload network --no-cpu-baseline" "PGBP_TUNING=chunk_max_tasks=3072" "PGBP_TUNING=chunk_max_tasks=4096" "PGBP_TUNING=chunk_max_tasks=6144" "PGBP_TUNING=chunk_max_tasks=8192" "PGBP_TUNING=chunk_max_tasks=12288" "PGBP_TUNING=chunk_max_tasks=4096,chunk_bins=512" "PGBP_TUNING=chunk_max_tasks=8192,chunk_bins=512" "PGBP_TUNING=chunk_max_tasks=3072" || exit 1
+bash tools/sweep_env.sh r04aa/be2 "--workload network --graph bethe --no-cpu-baseline" "PGBP_TUNING=chunk_max_tasks=3072" "PGBP_TUNING=chunk_max_tasks=4096" "PGBP_TUNING=chunk_max_tasks=6144" "PGBP_TUNING=chunk_max_tasks=8192" "PGBP_TUNING=chunk_max_tasks=4096,chunk_bins=512" "PGBP_TUNING=chunk_max_tasks=8192,chunk_bins=512" || exit 1
