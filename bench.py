@@ -507,7 +507,7 @@ def run_network(args, torch, dist, rank, world, local_rank, emit=True):
                      "traffic_stale": (net_traffic or {}).get("stale") if default_net else None,
                      "traffic_unit": "bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, every message-kernel "
                                      f"launch of one calibrate iteration; profiles/pmc_traffic_network_{args.graph}_latest.json)",
-                     "kernel": "bp_level_small4 (wide levels: four rows of 16 lanes per wavefront) + bp_level_generic + bp_chunk_generic (fused narrow levels)", "algorithmic_bytes_per_step": bytes_per_cal,
+                     "kernel": "bp_level_small4 (wide levels: four rows of 16 lanes per wavefront) + bp_level_generic + bp_chunk_pair (fused narrow levels: a provider and a consumer wavefront per task)", "algorithmic_bytes_per_step": bytes_per_cal,
                      "note": "algorithmic bytes of one calibrate iteration / its wall time; launch-latency-bound (levels per tree >> width)"},
         "host_setup_s": t_host,
     }

@@ -53,6 +53,8 @@ bash tools/pmc_network.sh $tag bethe > /dev/null 2>&1; cp $PWD/gpurun_out/${tag}
 step "cfg5 level times"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p9b -- python3 tools/level_times.py run-network joingraph > $out/lt5_run.txt 2>&1 || exit 1
 python3 tools/level_times.py parse /tmp/p9b $out/cfg5_joingraph_level_times.json > $out/cfg5_joingraph_level_times.txt 2>&1; rm -rf /tmp/p9b
+step "cfg5: the two wavefronts of a task of bp_chunk_pair (phase stamps; instrumented build build/libpgbp_pstamp.so)"
+[ -f build/libpgbp_pstamp.so ] && PGBP_LIB=$PWD/build/libpgbp_pstamp.so timeout -k 10 300 python3 tools/stamp_pair.py joingraph > $out/cfg5_joingraph_pair_phase_stamps.txt 2>$out/e_stamp.txt
 step "cfg4 at a rank's share of 8 GPUs (1 000 problems)"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5b -- python3 bench.py --workload sites --sites 125 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_cfg4_125_sites_under_profiler.json 2>$out/e5b.txt || exit 1
 keep_stats /tmp/p5b cfg4_125_sites_kernel_stats.csv; rm -rf /tmp/p5b
