@@ -125,6 +125,7 @@ constexpr int kFOwn = 1, kFAccum = 2;
 constexpr int kFPro = 8;           // the record has a PROLOGUE (FPro, same index in the parallel array): see bp_fast16
 constexpr int kFNoBlock = 4;       // accumulate task whose messages are all constants (dimension-0 sepsets): only the receiver's g
 constexpr int kFastMaxWaves = 4;   // messages per fast-class task at most = records per group of a level launch
+constexpr int kPassRotate = 3;     // loop launches of the wave-per-task class: slot i of pass k runs on wavefront / pair (i + 3 k) mod kTailWaves
 constexpr int kTailWaves = 8;      // records per step of the tail launch (one workgroup of 8 wavefronts)
 constexpr int kGenericMaxDim = 64;    // largest sender the wave-per-task generic kernel's lane grids handle
 // a message of the large-belief kernel (bp_level_big: descriptors with 32-bit dimensions): its sender is beyond the wave-per-task

@@ -1005,10 +1005,10 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, 
     int ri_next = -1;
     GLoad nxt = {0u, 0, 0};
     if (g + 1 < g1) {
-      // (slot i of pass k runs on wavefront (i + k) mod 8: where a level has a task or two -- the top of every tree --,
+      // (slot i of pass k runs on wavefront (i + 3 k) mod 8, kPassRotate: where a level has a task or two -- the top of every tree --,
       // consecutive passes fall to different wavefronts, and the one whose turn is next has its record decoded and waits
       // at the barrier while the current one still works: small_message, `pend`)
-      ri_next = grp_recs[(int64_t)(g + 1) * kTailWaves + ((wave - (g + 1 - g0)) & (kTailWaves - 1))];
+      ri_next = grp_recs[(int64_t)(g + 1) * kTailWaves + ((wave - kPassRotate * (g + 1 - g0)) & (kTailWaves - 1))];
       if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
     }
     // the barrier between pass g - 1 and pass g: a wavefront with a task runs it behind the decode of the task's first

@@ -370,19 +370,23 @@ __global__ __launch_bounds__(kPairWaves * 64) void bp_chunk_pair(DevState S, con
   double* __restrict__ rpool = S.rpool + (int64_t)site * S.rpool_stride;
   unsigned int cnt = 0;   // messages of this pair so far: both of its wavefronts count alike
   const int g0 = wg_off[blockIdx.x], g1 = wg_off[blockIdx.x + 1];
-  // slot i of pass k runs on pair (i + k) mod 8 (bp_chunk_generic).  The task index of pass g + 2 is requested (a scalar load)
+  // slot i of pass k runs on pair (i + 3 k) mod 8 (kPassRotate: a pass of up to three tasks shares no pair with the pass before,
+  // so whoever works in pass k + 1 has decoded its record and formed its addresses while pass k ran; stride 1 / 3 / 4: cfg5 join
+  // graph 0.958 / 0.931 / 0.934 ms per iteration, Bethe 1.174 / 1.145 / 1.148).  The task index of pass g + 2 is requested (a scalar load)
   // and the record of pass g + 1 (whose index came in a pass ago) is requested at the top of pass g: nothing of it is waited
   // for between a pass's last store and the barrier
-  auto task_of = [&](int g) { return grp_recs[(int64_t)g * kTailWaves + ((pair - (g - g0)) & (kTailWaves - 1))]; };
+  auto task_of = [&](int g) { return grp_recs[(int64_t)g * kTailWaves + ((pair - kPassRotate * (g - g0)) & (kTailWaves - 1))]; };
   int ri = task_of(g0);
   int ri_next = g0 + 1 < g1 ? task_of(g0 + 1) : -1;
   GLoad cur = {0u, 0, 0};
   if (ri >= 0) cur = load_grec(recs, ri, lane);
   for (int g = g0; g < g1; ++g) {
     GLoad nxt = {0u, 0, 0};
-    if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
     const int ri_next2 = g + 2 < g1 ? task_of(g + 2) : -1;
     int pend = g > g0 ? 1 : 0;
+    // (a wavefront without a task in this pass goes to the barrier first -- it may be the one the pass before ended on, its
+    // last stores just issued -- and requests the next pass's record behind it)
+    if (ri >= 0 && ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
     if (ri >= 0) {
       // the task: its messages in order, the record of the next one requested beside the current one
       double gmsg = 0.0;
@@ -412,6 +416,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void bp_chunk_pair(DevState S, con
     } else {
       // (no task in this pass: straight to the barrier -- the record requested a moment ago is waited for behind it)
       if (pend) __syncthreads();
+      if (ri_next >= 0) nxt = load_grec(recs, ri_next, lane);
       settle(nxt);
     }
     ri = ri_next;
