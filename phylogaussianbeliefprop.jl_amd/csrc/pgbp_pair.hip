@@ -75,9 +75,16 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
   const int k0 = (fl & 255) == 255 ? -1 : (fl & 255);
   const bool en_reuse = ((fl >> 16) & 255) != 0;
   const double* __restrict__ from = pool + grec_i64(rv, 0);
-  const bool is_int = lane < KI;
-  const int fi = KI == 8 ? (lane & 7) : (is_int ? lane : lane - KI);
-  const bool kept_live = lane >= KI && lane < KI + KK && fi < s;
+  // FOUR COLUMN GROUPS: every row of 16 lanes (a DPP row) holds the frame's rows as small_message does -- integrated variable k in
+  // lane k of the row, kept variable a in lane KI + a -- but only the columns of its GROUP g = lane / 16: all KI integrated
+  // columns and h (every group keeps them: the multipliers and the pivot's terms are formed where they are used), and KK / 4 of
+  // the kept columns.  A pivot then updates KI - k + KK / 4 entries per lane where the one-row frame updated KI - k + KK, its row
+  // still travels by one DPP row broadcast per entry, and every entry goes through the operations it went through before.
+  constexpr int KQ = KK / 4;
+  const int grp = lane >> 4, rl16 = lane & 15;
+  const bool is_int = rl16 < KI;
+  const int fi = KI == 8 ? (rl16 & 7) : (is_int ? rl16 : rl16 - KI);
+  const bool kept_live = rl16 >= KI && rl16 < KI + KK && fi < s;
   const bool row_live = is_int ? fi < ni : kept_live;
   int cjv[KI], cbv[KK];
   const int q = is_int ? fi : ni + fi;
@@ -93,12 +100,15 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
     const int rl = __builtin_amdgcn_readlane(cur.pb, (ni + b) & 63);
     cbv[b] = k0 >= 0 ? k0 + b : rl;
   }
-  unsigned int oX[KI], oY[KI], oZ[KK];
+  unsigned int oX[KI], oY[KI], oZ[KQ];
   const int rowbase = pi * mf;
 #pragma unroll
-  for (int b = 0; b < KK; ++b) {
-    const int cb = b < s ? cbv[b] : cjv[0];
-    oZ[b] = (unsigned int)(is_int ? cb + rowbase : pi + cb * mf) << 3;
+  for (int qq = 0; qq < KQ; ++qq) {   // this group's kept columns b = grp KQ + qq
+    int cb = cjv[0];
+#pragma unroll
+    for (int b = 0; b < KK; ++b)
+      if (b == grp * KQ + qq && b < s) cb = cbv[b];
+    oZ[qq] = (unsigned int)(is_int ? cb + rowbase : pi + cb * mf) << 3;
   }
 #pragma unroll
   for (int j = 0; j < KI; ++j) {
@@ -112,7 +122,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
   const bool chained = prev_to_b >= 0 && !en_reuse && from_b == prev_to_b;
   if (pend != 0) {
 #pragma unroll
-    for (int b = 0; b < KK; ++b) asm volatile("" : "+v"(oZ[b]));
+    for (int qq = 0; qq < KQ; ++qq) asm volatile("" : "+v"(oZ[qq]));
 #pragma unroll
     for (int j = 0; j < KI; ++j) asm volatile("" : "+v"(oX[j]), "+v"(oY[j]));
     asm volatile("" : "+v"(ofh));
@@ -133,7 +143,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
   const int poisoned = S.poison[(int64_t)site * S.n_clusters + from_b + pz];
   double gmsg = gmsg_io;
   bool fake = false;
-  double row[KI + KK + 1];
+  double row[KI + KQ + 1];   // this lane's entries: integrated columns, its group's kept columns, h
   if (!en_reuse) {
     // The sender's record (mf <= 16: at most 273 contiguous doubles) comes in with FIVE coalesced loads of the whole wavefront
     // and goes through the pair's LDS stage; every lane then picks its row's entries from there with the offsets formed above.
@@ -156,14 +166,14 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
     }
     wave_sync_lds();
     PGBP_PST(7);
-    double X[KI], Y[KI], Z[KK], hv = 0.0;
+    double X[KI], Y[KI], Z[KQ], hv = 0.0;
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
       X[j] = 0.0;
       Y[j] = 0.0;
     }
 #pragma unroll
-    for (int b = 0; b < KK; ++b) Z[b] = 0.0;
+    for (int qq = 0; qq < KQ; ++qq) Z[qq] = 0.0;
     if (row_live) {
 #pragma unroll
       for (int j = 0; j < KI; ++j) X[j] = ld8o(stage, oX[j]);
@@ -172,7 +182,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
         for (int j = 0; j < KI; ++j) Y[j] = ld8o(stage, oY[j]);
       }
 #pragma unroll
-      for (int b = 0; b < KK; ++b) Z[b] = ld8o(stage, oZ[b]);
+      for (int qq = 0; qq < KQ; ++qq) Z[qq] = ld8o(stage, oZ[qq]);
       hv = ld8o(stage, ofh);
     }
 #pragma unroll
@@ -181,7 +191,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
       Y[j] = j < ni ? Y[j] : 0.0;
     }
 #pragma unroll
-    for (int b = 0; b < KK; ++b) Z[b] = b < s ? Z[b] : 0.0;
+    for (int qq = 0; qq < KQ; ++qq) Z[qq] = grp * KQ + qq < s ? Z[qq] : 0.0;
     gmsg = stage[mf * mf + mf];
     wave_sync_lds();   // (the stage is free again: the next message of the task may overwrite it)
     bool nz = is_int && fabs(hv) > PGBP_EPS;
@@ -191,8 +201,8 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
 #pragma unroll
     for (int j = 0; j < KI; ++j) row[j] = (is_int && j < fi) ? Y[j] : X[j];
 #pragma unroll
-    for (int b = 0; b < KK; ++b) row[KI + b] = Z[b];
-    row[KI + KK] = hv;
+    for (int qq = 0; qq < KQ; ++qq) row[KI + qq] = Z[qq];
+    row[KI + KQ] = hv;
   }
   PGBP_PST(3);
   const unsigned int e = cnt + 1;
@@ -202,7 +212,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
   double mant = 1.0, quad = 0.0;
   int expo = 0;
   if (!poison_stop && !en_reuse && !fake) {
-    Small4<KI, KK>::template pivot<0, decltype(row), (KI + KK <= 8)>(row, ni, info, mant, expo, quad);
+    Small4<KI, KQ>::template pivot<0, decltype(row), true>(row, ni, info, mant, expo, quad);
     info = __builtin_amdgcn_readfirstlane(info);
   }
   if (poison_stop || info != 0) {
@@ -225,14 +235,16 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
     }
     gmsg_io = gmsg;
     PGBP_PST(4);
-    // the slot is free once the consumer is done with the previous message (its marginal may be reused until then)
-    if (!acked)
+    // the slot is free once the consumer is done with the previous message (its marginal may be reused until then); the first
+    // message of a task needs no look: the consumer acknowledged the previous pass's last message in front of the barrier
+    if (!acked && prev_to_b >= 0)
       while (lds_acquire(&slot->ack) != e - 1) __builtin_amdgcn_s_sleep(1);
-    if (kept_live) {
-#pragma unroll
-      for (int b = 0; b < KK; b += 2)   // (rows of 80 bytes: pairs of entries as 16-byte LDS stores)
-        *reinterpret_cast<double2*>(&slot->row[fi][b]) = make_double2(row[KI + b], row[KI + b + 1]);
-      slot->row[fi][kSmallK] = row[KI + KK];
+    if (kept_live) {   // (every group its own columns of the marginal's row a = fi; h from group 0)
+      if constexpr (KQ == 2)
+        *reinterpret_cast<double2*>(&slot->row[fi][grp * 2]) = make_double2(row[KI], row[KI + 1]);
+      else
+        slot->row[fi][grp] = row[KI];
+      if (grp == 0) slot->row[fi][kSmallK] = row[KI + KQ];
     }
     if (lane == 0) slot->g = gmsg;
   }
