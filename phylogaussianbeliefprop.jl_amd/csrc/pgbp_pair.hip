@@ -37,13 +37,14 @@ __device__ unsigned int g_pstamp_n;
 // the consumer decodes, forms its addresses and requests its operands while the provider eliminates; the provider decodes
 // the NEXT pass's record and forms its addresses while the consumer stores (both in front of the barrier between two passes:
 // `pend`).  The hand-over is a sequence number per pair in LDS: pub = messages published so far, ack = messages whose stores
-// have been issued; a message that fails or whose sender is poisoned is published as abort_at = its number, which ends the
+// have been issued; a message that fails or whose sender is poisoned is published with kPubAbort set, which ends the
 // task on both sides.  Arithmetic, its order and every stored value are those of small_message (launch-mode fuzz: bit-identical).
 struct PairSlot {
   double row[kSmallK][kSmallK + 2];   // marginal, row a = kept variable a: J entries b < KK, h at [kSmallK] (rows of 80 bytes)
   double g;
-  unsigned int pub, ack, abort_at, pad;
+  unsigned int pub, ack, pad[2];
 };
+constexpr unsigned int kPubAbort = 0x80000000u;   // in `pub`: the message of this number did not happen (it ends the task)
 __device__ __forceinline__ void wave_sync_lds() {   // LDS stores of this wavefront visible to its own lanes' loads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -223,8 +224,7 @@ __device__ __forceinline__ int pair_provide(const DevState& S, const GRec* __res
       if (!poison_stop)
         atomicMin(&S.fail[site], ((seq_base + (unsigned long long)(unsigned int)en_seq) << kInfoBits) |
                                      (unsigned long long)(unsigned int)info);
-      __hip_atomic_store(&slot->abort_at, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(&slot->pub, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&slot->pub, e | kPubAbort, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     return 1;
   }
@@ -313,9 +313,12 @@ __device__ __forceinline__ int pair_consume(const DevState& S, const GLoad& cur,
   const unsigned int e = cnt + 1;
   cnt = e;
   PGBP_PST(3);
-  while (lds_acquire(&slot->pub) < e) {}   // (no s_sleep: the provider runs on another SIMD, and every 64 clocks of the hand-over are on the pass)
+  // (no s_sleep: the provider runs on another SIMD, and every 64 clocks of the hand-over are on the pass; the abort mark rides
+  // in the same word: one LDS round trip, not two, between the publication and the marginal)
+  unsigned int pw;
+  while (((pw = lds_acquire(&slot->pub)) & ~kPubAbort) < e) {}
   PGBP_PST(4);
-  if (lds_acquire(&slot->abort_at) == e) {
+  if (pw == (e | kPubAbort)) {
     if (lane == 0) __hip_atomic_store(&slot->ack, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     return 1;
   }
@@ -327,24 +330,33 @@ __device__ __forceinline__ int pair_consume(const DevState& S, const GLoad& cur,
                "+v"(thr_h), "+v"(thr_J), "+v"(msgh));
   PGBP_PST(5);
   double maxJ = 0.0, maxh = 0.0;
+  // (the RECEIVER's entries first: the next pass's provider loads them, and its load waits behind these stores on their way to
+  // the L2 -- the sepset and the residual are nobody's operand before the next traversal)
+  double dJ = 0.0, dh = 0.0, dg = 0.0;
   if (live) {
-    const double dJ = msgJ - psep;
+    dJ = msgJ - psep;
+    st8o(to, oto, pto + dJ);
+  }
+  if (hlive) {
+    dh = msgh - pseph;
+    st8o(to, otoh, ptoh + dh);
+  }
+  if (lane == 0) {
+    dg = gmsg - pre_sepg;
+    st8(to, mt * mt + mt, pre_tog + dg);
+  }
+  if (live) {
     st8o(sep, osep, msgJ);
     st8o(res, osep, dJ);
-    st8o(to, oto, pto + dJ);
     maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
   }
   if (hlive) {
-    const double dh = msgh - pseph;
     st8o(sep, oseph, msgh);
     st8o(res, oseph, dh);
-    st8o(to, otoh, ptoh + dh);
     maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
   }
   if (lane == 0) {
-    const double dg = gmsg - pre_sepg;
     st8(sep, s * s + s, gmsg);
-    st8(to, mt * mt + mt, pre_tog + dg);
     S.status[(int64_t)site * S.n_msgs + en_msg] = 0;
   }
   if (S.update_resnorm) {
@@ -375,7 +387,6 @@ __global__ __launch_bounds__(kPairWaves * 64) void bp_chunk_pair(DevState S, con
   if (threadIdx.x < kTailWaves) {
     slots[threadIdx.x].pub = 0;
     slots[threadIdx.x].ack = 0;
-    slots[threadIdx.x].abort_at = 0;
   }
   __syncthreads();
   double* __restrict__ pool = S.pool + (int64_t)site * S.pool_stride;
