@@ -1,7 +1,11 @@
 set -o pipefail
-mkdir -p gpurun_out/r04ag
-C=$PWD/build/libpgbp_new.so
-PGBP_LIB=$C timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "network_differential_fuzz or level3 or loopy or cfg5 or failure" > gpurun_out/r04ag/pytest.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -3 gpurun_out/r04ag/pytest.log
+mkdir -p gpurun_out/r04i
+timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > gpurun_out/r04i/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -3 gpurun_out/r04i/pytest_gpu.log
 [ $rc -eq 0 ] || exit 1
-bash tools/sweep_env.sh r04ag/jg "--workload network --no-cpu-baseline" "-" "PGBP_LIB=$C" "-" "PGBP_LIB=$C" || exit 1
-bash tools/sweep_env.sh r04ag/be "--workload network --graph bethe --no-cpu-baseline" "-" "PGBP_LIB=$C" || exit 1
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r04i/smoke.txt 2>&1; tail -1 gpurun_out/r04i/smoke.txt
+python3 bench.py > gpurun_out/r04i/bench_default.json 2>gpurun_out/r04i/e1.txt || exit 1
+python3 bench.py --workload sites > gpurun_out/r04i/bench_cfg4.json 2>gpurun_out/r04i/e2.txt || exit 1
+python3 bench.py --workload network > gpurun_out/r04i/bench_cfg5_joingraph.json 2>gpurun_out/r04i/e3.txt || exit 1
+python3 bench.py --workload network --graph bethe > gpurun_out/r04i/bench_cfg5_bethe.json 2>gpurun_out/r04i/e4.txt || exit 1
+PGBP_BENCH_REHEARSAL=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r04i/bench_default_2rank_rehearsal_one_gpu.json 2>gpurun_out/r04i/e5.txt; echo "rehearsal rc $?"
+tail -c 200 gpurun_out/r04i/bench_default_2rank_rehearsal_one_gpu.json
