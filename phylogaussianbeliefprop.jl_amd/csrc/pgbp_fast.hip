@@ -611,6 +611,10 @@ void launch_fast_p(const DevState& S, const FEntry* d_recs, const FPro* d_pros, 
 // R^-1[2a..2a+1][2b..2b+1] for the whole launch and writes it, scaled by 1/t and signed, into the tiles of the record
 // (32-byte stores, whole lines), h = R^-1 v / t by a butterfly over b, g from v'R^-1 v / t by a butterfly over a.
 // Formulas: pgbp_kernels.hip, bm_tree_fill_kernel (the general-dimension version of the same fill).
+// clusters per wavefront of bm_tree_fill_fast (1 / 2 / 3 / 4 / 8 / 16 / 32 / 64: 1 970 / 1 990 / 2 000 / 1 990 / 1 968 / 1 953 / 1 949 /
+// 1 893 log-likelihood evaluations per second on cfg3: the records want many wavefronts more than they want their descriptions
+// in one load)
+constexpr int kFillChunk = 2;
 template <int P, bool BS, bool ODD>
 __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ pool, int64_t pool_stride,
                                                          double* __restrict__ fpool, int64_t fpool_stride,
@@ -622,10 +626,12 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
                                                          const double* __restrict__ data, int n_rows,
                                                          const double* __restrict__ Rinv_all,
                                                          const double* __restrict__ logdetR_all,
-                                                         const double* __restrict__ mu_all, int per_site, int n_clusters) {
+                                                         const double* __restrict__ mu_all, int per_site, int n_clusters,
+                                                         int chunk) {
   static_assert(!(ODD && BS), "odd dimensions are filled in the plain layout");
   constexpr int PR = P - (ODD ? 1 : 0);  // the real trait count (ODD: the lane grid of P with a phantom index PR)
   constexpr int G = P / 2;
+  [[maybe_unused]] __shared__ double obuf[BS ? 4 : 1][BS ? (bs16::g2(P) + 1 + 15) / 16 * 16 : 1];   // a wavefront's record (the 2P one: 577 doubles for P = 16)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, site = blockIdx.y;
   const bool act = lane < G * G;
   const int a = act ? lane % G : 0, b = act ? lane / G : 0;
@@ -636,10 +642,37 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
   const double g_base = -0.5 * ((double)PR * PGBP_LOG2PI + logdetR_all[per_site ? site : 0]);
   const Blk Rb = load_blk<false, ODD>(Rinv, PR, a, b, up, kidx, PR);
   auto vec = [&](const double* __restrict__ v, int i) { return (!ODD || i < PR) ? v[i] : 0.0; };
-  for (int c = blockIdx.x * 4 + wave; c < n_clusters; c += gridDim.x * 4) {
-    const int k = kind[c], m = dim[c];
-    double* __restrict__ rec = pool + (int64_t)site * pool_stride + boff[c];
-    double* __restrict__ frec = fpool ? fpool + (int64_t)site * fpool_stride + boff[c] : nullptr;
+  // A wavefront fills `chunk` consecutive clusters.  Their descriptions -- kind, dimension, record offset, (1 / t, (p / 2) log t),
+  // data row -- come in with ONE coalesced load each (lane l: cluster c0 + l) and are handed out by v_readlane, and the absorbed
+  // vector of cluster i + 1 is requested before cluster i is formed.
+  const int c0 = (blockIdx.x * 4 + wave) * chunk;   // (chunk <= 64: a lane per cluster description)
+  if (c0 >= n_clusters) return;
+  const int nloc = n_clusters - c0 < chunk ? n_clusters - c0 : chunk;
+  const int cl = c0 + (lane < nloc ? lane : 0);
+  const int kind_v = kind[cl], dim_v = dim[cl], row_v = row[cl];
+  const long long boff_v = boff[cl];
+  const double2 il_v = ithl[cl];
+  auto absorbed = [&](int kk, int rw, double (&v)[4]) {   // v = {vb0, vb1, va0, va1} of a cluster of kind kk >= 1
+    const double* __restrict__ y = (kk >= 2) ? data + ((int64_t)site * n_rows + rw) * PR : mu;
+    v[0] = vec(y, 2 * b); v[1] = vec(y, 2 * b + 1); v[2] = vec(y, 2 * a); v[3] = vec(y, 2 * a + 1);
+    if (kk == 3) { v[0] -= vec(mu, 2 * b); v[1] -= vec(mu, 2 * b + 1); v[2] -= vec(mu, 2 * a); v[3] -= vec(mu, 2 * a + 1); }
+  };
+  double vnext[4] = {0.0, 0.0, 0.0, 0.0};
+  {
+    const int k_first = __builtin_amdgcn_readlane(kind_v, 0);
+    if (k_first >= 1) absorbed(k_first, __builtin_amdgcn_readlane(row_v, 0), vnext);
+  }
+  for (int i = 0; i < nloc; ++i) {
+    const int k = __builtin_amdgcn_readlane(kind_v, i), m = __builtin_amdgcn_readlane(dim_v, i);
+    const long long bo = (long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(boff_v >> 32), i) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readlane((int)boff_v, i));
+    double* __restrict__ rec = pool + (int64_t)site * pool_stride + bo;
+    double* __restrict__ frec = fpool ? fpool + (int64_t)site * fpool_stride + bo : nullptr;
+    const double vcur[4] = {vnext[0], vnext[1], vnext[2], vnext[3]};
+    if (i + 1 < nloc) {
+      const int k_next = __builtin_amdgcn_readlane(kind_v, i + 1);
+      if (k_next >= 1) absorbed(k_next, __builtin_amdgcn_readlane(row_v, i + 1), vnext);
+    }
     if (k < 0) {  // no factor: the constant function 1
       const int len = (BS && bs16::applies(m, P)) ? bs16::rec_len(m, P) : m * m + m + 1;
       for (int t = lane; t < len; t += kWave) {
@@ -650,15 +683,18 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
     }
     // (1 / t, (p / 2) log t) of the cluster's branch: formed once, when the tree is set up (bm_ithl_kernel) -- a division and a
     // log() less in every wavefront of every evaluation
-    const double2 il = ithl[c];
-    const double it = il.x;
-    double g = g_base - il.y;
+    auto lane_f64 = [&](double x) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+      const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, i);
+      const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(bits >> 32), i);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    const double it = lane_f64(il_v.x);
+    double g = g_base - lane_f64(il_v.y);
     double jv0 = 0.0, jv1 = 0.0;
     if (k >= 1) {
       // absorbed vector v: mu on the parent (1), the tip's data on the child (2), their difference (3)
-      const double* __restrict__ y = (k >= 2) ? data + ((int64_t)site * n_rows + row[c]) * PR : mu;
-      double vb0 = vec(y, 2 * b), vb1 = vec(y, 2 * b + 1), va0 = vec(y, 2 * a), va1 = vec(y, 2 * a + 1);
-      if (k == 3) { vb0 -= vec(mu, 2 * b); vb1 -= vec(mu, 2 * b + 1); va0 -= vec(mu, 2 * a); va1 -= vec(mu, 2 * a + 1); }
+      const double vb0 = vcur[0], vb1 = vcur[1], va0 = vcur[2], va1 = vcur[3];
       const double t0 = act ? fma(Rb.x, vb0, Rb.z * vb1) : 0.0, t1 = act ? fma(Rb.y, vb0, Rb.w * vb1) : 0.0;
       // rows 2a, 2a+1 of R^-1 v: the sum over the G lanes (a, 0 .. G-1), in a fixed order (any G, not only powers of 2)
       double p0 = 0.0, p1 = 0.0;
@@ -673,6 +709,44 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
       g -= 0.5 * q;
     }
     const Blk Jp{Rb.x * it, Rb.y * it, Rb.z * it, Rb.w * it}, Jm{-Jp.x, -Jp.y, -Jp.z, -Jp.w};
+    if constexpr (BS) {
+      // The packed record is put together in LDS and goes out as ONE contiguous stream of 16 bytes per lane: every store
+      // instruction then covers whole 128-byte lines.  (A lane's 2 x 2 block is 32 bytes = two 16-byte stores at a stride of
+      // 32 bytes between lanes: each instruction left half of every line it touched to the other, the L2 took twice the write
+      // requests, and the kernel ran at 3.3 TB/s where a plain fill of the same 292 MB reaches 6.1.)
+      double* r = obuf[wave];
+      int rl = 1;
+      if (k == 0) {  // 2P x 2P: [j -j; -j j], h = 0
+        store_blk<true>(r, P, a, b, up, act, kidx, Jp);
+        store_blk<true>(r + bs16::t11(P), P, a, b, up, act, kidx, Jp);
+        if (act) *reinterpret_cast<double4*>(r + bs16::t10(P) + (a + G * b) * 4) = make_double4(Jm.x, Jm.y, Jm.z, Jm.w);
+        if (act && b == 0) {
+          *reinterpret_cast<double2*>(r + bs16::h2(P) + 2 * a) = make_double2(0.0, 0.0);
+          *reinterpret_cast<double2*>(r + bs16::h2(P) + P + 2 * a) = make_double2(0.0, 0.0);
+        }
+        if (lane == 0) r[bs16::g2(P)] = g;
+        rl = bs16::g2(P) + 1;
+      } else if (k <= 2) {  // P x P block j on the kept variables, h = +j v
+        store_blk<true>(r, P, a, b, up, act, kidx, Jp);
+        if (act && b == 0) *reinterpret_cast<double2*>(r + bs16::h1(P) + 2 * a) = make_double2(jv0, jv1);
+        if (lane == 0) r[bs16::g1(P)] = g;
+        rl = bs16::g1(P) + 1;
+      } else {  // everything absorbed: a constant
+        if (lane == 0) r[0] = g;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int which = 0; which < (frec ? 2 : 1); ++which) {
+        double* __restrict__ dst = which ? frec : rec;
+        for (int t = lane; t < (rl >> 1); t += kWave) reinterpret_cast<double2*>(dst)[t] = reinterpret_cast<const double2*>(r)[t];
+        if ((rl & 1) && lane == 0) dst[rl - 1] = r[rl - 1];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // (the next cluster's record overwrites the buffer)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      continue;
+    }
     for (int which = 0; which < (frec ? 2 : 1); ++which) {
       double* __restrict__ r = which ? frec : rec;
       if (k == 0) {  // 2P x 2P: [j -j; -j j], h = 0
@@ -712,21 +786,20 @@ static void launch_fill_p(double* pool, int64_t pool_stride, double* fpool, int6
                           const int32_t* d_dim, const int32_t* d_kind, const double2* d_length, const int32_t* d_row,
                           const double* d_data, int n_rows, const double* d_Rinv, const double* d_logdetR,
                           const double* d_mu, int per_site, int bs16, int n_clusters, int n_sites, hipStream_t st) {
-  // (a grid-stride loop: as many workgroups as give every one the same number of rounds -- 25 000 groups of four clusters over
-  // a grid capped at 16 384 were two rounds for 1.53 rounds of work)
-  const int nb = (n_clusters + 3) / 4, rounds = (nb + 16383) / 16384;
-  const int gx = (nb + rounds - 1) / std::max(1, rounds);
+  const int chunk = kFillChunk;
+  const int nchunks = (n_clusters + chunk - 1) / chunk;
+  const int gx = (nchunks + 3) / 4;   // four wavefronts per workgroup, kFillChunk clusters per wavefront
   if constexpr (!ODD) {
     if (bs16) {
       hipLaunchKernelGGL((bm_tree_fill_fast<P, true, false>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
                          fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
-                         per_site, n_clusters);
+                         per_site, n_clusters, chunk);
       return;
     }
   }
   hipLaunchKernelGGL((bm_tree_fill_fast<P, false, ODD>), dim3(gx, n_sites), dim3(256), 0, st, pool, pool_stride, fpool,
                      fpool_stride, d_boff, d_dim, d_kind, d_length, d_row, d_data, n_rows, d_Rinv, d_logdetR, d_mu,
-                     per_site, n_clusters);
+                     per_site, n_clusters, chunk);
 }
 
 // (1 / t, (p / 2) log t) per cluster: what every evaluation of the fill needs of a branch length, formed once

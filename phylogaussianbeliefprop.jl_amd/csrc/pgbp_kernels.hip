@@ -1662,6 +1662,58 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
   const int ld = (m + 1) | 1;
   const bool packed = bs && bs16::applies(m, fp);
   const double g = packed ? rec[bs16::g_off(m, fp)] : rec[(int64_t)m * m + m];
+  if constexpr (!WS) {
+    if (m <= 16 && mu == nullptr) {
+      // the normalisation constant alone of a belief of at most 16 variables (the root of a log-likelihood evaluation): the
+      // system in registers, one row per lane of the wavefront's first DPP row, the pivot row by row broadcast -- no LDS, no
+      // barrier per pivot (Small4<16, 0>: the elimination of the register-resident small-message body with nothing kept).
+      // Entry by entry the operations of eliminate_leading below, in its order (the mantissa product renormalised where it does).
+      const int i = lane & 15;
+      const bool live = lane < m;
+      double row[17];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        row[j] = 0.0;
+        if (live && j < m)
+          row[j] = packed ? rec[bs16::J_off(m, i, j, fp)] : ((i <= j) ? rec[i + (int64_t)j * m] : rec[j + (int64_t)i * m]);
+      }
+      row[16] = live ? (packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i]) : 0.0;
+      bool nzr = live && row[16] != 0.0;
+      if (live) {
+        if (packed) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) nzr |= row[j] != 0.0;
+        } else {   // (the generic path looks at every stored entry, both triangles)
+          for (int j = 0; j < m; ++j) nzr |= rec[i + (int64_t)j * m] != 0.0;
+        }
+      }
+      if (!__any(nzr)) {  // constant belief: norm = g (:189-191)
+        if (lane == 0) {
+          norm[site] = g;
+          if (info_out) info_out[site] = 0;
+        }
+        return;
+      }
+      double mant = 1.0, quad = 0.0;
+      int expo = 0, info = 0;
+      Small4<16, 0>::template pivot<0, decltype(row), false>(row, m, info, mant, expo, quad);
+      info = __builtin_amdgcn_readfirstlane(info);
+      if (info != 0) {
+        if (lane == 0) {
+          norm[site] = NAN;
+          if (info_out) info_out[site] = info;
+        }
+        return;
+      }
+      if (m == 16) { int ex; mant = frexp(mant, &ex); expo += ex; }   // (eliminate_leading: after every sixteenth pivot)
+      const double logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
+      if (lane == 0) {
+        norm[site] = g + 0.5 * ((double)m * PGBP_LOG2PI - logdet + quad);
+        if (info_out) info_out[site] = 0;
+      }
+      return;
+    }
+  }
   bool nz = false;
   for (int idx = lane; idx < m * m; idx += kWave) {
     const int j = idx / m, i = idx - j * m;
