@@ -18,7 +18,10 @@ from pgbp_amd import synth as S  # noqa: E402
 
 
 def run(n_cases, seed):
-    """Returns (cases with an injected failure, worst relative belief error); asserts on any disagreement."""
+    """Returns (cases with an injected failure, worst relative belief error, sha256 over every bit of the calibrated states
+    and flags: equal across launch modes that run the same arithmetic in the same order); asserts on any disagreement."""
+    import hashlib
+    digest = hashlib.sha256()
     rng = np.random.default_rng(seed)
     worst = 0.0
     n_fail = 0
@@ -72,6 +75,8 @@ def run(n_cases, seed):
                 n_fail += 1
                 continue   # the state after a failed calibration is not compared (later levels may have run)
             a, b = eng._packed[s], ref.packed()
+            digest.update(np.ascontiguousarray(a).tobytes())
+            digest.update(np.ascontiguousarray(eng._flags().astype(np.uint8)).tobytes())
             off = prob.packed_off
             for i in range(len(prob.dims)):
                 x, y = a[off[i]:off[i + 1]], b[off[i]:off[i + 1]]
@@ -83,14 +88,15 @@ def run(n_cases, seed):
             assert np.array_equal(eng._flags().astype(bool), flags.astype(bool)), (case, s)
         assert got == (bool(eng.last_results[0].succ), bool(eng.last_results[0].iscal))
         del eng
-    return n_fail, worst
+    return n_fail, worst, digest.hexdigest()
 
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    n_fail, worst = run(n_cases, seed)
-    print(f"{n_cases} cases ok ({n_fail} with an injected failure reported identically), worst relative belief error {worst:.2e}")
+    n_fail, worst, digest = run(n_cases, seed)
+    print(f"{n_cases} cases ok ({n_fail} with an injected failure reported identically), worst relative belief error {worst:.2e}, "
+          f"digest {digest}")
 
 
 if __name__ == "__main__":

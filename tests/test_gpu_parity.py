@@ -1212,7 +1212,7 @@ def test_differential_fuzz_against_c_oracle(P):
     sites, iterations) cases, a quarter of them with a non-positive-definite block injected into one site, against the
     plain-C sequential engine: beliefs to 1e-8 * max|.|, flags, (succ, iscal), the first failure's (edge, dir, info)."""
     import fuzz_gpu_vs_c_oracle as F
-    n_fail, worst = F.run(150, 2024)
+    n_fail, worst, _ = F.run(150, 2024)
     assert n_fail >= 10 and worst <= 1e-8
 
 
@@ -1301,6 +1301,31 @@ def test_launch_modes_differential_fuzz(P, env):
     out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "120", "91"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "120 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+def test_loop_launch_modes_are_bitwise_identical(P):
+    """The loop launches of the packed layout (pgbp_loop.hip: two wavefronts per record, chains through LDS), pgbp_fast.hip's
+    own loop mode (`loop=0`: one wavefront per record) and the chunks packed into two workgroups run the same operations in
+    the same order on every entry: the calibrated states and the flags of the fuzz's 120 cases (caterpillars: whole
+    traversals in the tail; polytomies; Bethe graphs with prologues; 1-16 traits; injected failures) are BIT FOR BIT the
+    same -- one sha256 over all of them per run (tests/fuzz_gpu_vs_c_oracle.py prints it).  (Round 4 used the same check for
+    two experiments that are not in the library: tools/rejected/README.md, "helpers" and "strands".)"""
+    import os
+    import re
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    digests = {}
+    for tuning in ("", "loop=0", "chunk_bins=2"):
+        env = dict(os.environ)
+        env.pop("PGBP_TUNING", None)
+        if tuning:
+            env["PGBP_TUNING"] = tuning
+        out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu_vs_c_oracle.py"), "120", "4242"], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "120 cases ok" in out.stdout, (tuning, out.stdout[-1500:], out.stderr[-1500:])
+        digests[tuning] = re.search(r"digest ([0-9a-f]{64})", out.stdout).group(1)
+    assert len(set(digests.values())) == 1, digests
 
 
 def test_auto_stop_is_per_site(P):
