@@ -39,7 +39,7 @@ extern "C" {
                             in a workspace in global memory that stays in the L2 (the 54-node clique of the reference's
                             documented clique tree, docs/src/man/clustergraphs.md:40-89, has 162 / 216 / 324 variables with
                             3 / 4 / 6 traits).  The scores and the KL residuals have the same two paths: in LDS up to 96
-                            (residual_kldiv!: two systems side by side) / 139 (free_energy) variables, in the workspace
+                            (residual_kldiv!: two systems side by side; free_energy) variables, in the workspace
                             above -- no size of the reference's is refused below PGBP_MAX_DIM (src/beliefs.jl:1060-1075 and
                             src/score.jl:162-182 have no bound). */
 

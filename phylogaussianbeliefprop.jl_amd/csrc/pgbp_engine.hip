@@ -1345,7 +1345,7 @@ int pgbp_free_energy(pgbp_engine* e, double* out3, int32_t* info) {
   }
   const Plan& p = e->plan;
   const int ns = p.n_sites;
-  // beliefs whose [J | one column of J_t | h] does not fit a CU's LDS (more than kFreeEnergyLdsMaxDim variables): a second
+  // beliefs whose [J | J_t | h] does not fit a CU's LDS whole (more than kFreeEnergyLdsMaxDim variables): a second
   // launch, their working matrix in the workspace
   std::vector<int32_t> big;
   for (int b = 0; b < p.n_beliefs(); ++b)

@@ -1875,10 +1875,12 @@ __device__ __forceinline__ double fe_elem(const double* __restrict__ rec, int m,
   return packed ? rec[bs16::J_off(m, i, j, fp)] : rec[(i <= j) ? i + (int64_t)j * m : j + (int64_t)i * m];
 }
 
-// Gauss-Jordan on the m x nc augmented system W = [A | B] (row stride ld) held in LDS, by ONE wavefront:
-// on return the right block holds A^-1 B and logdet = log det A.  Pivots are the Cholesky pivots of A
-// (no pivoting); returns false (uniformly) as soon as a pivot is not positive, i.e. A is not positive definite.
-__device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int ld, int lane, double& logdet) {
+// Gauss-Jordan on the m x nc augmented system W = [A | B] (row stride ld) held in LDS (or in a workspace slab), by the
+// whole workgroup (one wavefront: the LDS instances; sixteen: the workspace ones, round 4): on return the right block holds
+// A^-1 B and logdet = log det A.  Pivots are the Cholesky pivots of A (no pivoting); returns false (uniformly) as soon as a
+// pivot is not positive, i.e. A is not positive definite.  Every entry sees the same operations whatever the workgroup's size.
+__device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int ld, int tid, double& logdet) {
+  const int nthr = blockDim.x, wv = tid >> 6, ln = tid & 63, nw = nthr >> 6;
   double mant = 1.0;
   int expo = 0;
   for (int k = 0; k < m; ++k) {
@@ -1890,16 +1892,24 @@ __device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int l
     if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
     const double rd = 1.0 / d;
     __syncthreads();
-    for (int j = k + 1 + lane; j < nc; j += kWave) W[k * ld + j] *= rd;  // normalise the pivot row
+    for (int j = k + 1 + tid; j < nc; j += nthr) W[k * ld + j] *= rd;  // normalise the pivot row
     __syncthreads();
     // eliminate column k from every other row (columns > k only: the rest is never read again)
     const int ncol = nc - (k + 1);
-    if (ncol > 0) {
-      for (int idx = lane; idx < (m - 1) * ncol; idx += kWave) {
-        int i = idx / ncol;
-        const int j = k + 1 + (idx - i * ncol);
-        if (i >= k) ++i;
-        W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
+    if (nw <= 1) {   // one wavefront (small systems): the entries flat over the lanes
+      if (ncol > 0) {
+        for (int idx = tid; idx < (m - 1) * ncol; idx += kWave) {
+          int i = idx / ncol;
+          const int j = k + 1 + (idx - i * ncol);
+          if (i >= k) ++i;
+          W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
+        }
+      }
+    } else {         // sixteen wavefronts (workspace instances): rows by wavefront, columns by lane, no division
+      for (int i0 = wv; i0 < m - 1; i0 += nw) {
+        const int i = i0 + (i0 >= k ? 1 : 0);
+        const double wik = W[i * ld + k];
+        for (int j = k + 1 + ln; j < nc; j += kWave) W[i * ld + j] -= wik * W[k * ld + j];
       }
     }
     __syncthreads();
@@ -1908,13 +1918,27 @@ __device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int l
   return true;
 }
 
+// sum of `v` over the workgroup (every thread gets it); one wavefront: shuffles only
+__device__ __forceinline__ double workgroup_sum(double v, int tid) {
+  __shared__ double part[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (blockDim.x <= kWave) return v;
+  if ((tid & 63) == 0) part[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+  __syncthreads();
+  return t;
+}
+
 // kb: columns of J_t per pass (m: one pass, the whole [J | J_t | h] at once; fewer when m x (2m + 1) doubles exceed the
 // LDS a workgroup may have: the elimination of J is then repeated per block of columns, mu kept from the first pass)
 // WS: the beliefs listed in big_idx (more than lds_max_m variables: their [J | J_t | h] does not fit a CU's LDS even a column
 // block at a time), one workgroup each, the working matrix in a workspace slab in global memory (the barriers of the
 // elimination order its accesses: same CU, same vector L1, as in bp_level_big<true>); the LDS instance skips those
 template <bool WS>
-__global__ __launch_bounds__(64) void free_energy_kernel(const double* __restrict__ pool, int64_t pool_stride,
+__global__ __launch_bounds__(WS ? 1024 : 512) void free_energy_kernel(const double* __restrict__ pool, int64_t pool_stride,
                                                          const double* __restrict__ fpool, int64_t fpool_stride,
                                                          const int64_t* __restrict__ boff,
                                                          const int32_t* __restrict__ dim, int n_clusters,
@@ -1922,7 +1946,7 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
                                                          double2* __restrict__ contrib, int32_t* __restrict__ info,
                                                          const int32_t* __restrict__ big_idx, int lds_max_m,
                                                          double* __restrict__ ws, int64_t ws_stride) {
-  const int lane = threadIdx.x, b = WS ? big_idx[blockIdx.x] : (int)blockIdx.x, site = blockIdx.y;
+  const int lane = threadIdx.x, nthr = blockDim.x, b = WS ? big_idx[blockIdx.x] : (int)blockIdx.x, site = blockIdx.y;
   const int m = dim[b];
   if (!WS && m > lds_max_m) return;
   const bool is_cluster = b < n_clusters;
@@ -1944,16 +1968,16 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
     const int nb = is_cluster ? (m - c0 < kb ? m - c0 : kb) : 0;  // columns of J_t in this pass
     const int nc = m + nb + (c0 == 0 && is_cluster ? 1 : 0);      // + h in the first pass
     __syncthreads();
-    for (int idx = lane; idx < m * m; idx += kWave) {
+    for (int idx = lane; idx < m * m; idx += nthr) {
       const int j = idx / m, i = idx - j * m;
       W[i * ld + j] = fe_elem(rec, m, packed, fp, i, j);  // Symmetric(J): upper triangle
     }
-    for (int idx = lane; idx < m * nb; idx += kWave) {
+    for (int idx = lane; idx < m * nb; idx += nthr) {
       const int jj = idx / m, i = idx - jj * m, j = c0 + jj;
       W[i * ld + m + jj] = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
     }
     if (c0 == 0 && is_cluster)
-      for (int i = lane; i < m; i += kWave) W[i * ld + m + nb] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
+      for (int i = lane; i < m; i += nthr) W[i * ld + m + nb] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
     __syncthreads();
     double ld_pass;
     if (!gauss_jordan_spd(W, m, nc, ld, lane, ld_pass)) {
@@ -1963,9 +1987,9 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
     if (c0 == 0) logdet = ld_pass;
     if (!is_cluster) break;
     // right block: J^-1 J_t[:, c0 .. c0 + nb) and, in the first pass, mu = J^-1 h behind it
-    for (int jj = lane; jj < nb; jj += kWave) acc += 0.5 * W[(c0 + jj) * ld + m + jj];  // tr(J^-1 J_t) / 2
+    for (int jj = lane; jj < nb; jj += nthr) acc += 0.5 * W[(c0 + jj) * ld + m + jj];  // tr(J^-1 J_t) / 2
     if (c0 == 0)
-      for (int i = lane; i < m; i += kWave) mu[i] = W[i * ld + m + nb];
+      for (int i = lane; i < m; i += nthr) mu[i] = W[i * ld + m + nb];
   }
   __syncthreads();
   const double ent = 0.5 * ((double)m * (PGBP_LOG2PI + 1.0) - logdet);
@@ -1973,15 +1997,14 @@ __global__ __launch_bounds__(64) void free_energy_kernel(const double* __restric
     if (lane == 0) *out = make_double2(0.0, -ent);
     return;
   }
-  for (int idx = lane; idx < m * m; idx += kWave) {
+  for (int idx = lane; idx < m * m; idx += nthr) {
     const int j = idx / m, i = idx - j * m;
     const double jt = packed ? frec[bs16::J_off(m, i, j, fp)] : frec[i + (int64_t)j * m];
     acc += 0.5 * mu[i] * jt * mu[j];                                     // mu'J_t mu / 2
   }
-  for (int i = lane; i < m; i += kWave)
+  for (int i = lane; i < m; i += nthr)
     acc -= (packed ? frec[bs16::h_off(m, i, fp)] : frec[(int64_t)m * m + i]) * mu[i];  // - h_t'mu
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  acc = workgroup_sum(acc, lane);
   if (lane == 0) *out = make_double2(acc - (packed ? frec[bs16::g_off(m, fp)] : frec[(int64_t)m * m + m]), ent);
 }
 
@@ -2009,6 +2032,8 @@ __global__ __launch_bounds__(256) void free_energy_reduce_kernel(const double2* 
   }
 }
 
+constexpr int kLdsBigThreads = 512;   // the LDS instances where the launch's largest belief / sepset has more than 32 variables
+constexpr int kWsThreads = 1024;   // the workspace instances of free_energy / residual_kldiv!: sixteen wavefronts per belief / message
 int64_t free_energy_ws_doubles(int m) { return (int64_t)m * ((2 * m + 1) | 1) + m; }
 
 void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
@@ -2022,12 +2047,14 @@ void launch_free_energy(const double* pool, int64_t pool_stride, const double* f
   while (kb > 1 && (size_t)mm * (size_t)((mm + kb + 1) | 1) + (size_t)mm > cap) --kb;
   const size_t ldsb = sizeof(double) * ((size_t)mm * (size_t)((mm + kb + 1) | 1) + (size_t)mm);
   allow_large_lds(reinterpret_cast<const void*>(free_energy_kernel<false>), ldsb);
-  hipLaunchKernelGGL(free_energy_kernel<false>, dim3(n_beliefs, n_sites), dim3(kWave), ldsb, st, pool, pool_stride, fpool,
+  // (one wavefront per belief while the beliefs are small -- a network's 100 000 clusters of a dozen variables --, eight from
+  // 33 variables on: the elimination of a 96-variable belief is 95 x 193 entries a pivot)
+  hipLaunchKernelGGL(free_energy_kernel<false>, dim3(n_beliefs, n_sites), dim3(mm > 32 ? kLdsBigThreads : kWave), ldsb, st, pool, pool_stride, fpool,
                      fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p, kb,
                      reinterpret_cast<double2*>(d_contrib), d_info, (const int32_t*)nullptr, kFreeEnergyLdsMaxDim,
                      (double*)nullptr, (int64_t)0);
   if (n_big > 0)   // beliefs above kFreeEnergyLdsMaxDim variables: n_big * n_sites slabs of free_energy_ws_doubles(max_dim)
-    hipLaunchKernelGGL(free_energy_kernel<true>, dim3(n_big, n_sites), dim3(kWave), 0, st, pool, pool_stride, fpool,
+    hipLaunchKernelGGL(free_energy_kernel<true>, dim3(n_big, n_sites), dim3(kWsThreads), 0, st, pool, pool_stride, fpool,
                        fpool_stride, d_boff, d_dim, n_clusters, n_beliefs, bs16, fast_p, max_dim,
                        reinterpret_cast<double2*>(d_contrib), d_info, d_big_idx, kFreeEnergyLdsMaxDim, d_ws,
                        free_energy_ws_doubles(max_dim));
@@ -2050,12 +2077,12 @@ static int grid_for(int64_t n, int n_sites) {
 // WS: the entries listed in big_ent (sepsets of more than kKlLdsMaxS variables), the two systems in a workspace slab in
 // global memory; the LDS instance skips those
 template <bool WS>
-__global__ __launch_bounds__(64) void residual_kldiv_kernel(DevState S, const Entry* __restrict__ entries, int e0,
+__global__ __launch_bounds__(WS ? 1024 : 512) void residual_kldiv_kernel(DevState S, const Entry* __restrict__ entries, int e0,
                                                             double* __restrict__ kldiv, int32_t* __restrict__ klflags,
                                                             unsigned long long stop_below,
                                                             const int32_t* __restrict__ big_ent, double* __restrict__ ws,
                                                             int64_t ws_stride) {
-  const int lane = threadIdx.x, site = blockIdx.y;
+  const int lane = threadIdx.x, nthr = blockDim.x, site = blockIdx.y;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
   const int msg = entries[WS ? big_ent[blockIdx.x] : e0 + (int)blockIdx.x].msg;
   const MsgDesc m = S.msgs[msg];
@@ -2083,39 +2110,37 @@ __global__ __launch_bounds__(64) void residual_kldiv_kernel(DevState S, const En
   const int nc0 = 2 * s + 1, ld0 = nc0 | 1;
   double* W = WS ? ws + ((int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y) * ws_stride : lds;
   double* vec = W + (size_t)s * ld0;  // mu0, later mu1 - mu0
-  for (int idx = lane; idx < s * s; idx += kWave) {
+  for (int idx = lane; idx < s * s; idx += nthr) {
     const int j = idx / s, i = idx - j * s;
     W[i * ld0 + j] = Jm(i, j);
     W[i * ld0 + s + j] = dJ(i, j);
   }
-  for (int i = lane; i < s; i += kWave) W[i * ld0 + 2 * s] = hm(i);
+  for (int i = lane; i < s; i += nthr) W[i * ld0 + 2 * s] = hm(i);
   __syncthreads();
   double logdet0, logdet1;
   if (!gauss_jordan_spd(W, s, nc0, ld0, lane, logdet0)) return;
   double tr = 0.0;
-  for (int i = lane; i < s; i += kWave) {
+  for (int i = lane; i < s; i += nthr) {
     tr += W[i * ld0 + s + i];
     vec[i] = W[i * ld0 + 2 * s];
   }
   __syncthreads();
   const int nc1 = s + 1, ld1 = nc1 | 1;
-  for (int idx = lane; idx < s * s; idx += kWave) {
+  for (int idx = lane; idx < s * s; idx += nthr) {
     const int j = idx / s, i = idx - j * s;
     W[i * ld1 + j] = J1u(i, j);
   }
-  for (int i = lane; i < s; i += kWave) W[i * ld1 + s] = hm(i) - dh(i);
+  for (int i = lane; i < s; i += nthr) W[i * ld1 + s] = hm(i) - dh(i);
   __syncthreads();
   if (!gauss_jordan_spd(W, s, nc1, ld1, lane, logdet1)) return;
-  for (int i = lane; i < s; i += kWave) vec[i] = W[i * ld1 + s] - vec[i];
+  for (int i = lane; i < s; i += nthr) vec[i] = W[i * ld1 + s] - vec[i];
   __syncthreads();
   double quad = 0.0;
-  for (int idx = lane; idx < s * s; idx += kWave) {
+  for (int idx = lane; idx < s * s; idx += nthr) {
     const int j = idx / s, i = idx - j * s;
     quad += vec[i] * J1u(i, j) * vec[j];
   }
-  double acc = quad - tr;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  const double acc = workgroup_sum(quad - tr, lane);
   if (lane == 0) {
     const double kl = 0.5 * (acc + logdet0 - logdet1);
     kldiv[(int64_t)site * S.n_msgs + msg] = kl;
@@ -2132,10 +2157,10 @@ void launch_residual_kldiv(const DevState& S, const Entry* d_entries, int e0, in
   const int ms = max_s > kKlLdsMaxS ? kKlLdsMaxS : max_s;   // (the LDS a launch asks for: this level's largest sepset that fits)
   const size_t ldsb = sizeof(double) * (size_t)kldiv_ws_doubles(ms);
   allow_large_lds(reinterpret_cast<const void*>(residual_kldiv_kernel<false>), ldsb);
-  hipLaunchKernelGGL(residual_kldiv_kernel<false>, dim3(n_entries, n_sites), dim3(kWave), ldsb, st, S, d_entries, e0, d_kldiv,
+  hipLaunchKernelGGL(residual_kldiv_kernel<false>, dim3(n_entries, n_sites), dim3(ms > 32 ? kLdsBigThreads : kWave), ldsb, st, S, d_entries, e0, d_kldiv,
                      d_klflags, stop_below, (const int32_t*)nullptr, (double*)nullptr, (int64_t)0);
   if (n_big > 0)   // sepsets above kKlLdsMaxS variables: n_big * n_sites slabs of kldiv_ws_doubles(max_s)
-    hipLaunchKernelGGL(residual_kldiv_kernel<true>, dim3(n_big, n_sites), dim3(kWave), 0, st, S, d_entries, e0, d_kldiv,
+    hipLaunchKernelGGL(residual_kldiv_kernel<true>, dim3(n_big, n_sites), dim3(kWsThreads), 0, st, S, d_entries, e0, d_kldiv,
                        d_klflags, stop_below, d_big_ent, d_ws, kldiv_ws_doubles(max_s));
 }
 

@@ -229,7 +229,7 @@ void launch_bm_ithl(const double* d_length, const int32_t* d_kind, int p, double
 
 // d_big_idx / n_big: the beliefs of more than kFreeEnergyLdsMaxDim variables (their working matrix in d_ws: n_big * n_sites
 // slabs of free_energy_ws_doubles(max_dim))
-constexpr int kFreeEnergyLdsMaxDim = 139;   // [J | one column of J_t | h] of a belief in 150 KB of LDS
+constexpr int kFreeEnergyLdsMaxDim = 96;    // [J | J_t | h] of a belief whole in 150 KB of LDS (one elimination; until round 4, second session, 139 with J_t in column blocks: a belief of 138 variables repeated its elimination 138 times, 250 ms)
 int64_t free_energy_ws_doubles(int m);
 void launch_free_energy(const double* pool, int64_t pool_stride, const double* fpool, int64_t fpool_stride,
                         const int64_t* d_boff, const int32_t* d_dim, int n_clusters, int n_beliefs, int max_dim, int bs16,

@@ -247,7 +247,7 @@ def test_muller_clique_tree_with_beliefs_beyond_64_dimensions(p):
         if st.dims[i] > 0:
             v = cgb.integratebelief_(int(i))[1]
             assert abs(v - ll) <= 1e-8 * max(1.0, abs(ll)), (i, v, ll)
-    fe = cgb.free_energy()      # (beliefs above 139 variables: the workspace instance of the kernel)
+    fe = cgb.free_energy()      # (beliefs above 96 variables: the workspace instance of the kernel)
     assert abs(fe[2] + ll) <= 1e-8 * max(1.0, abs(ll)), (fe, ll)
     # one message on its own, from the start state: the largest sender towards one of its neighbours
     cgb._packed[0][:] = start
