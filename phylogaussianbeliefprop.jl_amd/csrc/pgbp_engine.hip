@@ -53,6 +53,9 @@ struct DevTraversal {
 struct pgbp_engine {
   Plan plan;
   hipStream_t st = nullptr;
+  // the KL flags and divergences are as the last reset left them (nothing computed a KL residual since): the next reset of
+  // the message flags leaves them alone (two of its three arrays; cfg4: 2.6 GB a call)
+  bool kl_flags_clean = false, kl_div_clean = false;
   // device state
   double* d_pool = nullptr;    // [n_sites][pool_stride] beliefs
   double* d_fpool = nullptr;   // [n_sites][cluster_stride] factors
@@ -243,11 +246,44 @@ DevState dev_state(pgbp_engine* e, const pgbp_opts* o) {
   return S;
 }
 
+// The downstream-of-a-failure marks are one word per (site, cluster) -- 1.3 GB for cfg4's 8 000 problems x 40 000 clusters,
+// a memset of it in front of every enqueue call was 3 % of a sharded step -- and a mark is only ever set beside a failure key
+// in the site's fail word (the message that failed, or one downstream of it), which stays until the next reset_fail: so the
+// marks are cleared only where some site's fail word holds a failure (every workgroup looks at the fail words first).
+__global__ __launch_bounds__(256) void clear_poison_if_failed(const unsigned long long* __restrict__ fail, int n_sites,
+                                                              int32_t* __restrict__ poison, int64_t n_words) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  for (int s = threadIdx.x; s < n_sites; s += blockDim.x)
+    if (is_failure_key(fail[s])) any = 1;   // (every writer writes the same value)
+  __syncthreads();
+  if (!any) return;
+  int4* p4 = reinterpret_cast<int4*>(poison);
+  const int64_t n4 = n_words / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    p4[i] = make_int4(0, 0, 0, 0);
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x)
+    poison[i] = 0;
+}
+
+// init_messagecalibrationflags_reset! on the device (src/clustergraphbeliefs.jl:190-202); reset_kl: the KL divergences too
+void reset_message_flags(pgbp_engine* e, int reset_kl) {
+  const int mode = ((reset_kl && !e->kl_div_clean) ? 1 : 0) | (e->kl_flags_clean ? 0 : 2);
+  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, mode, e->st,
+                     e->layout_sm ? 1 : 0);
+  e->kl_flags_clean = true;
+  if (reset_kl) e->kl_div_clean = true;
+}
+
 int reset_fail(pgbp_engine* e) {
   const size_t ns = (size_t)e->plan.n_sites;
-  HIPCHK(e, hipMemsetAsync(e->d_fail, 0xFF, sizeof(unsigned long long) * ns, e->st));
   // (either layout: the site-minor one has padded rows)
-  HIPCHK(e, hipMemsetAsync(e->d_poison, 0, sizeof(int32_t) * (size_t)sm_row(e->plan.n_sites) * (size_t)e->plan.n_clusters, e->st));
+  const int64_t n_words = (int64_t)sm_row(e->plan.n_sites) * (int64_t)e->plan.n_clusters;
+  const int64_t want = (n_words / 4 + 255) / 256;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 2048));
+  hipLaunchKernelGGL(clear_poison_if_failed, dim3(grid), dim3(256), 0, e->st, e->d_fail, (int)ns, e->d_poison, n_words);
+  HIPCHK(e, hipMemsetAsync(e->d_fail, 0xFF, sizeof(unsigned long long) * ns, e->st));
   return PGBP_OK;
 }
 
@@ -467,6 +503,7 @@ void enqueue_levels(pgbp_engine* e, const DevState& S, const Traversal& tr, cons
       // the level's entries whose sepset is beyond the LDS instance: a second launch with a workspace slab each
       const auto b0 = std::lower_bound(d.kl_big.begin(), d.kl_big.end(), e0), b1 = std::lower_bound(d.kl_big.begin(), d.kl_big.end(), e1);
       const int n_big = (int)(b1 - b0);
+      e->kl_flags_clean = e->kl_div_clean = false;
       if (n_big == 0 || ensure_ws(e, (int64_t)n_big * e->plan.n_sites * kldiv_ws_doubles(level_s)) == PGBP_OK)
         launch_residual_kldiv(S, d.d_entries, e0, e1 - e0, level_s, e->d_kldiv, e->d_klflags, e->plan.n_sites, stop_below, e->st,
                               d.d_kl_big + (b0 - d.kl_big.begin()), n_big, e->d_ws);
@@ -719,7 +756,7 @@ int pgbp_create(const pgbp_desc* desc, pgbp_engine** out) {
     e->err = "hipMemsetAsync failed";
     return bail(PGBP_ERR_HIP);
   }
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, (int)nm, p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);
+  reset_message_flags(e, 1);
   if (hipStreamSynchronize(e->st) != hipSuccess) {
     e->err = "initialisation kernels failed";
     return bail(PGBP_ERR_HIP);
@@ -943,7 +980,7 @@ int pgbp_reset_from_factors(pgbp_engine* e) {
 int pgbp_reset_flags(pgbp_engine* e, int32_t reset_kl) {
   DeviceScope device_scope(e);
   if (!e) return PGBP_ERR_INVALID;
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, e->plan.n_msgs(), e->plan.n_sites, reset_kl, e->st, e->layout_sm ? 1 : 0);
+  reset_message_flags(e, reset_kl);
   return pgbp_sync(e);
 }
 
@@ -1139,6 +1176,7 @@ int pgbp_residual_kldiv(pgbp_engine* e, int32_t cluster_to, int32_t sepset, int3
   if (e->layout_sm && (rc = ensure_site_minor(e, false))) return rc;
   DevState S = dev_state(e, opts);
   // a standalone call always computes (stop_below = 0; the status of the last attempt of this message still gates)
+  e->kl_flags_clean = e->kl_div_clean = false;
   launch_residual_kldiv(S, e->d_one_entry, 0, 1, s_msg, e->d_kldiv, e->d_klflags, p.n_sites, 0, e->st,
                         kl_ws ? e->d_one_task_off : nullptr, kl_ws ? 1 : 0, e->d_ws);
   if (iscalibrated_kl) {
@@ -1437,7 +1475,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
                                e->d_bm_logdet, e->d_bm_mu, e->bm_per_site, p.n_clusters, p.n_sites, e->st);
     const int64_t nc = p.packed_off[p.n_clusters] * sm_row(p.n_sites), nall = p.packed_off.back() * sm_row(p.n_sites);
     if (!skip_sepsets) HIPCHK(e, hipMemsetAsync(e->d_pool_sm + nc, 0, sizeof(double) * (size_t)(nall - nc), e->st));  // sepsets = 1
-    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
+    reset_message_flags(e, also_factors ? 1 : 0);
     if (also_factors) e->have_factors = true;
     return PGBP_OK;
   }
@@ -1461,7 +1499,7 @@ static int bm_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
   if (!skip_sepsets)
     launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                         p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st, e->layout_sm ? 1 : 0);
+  reset_message_flags(e, also_factors ? 1 : 0);
   if (also_factors) e->have_factors = true;
   return PGBP_OK;
 }
@@ -1688,8 +1726,7 @@ static int lg_fill_async(pgbp_engine* e, bool also_factors, bool skip_sepsets = 
       launch_zero_strided(e->d_pool + p.cluster_stride(), p.pool_stride(), p.pool_stride() - p.cluster_stride(),
                           p.n_sites, e->st);  // sepsets = 1 (init_beliefs_reset!)
   }
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, also_factors ? 1 : 0, e->st,
-                     e->layout_sm ? 1 : 0);
+  reset_message_flags(e, also_factors ? 1 : 0);
   if (also_factors) e->have_factors = true;
   return PGBP_OK;
 }
@@ -1754,7 +1791,7 @@ static int enqueue_calibrate_once(pgbp_engine* e, const DevState& S, int reset_e
   if (reset_each) {
     int rc = reset_from_factors_async(e);
     if (rc) return rc;
-    launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);
+    reset_message_flags(e, 1);
   }
   for (int j = 0; j < (int)p.trees.size(); ++j) {
     hipEvent_t a = nullptr, b = nullptr;
@@ -1849,7 +1886,7 @@ static int enqueue_loglik_once(pgbp_engine* e, const DevState& S0) {
   S.sep_zero = fresh_sepsets_shortcut(e) ? 1 : 0;
   int rc = reset_from_factors_async(e, S.sep_zero != 0);
   if (rc) return rc;
-  launch_reset_flags(e->d_msgs, e->d_flags, e->d_klflags, e->d_kldiv, p.n_msgs(), p.n_sites, 1, e->st, e->layout_sm ? 1 : 0);  // calibration.jl:209
+  reset_message_flags(e, 1);  // calibration.jl:209
   enqueue_tree(e, S, 0, 1, 0);                                                              // :210
   const int root = p.trees[0].pa.empty() ? 0 : p.trees[0].pa[0];
   integrate_async(e, root, nullptr);         // :212

@@ -1033,13 +1033,13 @@ __global__ __launch_bounds__(kTailWaves * 64) void bp_chunk_generic(DevState S, 
 // WS: senders of more than kLdsMaxDim variables (up to PGBP_MAX_DIM): the working matrix does not fit the CU's LDS and lives
 // in a WORKSPACE in global memory, one slab per workgroup (engine: pgbp_engine::d_ws) -- a few hundred KB that stay in the
 // XCD's L2 between the rank-1 updates; the barriers of the elimination order its accesses (same CU, same vector L1).
-constexpr int kBigThreads = 256;
+constexpr int kBigThreads = 1024;   // sixteen wavefronts per task (256 threads until round 4, last session: Mueller clique tree)
 template <bool WS>
 __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const int32_t* __restrict__ task_off,
                                                             const Entry* __restrict__ entries, int task0,
                                                             unsigned long long seq_base, unsigned long long stop_below,
                                                             double* __restrict__ ws, int64_t ws_stride) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   const int site = blockIdx.y;
   if ((S.fail[site] >> kInfoBits) < stop_below) return;
   const int task = task0 + blockIdx.x;
@@ -1072,14 +1072,14 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
       ni = m.ni;
       ld = (mf + 1) | 1;
       __syncthreads();  // W / perm of the previous entry no longer needed
-      for (int i = tid; i < mf; i += kBigThreads)
+      for (int i = tid; i < mf; i += nthr)
         perm[i] = (i < ni) ? S.idx[m.int_map + i] : S.idx[m.keep_map + (i - ni)];  // integrated first, kept last
       __syncthreads();
-      for (int idx = tid; idx < mf * mf; idx += kBigThreads) {
+      for (int idx = tid; idx < mf * mf; idx += nthr) {
         const int j = idx / mf, i = idx - j * mf;
         W[i * ld + j] = from[perm[i] + (int64_t)perm[j] * mf];
       }
-      for (int i = tid; i < mf; i += kBigThreads) W[i * ld + mf] = from[(int64_t)mf * mf + perm[i]];
+      for (int i = tid; i < mf; i += nthr) W[i * ld + mf] = from[(int64_t)mf * mf + perm[i]];
       {
         int z = 0;
         asm volatile("" : "+v"(z));   // vector load: the sender may have been written by this workgroup (an earlier entry)
@@ -1090,21 +1090,21 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
       if (ni > 0) {
         // "fake" message: J_I, h_I, J_SI all ~ 0 (src/beliefupdates.jl:62-66): rows 0 .. mf-1, columns 0 .. ni-1, and h_I
         bool nz = false;
-        for (int idx = tid; idx < mf * ni; idx += kBigThreads) {
+        for (int idx = tid; idx < mf * ni; idx += nthr) {
           const int j = idx / mf, i = idx - j * mf;
           nz |= fabs(W[i * ld + j]) > PGBP_EPS;
         }
-        for (int i = tid; i < ni; i += kBigThreads) nz |= fabs(W[i * ld + mf]) > PGBP_EPS;
+        for (int i = tid; i < ni; i += nthr) nz |= fabs(W[i * ld + mf]) > PGBP_EPS;
         if (nz) s_flag = 1;
         __syncthreads();
         if (s_flag) {
           // Symmetric(J_I): upper triangle only (:68); pivot rows get J_SI' for the kept columns (:77)
-          for (int idx = tid; idx < ni * mf; idx += kBigThreads) {
+          for (int idx = tid; idx < ni * mf; idx += nthr) {
             const int i = idx / mf, j = idx - i * mf;   // i < ni
             if (j > i && j >= ni) W[i * ld + j] = W[j * ld + i];
           }
           __syncthreads();
-          for (int idx = tid; idx < ni * ni; idx += kBigThreads) {
+          for (int idx = tid; idx < ni * ni; idx += nthr) {
             const int i = idx / ni, j = idx - i * ni;
             if (j > i) W[j * ld + i] = W[i * ld + j];
           }
@@ -1125,11 +1125,29 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
             expo += ex;
             if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
             quad += hk * hk * rd;
-            const int nr = mf - (k + 1), ncol = mf - k;   // rows k+1 .. mf-1, columns k+1 .. mf (h)
-            for (int idx = tid; idx < nr * ncol; idx += kBigThreads) {
-              const int ii = idx / ncol, jj = idx - ii * ncol;
-              const int i = k + 1 + ii, j = k + 1 + jj;
-              W[i * ld + j] -= (W[i * ld + k] * rd) * W[k * ld + j];
+            // rows k+1 .. mf-1 by wavefront, columns k+1 .. mf (h) by lane (every entry: the same operations as ever)
+            if constexpr (!WS) {   // (in LDS)
+              for (int i = k + 1 + (tid >> 6); i < mf; i += (nthr >> 6)) {
+                const double lik = W[i * ld + k] * rd;
+                for (int j = k + 1 + (tid & 63); j <= mf; j += kWave) W[i * ld + j] -= lik * W[k * ld + j];
+              }
+            } else {
+              // the pivot row's entries of the lane's columns once per pivot, a row's entries requested together: in the
+              // workspace every access is a round trip to the L2, and the compiler must assume W aliases itself
+              constexpr int kChunks = (PGBP_MAX_DIM + 1 + kWave - 1) / kWave;
+              const int j0 = k + 1 + (tid & 63);
+              double rk[kChunks];
+#pragma unroll
+              for (int c = 0; c < kChunks; ++c) rk[c] = (j0 + c * kWave <= mf) ? W[k * ld + j0 + c * kWave] : 0.0;
+              for (int i = k + 1 + (tid >> 6); i < mf; i += (nthr >> 6)) {
+                const double lik = W[i * ld + k] * rd;
+                double wv[kChunks];
+#pragma unroll
+                for (int c = 0; c < kChunks; ++c) wv[c] = (j0 + c * kWave <= mf) ? W[i * ld + j0 + c * kWave] : 0.0;
+#pragma unroll
+                for (int c = 0; c < kChunks; ++c)
+                  if (j0 + c * kWave <= mf) W[i * ld + j0 + c * kWave] = wv[c] - lik * rk[c];
+              }
             }
             __syncthreads();
           }
@@ -1150,7 +1168,7 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
     __syncthreads();
     // ---- divide! and mult!
     double maxJ = 0.0, maxh = 0.0;
-    for (int idx = tid; idx < s * s; idx += kBigThreads) {
+    for (int idx = tid; idx < s * s; idx += nthr) {
       const int b = idx / s, a = idx - b * s;
       const double msg = W[(ni + a) * ld + ni + b];
       const int64_t o = a + (int64_t)b * s;
@@ -1160,7 +1178,7 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
       to[up[a] + (int64_t)up[b] * mt] += dJ;
       maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
     }
-    for (int a = tid; a < s; a += kBigThreads) {
+    for (int a = tid; a < s; a += nthr) {
       const double msg = W[(ni + a) * ld + mf];
       const int64_t o = (int64_t)s * s + a;
       const double dh = msg - sep[o];
@@ -1182,7 +1200,7 @@ __global__ __launch_bounds__(kBigThreads) void bp_level_big(DevState S, const in
       __syncthreads();
       if (tid == 0) {
         bool all = true;
-        for (int t = 0; t < kBigThreads; ++t) all &= s_red[t] != 0.0;
+        for (int t = 0; t < nthr; ++t) all &= s_red[t] != 0.0;
         S.flags[(int64_t)site * S.n_msgs + en.msg] = all ? 1 : 0;
       }
     }
@@ -1879,6 +1897,7 @@ __device__ __forceinline__ double fe_elem(const double* __restrict__ rec, int m,
 // whole workgroup (one wavefront: the LDS instances; sixteen: the workspace ones, round 4): on return the right block holds
 // A^-1 B and logdet = log det A.  Pivots are the Cholesky pivots of A (no pivoting); returns false (uniformly) as soon as a
 // pivot is not positive, i.e. A is not positive definite.  Every entry sees the same operations whatever the workgroup's size.
+template <bool WS>
 __device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int ld, int tid, double& logdet) {
   const int nthr = blockDim.x, wv = tid >> 6, ln = tid & 63, nw = nthr >> 6;
   double mant = 1.0;
@@ -1905,11 +1924,28 @@ __device__ __forceinline__ bool gauss_jordan_spd(double* W, int m, int nc, int l
           W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
         }
       }
-    } else {         // sixteen wavefronts (workspace instances): rows by wavefront, columns by lane, no division
+    } else if (!WS) {   // eight wavefronts in LDS: rows by wavefront, columns by lane, no division
       for (int i0 = wv; i0 < m - 1; i0 += nw) {
         const int i = i0 + (i0 >= k ? 1 : 0);
         const double wik = W[i * ld + k];
         for (int j = k + 1 + ln; j < nc; j += kWave) W[i * ld + j] -= wik * W[k * ld + j];
+      }
+    } else {            // sixteen wavefronts, the system in the workspace: every access is a round trip to the L2 and the
+      // compiler must assume W aliases itself -- the pivot row's entries once per pivot, a row's entries requested together
+      constexpr int kChunks = (2 * PGBP_MAX_DIM + 1 + kWave - 1) / kWave;
+      const int j0 = k + 1 + ln;
+      double rk[kChunks];
+#pragma unroll
+      for (int c = 0; c < kChunks; ++c) rk[c] = (j0 + c * kWave < nc) ? W[k * ld + j0 + c * kWave] : 0.0;
+      for (int i0 = wv; i0 < m - 1; i0 += nw) {
+        const int i = i0 + (i0 >= k ? 1 : 0);
+        const double wik = W[i * ld + k];
+        double wr[kChunks];
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) wr[c] = (j0 + c * kWave < nc) ? W[i * ld + j0 + c * kWave] : 0.0;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c)
+          if (j0 + c * kWave < nc) W[i * ld + j0 + c * kWave] = wr[c] - wik * rk[c];
       }
     }
     __syncthreads();
@@ -1980,7 +2016,7 @@ __global__ __launch_bounds__(WS ? 1024 : 512) void free_energy_kernel(const doub
       for (int i = lane; i < m; i += nthr) W[i * ld + m + nb] = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
     __syncthreads();
     double ld_pass;
-    if (!gauss_jordan_spd(W, m, nc, ld, lane, ld_pass)) {
+    if (!gauss_jordan_spd<WS>(W, m, nc, ld, lane, ld_pass)) {
       if (lane == 0) { atomicMin(&info[site], b + 1); *out = make_double2(NAN, NAN); }
       return;
     }
@@ -2118,7 +2154,7 @@ __global__ __launch_bounds__(WS ? 1024 : 512) void residual_kldiv_kernel(DevStat
   for (int i = lane; i < s; i += nthr) W[i * ld0 + 2 * s] = hm(i);
   __syncthreads();
   double logdet0, logdet1;
-  if (!gauss_jordan_spd(W, s, nc0, ld0, lane, logdet0)) return;
+  if (!gauss_jordan_spd<WS>(W, s, nc0, ld0, lane, logdet0)) return;
   double tr = 0.0;
   for (int i = lane; i < s; i += nthr) {
     tr += W[i * ld0 + s + i];
@@ -2132,7 +2168,7 @@ __global__ __launch_bounds__(WS ? 1024 : 512) void residual_kldiv_kernel(DevStat
   }
   for (int i = lane; i < s; i += nthr) W[i * ld1 + s] = hm(i) - dh(i);
   __syncthreads();
-  if (!gauss_jordan_spd(W, s, nc1, ld1, lane, logdet1)) return;
+  if (!gauss_jordan_spd<WS>(W, s, nc1, ld1, lane, logdet1)) return;
   for (int i = lane; i < s; i += nthr) vec[i] = W[i * ld1 + s] - vec[i];
   __syncthreads();
   double quad = 0.0;
@@ -2555,13 +2591,15 @@ __global__ void reset_flags_kernel(const MsgDesc* __restrict__ msgs, int32_t* __
                                    int reset_kl) {
   const int site = blockIdx.y;
   for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < n_msgs; d += gridDim.x * blockDim.x) {
+    // reset_kl: bit 0 = the KL divergences of non-empty messages back to -1, bit 1 = the KL flags (and the empty messages'
+    // divergences) are written at all (the engine leaves them alone while nothing has touched them since the last reset)
     const bool empty = msgs[d].s == 0;
     flags[(int64_t)site * n_msgs + d] = empty ? 1 : 0;
-    klflags[(int64_t)site * n_msgs + d] = empty ? 1 : 0;
-    if (empty)
-      kldiv[(int64_t)site * n_msgs + d] = 0.0;
-    else if (reset_kl)
-      kldiv[(int64_t)site * n_msgs + d] = -1.0;
+    if (reset_kl & 2) {
+      klflags[(int64_t)site * n_msgs + d] = empty ? 1 : 0;
+      if (empty) kldiv[(int64_t)site * n_msgs + d] = 0.0;
+    }
+    if (!empty && (reset_kl & 1)) kldiv[(int64_t)site * n_msgs + d] = -1.0;
   }
 }
 
@@ -2575,9 +2613,11 @@ __global__ __launch_bounds__(256) void reset_flags_sm_kernel(const MsgDesc* __re
     const bool empty = msgs[d].s == 0;
     const int64_t o = (int64_t)d * sm_row(n_sites) + site;
     flags[o] = empty ? 1 : 0;
-    klflags[o] = empty ? 1 : 0;
-    if (empty) kldiv[o] = 0.0;
-    else if (reset_kl) kldiv[o] = -1.0;
+    if (reset_kl & 2) {
+      klflags[o] = empty ? 1 : 0;
+      if (empty) kldiv[o] = 0.0;
+    }
+    if (!empty && (reset_kl & 1)) kldiv[o] = -1.0;
   }
 }
 
