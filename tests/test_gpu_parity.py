@@ -205,6 +205,48 @@ def test_first_failure_is_the_reference_order_first(P):
     assert r.fail_dir == 0 and r.fail_info == 1 and r.fail_edge == max(bad)
 
 
+def test_a_failed_run_leaves_no_marks_behind(P):
+    """The downstream-of-a-failure marks (one word per site and cluster) are cleared at the next enqueue call only where a
+    fail word holds a failure (round 4: a 1.3 GB memset per call at cfg4's size otherwise).  One engine, two sites: a good
+    run, a run with a non-positive-definite block in site 1 (its failure reported, site 0 untouched), then the good state
+    again -- both sites must calibrate to the plain-C engine's beliefs, i.e. no mark of the failed run survives --, and a
+    log-likelihood style postorder after that as well."""
+    from oracle import cengine
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(2027)
+    tr = S.random_tree(70, rng)
+    p = 4
+    prob = S.cliquetree_of_tree(tr, p)
+    R = S.random_rate_matrix(p, rng)
+    mu = np.zeros(p)
+    packs = [S.bm_factors_cliquetree(tr, prob, R, mu, S.simulate_bm(tr, R, mu, rng)) for _ in range(2)]
+    good = np.stack(packs)
+    pa, ch = prob.schedule[0]
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, good.copy(), n_sites=2)
+
+    def check_good():
+        assert P.calibrate_(cgb, prob.schedule, 1, verbose=False)[0]
+        for s_ in range(2):
+            ref = cengine.Engine(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packs[s_])
+            assert ref.calibrate(pa, ch, 1, return_iscal=True)[0] and cgb.last_results[s_].succ == 1
+            want = ref.packed()
+            assert np.max(np.abs(cgb._packed[s_] - want)) <= 1e-8 * max(1.0, np.max(np.abs(want))), s_
+    check_good()
+    bad = good.copy()
+    snd = int(next(c for c in ch if prob.dims[c] == 2 * p))
+    bad[1][prob.packed_off[snd]] = -1.0e6
+    cgb._packed[...] = bad
+    cgb.push()
+    cgb.init_messagecalibrationflags_reset_()
+    P.calibrate_(cgb, prob.schedule, 1, verbose=False)
+    assert (cgb.last_results[0].succ, cgb.last_results[1].succ) == (1, 0)
+    for _ in range(2):   # (the second time nothing failed in the run before: the marks are left alone, and must be clean)
+        cgb._packed[...] = good
+        cgb.push()
+        cgb.init_messagecalibrationflags_reset_()
+        check_good()
+
+
 def test_auto_stop_and_info_log(P, caplog):
     """calibrate!(...; auto=true, info=true): on a clique tree calibration is reached at iteration 2
     (the second pass changes nothing), and the log line is the reference's (src/calibration.jl:54)."""
