@@ -741,6 +741,12 @@ def main():
                                   "postorder reads) + bp_fast16 / bp_loop16 (postorder) + integrate_kernel (root); kernel rows: "
                                   "profiles/r04_*_cfg3_kernel_stats.csv",
                        "traffic": None}
+        ll_pmc = load_pmc_traffic("pmc_traffic_ll_eval_latest.json")
+        if ll_pmc and (args.traits, args.ntips, args.graph, args.seed) == (16, 50000, "cliquetree", 3):
+            ll_roofline.update({"traffic": ll_pmc.get("hbm_bytes_per_calibrate"), "traffic_stale": ll_pmc.get("stale"),
+                                "traffic_unit": "bytes per evaluation (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, every "
+                                                "launch of the fill, the flag reset, the postorder and the root integrate of one "
+                                                "evaluation: tools/level_times.py run-ll; profiles/pmc_traffic_ll_eval_latest.json)"})
         # ---- the DROP-IN call: what a user of the kept-intact API gets (calibrate_ with its write-back, then
         # integratebelief! at the root), end to end on the host clock, beside the upload of the 0.76 GB belief state and
         # the eager pull of everything (the round-3 behaviour of every call)

@@ -4,6 +4,7 @@
   step 1 (under the profiler; the program itself after `--`):
      rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lt -- python3 tools/level_times.py run [ntips] [traits]
      (or `run-network [joingraph|bethe] [ntips]`: the cfg5 network workload of bench.py;
+      `run-ll [ntips] [traits]`: cfg3's log-likelihood evaluation, for the PMC passes of `ll_eval.roofline.traffic`;
       `run-bethe [ntips] [traits]`: cfg2, the Bethe cluster graph of a tree)
   step 2 (plain): python3 tools/level_times.py parse gpurun_out/lt [out.json]
 
@@ -39,6 +40,37 @@ def run(ntips, p, bethe=False):
         assert P.calibrate_(cgb, prob.schedule, 1, sync=False)[0]
         time.sleep(0.003)
     print("loglik", cgb.integratebelief_(prob.root_cluster)[1])
+
+
+def run_ll(ntips, p):
+    """the log-likelihood evaluation of cfg3 (bench.py's `ll_eval`): assignfactors! on the device, postorder, root
+    integratebelief! -- 3 warm-up evaluations and 8 more, each behind a device sync, and nothing else behind the set-up"""
+    import ctypes as C
+    import time
+    import numpy as np
+    import pgbp_amd as P
+    from pgbp_amd import synth as S
+    rng = np.random.default_rng(3)
+    tr = S.random_tree(ntips, rng)
+    R = S.random_rate_matrix(p, rng)
+    X = S.simulate_bm(tr, R, np.zeros(p), rng)
+    prob = S.cliquetree_of_tree(tr, p)
+    packed = S.bm_factors_cliquetree(tr, prob, R, np.zeros(p), X)
+    cgb = P.ClusterGraphBelief.from_arrays(prob.dims, prob.sepset_clusters, prob.scope_off, prob.scope_idx, packed)
+    cgb.set_schedule(prob.schedule)
+    cgb.bm_tree_setup(*S.bm_tree_table(tr, prob), X)
+    cgb.assignfactors_bm_(R, np.zeros(p))
+    lib = P.load()
+    opts = cgb._opts()
+    for _ in range(11):
+        assert lib.pgbp_enqueue_loglik_bm(cgb._eng, 1, C.byref(opts)) == 0
+        assert lib.pgbp_sync(cgb._eng) == 0
+        time.sleep(0.003)
+    norm = np.zeros(1)
+    info = np.zeros(1, dtype=np.int32)
+    from pgbp_amd import _lib as L
+    assert lib.pgbp_fetch_loglik(cgb._eng, L.f64p(norm), L.i32p(info)) == 0
+    print("loglik", norm[0], "pruning", S.bm_loglik_pruning(tr, R, np.zeros(p), X))
 
 
 def run_network(graph, ntips):
@@ -111,6 +143,8 @@ if __name__ == "__main__":
         run_network(sys.argv[2] if len(sys.argv) > 2 else "joingraph", int(sys.argv[3]) if len(sys.argv) > 3 else 20000)
     elif sys.argv[1] == "run-bethe":   # cfg2: 10 000 tips, 8 traits
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 10000, int(sys.argv[3]) if len(sys.argv) > 3 else 8, bethe=True)
+    elif sys.argv[1] == "run-ll":      # cfg3's log-likelihood evaluation (fill + postorder + root integrate)
+        run_ll(int(sys.argv[2]) if len(sys.argv) > 2 else 50000, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
     elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 50000, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
     else:

@@ -26,6 +26,12 @@ step "cfg3 pmc write"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p4 -- python3 tools/level_times.py run > $out/pmc_w.txt 2>&1 || exit 1
 F=$(find /tmp/p3 -name "*counter_collection.csv" | head -1); W=$(find /tmp/p4 -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py $F $W 0 $out/cfg3_pmc_traffic.json none bp_fast16+bp_loop16 8 > $out/cfg3_pmc_traffic.txt 2>&1; rm -rf /tmp/p3 /tmp/p4
+step "cfg3 log-likelihood evaluation: pmc fetch / write (ll_eval.roofline.traffic)"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p3l -- python3 tools/level_times.py run-ll > $out/pmc_ll_f.txt 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p4l -- python3 tools/level_times.py run-ll > $out/pmc_ll_w.txt 2>&1 || exit 1
+F=$(find /tmp/p3l -name "*counter_collection.csv" | head -1); W=$(find /tmp/p4l -name "*counter_collection.csv" | head -1)
+# (the last 8 evaluations: 16 launches each -- fill, flag reset, 7 level + 6 loop launches of the postorder, root integrate)
+python3 tools/pmc_traffic.py $F $W 0 $out/cfg3_ll_eval_pmc_traffic.json none bm_tree_fill_fast+reset_flags_kernel+bp_fast16+bp_loop16+integrate_kernel 8 128 > $out/cfg3_ll_eval_pmc_traffic.txt 2>&1; rm -rf /tmp/p3l /tmp/p4l
 step "cfg3 instruction issue (pmc)"
 bash tools/pmc_issue.sh ${tag}_cfg3 > /dev/null 2>&1; cp $PWD/gpurun_out/${tag}_cfg3_pmc_issue.txt $out/cfg3_pmc_issue.txt 2>/dev/null
 step "cfg2 kernel stats + level times"
