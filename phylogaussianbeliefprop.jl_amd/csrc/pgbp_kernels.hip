@@ -1667,13 +1667,13 @@ void launch_chunk_generic(const DevState& S, const GRec* d_recs, const int32_t* 
 // integratebelief(h, J, g) (src/beliefupdates.jl:187-200): mu = J \ h, norm = g + (m log 2pi - logdet J + h'mu)/2
 // WS: a belief of more than kLdsMaxDim variables: [J | h] in a workspace slab in global memory (one per site)
 template <bool WS>
-__global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict__ pool_all, int64_t pool_stride,
+__global__ __launch_bounds__(WS ? 1024 : 64) void integrate_kernel(const double* __restrict__ pool_all, int64_t pool_stride,
                                                        int64_t rec_off, int m, int bs, int fp,
                                                        double* __restrict__ mu,
                                                        int mu_stride, double* __restrict__ norm,
                                                        int32_t* __restrict__ info_out, double* __restrict__ ws,
                                                        int64_t ws_stride) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, nthr = blockDim.x;   // (WS: sixteen wavefronts -- round 4, last session; else one)
   const int site = blockIdx.x;
   const double* __restrict__ rec = pool_all + (int64_t)site * pool_stride + rec_off;
   double* W = WS ? ws + (int64_t)site * ws_stride : lds + kPermDoubles;
@@ -1733,7 +1733,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
     }
   }
   bool nz = false;
-  for (int idx = lane; idx < m * m; idx += kWave) {
+  for (int idx = lane; idx < m * m; idx += nthr) {
     const int j = idx / m, i = idx - j * m;
     if (packed) {
       const double v = rec[bs16::J_off(m, i, j, fp)];  // symmetric by construction
@@ -1746,15 +1746,15 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
       W[i * ld + j] = (i <= j) ? raw : rec[j + (int64_t)i * m];
     }
   }
-  for (int i = lane; i < m; i += kWave) {
+  for (int i = lane; i < m; i += nthr) {
     const double hv = packed ? rec[bs16::h_off(m, i, fp)] : rec[(int64_t)m * m + i];
     nz |= hv != 0.0;
     W[i * ld + m] = hv;
   }
-  __syncthreads();
-  if (!__any(nz)) {  // constant belief: mu = Inf, norm = g (:189-191)
+  const bool any_nz = WS ? (__syncthreads_or(nz ? 1 : 0) != 0) : (__syncthreads(), __any(nz) != 0);
+  if (!any_nz) {  // constant belief: mu = Inf, norm = g (:189-191)
     if (mu)
-      for (int i = lane; i < m; i += kWave) mu[(int64_t)site * mu_stride + i] = INFINITY;
+      for (int i = lane; i < m; i += nthr) mu[(int64_t)site * mu_stride + i] = INFINITY;
     if (lane == 0) {
       norm[site] = g;
       if (info_out) info_out[site] = 0;
@@ -1762,7 +1762,48 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
     return;
   }
   double logdet, quad;
-  const int info = eliminate_leading(W, ld, m, m, lane, logdet, quad);
+  int info = 0;
+  if constexpr (!WS) {
+    info = eliminate_leading(W, ld, m, m, lane, logdet, quad);
+  } else {
+    // eliminate_leading by the whole workgroup on the workspace slab: rows by wavefront, columns by lane, the pivot row's
+    // entries once per pivot and a row's entries requested together (every access is a round trip to the L2: bp_level_big)
+    constexpr int kChunks = (PGBP_MAX_DIM + 1 + kWave - 1) / kWave;
+    double mant = 1.0;
+    int expo = 0;
+    quad = 0.0;
+    for (int k = 0; k < m; ++k) {
+      const double d = W[k * ld + k];
+      const double hk = W[k * ld + m];
+      if (!(d > 0.0)) {
+        info = k + 1;
+        break;
+      }
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      int ex;
+      mant *= frexp(d, &ex);
+      expo += ex;
+      if ((k & 15) == 15) { mant = frexp(mant, &ex); expo += ex; }
+      quad += hk * hk * rd;
+      const int j0 = k + 1 + (lane & 63);
+      double rk[kChunks];
+#pragma unroll
+      for (int c = 0; c < kChunks; ++c) rk[c] = (j0 + c * kWave <= m) ? W[k * ld + j0 + c * kWave] : 0.0;
+      for (int i = k + 1 + (lane >> 6); i < m; i += (nthr >> 6)) {
+        const double lik = W[i * ld + k] * rd;
+        double wv[kChunks];
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) wv[c] = (j0 + c * kWave <= m) ? W[i * ld + j0 + c * kWave] : 0.0;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c)
+          if (j0 + c * kWave <= m) W[i * ld + j0 + c * kWave] = wv[c] - lik * rk[c];
+      }
+      __syncthreads();
+    }
+    logdet = log(mant) + (double)expo * 0.69314718055994530941723212145818;
+  }
   if (info != 0) {
     if (lane == 0) {
       norm[site] = NAN;
@@ -1776,10 +1817,10 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
       if (lane == 0) W[k * ld + m] = W[k * ld + m] / W[k * ld + k];
       __syncthreads();
       const double xk = W[k * ld + m];
-      for (int i = lane; i < k; i += kWave) W[i * ld + m] -= W[i * ld + k] * xk;
+      for (int i = lane; i < k; i += nthr) W[i * ld + m] -= W[i * ld + k] * xk;
       __syncthreads();
     }
-    for (int i = lane; i < m; i += kWave) mu[(int64_t)site * mu_stride + i] = W[i * ld + m];
+    for (int i = lane; i < m; i += nthr) mu[(int64_t)site * mu_stride + i] = W[i * ld + m];
   }
   if (lane == 0) {
     norm[site] = g + 0.5 * ((double)m * PGBP_LOG2PI - logdet + quad);
@@ -1790,7 +1831,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const double* __restrict_
 void launch_integrate(const double* pool, int64_t pool_stride, int64_t rec_off, int m, int bs16, int fast_p,
                       double* d_mu, int mu_stride, double* d_norm, int32_t* d_info, int n_sites, double* d_ws, hipStream_t st) {
   if (m > kLdsMaxDim) {   // (n_sites slabs of big_ws_doubles(m))
-    hipLaunchKernelGGL(integrate_kernel<true>, dim3(n_sites), dim3(kWave), 0, st, pool, pool_stride, rec_off, m, bs16, fast_p,
+    hipLaunchKernelGGL(integrate_kernel<true>, dim3(n_sites), dim3(1024), 0, st, pool, pool_stride, rec_off, m, bs16, fast_p,
                        d_mu, mu_stride, d_norm, d_info, d_ws, big_ws_doubles(m));
     return;
   }

@@ -52,6 +52,12 @@ def main():
             return (time.perf_counter() - t0) / n * 1e3
         ms_plain = wall(cgb._opts(), 3)
         ms_kl = wall(cgb._opts(update_residualkldiv=True), 3)
+        # integratebelief! of the LARGEST calibrated belief (src/beliefupdates.jl:187-200), host wall clock incl. the result's way back
+        biggest = int(np.argmax(st.dims[:len(cn)]))
+        cgb.integratebelief_(biggest)
+        t0 = time.perf_counter()
+        ib = cgb.integratebelief_(biggest)
+        ms_ib = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         fe = cgb.free_energy()
         ms_fe = (time.perf_counter() - t0) * 1e3
@@ -63,6 +69,7 @@ def main():
                           "largest_sepset": int(st.dims[len(cn):].max()), "ms_per_calibrate": ms.value / reps,
                           "ms_per_pgbp_calibrate_wall": ms_plain, "ms_per_pgbp_calibrate_wall_with_residual_kldiv": ms_kl,
                           "free_energy_ms": ms_fe, "minus_free_energy": -fe[2],
+                          "integratebelief_largest_ms": ms_ib, "integratebelief_largest_norm": float(np.ravel(ib[1])[0]),
                           "loglik": float(ll[0]), "info": int(info[0])}), flush=True)
 
 
