@@ -278,14 +278,21 @@ struct Blk { double x, y, z, w; };
 // BS16: packed upper blocks, lanes a <= b only (one double4), pgbp_bs16.hpp.
 // ODD (plain layout only): the quantity really is n x n with n = P - 1 odd; the lane grid is the one of P, index n is
 // a phantom (reads 0, is never stored), and the accesses are element-wise because rows no longer pair up on 16 bytes.
-template <bool BS, bool ODD = false>
+typedef double pgbp_d4v __attribute__((ext_vector_type(4)));
+// NT: a streaming load (an operand this calibrate reads once: a sepset, a leaf's belief)
+template <bool BS, bool ODD = false, bool NT = false>
 __device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld, int a, int b, bool up, int kidx,
                                         int n = 0) {
   Blk r{0.0, 0.0, 0.0, 0.0};
   if constexpr (BS) {
     if (up) {
-      const double4 v = *reinterpret_cast<const double4*>(base + kidx);
-      r = Blk{v.x, v.y, v.z, v.w};
+      if constexpr (NT) {
+        const pgbp_d4v v = __builtin_nontemporal_load(reinterpret_cast<const pgbp_d4v*>(base + kidx));
+        r = Blk{v.x, v.y, v.z, v.w};
+      } else {
+        const double4 v = *reinterpret_cast<const double4*>(base + kidx);
+        r = Blk{v.x, v.y, v.z, v.w};
+      }
     }
   } else if constexpr (ODD) {
     const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
@@ -300,11 +307,14 @@ __device__ __forceinline__ Blk load_blk(const double* __restrict__ base, int ld,
   }
   return r;
 }
-template <bool BS, bool ODD = false>
+// NT: a streaming store (the residuals: written by every message, read by nobody before the next reset)
+template <bool BS, bool ODD = false, bool NT = false>
 __device__ __forceinline__ void store_blk(double* __restrict__ base, int ld, int a, int b, bool up, bool act, int kidx,
                                           const Blk& v, int n = 0) {
   if constexpr (BS) {
-    if (up) *reinterpret_cast<double4*>(base + kidx) = make_double4(v.x, v.y, v.z, v.w);
+    if constexpr (NT) {
+      if (up) __builtin_nontemporal_store(pgbp_d4v{v.x, v.y, v.z, v.w}, reinterpret_cast<pgbp_d4v*>(base + kidx));
+    } else if (up) *reinterpret_cast<double4*>(base + kidx) = make_double4(v.x, v.y, v.z, v.w);
   } else if constexpr (ODD) {
     if (act) {
       const int r0 = 2 * a, r1 = 2 * a + 1, c0 = 2 * b, c1 = 2 * b + 1;
@@ -324,11 +334,14 @@ __device__ __forceinline__ double2 load_pair(const double* __restrict__ v, int a
   if constexpr (ODD) return make_double2(2 * a < n ? v[2 * a] : 0.0, 2 * a + 1 < n ? v[2 * a + 1] : 0.0);
   else return *reinterpret_cast<const double2*>(v + 2 * a);
 }
-template <bool ODD>
+typedef double pgbp_d2v __attribute__((ext_vector_type(2)));
+template <bool ODD, bool NT = false>
 __device__ __forceinline__ void store_pair(double* __restrict__ v, int a, double x, double y, int n) {
   if constexpr (ODD) {
     if (2 * a < n) v[2 * a] = x;
     if (2 * a + 1 < n) v[2 * a + 1] = y;
+  } else if constexpr (NT) {
+    __builtin_nontemporal_store(pgbp_d2v{x, y}, reinterpret_cast<pgbp_d2v*>(v + 2 * a));
   } else {
     *reinterpret_cast<double2*>(v + 2 * a) = make_double2(x, y);
   }
