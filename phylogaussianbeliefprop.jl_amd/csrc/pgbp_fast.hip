@@ -361,7 +361,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
               const Blk d2{xJ.x - s2.x, xJ.y - s2.y, xJ.z - s2.z, xJ.w - s2.w};
               const double d2h0 = xh.x - s2h.x, d2h1 = xh.y - s2h.y, d2g = xg - s2g;
               store_blk<BS, ODD>(sep2, PR, a, b, up, act, kidx, xJ, PR);
-              store_blk<BS, ODD>(res2, PR, a, b, up, act, kidx, d2, PR);
+              store_blk<BS, ODD, true>(res2, PR, a, b, up, act, kidx, d2, PR);
               double maxJ2 = 0.0, maxh2 = 0.0;
               if (BS ? up : act) {
                 maxJ2 = fmax(fmax(fabs(d2.x), fabs(d2.y)), fmax(fabs(d2.z), fabs(d2.w)));
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
               }
               if (act && b == 0) {
                 store_pair<ODD>(sep2 + xH, a, xh.x, xh.y, PR);
-                store_pair<ODD>(res2 + xH, a, d2h0, d2h1, PR);
+                store_pair<ODD, true>(res2 + xH, a, d2h0, d2h1, PR);
                 maxh2 = (d2h0 != d2h0 || d2h1 != d2h1) ? INFINITY : fmax(fabs(d2h0), fabs(d2h1));
               }
               if (lane == 0) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
       if (has_block) {
         dJ = Blk{mJ.x - sJ.x, mJ.y - sJ.y, mJ.z - sJ.z, mJ.w - sJ.w};
         store_blk<BS, ODD, kStream>(sep, PR, a, b, up, act, kidx, mJ, PR);
-        store_blk<BS, ODD, kStream>(res, PR, a, b, up, act, kidx, dJ, PR);
+        store_blk<BS, ODD, true>(res, PR, a, b, up, act, kidx, dJ, PR);
         if (BS ? up : act) {
           maxJ = fmax(fmax(fabs(dJ.x), fabs(dJ.y)), fmax(fabs(dJ.z), fabs(dJ.w)));
           if (dJ.x != dJ.x || dJ.y != dJ.y || dJ.z != dJ.z || dJ.w != dJ.w) maxJ = INFINITY;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(MODE == kTail ? kTailWaves * 64 : kFastMaxWaves * 6
         if (act && b == 0) {
           dh0 = mh[0] - sh.x; dh1 = mh[1] - sh.y;
           store_pair<ODD, kStream>(sep + sepH, a, mh[0], mh[1], PR);
-          store_pair<ODD, kStream>(res + (BS ? bs16::h1(P) : PR * PR), a, dh0, dh1, PR);
+          store_pair<ODD, true>(res + (BS ? bs16::h1(P) : PR * PR), a, dh0, dh1, PR);
           maxh = (dh0 != dh0 || dh1 != dh1) ? INFINITY : fmax(fabs(dh0), fabs(dh1));
         }
       }

@@ -1455,12 +1455,14 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
     auto to = [&](int t) -> double& { return *bel(m.to_p, m.to_off, t); };
     const int og = s * s + s;
     double pre_sJ = 0.0, pre_sh = 0.0, pre_tJ = 0.0, pre_th = 0.0;
+    // (STREAMING accesses, round 4: the sepset, the residual, the status and flag words are touched once per traversal; the
+    // sender's and the receiver's entries are what the next level reads again)
     if (s == 1) {
-      if (!sz) { pre_sJ = sep(0); pre_sh = sep(1); }
+      if (!sz) { pre_sJ = __builtin_nontemporal_load(&sep(0)); pre_sh = __builtin_nontemporal_load(&sep(1)); }
       pre_tJ = to(m.u + m.u * mt);
       pre_th = to(mt * mt + m.u);
     }
-    const double pre_sg = sz ? 0.0 : sep(og), pre_tg = to(mt * mt + mt);
+    const double pre_sg = sz ? 0.0 : __builtin_nontemporal_load(&sep(og)), pre_tg = to(mt * mt + mt);
     if (!m.reuse) {
       gmsg = from(mf * mf + mf);
       int info = 0;
@@ -1531,23 +1533,23 @@ __device__ __forceinline__ void uni1_task(const DevState& S, const int32_t* __re
     if (s == 1) {
       const int u = m.u;
       const double dJ = mJ - pre_sJ;
-      sep(0) = mJ;
-      *rsd(m.res_p, m.res_off, 0) = dJ;
+      __builtin_nontemporal_store(mJ, &sep(0));
+      __builtin_nontemporal_store(dJ, rsd(m.res_p, m.res_off, 0));
       to(u + u * mt) = pre_tJ + dJ;
       maxJ = (dJ != dJ) ? INFINITY : fmax(maxJ, fabs(dJ));
       const double dh = mh - pre_sh;
-      sep(1) = mh;
-      *rsd(m.res_p, m.res_off, 1) = dh;
+      __builtin_nontemporal_store(mh, &sep(1));
+      __builtin_nontemporal_store(dh, rsd(m.res_p, m.res_off, 1));
       to(mt * mt + u) = pre_th + dh;
       maxh = (dh != dh) ? INFINITY : fmax(maxh, fabs(dh));
     }
     const double dg = gmsg - pre_sg;
-    sep(og) = gmsg;
+    __builtin_nontemporal_store(gmsg, &sep(og));
     to(mt * mt + mt) = pre_tg + dg;
-    *mword(S.status, m.msg) = 0;
+    __builtin_nontemporal_store(0, mword(S.status, m.msg));
     if (S.update_resnorm) {
       const bool ok = maxh <= S.thr[s] && maxJ <= S.thr[PGBP_MAX_DIM + 1 + s];
-      *mword(S.flags, m.msg) = ok ? 1 : 0;
+      __builtin_nontemporal_store(ok ? 1 : 0, mword(S.flags, m.msg));
       if (!ok && S.notcal) S.notcal[site] = 1;   // (every writer stores the same 1: no atomic)
     }
   }

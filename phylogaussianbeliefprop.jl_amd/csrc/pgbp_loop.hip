@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kLoopWaves * 64) void bp_loop16(DevState S_arg, con
       if (live) {
         if (!sepz) {
           if (has_block) {
-            sJ = load_blk<true>(sep, P, a, b, up, kidx);
+            sJ = load_blk<true, false, !PRO>(sep, P, a, b, up, kidx);
             if (b == 0) sh = load_pair<false>(sep + bs16::h1(P), a, P);
           }
           sg = sep[sepG];
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kLoopWaves * 64) void bp_loop16(DevState S_arg, con
         double* __restrict__ fw = pool + en.from_off;
         constexpr int xH = bs16::h1(P), xG = bs16::g1(P);
         store_blk<true>(sep2, P, a, b, up, act, kidx, p_x);
-        store_blk<true>(res2, P, a, b, up, act, kidx, p_d);
+        store_blk<true, false, true>(res2, P, a, b, up, act, kidx, p_d);
         double maxJ2 = 0.0, maxh2 = 0.0;
         if (up) {
           maxJ2 = fmax(fmax(fabs(p_d.x), fabs(p_d.y)), fmax(fabs(p_d.z), fabs(p_d.w)));
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kLoopWaves * 64) void bp_loop16(DevState S_arg, con
         }
         if (act && b == 0) {
           store_pair<false>(sep2 + xH, a, p_xh0, p_xh1, P);
-          store_pair<false>(res2 + xH, a, p_dh0, p_dh1, P);
+          store_pair<false, true>(res2 + xH, a, p_dh0, p_dh1, P);
           maxh2 = (p_dh0 != p_dh0 || p_dh1 != p_dh1) ? INFINITY : fmax(fabs(p_dh0), fabs(p_dh1));
         }
         if (lane == 0) {
@@ -618,11 +618,12 @@ __global__ __launch_bounds__(kLoopWaves * 64) void bp_loop16(DevState S_arg, con
       }
       if (state == 1) {
         if (has_block) {
-          store_blk<true>(sep, P, a, b, up, act, kidx, mJ);
-          store_blk<true>(res, P, a, b, up, act, kidx, dJ);
+          // (streaming stores, as in bp_fast16: nothing reads the residual, and the sepset not before the other traversal)
+          store_blk<true, false, !PRO>(sep, P, a, b, up, act, kidx, mJ);
+          store_blk<true, false, true>(res, P, a, b, up, act, kidx, dJ);
           if (act && b == 0) {
-            store_pair<false>(sep + bs16::h1(P), a, mh0, mh1, P);
-            store_pair<false>(res + bs16::h1(P), a, dh0, dh1, P);
+            store_pair<false, !PRO>(sep + bs16::h1(P), a, mh0, mh1, P);
+            store_pair<false, true>(res + bs16::h1(P), a, dh0, dh1, P);
           }
         }
         if (lane == 0) {
