@@ -761,7 +761,10 @@ __global__ __launch_bounds__(256) void bm_tree_fill_fast(double* __restrict__ po
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       for (int which = 0; which < (frec ? 2 : 1); ++which) {
         double* __restrict__ dst = which ? frec : rec;
-        for (int t = lane; t < (rl >> 1); t += kWave) reinterpret_cast<double2*>(dst)[t] = reinterpret_cast<const double2*>(r)[t];
+        for (int t = lane; t < (rl >> 1); t += kWave) {
+          const double2 q = reinterpret_cast<const double2*>(r)[t];
+          __builtin_nontemporal_store(pgbp_d2v{q.x, q.y}, reinterpret_cast<pgbp_d2v*>(dst) + t);   // (292 MB at cfg3's size: streamed)
+        }
         if ((rl & 1) && lane == 0) dst[rl - 1] = r[rl - 1];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
